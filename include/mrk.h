@@ -1,0 +1,209 @@
+/*
+ * mrk.h — C ABI of libmrk_hip.so, the MI355X-native /rank hot path for Metarank.
+ *
+ * This is the drop-in boundary.  The Scala host keeps its HTTP API,
+ * event schema, feature registry and persistence; it binds these entry points through
+ * JNA / Panama and nothing else.  Plain C: opaque handles,
+ * caller-owned buffers, no exceptions, no C++/torch types in any signature.
+ *
+ * Every function returns MRK_OK (0) on success and a negative mrk_status on failure;
+ * mrk_last_error() returns a thread-local human readable message for the last failure
+ * on the calling thread.  Handles are thread-safe: many request threads may call
+ * mrk_model_predict_f64 / mrk_rank on the same handles concurrently while a feedback
+ * thread calls mrk_store_put_* (reference threading model: cats-effect compute pool,
+ * src/main/scala/ai/metarank/ml/rank/LambdaMARTRanker.scala:348 and
+ * src/main/scala/ai/metarank/fstore/cache/CachedModelStore.scala:39-42).
+ *
+ * Reference interfaces replaced (all paths relative to the reference repo root,
+ * M = src/main/scala/ai/metarank):
+ *
+ *   mrk_model_load*            <- LightGBMBooster(bytes) / XGBoostBooster(bytes)
+ *                                 M/ml/rank/LambdaMARTRanker.scala:228-232 and the
+ *                                 bitstream reader :192-236
+ *   mrk_model_predict_f64      <- ltrlib Booster.predictMat(values, rows, cols)
+ *                                 M/ml/rank/LambdaMARTRanker.scala:348
+ *   mrk_model_free             <- Booster.close()/isClosed() :361-365
+ *   mrk_config_load_json       <- FeatureMapping.fromFeatureSchema + makeDatasetDescriptor
+ *                                 M/FeatureMapping.scala:56-99
+ *   mrk_store_put_*            <- KVStore[Key,FeatureValue].put  M/fstore/Persistence.scala:85-89
+ *                                 fed by FeatureValueSink.write   M/flow/FeatureValueSink.scala:10-14
+ *   mrk_rank / mrk_rank_batch  <- Ranker.rerank = makeQuery + predict + sortBy(-score)
+ *                                 M/ml/Ranker.scala:27-83,97-106
+ */
+#ifndef MRK_H
+#define MRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRK_ABI_VERSION 1
+
+typedef enum mrk_status {
+  MRK_OK = 0,
+  MRK_ERR_INVALID_ARG = -1,   /* null handle, bad sizes, unknown enum                    */
+  MRK_ERR_PARSE = -2,         /* model / config bytes could not be parsed                 */
+  MRK_ERR_DEVICE = -3,        /* HIP runtime failure (message carries hipGetErrorString)  */
+  MRK_ERR_DIM_MISMATCH = -4,  /* IllegalStateException "dim mismatch" M/model/ItemValue.scala:47,56,60 */
+  MRK_ERR_ARITHMETIC = -5,    /* java.lang.ArithmeticException: / by zero in the normalised rate,
+                                 M/feature/RateFeature.scala:346-348 (global top counter == 0)  */
+  MRK_ERR_UNSUPPORTED = -6,   /* valid input the device path does not implement (yet)     */
+  MRK_ERR_NOT_FOUND = -7,     /* unknown model / feature name                             */
+  MRK_ERR_FEATURE_MISMATCH = -8 /* "booster trained with X features, but config defines Y"
+                                 M/ml/rank/LambdaMARTRanker.scala:208-213                   */
+} mrk_status;
+
+typedef struct mrk_ctx mrk_ctx;       /* one per process per device set           */
+typedef struct mrk_model mrk_model;   /* one per loaded booster (ref-counted)     */
+typedef struct mrk_batch mrk_batch;   /* a prepared, device-resident request batch */
+
+/* ---------------------------------------------------------------- lifecycle */
+
+int mrk_abi_version(void);
+const char *mrk_last_error(void);
+
+/* device_ids: HIP ordinals this context may use; n_devices >= 1.  Round 1 uses device_ids[0]. */
+int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out);
+void mrk_shutdown(mrk_ctx *ctx);
+
+/* ------------------------------------------------- model (replaces Booster) */
+
+enum { MRK_BACKEND_LIGHTGBM = 0, MRK_BACKEND_XGBOOST = 1 }; /* = boosterTag, LambdaMARTRanker.scala:229-230 */
+
+/* Inner booster bytes: LightGBM model string, or XGBoost JSON / UBJSON.  Bytes are copied. */
+int mrk_model_load(mrk_ctx *ctx, int backend, const uint8_t *bytes, size_t len, mrk_model **out);
+
+/* Metarank model container (bitstream v2/v3, LambdaMARTRanker.scala:367-389).
+ * If feature_names != NULL the stored list must equal it in order, else MRK_ERR_FEATURE_MISMATCH. */
+int mrk_model_load_container(mrk_ctx *ctx, const uint8_t *blob, size_t len,
+                             const char *const *feature_names, int n_features, mrk_model **out);
+
+/* == predictMat: rowmajor is rows*cols f64 (host memory), out_scores is rows f64 (host memory). */
+int mrk_model_predict_f64(mrk_model *model, const double *rowmajor, int rows, int cols,
+                          double *out_scores);
+/* Same with all three buffers already in device memory of ctx's device (no copies, async on the
+ * context stream; call mrk_sync before reading). */
+int mrk_model_predict_device(mrk_model *model, const double *d_rowmajor, int rows, int cols,
+                             double *d_out_scores);
+
+typedef struct mrk_model_info {
+  int32_t backend;       /* MRK_BACKEND_*                                   */
+  int32_t n_trees;
+  int32_t max_depth;     /* longest root->leaf path in node visits          */
+  int32_t n_features;    /* max_feature_idx + 1 / num_feature               */
+  int32_t is_f64;        /* 1: LightGBM f64 arithmetic, 0: XGBoost f32       */
+  int32_t n_categorical; /* number of categorical split nodes               */
+  int64_t n_nodes;       /* internal nodes                                  */
+  int64_t n_leaves;
+  int64_t device_bytes;  /* packed forest bytes resident in HBM             */
+  double base_score;     /* XGBoost base margin (0.0 for LightGBM)          */
+} mrk_model_info;
+int mrk_model_get_info(mrk_model *model, mrk_model_info *out);
+
+void mrk_model_retain(mrk_model *model);
+void mrk_model_free(mrk_model *model); /* drops one reference; idempotent at zero (close()/isClosed()) */
+
+/* ------------------------------------ feature schema (FeatureMapping mirror) */
+
+/* json: {"features":[<Metarank feature schemas>], "models": {"<name>": {"type":"lambdamart",
+ * "features":[...]}}} i.e. the `features:` and `models:` sections of Metarank's config.yml
+ * rendered as JSON (the Scala host has circe encoders for every schema).  Builds the feature
+ * registry, the device store layout and, per lambdamart model, the DatasetDescriptor
+ * (column order = models.<name>.features order, M/FeatureMapping.scala:66-72,89-99). */
+int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len);
+
+/* number of matrix columns (DatasetDescriptor.dim) for a configured model, <0 on error */
+int mrk_model_dim(mrk_ctx *ctx, const char *model_name);
+
+/* ------------------------- feature store (KVStore[Key, FeatureValue] mirror) */
+
+/* `key` is Key.encode (M/model/Key.scala:9): "<ScopeCodec.encode(scope)>/<feature name>", e.g.
+ * "item=42/popularity", "global/ctr_click_norm", "field=genre:drama/ctr_genre_click",
+ * "session=s1/profile_interactions", "irf=query:socks:p1/ctr_click".
+ * Each put replaces the previous value of that key (KVStore.put semantics).  Puts are staged on
+ * the host and become visible to mrk_rank calls that start after mrk_store_flush returns
+ * (mrk_rank / mrk_batch_prepare flush implicitly). */
+int mrk_store_put_double(mrk_ctx *ctx, const char *key, double v);               /* ScalarValue(SDouble)      */
+int mrk_store_put_bool(mrk_ctx *ctx, const char *key, int v);                    /* ScalarValue(SBoolean)     */
+int mrk_store_put_string(mrk_ctx *ctx, const char *key, const char *v);          /* ScalarValue(SString)      */
+int mrk_store_put_string_list(mrk_ctx *ctx, const char *key, const char *const *v, int n); /* SStringList    */
+int mrk_store_put_double_list(mrk_ctx *ctx, const char *key, const double *v, int n);      /* SDoubleList    */
+int mrk_store_put_counter(mrk_ctx *ctx, const char *key, int64_t v);             /* CounterValue             */
+int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *values, int n); /* PeriodicCounterValue.values(i).value */
+int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *values, int n); /* BoundedListValue of SString */
+int mrk_store_delete(mrk_ctx *ctx, const char *key);
+int mrk_store_flush(mrk_ctx *ctx);
+
+/* ---------------------------------------------------------------- requests */
+
+enum {
+  MRK_FIELD_STRING = 0,      /* Field.StringField     */
+  MRK_FIELD_NUMBER = 1,      /* Field.NumberField     */
+  MRK_FIELD_BOOL = 2,        /* Field.BooleanField    */
+  MRK_FIELD_STRING_LIST = 3, /* Field.StringListField */
+  MRK_FIELD_NUMBER_LIST = 4  /* Field.NumberListField */
+};
+
+typedef struct mrk_field {
+  const char *name;
+  int32_t type;               /* MRK_FIELD_*                                  */
+  int32_t n;                  /* list length for the *_LIST types              */
+  double num;                 /* NUMBER / BOOL (0|1)                           */
+  const char *str;            /* STRING                                        */
+  const char *const *strs;    /* STRING_LIST                                   */
+  const double *nums;         /* NUMBER_LIST                                   */
+} mrk_field;
+
+/* RankingEvent (M/model/Event.scala) restricted to what the hot path reads. */
+typedef struct mrk_request {
+  const char *id;             /* RankingEvent.id                                */
+  int64_t timestamp_ms;       /* RankingEvent.timestamp.ts                      */
+  const char *user;           /* nullable                                       */
+  const char *session;        /* nullable                                       */
+  const mrk_field *fields;    /* ranking-level fields                           */
+  int32_t n_fields;
+  int32_t n_items;
+  const char *const *item_ids;        /* n_items item ids, request order        */
+  const int32_t *item_field_offsets;  /* nullable; CSR n_items+1 offsets into item_fields */
+  const mrk_field *item_fields;       /* per-item fields (relevancy, overrides) */
+} mrk_request;
+
+/* Ranker.rerank for one request.  out_scores[n_items]: score of item i (request order);
+ * out_order[n_items]: indices into the request in response order (stable sort by -score with
+ * java.lang.Double.compare semantics); out_matrix: nullable, n_items*dim row-major f64 = the
+ * ClickthroughQuery matrix (explain / parity). */
+int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req,
+             double *out_scores, int32_t *out_order, double *out_matrix);
+
+/* Batched form: resolve n_req requests once into a device-resident batch, then run it any number
+ * of times (the benchmark's timed region is mrk_batch_run only). */
+int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req,
+                      mrk_batch **out);
+int mrk_batch_total_items(mrk_batch *batch);
+/* asynchronous on the context stream */
+int mrk_batch_run(mrk_batch *batch, mrk_model *model);
+/* device pointers of the batch outputs (valid until mrk_batch_free): scores f64[total_items],
+ * order i32[total_items] (request-local indices), matrix f64[total_items*dim] */
+int mrk_batch_device_outputs(mrk_batch *batch, double **d_scores, int32_t **d_order, double **d_matrix);
+/* copy results to host; any pointer may be NULL */
+int mrk_batch_fetch(mrk_batch *batch, double *out_scores, int32_t *out_order, double *out_matrix);
+void mrk_batch_free(mrk_batch *batch);
+
+/* -------------------------------------------------------------- utilities */
+
+int mrk_sync(mrk_ctx *ctx);            /* hipStreamSynchronize on the context stream */
+void *mrk_stream(mrk_ctx *ctx);        /* the hipStream_t all work is enqueued on     */
+
+/* HIP-event timing of the kernels launched by the last mrk_batch_run / predict call on this ctx.
+ * names: scorer "score", assembly "assemble", request pre-pass "prepass", sort "sort".
+ * Enable with mrk_profile_enable(ctx, 1); returns accumulated ms and launch count since enable. */
+int mrk_profile_enable(mrk_ctx *ctx, int on);
+int mrk_profile_get(mrk_ctx *ctx, const char *kernel, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRK_H */

@@ -1,0 +1,7 @@
+"""metarank_amd — MI355X-native /rank hot path for Metarank (feature assembly + LambdaMART scoring).
+
+The product is libmrk_hip.so (metarank_amd/csrc, C ABI in include/mrk.h); this package is the
+thin host-side mirror of the reference's interfaces used by tests and benchmarks.
+"""
+from ._native import MrkError, build, lib  # noqa: F401
+from .booster import LIGHTGBM, XGBOOST, Context, HipBooster, default_context  # noqa: F401

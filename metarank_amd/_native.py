@@ -1,0 +1,131 @@
+"""ctypes binding of libmrk_hip.so (include/mrk.h).  Plumbing only: the product is the library."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
+SOURCES = ["forest.cpp", "capi.cpp", "capi_rank.cpp", "score.hip"]
+HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
+
+MRK_OK = 0
+ERR_INVALID_ARG, ERR_PARSE, ERR_DEVICE, ERR_DIM_MISMATCH = -1, -2, -3, -4
+ERR_ARITHMETIC, ERR_UNSUPPORTED, ERR_NOT_FOUND, ERR_FEATURE_MISMATCH = -5, -6, -7, -8
+
+
+class MrkError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[{status}] {message}")
+        self.status = status
+        self.message = message
+
+
+def sources():
+    extra = sorted(f for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")) and f not in SOURCES)
+    return [os.path.join(CSRC, f) for f in SOURCES + extra]
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every source into metarank_amd/libmrk_hip.so (in-tree)."""
+    srcs = sources()
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [
+        os.path.join(REPO, "include", "mrk.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-o", LIB_PATH] + srcs
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class mrk_model_info(C.Structure):
+    _fields_ = [("backend", C.c_int32), ("n_trees", C.c_int32), ("max_depth", C.c_int32), ("n_features", C.c_int32),
+                ("is_f64", C.c_int32), ("n_categorical", C.c_int32), ("n_nodes", C.c_int64), ("n_leaves", C.c_int64),
+                ("device_bytes", C.c_int64), ("base_score", C.c_double)]
+
+
+class mrk_field(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("n", C.c_int32), ("num", C.c_double), ("str", C.c_char_p),
+                ("strs", C.POINTER(C.c_char_p)), ("nums", C.POINTER(C.c_double))]
+
+
+class mrk_request(C.Structure):
+    _fields_ = [("id", C.c_char_p), ("timestamp_ms", C.c_int64), ("user", C.c_char_p), ("session", C.c_char_p),
+                ("fields", C.POINTER(mrk_field)), ("n_fields", C.c_int32), ("n_items", C.c_int32),
+                ("item_ids", C.POINTER(C.c_char_p)), ("item_field_offsets", C.POINTER(C.c_int32)),
+                ("item_fields", C.POINTER(mrk_field))]
+
+
+# every symbol include/mrk.h declares: (restype, argtypes)
+_V, _I, _P, _S = C.c_void_p, C.c_int, C.c_void_p, C.c_char_p
+SIGNATURES = {
+    "mrk_abi_version": (_I, []),
+    "mrk_last_error": (_S, []),
+    "mrk_init": (_I, [_P, _I, C.POINTER(_V)]),
+    "mrk_shutdown": (None, [_V]),
+    "mrk_model_load": (_I, [_V, _I, _P, C.c_size_t, C.POINTER(_V)]),
+    "mrk_model_load_container": (_I, [_V, _P, C.c_size_t, C.POINTER(_S), _I, C.POINTER(_V)]),
+    "mrk_model_predict_f64": (_I, [_V, _P, _I, _I, _P]),
+    "mrk_model_predict_device": (_I, [_V, _P, _I, _I, _P]),
+    "mrk_model_get_info": (_I, [_V, C.POINTER(mrk_model_info)]),
+    "mrk_model_retain": (None, [_V]),
+    "mrk_model_free": (None, [_V]),
+    "mrk_config_load_json": (_I, [_V, _S, C.c_size_t]),
+    "mrk_model_dim": (_I, [_V, _S]),
+    "mrk_store_put_double": (_I, [_V, _S, C.c_double]),
+    "mrk_store_put_bool": (_I, [_V, _S, _I]),
+    "mrk_store_put_string": (_I, [_V, _S, _S]),
+    "mrk_store_put_string_list": (_I, [_V, _S, C.POINTER(_S), _I]),
+    "mrk_store_put_double_list": (_I, [_V, _S, _P, _I]),
+    "mrk_store_put_counter": (_I, [_V, _S, C.c_int64]),
+    "mrk_store_put_periodic": (_I, [_V, _S, _P, _I]),
+    "mrk_store_put_bounded_list": (_I, [_V, _S, C.POINTER(_S), _I]),
+    "mrk_store_delete": (_I, [_V, _S]),
+    "mrk_store_flush": (_I, [_V]),
+    "mrk_rank": (_I, [_V, _V, _S, C.POINTER(mrk_request), _P, _P, _P]),
+    "mrk_batch_prepare": (_I, [_V, _S, C.POINTER(mrk_request), _I, C.POINTER(_V)]),
+    "mrk_batch_total_items": (_I, [_V]),
+    "mrk_batch_run": (_I, [_V, _V]),
+    "mrk_batch_device_outputs": (_I, [_V, C.POINTER(_V), C.POINTER(_V), C.POINTER(_V)]),
+    "mrk_batch_fetch": (_I, [_V, _P, _P, _P]),
+    "mrk_batch_free": (None, [_V]),
+    "mrk_sync": (_I, [_V]),
+    "mrk_stream": (_V, [_V]),
+    "mrk_profile_enable": (_I, [_V, _I]),
+    "mrk_profile_get": (_I, [_V, _S, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libmrk_hip.so; fails loudly when the HIP extension is missing (no CPU fallback exists)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            L = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def check(status: int):
+    if status != MRK_OK:
+        msg = lib().mrk_last_error()
+        raise MrkError(status, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,286 @@
+// C ABI (include/mrk.h): lifecycle, model handles, predictMat replacement, profiling.
+// Feature store / rank entry points live in capi_rank.cpp.
+#include <cmath>
+#include <cstring>
+
+#include "runtime.hpp"
+
+namespace mrk {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+ScopedKernelTimer::ScopedKernelTimer(mrk_ctx *c, const char *n) : ctx(c), name(n) {
+  if (!ctx->profile) return;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+    a = b = nullptr;
+    return;
+  }
+  (void)hipEventRecord(a, ctx->stream);
+}
+ScopedKernelTimer::~ScopedKernelTimer() {
+  if (!a || !b) return;
+  (void)hipEventRecord(b, ctx->stream);
+  ctx->pending_events.emplace_back(name, a, b);
+}
+void drain_profile_events(mrk_ctx *ctx) {
+  for (auto &e : ctx->pending_events) {
+    hipEvent_t a = std::get<1>(e), b = std::get<2>(e);
+    if (hipEventSynchronize(b) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, a, b) == hipSuccess) {
+        auto &t = ctx->timers[std::get<0>(e)];
+        t.total_ms += ms;
+        t.launches += 1;
+      }
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+  ctx->pending_events.clear();
+}
+
+template <typename F>
+static int guard(F &&f) {
+  try {
+    f();
+    return MRK_OK;
+  } catch (const StatusError &e) {
+    set_last_error(e.what());
+    return e.status;
+  } catch (const std::bad_alloc &) {
+    set_last_error("out of host memory");
+    return MRK_ERR_DEVICE;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return MRK_ERR_PARSE;
+  }
+}
+
+static void upload_model(mrk_ctx *ctx, mrk_model *m) {
+  m->packed = pack_forest(m->forest, score_chunk_budget());
+  MRK_HIP(hipSetDevice(ctx->device));
+  auto up = [&](DevBuf &b, const void *src, size_t bytes) {
+    b.reserve(bytes ? bytes : 16);
+    if (bytes) MRK_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  };
+  up(m->d_image, m->packed.image.data(), m->packed.image.size());
+  up(m->d_trees, m->packed.trees.data(), m->packed.trees.size() * sizeof(TreeRef));
+  up(m->d_chunks, m->packed.chunks.data(), m->packed.chunks.size() * sizeof(ChunkRef));
+  up(m->d_cat, m->forest.cat_bits.data(), m->forest.cat_bits.size() * 4);
+}
+
+static mrk_model *make_model(mrk_ctx *ctx, int backend, const uint8_t *bytes, size_t len) {
+  if (!ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
+  if (!bytes && len) throw StatusError(MRK_ERR_INVALID_ARG, "null model bytes");
+  std::unique_ptr<mrk_model> m(new mrk_model());
+  m->ctx = ctx;
+  if (backend == MRK_BACKEND_LIGHTGBM) m->forest = parse_lightgbm_text((const char *)bytes, len);
+  else if (backend == MRK_BACKEND_XGBOOST) m->forest = parse_xgboost(bytes, len);
+  else throw StatusError(MRK_ERR_INVALID_ARG, "unsupported booster tag " + std::to_string(backend));
+  if (m->forest.average_output)
+    throw StatusError(MRK_ERR_UNSUPPORTED, "lightgbm: average_output (random forest) models are not supported");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  upload_model(ctx, m.get());
+  return m.release();
+}
+
+}  // namespace mrk
+
+using namespace mrk;
+
+mrk_ctx::mrk_ctx() {}
+mrk_ctx::~mrk_ctx() { mrk::free_rank_state(this); }
+
+extern "C" {
+
+int mrk_abi_version(void) { return MRK_ABI_VERSION; }
+const char *mrk_last_error(void) { return g_last_error.c_str(); }
+
+int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out) {
+  return guard([&] {
+    if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (n_devices < 1 || !device_ids) throw StatusError(MRK_ERR_INVALID_ARG, "need at least one device id");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      throw StatusError(MRK_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_ids[0] < 0 || device_ids[0] >= count)
+      throw StatusError(MRK_ERR_INVALID_ARG, "device id out of range");
+    std::unique_ptr<mrk_ctx> ctx(new mrk_ctx());
+    ctx->device = device_ids[0];
+    MRK_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    MRK_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->lds_per_block = prop.sharedMemPerBlock;
+    MRK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->d_flag.reserve(256);
+    ctx->h_flag.reserve(4096);
+    MRK_HIP(hipMemset(ctx->d_flag.p, 0, 256));
+    *out = ctx.release();
+  });
+}
+
+void mrk_shutdown(mrk_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_profile_events(ctx);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+}
+
+int mrk_model_load(mrk_ctx *ctx, int backend, const uint8_t *bytes, size_t len, mrk_model **out) {
+  return guard([&] {
+    if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    *out = make_model(ctx, backend, bytes, len);
+  });
+}
+
+int mrk_model_load_container(mrk_ctx *ctx, const uint8_t *blob, size_t len, const char *const *feature_names,
+                             int n_features, mrk_model **out) {
+  return guard([&] {
+    if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!blob) throw StatusError(MRK_ERR_INVALID_ARG, "cannot load model: not found, maybe you forgot to run train?");
+    Container c = parse_container(blob, len);
+    if (feature_names) {
+      bool same = (int)c.features.size() == n_features;
+      for (int i = 0; same && i < n_features; ++i) same = c.features[i] == feature_names[i];
+      if (!same) {
+        std::string exp, act;
+        for (auto &s : c.features) exp += (exp.empty() ? "" : ", ") + s;
+        for (int i = 0; i < n_features; ++i) act += (act.empty() ? "" : ", ") + std::string(feature_names[i]);
+        throw StatusError(MRK_ERR_FEATURE_MISMATCH, "booster trained with List(" + exp + ") features, but config defines List(" + act +
+                                                        ")\nYou may need to retrain the model with the newer config");
+      }
+    }
+    mrk_model *m = make_model(ctx, c.booster_tag, c.inner, c.inner_len);
+    m->container_features = c.features;
+    *out = m;
+  });
+}
+
+static void check_predict_args(mrk_model *model, const void *x, int rows, int cols, const void *out) {
+  if (!model) throw StatusError(MRK_ERR_INVALID_ARG, "null model");
+  if (model->refs.load() <= 0) throw StatusError(MRK_ERR_INVALID_ARG, "model is closed");
+  if (rows < 0 || cols < 0) throw StatusError(MRK_ERR_INVALID_ARG, "negative matrix shape");
+  if (rows > 0 && (!x || !out)) throw StatusError(MRK_ERR_INVALID_ARG, "null matrix / output");
+  int used = 0;
+  for (auto &t : model->forest.trees)
+    for (auto f : t.feat) used = std::max(used, f + 1);
+  if (rows > 0 && cols < used)
+    throw StatusError(MRK_ERR_DIM_MISMATCH, "matrix has " + std::to_string(cols) + " columns but the booster splits on feature " +
+                                                std::to_string(used - 1));
+}
+
+int mrk_model_predict_f64(mrk_model *model, const double *rowmajor, int rows, int cols, double *out_scores) {
+  return guard([&] {
+    check_predict_args(model, rowmajor, rows, cols, out_scores);
+    if (rows == 0) return;
+    mrk_ctx *ctx = model->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MRK_HIP(hipSetDevice(ctx->device));
+    const size_t xb = (size_t)rows * cols * sizeof(double);
+    ctx->d_x.reserve(xb ? xb : 16);
+    ctx->d_out.reserve((size_t)rows * sizeof(double));
+    if (xb) MRK_HIP(hipMemcpyAsync(ctx->d_x.p, rowmajor, xb, hipMemcpyHostToDevice, ctx->stream));
+    MRK_HIP(hipMemsetAsync(ctx->d_flag.p, 0, sizeof(int), ctx->stream));
+    launch_score(ctx, model, ctx->d_x.as<double>(), rows, cols, ctx->d_out.as<double>(), ctx->d_flag.as<int>());
+    MRK_HIP(hipMemcpyAsync(out_scores, ctx->d_out.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MRK_HIP(hipMemcpyAsync(ctx->h_flag.p, ctx->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MRK_HIP(hipStreamSynchronize(ctx->stream));
+    drain_profile_events(ctx);
+    if (*ctx->h_flag.as<int>() & 1)
+      throw StatusError(MRK_ERR_INVALID_ARG,
+                        "Input data contains `inf` or a value too large, while `missing` is not set to `inf`");
+  });
+}
+
+int mrk_model_predict_device(mrk_model *model, const double *d_rowmajor, int rows, int cols, double *d_out_scores) {
+  return guard([&] {
+    check_predict_args(model, d_rowmajor, rows, cols, d_out_scores);
+    if (rows == 0) return;
+    mrk_ctx *ctx = model->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MRK_HIP(hipSetDevice(ctx->device));
+    launch_score(ctx, model, d_rowmajor, rows, cols, d_out_scores, ctx->d_flag.as<int>());
+  });
+}
+
+int mrk_model_get_info(mrk_model *model, mrk_model_info *out) {
+  return guard([&] {
+    if (!model || !out) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    const Forest &f = model->forest;
+    out->backend = (int)f.backend;
+    out->n_trees = (int)f.trees.size();
+    out->max_depth = f.max_depth();
+    out->n_features = f.n_features;
+    out->is_f64 = f.backend == Backend::LightGBM ? 1 : 0;
+    out->n_categorical = (int)f.n_categorical();
+    out->n_nodes = f.n_nodes();
+    out->n_leaves = f.n_leaves();
+    out->device_bytes = (int64_t)(model->packed.image.size() + model->packed.trees.size() * sizeof(TreeRef) +
+                                  model->packed.chunks.size() * sizeof(ChunkRef) + f.cat_bits.size() * 4);
+    out->base_score = f.base_score;
+  });
+}
+
+void mrk_model_retain(mrk_model *model) {
+  if (model) model->refs.fetch_add(1);
+}
+
+void mrk_model_free(mrk_model *model) {
+  if (!model) return;
+  if (model->refs.fetch_sub(1) == 1) {
+    mrk_ctx *ctx = model->ctx;
+    if (ctx) {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      (void)hipSetDevice(ctx->device);
+      (void)hipStreamSynchronize(ctx->stream);
+      delete model;
+    } else {
+      delete model;
+    }
+  }
+}
+
+int mrk_sync(mrk_ctx *ctx) {
+  return guard([&] {
+    if (!ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
+    MRK_HIP(hipSetDevice(ctx->device));
+    MRK_HIP(hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_profile_events(ctx);
+  });
+}
+
+void *mrk_stream(mrk_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int mrk_profile_enable(mrk_ctx *ctx, int on) {
+  return guard([&] {
+    if (!ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_profile_events(ctx);
+    ctx->profile = on != 0;
+    ctx->timers.clear();
+  });
+}
+
+int mrk_profile_get(mrk_ctx *ctx, const char *kernel, double *total_ms, int64_t *launches) {
+  return guard([&] {
+    if (!ctx || !kernel) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_profile_events(ctx);
+    auto it = ctx->timers.find(kernel);
+    if (total_ms) *total_ms = it == ctx->timers.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.launches;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,522 @@
+// Model readers: LightGBM model string, XGBoost JSON/UBJSON, Metarank container; forest packing.
+//
+// The reference reaches these formats through third-party natives that are not vendored
+// (ltrlib 0.2.6 -> xgboost4j / lightgbm4j 4.6.0-1, build.sbt:57-58); the formats and the
+// prediction semantics are restated from those libraries' published behaviour (SURVEY.md §8c,
+// Appendix B).  The reference's own call sites: ml/rank/LambdaMARTRanker.scala:228-232 (load),
+// :348 (predictMat).
+#include "forest.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+
+#include "json.hpp"
+
+namespace mrk {
+
+int64_t Forest::n_nodes() const {
+  int64_t n = 0;
+  for (auto &t : trees) n += (int64_t)t.feat.size();
+  return n;
+}
+int64_t Forest::n_leaves() const {
+  int64_t n = 0;
+  for (auto &t : trees) n += (int64_t)t.leaf.size();
+  return n;
+}
+int Forest::max_depth() const {
+  int d = 0;
+  for (auto &t : trees) d = std::max(d, t.depth);
+  return d;
+}
+int64_t Forest::n_categorical() const {
+  int64_t n = 0;
+  for (auto &t : trees)
+    for (auto f : t.flags) n += (f & NF_CATEGORICAL) ? 1 : 0;
+  return n;
+}
+
+static int tree_depth(const Tree &t) {
+  if (t.feat.empty()) return 0;
+  // iterative DFS; children indices are validated by the callers
+  std::vector<std::pair<int, int>> st{{0, 1}};
+  int best = 0;
+  size_t visited = 0;
+  while (!st.empty()) {
+    auto [n, d] = st.back();
+    st.pop_back();
+    if (++visited > 4 * t.feat.size() + 8) throw std::runtime_error("tree has a cycle");
+    best = std::max(best, d);
+    if (t.left[n] >= 0) st.push_back({t.left[n], d + 1});
+    if (t.right[n] >= 0) st.push_back({t.right[n], d + 1});
+  }
+  return best;
+}
+
+static void validate_tree(const Tree &t, int n_features_hint) {
+  const int nn = (int)t.feat.size(), nl = (int)t.leaf.size();
+  if (nl < 1) throw std::runtime_error("tree without leaves");
+  for (int i = 0; i < nn; ++i) {
+    auto chk = [&](int c) {
+      if (c >= 0) {
+        if (c >= nn) throw std::runtime_error("child index out of range");
+      } else if (~c >= nl) {
+        throw std::runtime_error("leaf index out of range");
+      }
+    };
+    chk(t.left[i]);
+    chk(t.right[i]);
+    if (t.feat[i] < 0) throw std::runtime_error("negative split feature");
+    (void)n_features_hint;
+  }
+}
+
+// ------------------------------------------------------------------ LightGBM text model
+
+namespace {
+
+struct Lines {
+  const char *p, *end;
+  bool next(std::string &line) {
+    if (p >= end) return false;
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    const char *e = nl ? nl : end;
+    const char *le = e;
+    if (le > p && le[-1] == '\r') --le;
+    line.assign(p, le);
+    p = nl ? nl + 1 : end;
+    return true;
+  }
+};
+
+template <typename T, typename F>
+std::vector<T> split_parse(const std::string &s, F conv) {
+  std::vector<T> out;
+  const char *p = s.c_str();
+  while (*p) {
+    while (*p == ' ') ++p;
+    if (!*p) break;
+    const char *b = p;
+    while (*p && *p != ' ') ++p;
+    out.push_back(conv(std::string(b, p)));
+  }
+  return out;
+}
+
+double parse_f64(const std::string &s) {
+  // LightGBM writes %.17g and reads with a correctly rounded parser; "inf"/"nan" are accepted by strtod
+  return strtod(s.c_str(), nullptr);
+}
+
+}  // namespace
+
+Forest parse_lightgbm_text(const char *text, size_t len) {
+  Forest f;
+  f.backend = Backend::LightGBM;
+  Lines ln{text, text + len};
+  std::string line;
+  std::map<std::string, std::string> header;
+  bool in_tree = false, saw_tree = false, done = false;
+  std::map<std::string, std::string> kv;
+  int num_class = 1, num_tree_per_iteration = 1;
+
+  auto finish_tree = [&]() {
+    if (!in_tree) return;
+    Tree t;
+    auto get = [&](const char *k) -> const std::string * {
+      auto it = kv.find(k);
+      return it == kv.end() ? nullptr : &it->second;
+    };
+    const std::string *nl = get("num_leaves");
+    if (!nl) throw std::runtime_error("lightgbm: tree without num_leaves");
+    int num_leaves = atoi(nl->c_str());
+    if (num_leaves < 1) throw std::runtime_error("lightgbm: bad num_leaves");
+    int num_cat = get("num_cat") ? atoi(get("num_cat")->c_str()) : 0;
+    if (get("is_linear") && atoi(get("is_linear")->c_str()) != 0)
+      throw std::runtime_error("lightgbm: linear trees are not supported");
+    const std::string *lv = get("leaf_value");
+    if (!lv) throw std::runtime_error("lightgbm: tree without leaf_value");
+    t.leaf = split_parse<double>(*lv, parse_f64);
+    if ((int)t.leaf.size() != num_leaves) throw std::runtime_error("lightgbm: leaf_value length mismatch");
+    if (num_leaves > 1) {
+      auto need = [&](const char *k) -> const std::string & {
+        const std::string *v = get(k);
+        if (!v) throw std::runtime_error(std::string("lightgbm: tree without ") + k);
+        return *v;
+      };
+      auto toi = [](const std::string &s) { return (int32_t)strtol(s.c_str(), nullptr, 10); };
+      t.feat = split_parse<int32_t>(need("split_feature"), toi);
+      t.thr = split_parse<double>(need("threshold"), parse_f64);
+      std::vector<int32_t> dt = split_parse<int32_t>(need("decision_type"), toi);
+      t.left = split_parse<int32_t>(need("left_child"), toi);
+      t.right = split_parse<int32_t>(need("right_child"), toi);
+      const size_t nn = (size_t)num_leaves - 1;
+      if (t.feat.size() != nn || t.thr.size() != nn || dt.size() != nn || t.left.size() != nn ||
+          t.right.size() != nn)
+        throw std::runtime_error("lightgbm: split array length mismatch");
+      std::vector<int32_t> cat_boundaries;
+      std::vector<uint32_t> cat_threshold;
+      if (num_cat > 0) {
+        cat_boundaries = split_parse<int32_t>(need("cat_boundaries"), toi);
+        cat_threshold = split_parse<uint32_t>(
+            need("cat_threshold"), [](const std::string &s) { return (uint32_t)strtoul(s.c_str(), nullptr, 10); });
+        if ((int)cat_boundaries.size() != num_cat + 1) throw std::runtime_error("lightgbm: cat_boundaries length");
+      }
+      t.flags.resize(nn);
+      t.cat_begin.assign(nn, 0);
+      t.cat_words.assign(nn, 0);
+      for (size_t i = 0; i < nn; ++i) {
+        // include/LightGBM/tree.h: kCategoricalMask = 1, kDefaultLeftMask = 2, missing type = (dt >> 2) & 3
+        uint8_t fl = 0;
+        int d = dt[i];
+        if (d & 1) fl |= NF_CATEGORICAL;
+        if (d & 2) fl |= NF_DEFAULT_LEFT;
+        int mt = (d >> 2) & 3;
+        if (mt == 1) fl |= NF_MISS_ZERO;
+        else if (mt == 2) fl |= NF_MISS_NAN;
+        t.flags[i] = fl;
+        if (fl & NF_CATEGORICAL) {
+          int ci = (int)t.thr[i];
+          if (ci < 0 || ci >= num_cat) throw std::runtime_error("lightgbm: categorical threshold index out of range");
+          int b = cat_boundaries[ci], e = cat_boundaries[ci + 1];
+          if (b < 0 || e < b || (size_t)e > cat_threshold.size()) throw std::runtime_error("lightgbm: cat_boundaries out of range");
+          t.cat_begin[i] = (uint32_t)f.cat_bits.size();
+          t.cat_words[i] = (uint32_t)(e - b);
+          f.cat_bits.insert(f.cat_bits.end(), cat_threshold.begin() + b, cat_threshold.begin() + e);
+        }
+      }
+    }
+    validate_tree(t, 0);
+    t.depth = tree_depth(t);
+    f.trees.push_back(std::move(t));
+    kv.clear();
+    in_tree = false;
+  };
+
+  while (!done && ln.next(line)) {
+    if (line.empty()) {
+      finish_tree();
+      continue;
+    }
+    if (line.rfind("Tree=", 0) == 0) {
+      finish_tree();
+      in_tree = true;
+      saw_tree = true;
+      continue;
+    }
+    if (line == "end of trees") {
+      finish_tree();
+      done = true;
+      break;
+    }
+    size_t eq = line.find('=');
+    if (in_tree) {
+      if (eq != std::string::npos) kv[line.substr(0, eq)] = line.substr(eq + 1);
+    } else if (!saw_tree) {
+      if (eq != std::string::npos) header[line.substr(0, eq)] = line.substr(eq + 1);
+      else header[line] = "";
+    }
+  }
+  finish_tree();
+  if (header.find("tree") == header.end() && header.find("version") == header.end() && f.trees.empty())
+    throw std::runtime_error("lightgbm: not a LightGBM model string");
+  if (header.count("num_class")) num_class = atoi(header["num_class"].c_str());
+  if (header.count("num_tree_per_iteration")) num_tree_per_iteration = atoi(header["num_tree_per_iteration"].c_str());
+  if (num_class != 1 || num_tree_per_iteration != 1)
+    throw std::runtime_error("lightgbm: only single-output models are supported (num_class=1)");
+  if (header.count("max_feature_idx")) f.n_features = atoi(header["max_feature_idx"].c_str()) + 1;
+  if (header.count("objective")) f.objective = header["objective"];
+  f.average_output = header.count("average_output") > 0;
+  for (auto &t : f.trees)
+    for (auto ft : t.feat) f.n_features = std::max(f.n_features, ft + 1);
+  return f;
+}
+
+// ------------------------------------------------------------------ XGBoost JSON / UBJSON
+
+static uint64_t f32_bits_widen(float v) {
+  double d = (double)v;
+  uint64_t b;
+  memcpy(&b, &d, 8);
+  return b;
+}
+
+Forest parse_xgboost(const uint8_t *bytes, size_t len) {
+  if (len == 0) throw std::runtime_error("xgboost: empty model");
+  json::Value root;
+  // JSON text starts with '{' followed by whitespace or '"'; UBJSON starts with '{' followed by a
+  // length marker.  Legacy binary ("binf" / raw struct) is not supported.
+  bool is_json = false;
+  if (bytes[0] == '{') {
+    size_t k = 1;
+    while (k < len && (bytes[k] == ' ' || bytes[k] == '\n' || bytes[k] == '\r' || bytes[k] == '\t')) ++k;
+    is_json = k < len && (bytes[k] == '"' || bytes[k] == '}');
+  } else {
+    throw std::runtime_error(
+        "xgboost: unsupported serialisation (legacy binary format); re-save the booster as JSON or UBJSON");
+  }
+  root = is_json ? json::parse((const char *)bytes, len) : json::parse_ubjson(bytes, len);
+
+  Forest f;
+  f.backend = Backend::XGBoost;
+  const json::Value &learner = root.at("learner");
+  const json::Value &lmp = learner.at("learner_model_param");
+  f.base_score = (double)lmp.at("base_score").as_float();  // margin space for rank:* objectives (identity link)
+  if (const json::Value *nf = lmp.find("num_feature")) f.n_features = (int)nf->as_int();
+  if (const json::Value *nc = lmp.find("num_class"))
+    if (nc->as_int() > 1) throw std::runtime_error("xgboost: multi-class models are not supported");
+  if (const json::Value *obj = learner.find("objective"))
+    if (const json::Value *nm = obj->find("name")) f.objective = nm->as_string();
+  if (!f.objective.empty()) {
+    // Only identity-link objectives keep base_score == base margin and need no output transform.
+    const char *ok[] = {"rank:pairwise", "rank:ndcg", "rank:map", "reg:squarederror", "reg:linear"};
+    bool found = false;
+    for (auto o : ok) found = found || f.objective == o;
+    if (!found) throw std::runtime_error("xgboost: objective '" + f.objective + "' is not supported (need an identity-link objective such as rank:ndcg)");
+  }
+  const json::Value &gb = learner.at("gradient_booster");
+  if (const json::Value *nm = gb.find("name"))
+    if (nm->as_string() != "gbtree") throw std::runtime_error("xgboost: only gbtree boosters are supported");
+  const json::Value &model = gb.at("model");
+  const json::Value &trees = model.at("trees");
+  if (!trees.is_array()) throw std::runtime_error("xgboost: trees is not an array");
+
+  for (const json::Value &jt : trees.arr) {
+    const auto &lc = jt.at("left_children").arr;
+    const auto &rc = jt.at("right_children").arr;
+    const auto &si = jt.at("split_indices").arr;
+    const auto &sc = jt.at("split_conditions").arr;
+    const auto &dl = jt.at("default_left").arr;
+    const size_t n = lc.size();
+    if (rc.size() != n || si.size() != n || sc.size() != n || dl.size() != n)
+      throw std::runtime_error("xgboost: node array length mismatch");
+    if (n == 0) throw std::runtime_error("xgboost: empty tree");
+    std::vector<int> split_type(n, 0);
+    if (const json::Value *st = jt.find("split_type"))
+      for (size_t i = 0; i < n && i < st->arr.size(); ++i) split_type[i] = (int)st->arr[i].as_int();
+    // categorical side tables
+    std::map<int, std::pair<size_t, size_t>> cat_of_node;  // node -> (segment begin, size) in `categories`
+    const json::Value *cats = jt.find("categories");
+    if (const json::Value *cn = jt.find("categories_nodes")) {
+      const auto &segs = jt.at("categories_segments").arr;
+      const auto &sizes = jt.at("categories_sizes").arr;
+      for (size_t k = 0; k < cn->arr.size(); ++k)
+        cat_of_node[(int)cn->arr[k].as_int()] = {(size_t)segs.at(k).as_int(), (size_t)sizes.at(k).as_int()};
+    }
+    // Renumber: XGBoost keeps leaves and internal nodes in one array; split them.
+    std::vector<int> inner_id(n, -1), leaf_id(n, -1);
+    // reachability from root 0 (deleted nodes may linger in the arrays)
+    std::vector<int> order;
+    {
+      std::vector<int> st{0};
+      std::vector<char> seen(n, 0);
+      while (!st.empty()) {
+        int u = st.back();
+        st.pop_back();
+        if (u < 0 || (size_t)u >= n) throw std::runtime_error("xgboost: child index out of range");
+        if (seen[u]) throw std::runtime_error("xgboost: tree has a cycle");
+        seen[u] = 1;
+        order.push_back(u);
+        int l = (int)lc[u].as_int(), r = (int)rc[u].as_int();
+        if (l != -1) {
+          st.push_back(r);
+          st.push_back(l);
+        }
+      }
+    }
+    Tree t;
+    for (int u : order) {
+      if ((int)lc[u].as_int() == -1) {
+        leaf_id[u] = (int)t.leaf.size();
+        t.leaf.push_back((double)sc[u].as_float());
+      } else {
+        inner_id[u] = (int)t.feat.size();
+        t.feat.push_back(0);
+      }
+    }
+    const size_t nn = t.feat.size();
+    t.thr.assign(nn, 0.0);
+    t.flags.assign(nn, 0);
+    t.left.assign(nn, 0);
+    t.right.assign(nn, 0);
+    t.cat_begin.assign(nn, 0);
+    t.cat_words.assign(nn, 0);
+    for (int u : order) {
+      int id = inner_id[u];
+      if (id < 0) continue;
+      int l = (int)lc[u].as_int(), r = (int)rc[u].as_int();
+      t.feat[id] = (int32_t)si[u].as_int();
+      t.left[id] = inner_id[l] >= 0 ? inner_id[l] : ~leaf_id[l];
+      t.right[id] = inner_id[r] >= 0 ? inner_id[r] : ~leaf_id[r];
+      uint8_t fl = NF_MISS_NAN;
+      if (dl[u].as_bool()) fl |= NF_DEFAULT_LEFT;
+      if (split_type[u] == 1) {
+        fl |= NF_CATEGORICAL;
+        auto it = cat_of_node.find(u);
+        if (it == cat_of_node.end() || !cats) throw std::runtime_error("xgboost: categorical node without categories");
+        size_t b = it->second.first, sz = it->second.second;
+        if (b + sz > cats->arr.size()) throw std::runtime_error("xgboost: categories segment out of range");
+        int64_t maxc = -1;
+        for (size_t k = 0; k < sz; ++k) maxc = std::max<int64_t>(maxc, cats->arr[b + k].as_int());
+        uint32_t words = (uint32_t)(maxc < 0 ? 0 : (maxc / 32 + 1));
+        t.cat_begin[id] = (uint32_t)f.cat_bits.size();
+        t.cat_words[id] = words;
+        f.cat_bits.resize(f.cat_bits.size() + words, 0u);
+        for (size_t k = 0; k < sz; ++k) {
+          int64_t c = cats->arr[b + k].as_int();
+          if (c < 0) throw std::runtime_error("xgboost: negative category");
+          f.cat_bits[t.cat_begin[id] + (size_t)(c / 32)] |= 1u << (c % 32);
+        }
+      } else {
+        t.thr[id] = (double)sc[u].as_float();
+      }
+      t.flags[id] = fl;
+    }
+    (void)f32_bits_widen;
+    validate_tree(t, f.n_features);
+    t.depth = tree_depth(t);
+    f.trees.push_back(std::move(t));
+  }
+  if (const json::Value *ti = model.find("tree_info"))
+    for (auto &g : ti->arr)
+      if (g.as_int() != 0) throw std::runtime_error("xgboost: multi-group models are not supported");
+  for (auto &t : f.trees)
+    for (auto ft : t.feat) f.n_features = std::max(f.n_features, ft + 1);
+  return f;
+}
+
+// ------------------------------------------------------------------ Metarank container
+
+namespace {
+struct Rd {
+  const uint8_t *p, *end;
+  void need(size_t n) {
+    if ((size_t)(end - p) < n) throw std::runtime_error("model container: truncated");
+  }
+  uint8_t u8() { need(1); return *p++; }
+  int32_t i32() { need(4); int32_t v = (int32_t)((uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]); p += 4; return v; }
+  uint16_t u16() { need(2); uint16_t v = (uint16_t)(p[0] << 8 | p[1]); p += 2; return v; }
+  // java.io.DataInput.readUTF: u16 byte length + modified UTF-8 (U+0000 as C0 80, supplementary
+  // chars as surrogate pairs of 3-byte sequences).  Feature names are plain identifiers; the bytes
+  // are returned verbatim, which equals standard UTF-8 for everything inside the BMP except U+0000.
+  std::string utf() { uint16_t n = u16(); need(n); std::string s((const char *)p, n); p += n; return s; }
+};
+}  // namespace
+
+Container parse_container(const uint8_t *blob, size_t len) {
+  Rd r{blob, blob + len};
+  Container c;
+  c.version = r.u8();
+  if (c.version != 2 && c.version != 3)
+    throw std::runtime_error("model container: unsupported bitstream version " + std::to_string(c.version));
+  int32_t nf = r.i32();
+  if (nf < 0 || nf > 1 << 20) throw std::runtime_error("model container: bad feature count");
+  for (int i = 0; i < nf; ++i) c.features.push_back(r.utf());
+  c.booster_tag = r.u8();
+  if (c.booster_tag != 0 && c.booster_tag != 1)
+    throw std::runtime_error("unsupported booster tag " + std::to_string(c.booster_tag));
+  int32_t sz = r.i32();
+  if (sz < 0) throw std::runtime_error("model container: bad booster size");
+  r.need((size_t)sz);
+  c.inner = r.p;
+  c.inner_len = (size_t)sz;
+  // v3 appends warm-up requests (RankingEventFormat); they are host-side replay material and are
+  // not needed to score.
+  return c;
+}
+
+// ------------------------------------------------------------------ packing
+
+PackedForest pack_forest(const Forest &f, uint32_t chunk_bytes) {
+  PackedForest pf;
+  const bool f64 = f.backend == Backend::LightGBM;
+  const uint32_t leaf_sz = f64 ? 8 : 4;
+  auto tree_bytes = [&](const Tree &t) {
+    uint32_t b = (uint32_t)t.feat.size() * 16 + (uint32_t)t.leaf.size() * leaf_sz;
+    return (b + 15u) & ~15u;
+  };
+  pf.trees.resize(f.trees.size());
+  ChunkRef cur{0, 0, 0, 0};
+  auto close_chunk = [&]() {
+    if (cur.n_trees == 0) return;
+    pf.chunks.push_back(cur);
+    pf.max_chunk_bytes = std::max(pf.max_chunk_bytes, cur.byte_len);
+    pf.max_chunk_trees = std::max(pf.max_chunk_trees, cur.n_trees);
+    cur = ChunkRef{cur.byte_off + cur.byte_len, 0, cur.first_tree + cur.n_trees, 0};
+  };
+  for (size_t ti = 0; ti < f.trees.size(); ++ti) {
+    const Tree &t = f.trees[ti];
+    if (t.feat.size() > 32767 || t.leaf.size() > 32768)
+      throw std::runtime_error("tree too large for the packed node format (> 32767 internal nodes)");
+    uint32_t tb = tree_bytes(t);
+    if (tb > chunk_bytes) throw std::runtime_error("a single tree exceeds the LDS chunk budget");
+    if (cur.byte_len + tb > chunk_bytes) close_chunk();
+    TreeRef &tr = pf.trees[ti];
+    tr.node_off = cur.byte_len;
+    tr.leaf_off = cur.byte_len + (uint32_t)t.feat.size() * 16;
+    tr.n_nodes = (uint16_t)t.feat.size();
+    tr.depth = (uint16_t)t.depth;
+    size_t base = pf.image.size();
+    pf.image.resize(base + tb, 0);
+    uint8_t *dst = pf.image.data() + base;
+    for (size_t i = 0; i < t.feat.size(); ++i) {
+      if (t.feat[i] > 65535) throw std::runtime_error("split feature index exceeds 65535");
+      const uint8_t fl = t.flags[i];
+      if (f64) {
+        PackedNode64 n{};
+        if (fl & NF_CATEGORICAL) {
+          uint64_t bits = (uint64_t)t.cat_begin[i] | ((uint64_t)t.cat_words[i] << 32);
+          memcpy(&n.thr, &bits, 8);
+        } else {
+          n.thr = t.thr[i];
+        }
+        n.feat = (uint16_t)t.feat[i];
+        n.flags = fl;
+        // where NaN goes for a numerical node (LightGBM Tree::NumericalDecision):
+        //   missing None : NaN is replaced by 0.0 and compared
+        //   missing Zero : NaN -> 0.0 -> IsZero -> default direction
+        //   missing NaN  : default direction
+        bool nan_left;
+        if (fl & (NF_MISS_ZERO | NF_MISS_NAN)) nan_left = (fl & NF_DEFAULT_LEFT) != 0;
+        else nan_left = 0.0 <= t.thr[i];
+        n.nan_left = nan_left ? 1 : 0;
+        n.left = (int16_t)t.left[i];
+        n.right = (int16_t)t.right[i];
+        memcpy(dst + i * 16, &n, 16);
+      } else {
+        PackedNode32 n{};
+        if (fl & NF_CATEGORICAL) {
+          uint32_t b = t.cat_begin[i];
+          memcpy(&n.thr, &b, 4);
+          n.pad2 = t.cat_words[i];
+        } else {
+          n.thr = (float)t.thr[i];
+        }
+        n.feat = (uint16_t)t.feat[i];
+        n.flags = fl;
+        n.left = (int16_t)t.left[i];
+        n.right = (int16_t)t.right[i];
+        memcpy(dst + i * 16, &n, 16);
+      }
+    }
+    uint8_t *ldst = dst + t.feat.size() * 16;
+    for (size_t i = 0; i < t.leaf.size(); ++i) {
+      if (f64) {
+        memcpy(ldst + i * 8, &t.leaf[i], 8);
+      } else {
+        float v = (float)t.leaf[i];
+        memcpy(ldst + i * 4, &v, 4);
+      }
+    }
+    cur.byte_len += tb;
+    cur.n_trees += 1;
+  }
+  close_chunk();
+  return pf;
+}
+
+}  // namespace mrk

@@ -1,0 +1,141 @@
+// Host runtime shared by the C-ABI translation units: context, model handle, HIP helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mrk.h"
+#include "forest.hpp"
+
+namespace mrk {
+
+struct StatusError : std::runtime_error {
+  int status;
+  StatusError(int s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+void set_last_error(const std::string &msg);
+
+#define MRK_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      throw ::mrk::StatusError(MRK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// RAII device buffer (hipMalloc / hipFree), grow-only reserve.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  void reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    release();
+    size_t want = bytes < 256 ? 256 : bytes;
+    MRK_HIP(hipMalloc(&p, want));
+    cap = want;
+  }
+  template <typename T>
+  T *as() const { return (T *)p; }
+};
+
+// pinned host staging buffer
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf &) = delete;
+  PinBuf &operator=(const PinBuf &) = delete;
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  void reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    MRK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+  }
+  template <typename T>
+  T *as() const { return (T *)p; }
+};
+
+struct KernelTimer {
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct Store;     // store.hpp
+struct Registry;  // features.hpp
+
+}  // namespace mrk
+
+struct mrk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cus = 0;
+  size_t lds_per_block = 0;
+  std::mutex mu;  // serialises stream use + scratch buffers (one in-flight call per ctx)
+  // scratch for predict_f64
+  mrk::DevBuf d_x, d_out, d_flag;
+  mrk::PinBuf h_flag;
+  // profiling
+  bool profile = false;
+  std::map<std::string, mrk::KernelTimer> timers;
+  std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending_events;
+  // feature side (created by mrk_config_load_json)
+  mrk::Registry *registry = nullptr;  // owned; freed by mrk::free_rank_state
+  mrk::Store *store = nullptr;
+  mrk_ctx();
+  ~mrk_ctx();
+};
+
+struct mrk_model {
+  mrk_ctx *ctx = nullptr;
+  std::atomic<int> refs{1};
+  mrk::Forest forest;
+  mrk::PackedForest packed;
+  std::vector<std::string> container_features;
+  mrk::DevBuf d_image, d_trees, d_chunks, d_cat;
+};
+
+namespace mrk {
+
+// Times a kernel with HIP events on ctx->stream when profiling is enabled.
+struct ScopedKernelTimer {
+  mrk_ctx *ctx;
+  const char *name;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedKernelTimer(mrk_ctx *c, const char *n);
+  ~ScopedKernelTimer();
+};
+void drain_profile_events(mrk_ctx *ctx);
+
+// capi_rank.cpp: releases ctx->registry / ctx->store
+void free_rank_state(mrk_ctx *ctx);
+
+// score.hip
+void launch_score(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
+                  int *d_flag);
+uint32_t score_chunk_budget();
+
+}  // namespace mrk

@@ -1,0 +1,46 @@
+"""CPU: libmrk_hip.so loads and exports every symbol include/mrk.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+from metarank_amd import _native
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "mrk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    _native.build()
+    L = C.CDLL(_native.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mrk.h but not exported"
+        assert s in _native.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(_native.SIGNATURES) == set(syms)
+
+
+def test_abi_version_and_error_paths_without_gpu():
+    L = _native.lib()
+    assert L.mrk_abi_version() == 1
+    # null arguments are rejected before any device work
+    assert L.mrk_model_predict_f64(None, None, 1, 1, None) == _native.ERR_INVALID_ARG
+    assert b"null model" in L.mrk_last_error()
+    L.mrk_model_free(None)
+    L.mrk_shutdown(None)
+
+
+def test_no_product_file_references_the_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "metarank_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|oracle/|liboracle", src, flags=re.M):
+                    bad.append(f)
+    assert bad == []
