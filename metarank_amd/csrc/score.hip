@@ -167,22 +167,23 @@ score_kernel(const uint8_t *__restrict__ image, const TreeRef *__restrict__ tree
           const int n = max(node[u], 0);
           const Node16 nd = *(const Node16 *)(s_chunk + nbase[u] + (uint32_t)n * 16u);
           int next;
+          const bool walking = node[u] >= 0;  // finished lanes re-read node 0; keep their gather in range
           if constexpr (F64) {
-            const uint32_t feat = nd.w2 & 0xffffu;
+            const uint32_t feat = walking ? (nd.w2 & 0xffffu) : 0u;
             double v;
             if constexpr (ROWS_LDS) v = s_rows[feat * TILE + tid];
-            else v = row < rows ? prep<true>(X[row * cols + feat], flag) : 0.0;
+            else v = (walking && row < rows) ? prep<true>(X[row * cols + feat], flag) : 0.0;
             const bool left = decide64(nd.w0, nd.w1, nd.w2, v, cat_bits);
             next = left ? (int)(short)(nd.w3 & 0xffffu) : (int)(short)(nd.w3 >> 16);
           } else {
-            const uint32_t feat = nd.w1 & 0xffffu;
+            const uint32_t feat = walking ? (nd.w1 & 0xffffu) : 0u;
             float v;
             if constexpr (ROWS_LDS) v = s_rows[feat * TILE + tid];
-            else v = row < rows ? prep<false>(X[row * cols + feat], flag) : 0.f;
+            else v = (walking && row < rows) ? prep<false>(X[row * cols + feat], flag) : 0.f;
             const bool left = decide32(nd.w0, nd.w1, nd.w3, v, cat_bits);
             next = left ? (int)(short)(nd.w2 & 0xffffu) : (int)(short)(nd.w2 >> 16);
           }
-          node[u] = node[u] >= 0 ? next : node[u];
+          node[u] = walking ? next : node[u];
         }
       }
       // leaves are added strictly in tree order

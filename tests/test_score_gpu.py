@@ -29,7 +29,11 @@ def make_X(rng, rows, cols, cat_col=None, n_cats=16, nan_frac=0.05, zero_frac=0.
 
 
 def quantiles_of(X):
-    return [np.nan_to_num(np.quantile(X[:, j][~np.isnan(X[:, j])], np.linspace(0.02, 0.98, 49))) for j in range(X.shape[1])]
+    out = []
+    for j in range(X.shape[1]):
+        col = X[:, j][~np.isnan(X[:, j])]
+        out.append(np.quantile(col, np.linspace(0.02, 0.98, 49)) if len(col) else np.array([0.0, 0.5]))
+    return out
 
 
 def assert_same(got, exp):
