@@ -188,8 +188,11 @@ int mrk_batch_run(mrk_batch *batch, mrk_model *model);
 /* device pointers of the batch outputs (valid until mrk_batch_free): scores f64[total_items],
  * order i32[total_items] (request-local indices), matrix f64[total_items*dim] */
 int mrk_batch_device_outputs(mrk_batch *batch, double **d_scores, int32_t **d_order, double **d_matrix);
-/* copy results to host; any pointer may be NULL */
+/* copy results to host (synchronises); any pointer may be NULL */
 int mrk_batch_fetch(mrk_batch *batch, double *out_scores, int32_t *out_order, double *out_matrix);
+/* per-request outcome of the last run: out_status[n_req] = MRK_OK or the mrk_status the reference's
+ * exception for that request maps to (e.g. MRK_ERR_ARITHMETIC); results of failed requests are undefined */
+int mrk_batch_status(mrk_batch *batch, int32_t *out_status);
 void mrk_batch_free(mrk_batch *batch);
 
 /* -------------------------------------------------------------- utilities */

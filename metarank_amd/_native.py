@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
-SOURCES = ["forest.cpp", "capi.cpp", "capi_rank.cpp", "score.hip"]
+SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "capi.cpp", "capi_rank.cpp", "score.hip", "rank.hip"]
 HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
 
 MRK_OK = 0
@@ -41,6 +41,7 @@ def build(force: bool = False) -> str:
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-ffp-contract=off",  # the JVM never fuses a*b+c; parity with the reference is bit-exact
            "-o", LIB_PATH] + srcs
     subprocess.check_call(cmd)
     return LIB_PATH
@@ -96,6 +97,7 @@ SIGNATURES = {
     "mrk_batch_run": (_I, [_V, _V]),
     "mrk_batch_device_outputs": (_I, [_V, C.POINTER(_V), C.POINTER(_V), C.POINTER(_V)]),
     "mrk_batch_fetch": (_I, [_V, _P, _P, _P]),
+    "mrk_batch_status": (_I, [_V, _P]),
     "mrk_batch_free": (None, [_V]),
     "mrk_sync": (_I, [_V]),
     "mrk_stream": (_V, [_V]),

@@ -1,33 +1,329 @@
 // Feature store + rank entry points of the C ABI (include/mrk.h).
+#include <cstring>
+
+#include "features.hpp"
+#include "rank.hpp"
 #include "runtime.hpp"
 
 namespace mrk {
-void free_rank_state(mrk_ctx *ctx) { (void)ctx; }
-static int todo(const char *what) {
-  set_last_error(std::string(what) + ": not implemented yet");
-  return MRK_ERR_UNSUPPORTED;
+
+void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
+void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
+void launch_sort(mrk_ctx *ctx, const BatchDev &b);
+void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
+                        int *d_status, const uint32_t *d_row_req);
+
+void free_rank_state(mrk_ctx *ctx) {
+  delete ctx->registry;
+  delete ctx->store;
+  ctx->registry = nullptr;
+  ctx->store = nullptr;
 }
+
+template <typename F>
+static int guard(F &&f) {
+  try {
+    f();
+    return MRK_OK;
+  } catch (const StatusError &e) {
+    set_last_error(e.what());
+    return e.status;
+  } catch (const std::bad_alloc &) {
+    set_last_error("out of host memory");
+    return MRK_ERR_DEVICE;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return MRK_ERR_PARSE;
+  }
+}
+
+static Store &store_of(mrk_ctx *ctx) {
+  if (!ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
+  if (!ctx->store) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called first");
+  return *ctx->store;
+}
+
+int status_to_code(int st, std::string &msg) {
+  if (st & ST_ARITHMETIC) { msg = "java.lang.ArithmeticException: / by zero (normalised rate: global `top` counter is 0)"; return MRK_ERR_ARITHMETIC; }
+  if (st & ST_DIM) { msg = "dim mismatch: item embedding is shorter than the query embedding"; return MRK_ERR_DIM_MISMATCH; }
+  if (st & ST_ILLEGAL_ARG) { msg = "requirement failed: Duration is limited to +-(2^63-1)ns (ca. 292 years)"; return MRK_ERR_INVALID_ARG; }
+  if (st & 32) { msg = "Input data contains `inf` or a value too large, while `missing` is not set to `inf`"; return MRK_ERR_INVALID_ARG; }
+  if (st & ST_TOO_MANY) { msg = "diversity over more values than the device pre-pass supports: set `top`"; return MRK_ERR_UNSUPPORTED; }
+  if (st & ST_TABLE_FULL) { msg = "internal: pre-pass hash table under-sized (store changed between prepare and run?)"; return MRK_ERR_DEVICE; }
+  return MRK_OK;
+}
+
 }  // namespace mrk
+
 using namespace mrk;
 
-extern "C" {
-int mrk_config_load_json(mrk_ctx *, const char *, size_t) { return todo("mrk_config_load_json"); }
-int mrk_model_dim(mrk_ctx *, const char *) { return todo("mrk_model_dim"); }
-int mrk_store_put_double(mrk_ctx *, const char *, double) { return todo("mrk_store_put_double"); }
-int mrk_store_put_bool(mrk_ctx *, const char *, int) { return todo("mrk_store_put_bool"); }
-int mrk_store_put_string(mrk_ctx *, const char *, const char *) { return todo("mrk_store_put_string"); }
-int mrk_store_put_string_list(mrk_ctx *, const char *, const char *const *, int) { return todo("mrk_store_put_string_list"); }
-int mrk_store_put_double_list(mrk_ctx *, const char *, const double *, int) { return todo("mrk_store_put_double_list"); }
-int mrk_store_put_counter(mrk_ctx *, const char *, int64_t) { return todo("mrk_store_put_counter"); }
-int mrk_store_put_periodic(mrk_ctx *, const char *, const int64_t *, int) { return todo("mrk_store_put_periodic"); }
-int mrk_store_put_bounded_list(mrk_ctx *, const char *, const char *const *, int) { return todo("mrk_store_put_bounded_list"); }
-int mrk_store_delete(mrk_ctx *, const char *) { return todo("mrk_store_delete"); }
-int mrk_store_flush(mrk_ctx *) { return todo("mrk_store_flush"); }
-int mrk_rank(mrk_ctx *, mrk_model *, const char *, const mrk_request *, double *, int32_t *, double *) { return todo("mrk_rank"); }
-int mrk_batch_prepare(mrk_ctx *, const char *, const mrk_request *, int, mrk_batch **) { return todo("mrk_batch_prepare"); }
-int mrk_batch_total_items(mrk_batch *) { return todo("mrk_batch_total_items"); }
-int mrk_batch_run(mrk_batch *, mrk_model *) { return todo("mrk_batch_run"); }
-int mrk_batch_device_outputs(mrk_batch *, double **, int32_t **, double **) { return todo("mrk_batch_device_outputs"); }
-int mrk_batch_fetch(mrk_batch *, double *, int32_t *, double *) { return todo("mrk_batch_fetch"); }
-void mrk_batch_free(mrk_batch *) {}
+struct mrk_batch {
+  mrk_ctx *ctx = nullptr;
+  const Program *prog = nullptr;
+  int n_req = 0, total_items = 0;
+  DevBuf d_in, d_prep_out, d_arena, d_status, d_matrix, d_scores, d_order;
+  PinBuf h_in;
+  BatchDev view{};
+  std::vector<int32_t> h_status;
+  bool ran = false;
+};
+
+namespace mrk {
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// builds the device-resident batch (inputs uploaded, outputs allocated); ctx->mu must be held
+static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *reqs, int n_req, mrk_batch &b) {
+  Store &store = *ctx->store;
+  MRK_HIP(hipSetDevice(ctx->device));
+  store.flush(ctx->stream);
+  HostBatch hb;
+  resolve_requests(prog, store, reqs, n_req, hb);
+  b.ctx = ctx;
+  b.prog = &prog;
+  b.n_req = n_req;
+  b.total_items = hb.total_items;
+  const int T = hb.total_items;
+  // one staging blob for all inputs
+  size_t off = 0;
+  auto place = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t o_reqs = place(hb.reqs.size() * sizeof(ReqDev));
+  const size_t o_slot = place((size_t)T * 4);
+  const size_t o_ireq = place((size_t)T * 4);
+  const size_t o_consts = place(hb.consts.size() * 8);
+  const size_t o_irf = place(hb.irf.size() * 4);
+  const size_t o_ov = place(hb.overrides.size() * sizeof(Override));
+  const size_t o_prep = place(hb.prep_out.size() * sizeof(PrepOut));
+  const size_t total_bytes = std::max<size_t>(off, 256);
+  b.h_in.reserve(total_bytes);
+  b.d_in.reserve(total_bytes);
+  uint8_t *h = b.h_in.as<uint8_t>();
+  auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) memcpy(h + o, src, bytes); };
+  put(o_reqs, hb.reqs.data(), hb.reqs.size() * sizeof(ReqDev));
+  put(o_slot, hb.item_slot.data(), (size_t)T * 4);
+  put(o_ireq, hb.item_req.data(), (size_t)T * 4);
+  put(o_consts, hb.consts.data(), hb.consts.size() * 8);
+  put(o_irf, hb.irf.data(), hb.irf.size() * 4);
+  put(o_ov, hb.overrides.data(), hb.overrides.size() * sizeof(Override));
+  put(o_prep, hb.prep_out.data(), hb.prep_out.size() * sizeof(PrepOut));
+  MRK_HIP(hipMemcpyAsync(b.d_in.p, h, total_bytes, hipMemcpyHostToDevice, ctx->stream));
+  b.d_arena.reserve(std::max<size_t>(hb.arena_entries, 1) * 8);
+  b.d_status.reserve(std::max<size_t>(n_req, 1) * 4);
+  b.d_matrix.reserve(std::max<size_t>((size_t)T * prog.dim, 1) * 8);
+  b.d_scores.reserve(std::max<size_t>(T, 1) * 8);
+  b.d_order.reserve(std::max<size_t>(T, 1) * 4);
+  uint8_t *d = b.d_in.as<uint8_t>();
+  BatchDev &v = b.view;
+  v.reqs = (const ReqDev *)(d + o_reqs);
+  v.n_req = n_req;
+  v.total_items = T;
+  v.item_slot = (const int32_t *)(d + o_slot);
+  v.item_req = (const uint32_t *)(d + o_ireq);
+  v.consts = (const double *)(d + o_consts);
+  v.irf = (const int32_t *)(d + o_irf);
+  v.overrides = (const Override *)(d + o_ov);
+  v.n_overrides = (int)hb.overrides.size();
+  v.prep_out = (PrepOut *)(d + o_prep);
+  v.arena = (unsigned long long *)b.d_arena.p;
+  v.status = (int32_t *)b.d_status.p;
+  v.matrix = (double *)b.d_matrix.p;
+  v.scores = (double *)b.d_scores.p;
+  v.order = (int32_t *)b.d_order.p;
+  b.h_status.assign(n_req, 0);
+  b.ran = false;
 }
+
+static void check_model_fits(mrk_model *model, const Program &prog) {
+  if (!model) return;
+  if (model->refs.load() <= 0) throw StatusError(MRK_ERR_INVALID_ARG, "model is closed");
+  int used = 0;
+  for (auto &t : model->forest.trees)
+    for (auto f : t.feat) used = std::max(used, f + 1);
+  if (used > prog.dim)
+    throw StatusError(MRK_ERR_DIM_MISMATCH, "booster splits on feature " + std::to_string(used - 1) + " but model '" + prog.model +
+                                                "' has " + std::to_string(prog.dim) + " columns");
+}
+
+// enqueue the whole pipeline on the context stream; ctx->mu must be held
+static void run_batch(mrk_batch &b, mrk_model *model) {
+  mrk_ctx *ctx = b.ctx;
+  MRK_HIP(hipSetDevice(ctx->device));
+  check_model_fits(model, *b.prog);
+  const StoreDev st = ctx->store->device_view();
+  const ProgramDev pd = b.prog->device_view();
+  MRK_HIP(hipMemsetAsync(b.d_status.p, 0, std::max<size_t>(b.n_req, 1) * 4, ctx->stream));
+  launch_prepass(ctx, st, pd, b.view);
+  launch_assemble(ctx, st, pd, b.view);
+  if (model) {
+    launch_score_batch(ctx, model, b.view.matrix, b.total_items, pd.dim, b.view.scores, b.view.status, b.view.item_req);
+  } else if (b.total_items > 0) {
+    // NoopModel (ml/rank/NoopRanker.scala:22-26): every score is 0.0
+    MRK_HIP(hipMemsetAsync(b.d_scores.p, 0, (size_t)b.total_items * 8, ctx->stream));
+  }
+  launch_sort(ctx, b.view);
+  b.ran = true;
+}
+
+static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *matrix) {
+  mrk_ctx *ctx = b.ctx;
+  MRK_HIP(hipSetDevice(ctx->device));
+  const size_t T = (size_t)b.total_items;
+  if (scores && T) MRK_HIP(hipMemcpyAsync(scores, b.d_scores.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (order && T) MRK_HIP(hipMemcpyAsync(order, b.d_order.p, T * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (matrix && T && b.prog->dim) MRK_HIP(hipMemcpyAsync(matrix, b.d_matrix.p, T * b.prog->dim * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (b.n_req) MRK_HIP(hipMemcpyAsync(b.h_status.data(), b.d_status.p, (size_t)b.n_req * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MRK_HIP(hipStreamSynchronize(ctx->stream));
+  drain_profile_events(ctx);
+}
+
+}  // namespace mrk
+
+extern "C" {
+
+int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len) {
+  return guard([&] {
+    if (!ctx || !json) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "this context already has a configuration");
+    MRK_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<Store> st(new Store());
+    std::unique_ptr<Registry> reg = load_config(json, len, *st);
+    ctx->store = st.release();
+    ctx->registry = reg.release();
+  });
+}
+
+int mrk_model_dim(mrk_ctx *ctx, const char *model_name) {
+  int dim = -1;
+  int rc = guard([&] {
+    if (!ctx || !model_name) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called first");
+    const Program *p = ctx->registry->program(model_name);
+    if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
+    dim = p->dim;
+  });
+  return rc == MRK_OK ? dim : rc;
+}
+
+#define STORE_PUT(call)                                   \
+  return guard([&] {                                      \
+    if (!key) throw StatusError(MRK_ERR_INVALID_ARG, "null key"); \
+    Store &st = store_of(ctx);                            \
+    std::lock_guard<std::mutex> lk(ctx->mu);              \
+    (void)st.call;                                        \
+  })
+
+int mrk_store_put_double(mrk_ctx *ctx, const char *key, double v) { STORE_PUT(put_double(key, v)); }
+int mrk_store_put_bool(mrk_ctx *ctx, const char *key, int v) { STORE_PUT(put_bool(key, v != 0)); }
+int mrk_store_put_string(mrk_ctx *ctx, const char *key, const char *v) { STORE_PUT(put_string(key, v)); }
+int mrk_store_put_string_list(mrk_ctx *ctx, const char *key, const char *const *v, int n) { STORE_PUT(put_string_list(key, v, n)); }
+int mrk_store_put_double_list(mrk_ctx *ctx, const char *key, const double *v, int n) { STORE_PUT(put_double_list(key, v, n)); }
+int mrk_store_put_counter(mrk_ctx *ctx, const char *key, int64_t v) { STORE_PUT(put_counter(key, v)); }
+int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *v, int n) { STORE_PUT(put_periodic(key, v, n)); }
+int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *v, int n) { STORE_PUT(put_bounded_list(key, v, n)); }
+int mrk_store_delete(mrk_ctx *ctx, const char *key) { STORE_PUT(erase(key)); }
+
+int mrk_store_flush(mrk_ctx *ctx) {
+  return guard([&] {
+    Store &st = store_of(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MRK_HIP(hipSetDevice(ctx->device));
+    st.flush(ctx->stream);
+  });
+}
+
+static const Program &program_of(mrk_ctx *ctx, const char *model_name) {
+  if (!ctx || !model_name) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+  if (!ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called first");
+  const Program *p = ctx->registry->program(model_name);
+  if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
+  return *p;
+}
+
+int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
+             int32_t *out_order, double *out_matrix) {
+  return guard([&] {
+    if (!req) throw StatusError(MRK_ERR_INVALID_ARG, "null request");
+    if (!ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
+    if (model && model->ctx != ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const Program &prog = program_of(ctx, model_name);
+    mrk_batch b;
+    build_batch(ctx, prog, req, 1, b);
+    run_batch(b, model);
+    fetch_batch(b, out_scores, out_order, out_matrix);
+    std::string msg;
+    int code = status_to_code(b.h_status[0], msg);
+    if (code != MRK_OK) throw StatusError(code, msg);
+  });
+}
+
+int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req, mrk_batch **out) {
+  return guard([&] {
+    if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!ctx || n_req < 0 || (n_req > 0 && !reqs)) throw StatusError(MRK_ERR_INVALID_ARG, "bad arguments");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const Program &prog = program_of(ctx, model_name);
+    std::unique_ptr<mrk_batch> b(new mrk_batch());
+    build_batch(ctx, prog, reqs, n_req, *b);
+    MRK_HIP(hipStreamSynchronize(ctx->stream));
+    *out = b.release();
+  });
+}
+
+int mrk_batch_total_items(mrk_batch *batch) { return batch ? batch->total_items : MRK_ERR_INVALID_ARG; }
+
+int mrk_batch_run(mrk_batch *batch, mrk_model *model) {
+  return guard([&] {
+    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    if (model && model->ctx != batch->ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
+    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    run_batch(*batch, model);
+  });
+}
+
+int mrk_batch_device_outputs(mrk_batch *batch, double **d_scores, int32_t **d_order, double **d_matrix) {
+  return guard([&] {
+    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    if (d_scores) *d_scores = batch->view.scores;
+    if (d_order) *d_order = batch->view.order;
+    if (d_matrix) *d_matrix = batch->view.matrix;
+  });
+}
+
+int mrk_batch_fetch(mrk_batch *batch, double *out_scores, int32_t *out_order, double *out_matrix) {
+  return guard([&] {
+    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    fetch_batch(*batch, out_scores, out_order, out_matrix);
+  });
+}
+
+int mrk_batch_status(mrk_batch *batch, int32_t *out_status) {
+  return guard([&] {
+    if (!batch || !out_status) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    fetch_batch(*batch, nullptr, nullptr, nullptr);
+    for (int r = 0; r < batch->n_req; ++r) {
+      std::string msg;
+      out_status[r] = status_to_code(batch->h_status[r], msg);
+    }
+  });
+}
+
+void mrk_batch_free(mrk_batch *batch) {
+  if (!batch) return;
+  mrk_ctx *ctx = batch->ctx;
+  if (ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete batch;
+  } else {
+    delete batch;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,846 @@
+// Feature registry + host half of a request.  See features.hpp.
+#include "features.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <set>
+
+#include "json.hpp"
+
+namespace mrk {
+
+namespace {
+
+[[noreturn]] void bad(const std::string &msg) { throw StatusError(MRK_ERR_PARSE, msg); }
+
+const double kNaN = std::numeric_limits<double>::quiet_NaN();
+
+// ---- FieldName (model/FieldName.scala:38-58) and ScopeType (model/ScopeType.scala:99-110) decoders
+struct FieldName {
+  std::string event;  // item | user | ranking | * | interaction:<type>
+  std::string field;
+};
+
+bool is_ident(const std::string &s, bool dash) {
+  if (s.empty()) return false;
+  for (char c : s)
+    if (!(isalnum((unsigned char)c) || c == '_' || (dash && c == '-'))) return false;
+  return true;
+}
+
+FieldName parse_field_name(const std::string &s) {
+  size_t dot = s.rfind('.');
+  if (dot == std::string::npos || dot == 0) bad("cannot decode source field '" + s + "': it should have a format of <type>.<name>, like item.title, but the delimiter was not found.");
+  std::string src = s.substr(0, dot), field = s.substr(dot + 1);
+  if (!is_ident(field, false)) bad("cannot decode source field '" + s + "'");
+  FieldName out;
+  out.field = field;
+  if (src.rfind("interaction:", 0) == 0 && is_ident(src.substr(12), false)) out.event = src;
+  else if (src == "metadata" || src == "item") out.event = "item";
+  else if (src == "user" || src == "ranking" || src == "*") out.event = src;
+  else bad("cannot decode source field " + src);
+  return out;
+}
+
+void parse_scope(const std::string &s, ScopeId &scope, std::string &field) {
+  field.clear();
+  if (s == "global") scope = SC_GLOBAL;
+  else if (s == "item") scope = SC_ITEM;
+  else if (s == "user") scope = SC_USER;
+  else if (s == "session") scope = SC_SESSION;
+  else if (s == "ranking") scope = SC_RANKING;
+  else if (s.rfind("item.", 0) == 0 && is_ident(s.substr(5), true)) { scope = SC_FIELD; field = s.substr(5); }
+  else if (s.rfind("ranking.", 0) == 0 && is_ident(s.substr(8), true)) { scope = SC_IRF; field = s.substr(8); }
+  else bad("scope type " + s + " not supported");
+}
+
+const json::Value &need(const json::Value &o, const char *key, const std::string &fname) {
+  const json::Value *v = o.find(key);
+  if (!v || v->is_null()) bad("feature '" + fname + "': missing '" + key + "'");
+  return *v;
+}
+
+std::string source_field(const json::Value &o, const std::string &fname, const char *k1, const char *k2, bool &is_ranking,
+                         std::string *event_out = nullptr) {
+  const json::Value *v = o.find(k1);
+  if ((!v || v->is_null()) && k2) v = o.find(k2);
+  if (!v || v->is_null()) bad("feature '" + fname + "': missing source field");
+  FieldName fn = parse_field_name(v->as_string());
+  is_ranking = fn.event == "ranking";
+  if (event_out) *event_out = fn.event;
+  return fn.field;
+}
+
+int vector_dim(const json::Value *reduce) {
+  if (!reduce || reduce->is_null()) return 4;  // [min, max, size, avg] (NumVectorFeature.scala:28)
+  int d = 0;
+  for (auto &r : reduce->arr) {
+    const std::string &s = r.as_string();
+    static const char *one[] = {"first", "last", "min", "max", "avg", "random", "sum", "size", "euclidean_distance"};
+    bool ok = false;
+    for (auto o : one) ok = ok || s == o;
+    if (ok) { d += 1; continue; }
+    if (s.rfind("vector", 0) == 0 && s.size() > 6 && std::all_of(s.begin() + 6, s.end(), ::isdigit)) { d += atoi(s.c_str() + 6); continue; }
+    bad("reducer " + s + " is not supported");
+  }
+  return d;
+}
+
+std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
+  std::unique_ptr<FeatureDef> f(new FeatureDef());
+  const std::string type = o.at("type").as_string();
+  f->name = o.at("name").as_string();
+  const std::string &nm = f->name;
+  auto scope_required = [&]() { parse_scope(need(o, "scope", nm).as_string(), f->scope, f->scope_field); };
+  auto plain_scope = [&]() {
+    scope_required();
+    if (f->scope == SC_FIELD || f->scope == SC_IRF) {
+      // readKey gives None for field scopes (BaseFeature.scala:33-34): such a feature is always missing;
+      // keep it working by pointing at a scope that never resolves
+    }
+  };
+  if (type == "number") {
+    f->type = FType::Number;
+    f->field = source_field(o, nm, "source", "field", f->field_is_ranking);
+    plain_scope();
+  } else if (type == "boolean") {
+    f->type = FType::Boolean;
+    f->field = source_field(o, nm, "field", "source", f->field_is_ranking);
+    plain_scope();
+  } else if (type == "word_count") {
+    f->type = FType::WordCount;
+    f->field = source_field(o, nm, "source", nullptr, f->field_is_ranking);
+    plain_scope();
+  } else if (type == "vector") {
+    f->type = FType::Vector;
+    f->field = source_field(o, nm, "source", nullptr, f->field_is_ranking);
+    plain_scope();
+    f->dim = vector_dim(o.find("reduce"));
+  } else if (type == "string") {
+    f->type = FType::String;
+    f->field = source_field(o, nm, "source", "field", f->field_is_ranking);
+    plain_scope();
+    for (auto &v : need(o, "values", nm).arr) f->values.push_back(v.as_string());
+    if (f->values.empty()) bad("feature '" + nm + "': values must not be empty");
+    const json::Value *enc = o.find("encode");
+    if (enc && !enc->is_null()) {
+      if (enc->as_string() == "index") f->index_encode = true;
+      else if (enc->as_string() != "onehot") bad("string encoding method " + enc->as_string() + " is not supported");
+    }
+    f->dim = f->index_encode ? 1 : (int)f->values.size();
+  } else if (type == "interaction_count") {
+    f->type = FType::InteractionCount;
+    plain_scope();
+  } else if (type == "window_count") {
+    f->type = FType::WindowCount;
+    plain_scope();
+    f->dim = (int)need(o, "periods", nm).arr.size();
+  } else if (type == "rate") {
+    f->type = FType::Rate;
+    const json::Value *sc = o.find("scope");
+    if (sc && !sc->is_null()) {
+      parse_scope(sc->as_string(), f->scope, f->scope_field);
+      if (f->scope != SC_ITEM && f->scope != SC_FIELD && f->scope != SC_IRF)
+        bad("scope " + sc->as_string() + " is not supported for rate feature " + nm);
+    }
+    f->top = need(o, "top", nm).as_string();
+    f->bottom = need(o, "bottom", nm).as_string();
+    f->dim = (int)need(o, "periods", nm).arr.size();
+    const json::Value *norm = o.find("normalize");
+    if (norm && !norm->is_null()) {
+      f->normalize = true;
+      f->weight = norm->at("weight").as_double();
+    }
+  } else if (type == "interacted_with") {
+    f->type = FType::InteractedWith;
+    scope_required();
+    if (f->scope != SC_SESSION && f->scope != SC_USER) bad("feature '" + nm + "': can only be scoped to user/session");
+    const json::Value &fl = need(o, "field", nm);
+    std::vector<std::string> fields;
+    if (fl.is_string()) fields.push_back(fl.as_string());
+    else for (auto &v : fl.arr) fields.push_back(v.as_string());
+    std::set<std::string> seen;
+    for (auto &s : fields) {
+      FieldName fn = parse_field_name(s);
+      if (fn.event != "item") bad("feature '" + nm + "': can only be applied to item fields");
+      if (!seen.insert(fn.field).second) bad("feature '" + nm + "': field '" + fn.field + "' is listed twice (dim mismatch in the reference)");
+      f->values.push_back(fn.field);
+    }
+    // the reference keeps the fields in a Scala immutable Map: insertion order up to 4 entries, hash
+    // order beyond (InteractedWithFeature.scala:56-65,152-162) — the host must pass that order
+    if (const json::Value *ord = o.find("field_order")) {
+      std::vector<std::string> order;
+      for (auto &v : ord->arr) order.push_back(v.as_string());
+      std::vector<std::string> a = order, b2 = f->values;
+      std::sort(a.begin(), a.end());
+      std::sort(b2.begin(), b2.end());
+      if (a != b2) bad("feature '" + nm + "': field_order must be a permutation of the fields");
+      f->values = order;
+    } else if (f->values.size() > 4) {
+      throw StatusError(MRK_ERR_UNSUPPORTED, "feature '" + nm + "': more than 4 fields need an explicit \"field_order\" (the JVM's Map iteration order)");
+    }
+    f->dim = (int)f->values.size();
+  } else if (type == "diversity") {
+    f->type = FType::Diversity;
+    std::string ev;
+    f->field = source_field(o, nm, "source", nullptr, f->field_is_ranking, &ev);
+    if (ev != "item") bad("diversity feature '" + nm + "' can only accept item fields, but got '" + ev + "'");
+    const json::Value *top = o.find("top");
+    f->div_top = (top && !top->is_null()) ? (int)top->as_int() : 20;  // DiversityFeature.scala:164
+    if (f->div_top < 0) f->div_top = 0;
+  } else if (type == "item_age") {
+    f->type = FType::ItemAge;
+    std::string ev;
+    f->field = source_field(o, nm, "source", nullptr, f->field_is_ranking, &ev);
+    if (ev != "item") bad("feature '" + nm + "': can only work with fields from metadata events");
+  } else if (type == "local_time") {
+    f->type = FType::LocalTime;
+    f->field = source_field(o, nm, "source", nullptr, f->field_is_ranking);
+    if (!f->field_is_ranking) bad("feature '" + nm + "': can only work with ranking event fields");
+    const std::string p = need(o, "parse", nm).as_string();
+    static const char *names[] = {"time_of_day", "day_of_week", "month_of_year", "year", "second"};
+    f->mapper = -1;
+    for (int i = 0; i < 5; ++i) if (p == names[i]) f->mapper = i;
+    if (f->mapper < 0) bad("parsing method " + p + " is not supported");
+  } else if (type == "position") {
+    f->type = FType::Position;
+    f->position = (double)need(o, "position", nm).as_int();
+  } else if (type == "relevancy") {
+    f->type = FType::Relevancy;
+  } else if (type == "field_match" && o.find("method") && o.at("method").find("type") &&
+             o.at("method").at("type").as_string() == "bi-encoder") {
+    f->type = FType::Biencoder;
+    f->ext_field = "__embedding:" + nm;
+    const json::Value *d = o.at("method").find("dim");
+    if (!d || d->is_null()) bad("feature '" + nm + "': method.dim (embedding size) is required");
+    f->qdim = (int)d->as_int();
+    if (const json::Value *n = o.find("norm")) {
+      if (!n->is_null()) {
+        const std::string &s = n->as_string();
+        if (s == "noop") f->norm = NORM_NOOP;
+        else if (s == "linear") f->norm = NORM_MINMAX;
+        else if (s == "position") f->norm = NORM_POSITION;
+        else bad("normalizer " + s + " is not supported");
+      }
+    }
+    if (const json::Value *dist = o.find("distance"))
+      if (!dist->is_null()) {
+        const std::string &s = dist->as_string();
+        if (!(s == "cos" || s == "Cos" || s == "cosine" || s == "Cosine")) throw StatusError(MRK_ERR_UNSUPPORTED, "distance '" + s + "' is not supported");
+      }
+  } else if (type == "ua" || type == "referer") {
+    // request-level one-hot columns that need JVM-only parsers (uap-java / referer lists): the
+    // host computes them and sends them as NumberListField "__ext:<name>"
+    f->type = FType::ExternalRanking;
+    f->ext_field = "__ext:" + nm;
+    f->dim = (int)need(o, "dim", nm).as_int();
+  } else if (type == "field_match" || type == "random") {
+    // Lucene analyzers / ONNX cross-encoder / RNG stay on the JVM: per-item values arrive as
+    // item field "__ext:<name>"
+    f->type = FType::ExternalItem;
+    f->ext_field = "__ext:" + nm;
+    const json::Value *d = o.find("dim");
+    f->dim = (d && !d->is_null()) ? (int)d->as_int() : 1;
+  } else {
+    bad("feature type " + type + " is not supported");
+  }
+  if (f->dim < 1) bad("feature '" + nm + "': dimension must be positive");
+  return f;
+}
+
+ColRef col_ref(const Store &st, ScopeId scope, const std::string &name) {
+  const Table &t = st.tables[scope];
+  auto it = t.col_of.find(name);
+  if (it == t.col_of.end()) return ColRef{-1, 0};
+  return ColRef{t.cols[it->second].tag_index, t.cols[it->second].val_off};
+}
+
+ScopeId plain_table(const FeatureDef &f) {
+  // features read through BaseFeature.readKey: field scopes resolve to None => never present
+  return (f.scope == SC_FIELD || f.scope == SC_IRF) ? SC_COUNT : f.scope;
+}
+
+void declare_columns(const FeatureDef &f, Store &st) {
+  const ScopeId t = plain_table(f);
+  switch (f.type) {
+    case FType::Number: case FType::WordCount:
+      if (f.scope != SC_RANKING || f.type == FType::Number) { if (t != SC_COUNT) st.add_column(t, f.name, COL_SCALAR, 0); }
+      break;
+    case FType::Boolean: case FType::Vector: case FType::String:
+      if (t != SC_COUNT) st.add_column(t, f.name, COL_SCALAR, 0);
+      break;
+    case FType::InteractionCount:
+      if (t != SC_COUNT) st.add_column(t, f.name, COL_COUNTER, 0);
+      break;
+    case FType::WindowCount:
+      if (t != SC_COUNT) st.add_column(t, f.name, COL_PERIODIC, f.dim);
+      break;
+    case FType::Rate: {
+      const std::string top = f.name + "_" + f.top, bot = f.name + "_" + f.bottom;
+      ScopeId target = f.scope == SC_ITEM ? SC_ITEM : (f.scope == SC_FIELD ? SC_FIELD : SC_IRF);
+      st.add_column(target, top, COL_PERIODIC, f.dim);
+      st.add_column(target, bot, COL_PERIODIC, f.dim);
+      st.add_column(SC_GLOBAL, top + "_norm", COL_PERIODIC, f.dim);
+      st.add_column(SC_GLOBAL, bot + "_norm", COL_PERIODIC, f.dim);
+      if (f.scope == SC_FIELD) st.add_column(SC_ITEM, f.name + "_field", COL_SCALAR, 0, f.scope_field);
+      break;
+    }
+    case FType::InteractedWith:
+      st.add_column(f.scope, f.name + "_interactions", COL_BOUNDED_LIST, 0);
+      for (auto &fld : f.values) st.add_column(SC_ITEM, f.name + "_" + fld, COL_SCALAR, 0);
+      break;
+    case FType::Diversity: case FType::ItemAge: case FType::Biencoder:
+      st.add_column(SC_ITEM, f.name, COL_SCALAR, 0);
+      break;
+    default: break;
+  }
+}
+
+void build_program(Program &p, const std::vector<const FeatureDef *> &feats, const Store &st) {
+  int dst = 0;
+  for (const FeatureDef *f : feats) {
+    Op op{};
+    HostOp ho;
+    ho.def = f;
+    ho.dst = dst;
+    op.dst = dst;
+    op.dim = f->dim;
+    op.scope = f->scope;
+    op.c0 = op.c1 = op.c2 = op.c3 = op.c4 = op.c5 = ColRef{-1, 0};
+    auto as_const = [&](int n) {
+      op.kind = OP_CONST;
+      ho.const_idx = p.n_consts;
+      op.i0 = p.n_consts;
+      p.n_consts += n;
+    };
+    const ScopeId t = plain_table(*f);
+    auto scoped_col = [&]() {
+      if (t == SC_COUNT) { op.scope = SC_ITEM; op.c0 = ColRef{-1, 0}; }  // never resolves
+      else { op.scope = t; op.c0 = col_ref(st, t, f->name); }
+    };
+    switch (f->type) {
+      case FType::Number:
+        if (f->scope == SC_RANKING) as_const(1);
+        else { op.kind = OP_SCALAR_DOUBLE; scoped_col(); }
+        break;
+      case FType::WordCount:
+        if (f->scope == SC_RANKING) as_const(1);
+        else { op.kind = OP_SCALAR_DOUBLE; scoped_col(); }
+        break;
+      case FType::Boolean: op.kind = OP_SCALAR_BOOL; scoped_col(); break;
+      case FType::Vector: op.kind = OP_VECTOR; scoped_col(); break;
+      case FType::String:
+        if (f->field_is_ranking) { as_const(f->dim); break; }
+        op.kind = f->index_encode ? OP_STRING_INDEX : OP_STRING_ONEHOT;
+        scoped_col();
+        op.i0 = (int)p.aux.size();
+        op.i1 = (int)f->values.size();
+        for (auto &v : f->values) p.aux.push_back(const_cast<Store &>(st).intern(v));
+        break;
+      case FType::InteractionCount: op.kind = OP_COUNTER; scoped_col(); break;
+      case FType::WindowCount: op.kind = OP_WINDOW; scoped_col(); break;
+      case FType::Rate: {
+        op.kind = OP_RATE;
+        const std::string top = f->name + "_" + f->top, bot = f->name + "_" + f->bottom;
+        op.c2 = col_ref(st, SC_GLOBAL, top + "_norm");
+        op.c3 = col_ref(st, SC_GLOBAL, bot + "_norm");
+        op.i3 = f->normalize ? 1 : 0;
+        op.d0 = f->weight;
+        if (f->scope == SC_ITEM) {
+          op.i0 = RATE_ITEM;
+          op.c0 = col_ref(st, SC_ITEM, top);
+          op.c1 = col_ref(st, SC_ITEM, bot);
+        } else if (f->scope == SC_FIELD) {
+          op.i0 = RATE_ITEM_FIELD;
+          op.c0 = col_ref(st, SC_ITEM, f->name + "_field");
+          op.c4 = col_ref(st, SC_FIELD, top);
+          op.c5 = col_ref(st, SC_FIELD, bot);
+        } else {
+          op.i0 = RATE_RANKING_FIELD;
+          op.c4 = col_ref(st, SC_IRF, top);
+          op.c5 = col_ref(st, SC_IRF, bot);
+          ho.irf_id = p.n_irf;
+          op.i2 = p.n_irf++;
+        }
+        break;
+      }
+      case FType::InteractedWith: {
+        op.kind = OP_INTERACTED;
+        op.i0 = (int)p.aux.size();
+        op.i1 = (int)p.prep.size();
+        ho.prep_base = op.i1;
+        for (auto &fld : f->values) {
+          ColRef c = col_ref(st, SC_ITEM, f->name + "_" + fld);
+          p.aux.push_back((uint32_t)c.tag);
+          p.aux.push_back((uint32_t)c.val);
+          PrepEntry pe{};
+          pe.kind = PREP_IW_FIELD;
+          pe.item_col = c;
+          pe.list_scope = f->scope;
+          pe.list_col = col_ref(st, f->scope, f->name + "_interactions");
+          p.prep.push_back(pe);
+        }
+        break;
+      }
+      case FType::Diversity: {
+        op.kind = OP_DIVERSITY;
+        op.scope = SC_ITEM;
+        op.c0 = col_ref(st, SC_ITEM, f->name);
+        op.i1 = (int)p.prep.size();
+        ho.prep_base = op.i1;
+        PrepEntry pe{};
+        pe.kind = PREP_DIVERSITY;
+        pe.item_col = op.c0;
+        pe.top = f->div_top;
+        p.prep.push_back(pe);
+        break;
+      }
+      case FType::ItemAge:
+        op.kind = OP_ITEM_AGE;
+        op.scope = SC_ITEM;
+        op.c0 = col_ref(st, SC_ITEM, f->name);
+        break;
+      case FType::LocalTime: case FType::Position: as_const(1); break;
+      case FType::ExternalRanking: as_const(f->dim); break;
+      case FType::Relevancy: case FType::ExternalItem: op.kind = OP_FILL_NAN; break;
+      case FType::Biencoder:
+        if (f->norm != NORM_NOOP) throw StatusError(MRK_ERR_UNSUPPORTED, "feature '" + f->name + "': norm other than noop is not implemented on the device yet");
+        op.kind = OP_BIENCODER;
+        op.scope = SC_ITEM;
+        op.c0 = col_ref(st, SC_ITEM, f->name);
+        ho.const_idx = p.n_consts;
+        op.i0 = p.n_consts;
+        p.n_consts += 1 + f->qdim;
+        break;
+    }
+    dst += f->dim;
+    p.ops.push_back(op);
+    p.host_ops.push_back(ho);
+  }
+  p.dim = dst;
+}
+
+void upload(Program &p) {
+  auto up = [](DevBuf &b, const void *src, size_t bytes) {
+    b.reserve(bytes ? bytes : 16);
+    if (bytes) MRK_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  };
+  up(p.d_ops, p.ops.data(), p.ops.size() * sizeof(Op));
+  up(p.d_prep, p.prep.data(), p.prep.size() * sizeof(PrepEntry));
+  up(p.d_aux, p.aux.data(), p.aux.size() * sizeof(uint32_t));
+}
+
+}  // namespace
+
+ProgramDev Program::device_view() const {
+  ProgramDev d{};
+  d.ops = (const Op *)d_ops.p;
+  d.n_ops = (int)ops.size();
+  d.prep = (const PrepEntry *)d_prep.p;
+  d.n_prep = (int)prep.size();
+  d.aux = (const uint32_t *)d_aux.p;
+  d.dim = dim;
+  d.n_consts = n_consts;
+  return d;
+}
+
+const Program *Registry::program(const std::string &model) const {
+  auto it = programs.find(model);
+  return it == programs.end() ? nullptr : it->second.get();
+}
+
+std::unique_ptr<Registry> load_config(const char *json_text, size_t len, Store &store) {
+  json::Value root = json::parse(json_text, len);
+  std::unique_ptr<Registry> reg(new Registry());
+  const json::Value *feats = root.find("features");
+  if (!feats || !feats->is_array()) bad("config: 'features' must be a list");
+  std::set<std::string> names;
+  for (auto &fo : feats->arr) {
+    auto f = parse_feature(fo);
+    if (!names.insert(f->name).second) bad("config: feature '" + f->name + "' is defined twice");
+    reg->features.push_back(std::move(f));
+  }
+  for (auto &f : reg->features) declare_columns(*f, store);
+  store.freeze_layout();
+  const json::Value *models = root.find("models");
+  if (models && models->is_object()) {
+    for (auto &kv : models->obj) {
+      const json::Value *tp = kv.second.find("type");
+      if (!tp || tp->as_string() != "lambdamart") continue;
+      std::unique_ptr<Program> p(new Program());
+      p->model = kv.first;
+      std::vector<const FeatureDef *> ordered;
+      for (auto &fn : kv.second.at("features").arr) {
+        p->feature_names.push_back(fn.as_string());
+        // FeatureMapping.scala:66-71: names without a definition are silently dropped
+        for (auto &f : reg->features)
+          if (f->name == fn.as_string()) { ordered.push_back(f.get()); break; }
+      }
+      build_program(*p, ordered, store);
+      upload(*p);
+      reg->programs[kv.first] = std::move(p);
+    }
+  }
+  return reg;
+}
+
+// =====================================================================================================
+// host half of a request
+
+namespace {
+
+const mrk_field *fields_map_get(const mrk_request &r, const std::string &name) {  // fieldsMap: last wins
+  const mrk_field *hit = nullptr;
+  for (int i = 0; i < r.n_fields; ++i)
+    if (r.fields[i].name && name == r.fields[i].name) hit = &r.fields[i];
+  return hit;
+}
+const mrk_field *fields_find(const mrk_request &r, const std::string &name) {  // List.find: first wins
+  for (int i = 0; i < r.n_fields; ++i)
+    if (r.fields[i].name && name == r.fields[i].name) return &r.fields[i];
+  return nullptr;
+}
+
+// "\\s+".r.split(s).length (WordCountFeature.scala:73-76), java.util.regex.Pattern.split semantics
+int token_count(const char *s) {
+  auto ws = [](unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); };
+  const size_t n = strlen(s);
+  if (n == 0) return 1;
+  int pieces = 0, last_nonempty = 0;
+  size_t i = 0;
+  bool matched = false;
+  size_t start = 0;
+  while (i < n) {
+    if (ws((unsigned char)s[i])) {
+      size_t j = i;
+      while (j < n && ws((unsigned char)s[j])) ++j;
+      matched = true;
+      ++pieces;
+      if (i > start) last_nonempty = pieces;
+      start = j;
+      i = j;
+    } else {
+      ++i;
+    }
+  }
+  if (!matched) return 1;
+  ++pieces;
+  if (n > start) last_nonempty = pieces;
+  return last_nonempty;  // trailing empty pieces are dropped
+}
+
+void encode_string(const FeatureDef &f, const char *const *vals, int n, double *out) {
+  if (f.index_encode) {
+    double idx = 0;
+    if (n > 0)
+      for (size_t k = 0; k < f.values.size(); ++k)
+        if (f.values[k] == vals[0]) idx = (double)(k + 1);
+    out[0] = idx;
+  } else {
+    for (int k = 0; k < f.dim; ++k) out[k] = 0.0;
+    for (int j = 0; j < n; ++j)
+      for (size_t k = 0; k < f.values.size(); ++k)
+        if (f.values[k] == vals[j]) { out[k] = 1.0; break; }
+  }
+}
+
+// ---- java.time pieces of LocalDateTimeFeature.scala:31-93
+int64_t fdiv(int64_t a, int64_t b) { int64_t q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; }
+
+struct Civil { int64_t year; int month; int dow; int64_t sod; int64_t epoch; };
+
+Civil civil_of(int64_t epoch_second, int64_t offset) {
+  const int64_t local = epoch_second + offset;
+  const int64_t day = fdiv(local, 86400);
+  Civil c;
+  c.sod = local - day * 86400;
+  c.epoch = epoch_second;
+  c.dow = (int)(((day % 7) + 7 + 3) % 7) + 1;  // 1970-01-01 = Thursday
+  // Howard Hinnant's days -> civil
+  int64_t z = day + 719468;
+  const int64_t era = fdiv(z, 146097);
+  const uint64_t doe = (uint64_t)(z - era * 146097);
+  const uint64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const uint64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const uint64_t mp = (5 * doy + 2) / 153;
+  c.month = (int)(mp < 10 ? mp + 3 : mp - 9);
+  c.year = (int64_t)yoe + era * 400 + (c.month <= 2 ? 1 : 0);
+  return c;
+}
+
+bool two_digits(const char *&p, int &out) {
+  if (!isdigit((unsigned char)p[0]) || !isdigit((unsigned char)p[1])) return false;
+  out = (p[0] - '0') * 10 + (p[1] - '0');
+  p += 2;
+  return true;
+}
+
+// ZonedDateTime.parse(_, ISO_DATE_TIME) for offset forms; region ids need tzdata and are rejected
+bool parse_iso_datetime(const char *s, Civil &out) {
+  const char *p = s;
+  bool neg = false;
+  if (*p == '-' || *p == '+') { neg = *p == '-'; ++p; }
+  int64_t year = 0;
+  int nd = 0;
+  while (isdigit((unsigned char)*p)) { year = year * 10 + (*p - '0'); ++p; ++nd; }
+  if (nd < 4) return false;
+  if (neg) year = -year;
+  int mo, d, h, mi, sec = 0;
+  if (*p++ != '-' || !two_digits(p, mo) || *p++ != '-' || !two_digits(p, d)) return false;
+  if (*p++ != 'T' || !two_digits(p, h) || *p++ != ':' || !two_digits(p, mi)) return false;
+  if (*p == ':') { ++p; if (!two_digits(p, sec)) return false; }
+  if (*p == '.') { ++p; if (!isdigit((unsigned char)*p)) return false; while (isdigit((unsigned char)*p)) ++p; }
+  int64_t off = 0;
+  if (*p == 'Z') { ++p; }
+  else if (*p == '+' || *p == '-') {
+    const int sign = *p == '-' ? -1 : 1;
+    ++p;
+    int oh, om = 0, os = 0;
+    if (!two_digits(p, oh)) return false;
+    if (*p == ':') { ++p; if (!two_digits(p, om)) return false; if (*p == ':') { ++p; if (!two_digits(p, os)) return false; } }
+    off = sign * (oh * 3600 + om * 60 + os);
+  } else return false;
+  if (*p != 0) return false;
+  if (mo < 1 || mo > 12 || d < 1 || d > 31 || h > 23 || mi > 59 || sec > 59) return false;
+  // civil -> days
+  int64_t y = year - (mo <= 2);
+  const int64_t era = fdiv(y, 400);
+  const uint64_t yoe = (uint64_t)(y - era * 400);
+  const uint64_t doy = (153 * (uint64_t)(mo > 2 ? mo - 3 : mo + 9) + 2) / 5 + (uint64_t)d - 1;
+  const uint64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  const int64_t days = era * 146097 + (int64_t)doe - 719468;
+  const int64_t local = days * 86400 + h * 3600 + mi * 60 + sec;
+  out = civil_of(local - off, off);
+  return true;
+}
+
+double map_datetime(int mapper, const Civil &c) {
+  switch (mapper) {
+    case 0: return (double)c.sod / 3600.0;
+    case 1: return (double)c.dow;
+    case 2: return (double)c.month;
+    case 3: return (double)c.year;
+    default: return (double)c.epoch;
+  }
+}
+
+uint32_t pow2_at_least(uint64_t n) {
+  uint32_t c = 1;
+  while (c < n) c <<= 1;
+  return c;
+}
+
+struct HostCell { uint8_t tag; uint64_t bits; };
+HostCell host_cell(const Store &st, ScopeId scope, int32_t slot, ColRef c) {
+  if (slot < 0 || c.tag < 0) return {TAG_MISSING, 0};
+  const uint8_t *rec = st.record(scope, (uint32_t)slot);
+  HostCell h;
+  h.tag = rec[c.tag];
+  memcpy(&h.bits, rec + c.val, 8);
+  return h;
+}
+
+}  // namespace
+
+void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs, int n_req, HostBatch &hb) {
+  hb = HostBatch();
+  int total = 0;
+  for (int r = 0; r < n_req; ++r) {
+    if (reqs[r].n_items < 0 || (reqs[r].n_items > 0 && !reqs[r].item_ids)) throw StatusError(MRK_ERR_INVALID_ARG, "bad item list");
+    if (reqs[r].n_items > SORT_MAX_ITEMS)
+      throw StatusError(MRK_ERR_UNSUPPORTED, "requests with more than " + std::to_string(SORT_MAX_ITEMS) + " items are not supported yet");
+    total += reqs[r].n_items;
+  }
+  hb.total_items = total;
+  hb.reqs.resize(n_req);
+  hb.item_slot.resize(total);
+  hb.item_req.resize(total);
+  hb.consts.assign((size_t)n_req * prog.n_consts, kNaN);
+  hb.irf.assign((size_t)prog.n_irf * total, -1);
+  hb.prep_out.assign((size_t)n_req * prog.prep.size(), PrepOut{0, 0, 0.0, 0, 0});
+  uint64_t arena = 0;
+  int begin = 0;
+  std::vector<double> enc;
+  for (int r = 0; r < n_req; ++r) {
+    const mrk_request &rq = reqs[r];
+    ReqDev &rd = hb.reqs[r];
+    rd.item_begin = begin;
+    rd.n_items = rq.n_items;
+    auto slot_or = [&](ScopeId sc, const char *id) -> int32_t {
+      if (!id) return -1;
+      uint32_t s = store.slot(sc, id, false);
+      return s == Store::NO_SLOT ? -1 : (int32_t)s;
+    };
+    rd.user_slot = slot_or(SC_USER, rq.user);
+    rd.session_slot = slot_or(SC_SESSION, rq.session);
+    rd.ranking_slot = slot_or(SC_RANKING, rq.id ? rq.id : "");
+    rd.pad = 0;
+    rd.ts_ms = rq.timestamp_ms;
+    for (int i = 0; i < rq.n_items; ++i) {
+      hb.item_slot[begin + i] = slot_or(SC_ITEM, rq.item_ids[i] ? rq.item_ids[i] : "");
+      hb.item_req[begin + i] = (uint32_t)r;
+    }
+    double *cs = prog.n_consts ? &hb.consts[(size_t)r * prog.n_consts] : nullptr;
+    for (const HostOp &ho : prog.host_ops) {
+      const FeatureDef &f = *ho.def;
+      switch (f.type) {
+        case FType::Number:
+          if (f.scope == SC_RANKING) {  // NumberFeature.scala:77-82
+            const mrk_field *fl = fields_map_get(rq, f.field);
+            cs[ho.const_idx] = (fl && fl->type == MRK_FIELD_NUMBER) ? fl->num : kNaN;
+          }
+          break;
+        case FType::WordCount:
+          if (f.scope == SC_RANKING) {  // WordCountFeature.scala:58-63
+            const mrk_field *fl = fields_map_get(rq, f.field);
+            cs[ho.const_idx] = (fl && fl->type == MRK_FIELD_STRING && fl->str) ? (double)token_count(fl->str) : kNaN;
+          }
+          break;
+        case FType::String:
+          if (f.field_is_ranking) {  // StringFeature.scala:87-93
+            const mrk_field *fl = fields_find(rq, f.field);
+            if (fl && fl->type == MRK_FIELD_STRING && fl->str) { const char *one[1] = {fl->str}; encode_string(f, one, 1, cs + ho.const_idx); }
+            else if (fl && fl->type == MRK_FIELD_STRING_LIST) encode_string(f, fl->strs, fl->n, cs + ho.const_idx);
+            else encode_string(f, nullptr, 0, cs + ho.const_idx);
+          }
+          break;
+        case FType::LocalTime: {
+          double v = kNaN;
+          if (f.field == "timestamp") {  // LocalDateTimeFeature.scala:36-39
+            v = map_datetime(f.mapper, civil_of(fdiv(rq.timestamp_ms, 1000), 0));
+          } else {
+            const mrk_field *fl = fields_map_get(rq, f.field);
+            Civil c;
+            if (fl && fl->type == MRK_FIELD_STRING && fl->str && parse_iso_datetime(fl->str, c)) v = map_datetime(f.mapper, c);
+          }
+          cs[ho.const_idx] = v;
+          break;
+        }
+        case FType::Position: cs[ho.const_idx] = f.position; break;  // PositionFeature.scala:32
+        case FType::ExternalRanking: {
+          const mrk_field *fl = fields_map_get(rq, f.ext_field);
+          if (fl && fl->type == MRK_FIELD_NUMBER && f.dim == 1) cs[ho.const_idx] = fl->num;
+          else if (fl && fl->type == MRK_FIELD_NUMBER_LIST) {
+            if (fl->n != f.dim) throw StatusError(MRK_ERR_DIM_MISMATCH, "for " + f.name + " dim mismatch: " + std::to_string(f.dim) + " != " + std::to_string(fl->n));
+            for (int k = 0; k < f.dim; ++k) cs[ho.const_idx + k] = fl->nums[k];
+          }
+          break;
+        }
+        case FType::Biencoder: {
+          const mrk_field *fl = fields_map_get(rq, f.ext_field);
+          cs[ho.const_idx] = -1.0;
+          if (fl && fl->type == MRK_FIELD_NUMBER_LIST) {
+            if (fl->n > f.qdim) throw StatusError(MRK_ERR_DIM_MISMATCH, "query embedding of " + f.name + " is longer than method.dim");
+            cs[ho.const_idx] = (double)fl->n;
+            for (int k = 0; k < fl->n; ++k) cs[ho.const_idx + 1 + k] = (double)(float)fl->nums[k];
+          }
+          break;
+        }
+        case FType::Rate:
+          if (f.scope == SC_IRF) {  // RateFeature.scala:302-310
+            const mrk_field *fl = fields_map_get(rq, f.scope_field);
+            if (fl && fl->type == MRK_FIELD_STRING && fl->str) {
+              const std::string prefix = f.scope_field + ":" + fl->str + ":";
+              for (int i = 0; i < rq.n_items; ++i) {
+                uint32_t s = store.slot(SC_IRF, prefix + (rq.item_ids[i] ? rq.item_ids[i] : ""), false);
+                hb.irf[(size_t)ho.irf_id * total + begin + i] = s == Store::NO_SLOT ? -1 : (int32_t)s;
+              }
+            }
+          }
+          break;
+        default: break;
+      }
+      // pre-pass table sizes from the host mirror (counts only — the histograms are built on the device)
+      if (f.type == FType::InteractedWith) {
+        const ScopeId ls = f.scope;
+        const int32_t vslot = ls == SC_SESSION ? rd.session_slot : rd.user_slot;
+        for (size_t fi = 0; fi < f.values.size(); ++fi) {
+          const PrepEntry &pe = prog.prep[ho.prep_base + fi];
+          uint64_t count = 0;
+          HostCell lc = host_cell(store, ls, vslot, pe.list_col);
+          if (lc.tag != TAG_MISSING) {
+            const uint32_t off = (uint32_t)lc.bits, len = (uint32_t)(lc.bits >> 32);
+            for (uint32_t k = 0; k < len; ++k) {
+              HostCell ic = host_cell(store, SC_ITEM, (int32_t)store.slot_pool.host[off + k], pe.item_col);
+              if (ic.tag == TAG_STRING_LIST) count += (uint32_t)(ic.bits >> 32);
+            }
+          }
+          PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base + fi];
+          const uint32_t cap = pow2_at_least(std::max<uint64_t>(1, 2 * count));
+          po.tab_off = (uint32_t)arena;
+          po.tab_mask = cap - 1;
+          arena += cap;
+        }
+      } else if (f.type == FType::Diversity) {
+        const PrepEntry &pe = prog.prep[ho.prep_base];
+        uint64_t tokens = 0;
+        int taken = 0, doubles = 0;
+        int mode = -1;  // -1 undecided, 0 other, 1 string, 2 double
+        for (int i = 0; i < rq.n_items && taken < f.div_top; ++i) {
+          HostCell c = host_cell(store, SC_ITEM, hb.item_slot[begin + i], pe.item_col);
+          if (c.tag == TAG_MISSING) continue;
+          if (mode < 0) mode = (c.tag == TAG_STRING || c.tag == TAG_STRING_LIST) ? 1 : (c.tag == TAG_DOUBLE ? 2 : 0);
+          if (mode == 0) break;
+          if (mode == 1 && c.tag == TAG_STRING) { tokens += 1; ++taken; }
+          else if (mode == 1 && c.tag == TAG_STRING_LIST) { tokens += (uint32_t)(c.bits >> 32); ++taken; }
+          else if (mode == 2 && c.tag == TAG_DOUBLE) { ++doubles; ++taken; }
+        }
+        if (doubles > PREP_MAX_VALUES)
+          throw StatusError(MRK_ERR_UNSUPPORTED, "diversity feature '" + f.name + "' over more than " + std::to_string(PREP_MAX_VALUES) + " values: set `top`");
+        PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base];
+        const uint32_t cap = pow2_at_least(std::max<uint64_t>(1, 2 * tokens));
+        po.tab_off = (uint32_t)arena;
+        po.tab_mask = cap - 1;
+        arena += cap;
+      }
+    }
+    // per-item inputs that win over / replace the store
+    if (rq.item_field_offsets && rq.item_fields) {
+      for (int i = 0; i < rq.n_items; ++i) {
+        const mrk_field *fb = rq.item_fields + rq.item_field_offsets[i], *fe = rq.item_fields + rq.item_field_offsets[i + 1];
+        if (fb == fe) continue;
+        for (const HostOp &ho : prog.host_ops) {
+          const FeatureDef &f = *ho.def;
+          const uint32_t gi = (uint32_t)(begin + i);
+          if (f.type == FType::Number && f.scope != SC_RANKING) {  // NumberFeature.scala:86-92
+            for (const mrk_field *p = fb; p != fe; ++p)
+              if (p->type == MRK_FIELD_NUMBER && p->name && f.field == p->name) { hb.overrides.push_back({gi, (uint32_t)ho.dst, p->num}); break; }
+          } else if (f.type == FType::String && !f.field_is_ranking) {  // StringFeature.scala:96-99
+            for (const mrk_field *p = fb; p != fe; ++p) {
+              if (!p->name || f.field != p->name) continue;
+              if (p->type != MRK_FIELD_STRING && p->type != MRK_FIELD_STRING_LIST) continue;
+              enc.assign(f.dim, 0.0);
+              if (p->type == MRK_FIELD_STRING) { const char *one[1] = {p->str ? p->str : ""}; encode_string(f, one, 1, enc.data()); }
+              else encode_string(f, p->strs, p->n, enc.data());
+              for (int k = 0; k < f.dim; ++k) hb.overrides.push_back({gi, (uint32_t)(ho.dst + k), enc[k]});
+              break;
+            }
+          } else if (f.type == FType::Relevancy) {  // RelevancyFeature.scala:41-48: the first field called "relevancy" decides
+            for (const mrk_field *p = fb; p != fe; ++p)
+              if (p->name && !strcmp(p->name, "relevancy")) {
+                if (p->type == MRK_FIELD_NUMBER) hb.overrides.push_back({gi, (uint32_t)ho.dst, p->num});
+                break;
+              }
+          } else if (f.type == FType::ExternalItem) {
+            for (const mrk_field *p = fb; p != fe; ++p)
+              if (p->name && f.ext_field == p->name) {
+                if (p->type == MRK_FIELD_NUMBER && f.dim == 1) hb.overrides.push_back({gi, (uint32_t)ho.dst, p->num});
+                else if (p->type == MRK_FIELD_NUMBER_LIST) {
+                  if (p->n != f.dim) throw StatusError(MRK_ERR_DIM_MISMATCH, "for " + f.name + " dim mismatch: " + std::to_string(f.dim) + " != " + std::to_string(p->n));
+                  for (int k = 0; k < f.dim; ++k) hb.overrides.push_back({gi, (uint32_t)(ho.dst + k), p->nums[k]});
+                }
+                break;
+              }
+          }
+        }
+      }
+    }
+    begin += rq.n_items;
+  }
+  if (arena > 0xffffffffull) throw StatusError(MRK_ERR_UNSUPPORTED, "batch needs more than 2^32 hash-table entries");
+  hb.arena_entries = arena;
+}
+
+}  // namespace mrk

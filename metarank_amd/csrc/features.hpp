@@ -1,0 +1,89 @@
+// Feature registry: Metarank's `features:` / `models:` config -> store layout + per-model
+// assembly programs (reference: FeatureMapping.fromFeatureSchema, FeatureMapping.scala:56-99, and
+// the schema decoders in feature/*.scala), plus the host half of a request (everything that is a
+// function of the RankingEvent alone: slots, request-level constants, per-item overrides).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rank.hpp"
+
+namespace mrk {
+
+enum class FType {
+  Number, Boolean, WordCount, Vector, String, InteractionCount, WindowCount, Rate, InteractedWith, Diversity,
+  ItemAge, LocalTime, Position, Relevancy, Biencoder, ExternalRanking, ExternalItem
+};
+
+struct FeatureDef {
+  FType type = FType::Number;
+  std::string name;
+  ScopeId scope = SC_ITEM;      // SC_FIELD / SC_IRF stand for item.<f> / ranking.<f> scopes of `rate`
+  std::string scope_field;
+  std::string field;            // source field name
+  bool field_is_ranking = false;
+  int dim = 1;
+  bool index_encode = false;            // string
+  std::vector<std::string> values;      // string: possible values; interacted_with: field names
+  std::string top, bottom;              // rate
+  bool normalize = false;
+  double weight = 0;
+  int div_top = 20;
+  double position = 0;
+  int mapper = 0;                       // local_time
+  int norm = NORM_NOOP;                 // bi-encoder
+  int qdim = 0;                         // bi-encoder embedding size
+  std::string ext_field;                // request / item field carrying host-computed values
+};
+
+// host-side description of what a request has to supply for one op
+struct HostOp {
+  const FeatureDef *def = nullptr;
+  int dst = 0;
+  int const_idx = -1;   // offset of this op's constants inside the per-request const block
+  int irf_id = -1;      // index of its per-item IRF slot array
+  int prep_base = -1;   // first pre-pass entry
+};
+
+struct Program {
+  std::string model;
+  std::vector<std::string> feature_names;
+  std::vector<Op> ops;
+  std::vector<HostOp> host_ops;
+  std::vector<PrepEntry> prep;
+  std::vector<uint32_t> aux;
+  int dim = 0;
+  int n_consts = 0;
+  int n_irf = 0;
+  DevBuf d_ops, d_prep, d_aux;
+  ProgramDev device_view() const;
+};
+
+struct Registry {
+  std::vector<std::unique_ptr<FeatureDef>> features;
+  std::map<std::string, std::unique_ptr<Program>> programs;
+  const Program *program(const std::string &model) const;
+};
+
+// parses the config, declares every state column in `store`, freezes the layout, builds and
+// uploads the programs
+std::unique_ptr<Registry> load_config(const char *json, size_t len, Store &store);
+
+// ---- host half of a batch -------------------------------------------------------------------
+struct HostBatch {
+  std::vector<ReqDev> reqs;
+  std::vector<int32_t> item_slot;
+  std::vector<uint32_t> item_req;
+  std::vector<double> consts;
+  std::vector<int32_t> irf;
+  std::vector<Override> overrides;
+  std::vector<PrepOut> prep_out;
+  uint64_t arena_entries = 0;
+  int total_items = 0;
+};
+
+void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs, int n_req, HostBatch &out);
+
+}  // namespace mrk

@@ -1,0 +1,575 @@
+// Feature assembly + ordering kernels for gfx950 (CDNA4): the device side of
+//   Ranker.makeQuery  (FeatureValueLoader.fromStateBackend + ItemValue.fromState + ClickthroughQuery)
+//   Ranker.rerank's   sortBy(-_.score)
+// Reference: ml/Ranker.scala:27-83,97-106; feature/*.scala (cited per op in rank.hpp).
+//
+// Three launches per batch of requests (the scorer of score.hip runs between assemble and sort):
+//   prepass_kernel   one workgroup per request: the cross-item reductions (session-profile token
+//                    histograms for interacted_with, token histogram / median over the first `top`
+//                    present items for diversity) -> small open-addressing tables in HBM/L2
+//   assemble_kernel  one lane per candidate item: gathers the item's record (one contiguous
+//                    record per item, see store.hpp), evaluates every op of the model program and
+//                    writes its row of the dense f64 matrix
+//   sort_kernel      one workgroup per request: stable descending order, java.lang.Double.compare
+// Compiled with -ffp-contract=off: the JVM never fuses a*b+c, and parity is bit-exact.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rank.hpp"
+#include "runtime.hpp"
+
+namespace mrk {
+
+namespace {
+
+__device__ __forceinline__ double d_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+struct Cell {
+  uint32_t tag;
+  uint64_t bits;
+  __device__ __forceinline__ double f64() const { return __longlong_as_double((long long)bits); }
+  __device__ __forceinline__ long long i64() const { return (long long)bits; }
+  __device__ __forceinline__ uint32_t lo() const { return (uint32_t)bits; }
+  __device__ __forceinline__ uint32_t hi() const { return (uint32_t)(bits >> 32); }
+};
+
+__device__ __forceinline__ const uint8_t *record(const StoreDev &st, int scope, int slot) {
+  if (slot < 0) return nullptr;
+  return st.tab[scope].rows + (size_t)slot * st.tab[scope].stride;
+}
+
+__device__ __forceinline__ Cell load_cell(const uint8_t *rec, ColRef c, int idx = 0) {
+  Cell out;
+  if (rec == nullptr || c.tag < 0) {
+    out.tag = TAG_MISSING;
+    out.bits = 0;
+    return out;
+  }
+  out.tag = rec[c.tag];
+  out.bits = *(const uint64_t *)(rec + c.val + idx * 8);
+  return out;
+}
+
+__device__ __forceinline__ int scoped_slot(const ReqDev &rq, int scope, int item_slot) {
+  switch (scope) {
+    case SC_GLOBAL: return 0;
+    case SC_ITEM: return item_slot;
+    case SC_USER: return rq.user_slot;
+    case SC_SESSION: return rq.session_slot;
+    case SC_RANKING: return rq.ranking_slot;
+    default: return -1;
+  }
+}
+
+// ---------------------------------------------------------------- token -> count hash tables
+// entry = key (token id, >= 1) in the low 32 bits, count in the high 32 bits; 0 = empty.
+__device__ __forceinline__ uint32_t tok_hash(uint32_t tok) { return tok * 2654435761u; }
+
+__device__ bool table_add(unsigned long long *tab, uint32_t mask, uint32_t tok) {
+  uint32_t idx = (tok_hash(tok) >> 7) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long cur = tab[idx];
+    if (cur == 0ull) {
+      unsigned long long prev = atomicCAS(&tab[idx], 0ull, (unsigned long long)tok | (1ull << 32));
+      if (prev == 0ull) return true;
+      cur = prev;
+    }
+    if ((uint32_t)cur == tok) {
+      atomicAdd(&tab[idx], 1ull << 32);
+      return true;
+    }
+    idx = (idx + 1) & mask;
+  }
+  return false;
+}
+
+__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t mask, uint32_t tok) {
+  uint32_t idx = (tok_hash(tok) >> 7) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long cur = tab[idx];
+    if (cur == 0ull) return 0;
+    if ((uint32_t)cur == tok) return (uint32_t)(cur >> 32);
+    idx = (idx + 1) & mask;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- pre-pass
+constexpr int PREP_THREADS = 256;
+
+// exclusive prefix sum of a 0/1 flag over the workgroup + total (PREP_THREADS = 4 waves of 64)
+__device__ __forceinline__ int block_scan_flag(bool flag, int *s_wave_tot, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long ball = __ballot(flag);
+  const int within = __popcll(ball & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave_tot[wave] = __popcll(ball);
+  __syncthreads();
+  int before = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < PREP_THREADS / 64; ++w) {
+    int t = s_wave_tot[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  __syncthreads();
+  return before + within;
+}
+
+__global__ void __launch_bounds__(PREP_THREADS)
+prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
+  __shared__ double s_vals[PREP_MAX_VALUES];
+  __shared__ int s_wave_tot[PREP_THREADS / 64];
+  __shared__ int s_first;
+  __shared__ int s_misc[4];
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x;
+  const ReqDev rq = b.reqs[r];
+
+  for (int e = 0; e < prog.n_prep; ++e) {
+    const PrepEntry pe = prog.prep[e];
+    PrepOut *po = &b.prep_out[(size_t)r * prog.n_prep + e];
+    unsigned long long *tab = b.arena + po->tab_off;
+    const uint32_t mask = po->tab_mask;
+    for (uint32_t i = tid; i <= mask; i += PREP_THREADS) tab[i] = 0ull;
+    if (tid == 0) { s_first = 0x7fffffff; s_misc[0] = 0; s_misc[1] = 0; s_misc[2] = 0; }
+    __syncthreads();
+
+    if (pe.kind == PREP_IW_FIELD) {
+      // InteractedWithFeature.scala:134-147: histogram of the field tokens of every interacted item
+      const int vslot = pe.list_scope == SC_SESSION ? rq.session_slot : rq.user_slot;
+      const Cell lc = load_cell(record(st, pe.list_scope, vslot), pe.list_col);
+      if (lc.tag != TAG_MISSING) {
+        const uint32_t off = lc.lo(), len = lc.hi();
+        for (uint32_t k = tid; k < len; k += PREP_THREADS) {
+          const int islot = (int)st.slot_pool[off + k];
+          const Cell ic = load_cell(record(st, SC_ITEM, islot), pe.item_col);
+          if (ic.tag == TAG_STRING_LIST) {
+            const uint32_t toff = ic.lo(), tlen = ic.hi();
+            for (uint32_t j = 0; j < tlen; ++j)
+              if (!table_add(tab, mask, st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+
+    // ---- PREP_DIVERSITY (DiversityFeature.scala:72-103) ----
+    // (a) the first candidate that has a ScalarValue decides string vs number
+    for (int base = 0; base < rq.n_items; base += PREP_THREADS) {
+      const int i = base + tid;
+      if (i < rq.n_items) {
+        const Cell c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), pe.item_col);
+        if (c.tag != TAG_MISSING) atomicMin(&s_first, i);
+      }
+      __syncthreads();
+      const int found = s_first;
+      __syncthreads();  // nobody may start the next round's atomicMin before everyone has read
+      if (found != 0x7fffffff) break;
+    }
+    int mode = DIV_EMPTY;
+    if (s_first != 0x7fffffff) {
+      const Cell h = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + s_first]), pe.item_col);
+      if (h.tag == TAG_STRING || h.tag == TAG_STRING_LIST) mode = DIV_STRING;
+      else if (h.tag == TAG_DOUBLE) mode = DIV_DOUBLE;
+    }
+    double scalar = 0.0;
+    if (mode != DIV_EMPTY) {
+      // (b) the first `top` candidates of that type, in request order
+      int running = 0;
+      for (int base = 0; base < rq.n_items && running < pe.top; base += PREP_THREADS) {
+        const int i = base + tid;
+        Cell c;
+        c.tag = TAG_MISSING;
+        c.bits = 0;
+        if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), pe.item_col);
+        const bool cand = mode == DIV_STRING ? (c.tag == TAG_STRING || c.tag == TAG_STRING_LIST) : (c.tag == TAG_DOUBLE);
+        int total;
+        const int rank = running + block_scan_flag(cand, s_wave_tot, total);
+        if (cand && rank < pe.top) {
+          if (mode == DIV_STRING) {
+            if (c.tag == TAG_STRING) {
+              if (!table_add(tab, mask, c.lo())) atomicOr(&b.status[r], ST_TABLE_FULL);
+              atomicAdd(&s_misc[0], 1);
+            } else {
+              const uint32_t toff = c.lo(), tlen = c.hi();
+              for (uint32_t j = 0; j < tlen; ++j)
+                if (!table_add(tab, mask, st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
+              atomicAdd(&s_misc[0], (int)tlen);
+            }
+          } else {
+            if (rank < PREP_MAX_VALUES) s_vals[rank] = c.f64();
+            else atomicOr(&b.status[r], ST_TOO_MANY);
+          }
+        }
+        running += total;
+      }
+      __syncthreads();
+      if (mode == DIV_STRING) {
+        scalar = (double)s_misc[0];  // stringCounts.values.foldLeft(0.0)(_ + _): integers, exact in f64
+      } else {
+        // commons-math Percentile (LEGACY, NaN removed) .evaluate(50)
+        int n_raw = min(min(running, pe.top), PREP_MAX_VALUES);
+        if (n_raw == 1) {
+          scalar = s_vals[0];
+        } else {
+          // NaN -> +inf placeholder (sorts last), counted
+          for (int i = tid; i < n_raw; i += PREP_THREADS) {
+            double v = s_vals[i];
+            if (v != v) { s_vals[i] = __longlong_as_double(0x7ff0000000000000LL); atomicAdd(&s_misc[1], 1); }
+          }
+          int p2 = 1;
+          while (p2 < n_raw) p2 <<= 1;
+          for (int i = n_raw + tid; i < p2; i += PREP_THREADS) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
+          __syncthreads();
+          for (int k = 2; k <= p2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+              for (int i = tid; i < p2; i += PREP_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                  const double a = s_vals[i], c2 = s_vals[ixj];
+                  const bool up = (i & k) == 0;
+                  if ((a > c2) == up) { s_vals[i] = c2; s_vals[ixj] = a; }
+                }
+              }
+              __syncthreads();
+            }
+          }
+          const int m = n_raw - s_misc[1];
+          if (m <= 0) {
+            scalar = d_nan();
+          } else {
+            const double pos = 0.5 * (double)(m + 1);
+            const double fpos = floor(pos);
+            const int ipos = (int)fpos;
+            const double dif = pos - fpos;
+            if (pos < 1.0) scalar = s_vals[0];
+            else if (pos >= (double)m) scalar = s_vals[m - 1];
+            else {
+              const double lower = s_vals[ipos - 1], upper = s_vals[ipos];
+              scalar = __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
+            }
+          }
+        }
+      }
+    }
+    if (tid == 0) {
+      po->mode = mode;
+      po->scalar = scalar;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- assemble
+constexpr int ASM_THREADS = 256;
+
+// java.lang.Math.round(double)
+__device__ __forceinline__ long long java_round(double a) {
+  if (a != a) return 0;
+  if (a >= 9223372036854775807.0) return 0x7fffffffffffffffLL;
+  if (a <= -9223372036854775808.0) return (long long)0x8000000000000000ULL;
+  if (fabs(a) >= 4503599627370496.0) return (long long)a;
+  const double fl = floor(a);
+  return (long long)fl + ((a - fl) >= 0.5 ? 1 : 0);
+}
+
+// Scala Long / Long (truncating; Long.MinValue / -1 wraps); the zero divisor is reported by the caller
+__device__ __forceinline__ long long long_div(long long a, long long b) {
+  if (b == -1) return (long long)(0ull - (unsigned long long)a);
+  return a / b;
+}
+
+__global__ void __launch_bounds__(ASM_THREADS)
+assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
+  const int gi = blockIdx.x * ASM_THREADS + threadIdx.x;
+  if (gi >= b.total_items) return;
+  const int r = (int)b.item_req[gi];
+  const ReqDev rq = b.reqs[r];
+  const int islot = b.item_slot[gi];
+  const uint8_t *irec = record(st, SC_ITEM, islot);
+  double *row = b.matrix + (size_t)gi * prog.dim;
+  const double NaN = d_nan();
+
+  for (int oi = 0; oi < prog.n_ops; ++oi) {
+    const Op op = prog.ops[oi];
+    double *out = row + op.dst;
+    switch (op.kind) {
+      case OP_SCALAR_DOUBLE: {
+        const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
+        out[0] = c.tag == TAG_DOUBLE ? c.f64() : NaN;
+        break;
+      }
+      case OP_SCALAR_BOOL: {
+        const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
+        out[0] = c.tag == TAG_BOOL ? c.f64() : NaN;
+        break;
+      }
+      case OP_VECTOR: {
+        const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
+        if (c.tag == TAG_DOUBLE_LIST) {
+          const uint32_t off = c.lo(), len = c.hi();
+          for (int k = 0; k < op.dim; ++k) out[k] = (uint32_t)k < len ? st.f64_pool[off + k] : 0.0;
+        } else {
+          for (int k = 0; k < op.dim; ++k) out[k] = NaN;
+        }
+        break;
+      }
+      case OP_STRING_INDEX: {
+        const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
+        double idx = 0.0;
+        if (c.tag == TAG_STRING_LIST && c.hi() > 0) {
+          const uint32_t first = st.tok_pool[c.lo()];
+          for (int k = 0; k < op.i1; ++k)
+            if (prog.aux[op.i0 + k] == first) idx = (double)(k + 1);  // zipWithIndex.toMap: last duplicate wins
+        }
+        out[0] = idx;
+        break;
+      }
+      case OP_STRING_ONEHOT: {
+        const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
+        for (int k = 0; k < op.dim; ++k) out[k] = 0.0;
+        if (c.tag == TAG_STRING_LIST) {
+          const uint32_t off = c.lo(), len = c.hi();
+          for (uint32_t j = 0; j < len; ++j) {
+            const uint32_t tok = st.tok_pool[off + j];
+            for (int k = 0; k < op.i1; ++k)
+              if (prog.aux[op.i0 + k] == tok) { out[k] = 1.0; break; }  // indexOf: first match
+          }
+        }
+        break;
+      }
+      case OP_COUNTER: {
+        const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
+        out[0] = c.tag != TAG_MISSING ? (double)c.i64() : 0.0;
+        break;
+      }
+      case OP_WINDOW: {
+        const uint8_t *rec = record(st, op.scope, scoped_slot(rq, op.scope, islot));
+        const Cell c = load_cell(rec, op.c0);
+        const bool ok = c.tag != TAG_MISSING && (int)c.tag - 1 == op.dim;
+        for (int k = 0; k < op.dim; ++k) out[k] = ok ? (double)load_cell(rec, op.c0, k).i64() : NaN;
+        break;
+      }
+      case OP_RATE: {
+        for (int k = 0; k < op.dim; ++k) out[k] = NaN;
+        const uint8_t *trec = nullptr;  // record holding the target-scope counters
+        ColRef top = op.c0, bot = op.c1;
+        if (op.i0 == RATE_ITEM) {
+          trec = irec;
+        } else if (op.i0 == RATE_ITEM_FIELD) {
+          const Cell link = load_cell(irec, op.c0);  // item=<id>/<name>_field : SString -> field slot
+          if (link.tag == TAG_STRING && link.hi() != 0) trec = record(st, SC_FIELD, (int)link.hi() - 1);
+          top = op.c4;
+          bot = op.c5;
+        } else {
+          const int s = b.irf[(size_t)op.i2 * b.total_items + gi];
+          trec = record(st, SC_IRF, s);
+          top = op.c4;
+          bot = op.c5;
+        }
+        if (trec == nullptr) break;
+        const Cell t0 = load_cell(trec, top), b0 = load_cell(trec, bot);
+        if (t0.tag == TAG_MISSING || b0.tag == TAG_MISSING) break;
+        const bool len_ok = (int)t0.tag - 1 == op.dim && (int)b0.tag - 1 == op.dim;
+        if (op.i3 == 0) {
+          if (!len_ok) break;
+          for (int k = 0; k < op.dim; ++k)
+            out[k] = (double)load_cell(trec, top, k).i64() / (double)load_cell(trec, bot, k).i64();
+        } else {
+          const uint8_t *grec = record(st, SC_GLOBAL, 0);
+          const Cell gt = load_cell(grec, op.c2), gb = load_cell(grec, op.c3);
+          if (gt.tag == TAG_MISSING || gb.tag == TAG_MISSING) break;
+          if (!len_ok || (int)gt.tag - 1 != op.dim || (int)gb.tag - 1 != op.dim) break;
+          for (int k = 0; k < op.dim; ++k) {
+            const long long tg = load_cell(grec, op.c2, k).i64(), bg = load_cell(grec, op.c3, k).i64();
+            if (tg == 0) {  // java.lang.ArithmeticException: / by zero
+              atomicOr(&b.status[r], ST_ARITHMETIC);
+              break;
+            }
+            const double ratio = (double)long_div(bg, tg);
+            const double num = __dadd_rn(op.d0, (double)load_cell(trec, top, k).i64());
+            const double den = __dadd_rn(__dmul_rn(op.d0, ratio), (double)load_cell(trec, bot, k).i64());
+            out[k] = num / den;
+          }
+        }
+        break;
+      }
+      case OP_INTERACTED: {
+        // per field: sum over the candidate's tokens of the session histogram
+        for (int f = 0; f < op.dim; ++f) {
+          ColRef col;
+          col.tag = (int32_t)prog.aux[op.i0 + 2 * f];
+          col.val = (int32_t)prog.aux[op.i0 + 2 * f + 1];
+          const PrepOut po = b.prep_out[(size_t)r * prog.n_prep + op.i1 + f];
+          const unsigned long long *tab = b.arena + po.tab_off;
+          const Cell c = load_cell(irec, col);
+          double cnt = 0.0;
+          if (c.tag == TAG_STRING_LIST) {
+            const uint32_t off = c.lo(), len = c.hi();
+            for (uint32_t j = 0; j < len; ++j) cnt = cnt + (double)table_get(tab, po.tab_mask, st.tok_pool[off + j]);
+          }
+          out[f] = cnt;
+        }
+        break;
+      }
+      case OP_DIVERSITY: {
+        const PrepOut po = b.prep_out[(size_t)r * prog.n_prep + op.i1];
+        const Cell c = load_cell(irec, op.c0);
+        if (po.mode == DIV_EMPTY) {
+          out[0] = 0.0;
+        } else if (po.mode == DIV_DOUBLE) {
+          out[0] = c.tag == TAG_DOUBLE ? c.f64() - po.scalar : NaN;
+        } else {
+          const unsigned long long *tab = b.arena + po.tab_off;
+          if (c.tag == TAG_STRING) {
+            out[0] = (0.0 + (double)table_get(tab, po.tab_mask, c.lo())) / po.scalar;
+          } else if (c.tag == TAG_STRING_LIST) {
+            const uint32_t off = c.lo(), len = c.hi();
+            double w = 0.0;
+            for (uint32_t j = 0; j < len; ++j) w = w + (double)table_get(tab, po.tab_mask, st.tok_pool[off + j]);
+            out[0] = w / po.scalar;
+          } else {
+            out[0] = NaN;
+          }
+        }
+        break;
+      }
+      case OP_ITEM_AGE: {
+        const Cell c = load_cell(op.scope == SC_ITEM ? irec : nullptr, op.c0);
+        double v = NaN;
+        if (c.tag == TAG_DOUBLE) {
+          const long long updated = java_round(c.f64() * 1000.0);
+          long long diff = (long long)((unsigned long long)rq.ts_ms - (unsigned long long)updated);
+          if (diff < 0) diff = (long long)(0ull - (unsigned long long)diff);
+          if (diff < 0 || diff > 9223372036854LL) atomicOr(&b.status[r], ST_ILLEGAL_ARG);  // FiniteDuration bound
+          else v = (double)(diff / 1000);
+        }
+        out[0] = v;
+        break;
+      }
+      case OP_CONST: {
+        const double *cs = b.consts + (size_t)r * prog.n_consts + op.i0;
+        for (int k = 0; k < op.dim; ++k) out[k] = cs[k];
+        break;
+      }
+      case OP_FILL_NAN: {
+        for (int k = 0; k < op.dim; ++k) out[k] = NaN;
+        break;
+      }
+      case OP_BIENCODER: {
+        // consts: [0] = query length (or -1: no query), [1..] = query embedding (f32 values widened)
+        const double *cs = b.consts + (size_t)r * prog.n_consts + op.i0;
+        const int qn = (int)cs[0];
+        const Cell c = load_cell(irec, op.c0);
+        double v = NaN;
+        if (qn >= 0 && c.tag == TAG_DOUBLE_LIST) {
+          if ((int)c.hi() < qn) {
+            atomicOr(&b.status[r], ST_DIM);
+          } else {
+            const double *item = st.f64_pool + c.lo();
+            double top = 0.0, a = 0.0, bs = 0.0;
+            for (int k = 0; k < qn; ++k) {
+              const float q = (float)cs[1 + k];
+              top = __dadd_rn(top, __dmul_rn((double)q, item[k]));
+              a = __dadd_rn(a, (double)__fmul_rn(q, q));  // Float * Float is a Float product
+              bs = __dadd_rn(bs, __dmul_rn(item[k], item[k]));
+            }
+            v = top / (sqrt(a) * sqrt(bs));
+          }
+        }
+        out[0] = v;
+        break;
+      }
+      default: break;
+    }
+  }
+}
+
+__global__ void override_kernel(BatchDev b, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n_overrides) return;
+  const Override o = b.overrides[i];
+  b.matrix[(size_t)o.item * dim + o.col] = o.value;
+}
+
+// ---------------------------------------------------------------- ordering
+// sortBy(-_.score): ascending java.lang.Double.compare on the negated score, stable.
+__device__ __forceinline__ unsigned long long sort_key(double score) {
+  double k = -score;
+  unsigned long long bits = (unsigned long long)__double_as_longlong(k);
+  if (k != k) bits = 0x7ff8000000000000ULL;  // Double.compare canonicalises NaN: above +Infinity
+  return (bits & 0x8000000000000000ULL) ? ~bits : (bits | 0x8000000000000000ULL);
+}
+
+constexpr int SORT_THREADS = 256;
+
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_kernel(BatchDev b) {
+  __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
+  __shared__ int s_idx[SORT_MAX_ITEMS];
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x;
+  const ReqDev rq = b.reqs[r];
+  const int n = rq.n_items;
+  if (n <= 0) return;
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  for (int i = tid; i < p2; i += SORT_THREADS) {
+    s_key[i] = i < n ? sort_key(b.scores[rq.item_begin + i]) : ~0ull;
+    s_idx[i] = i < n ? i : 0x7fffffff;
+  }
+  __syncthreads();
+  // bitonic sort on (key, index): the index makes every pair distinct => equals the stable order
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < p2; i += SORT_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long ka = s_key[i], kb = s_key[ixj];
+          const int ia = s_idx[i], ib = s_idx[ixj];
+          const bool gt = ka > kb || (ka == kb && ia > ib);
+          const bool up = (i & k) == 0;
+          if (gt == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += SORT_THREADS) b.order[rq.item_begin + i] = s_idx[i];
+}
+
+}  // namespace
+
+void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b) {
+  if (b.n_req <= 0 || prog.n_prep <= 0) return;
+  ScopedKernelTimer timer(ctx, "prepass");
+  hipLaunchKernelGGL(prepass_kernel, dim3(b.n_req), dim3(PREP_THREADS), 0, ctx->stream, st, prog, b);
+  MRK_HIP(hipGetLastError());
+}
+
+void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b) {
+  if (b.total_items <= 0) return;
+  {
+    ScopedKernelTimer timer(ctx, "assemble");
+    const int grid = (b.total_items + ASM_THREADS - 1) / ASM_THREADS;
+    hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(ASM_THREADS), 0, ctx->stream, st, prog, b);
+    MRK_HIP(hipGetLastError());
+  }
+  if (b.n_overrides > 0) {
+    ScopedKernelTimer timer(ctx, "override");
+    hipLaunchKernelGGL(override_kernel, dim3((b.n_overrides + 255) / 256), dim3(256), 0, ctx->stream, b, prog.dim);
+    MRK_HIP(hipGetLastError());
+  }
+}
+
+void launch_sort(mrk_ctx *ctx, const BatchDev &b) {
+  if (b.n_req <= 0) return;
+  ScopedKernelTimer timer(ctx, "sort");
+  hipLaunchKernelGGL(sort_kernel, dim3(b.n_req), dim3(SORT_THREADS), 0, ctx->stream, b);
+  MRK_HIP(hipGetLastError());
+}
+
+}  // namespace mrk

@@ -81,7 +81,7 @@ struct RowT<false> { using type = float; };
 
 // dense-row preprocessing applied once per cell when the tile is staged
 template <bool F64>
-__device__ __forceinline__ typename RowT<F64>::type prep(double x, int *flag) {
+__device__ __forceinline__ typename RowT<F64>::type prep(double x, int *flag, int bit = 1) {
   if constexpr (F64) {
     // LightGBM RowFunctionFromDenseMatric keeps a cell only if |x| > kZeroThreshold (1e-35f) or NaN;
     // everything else reads back as 0.0 from the prediction buffer.
@@ -91,7 +91,7 @@ __device__ __forceinline__ typename RowT<F64>::type prep(double x, int *flag) {
     // ltrlib narrows Double -> Float before DMatrix (round-to-nearest-even, overflow -> inf);
     // XGBoost rejects +-inf when `missing` is NaN ("Input data contains `inf`").
     float f = (float)x;
-    if (__builtin_isinf(f)) atomicOr(flag, 1);
+    if (__builtin_isinf(f)) atomicOr(flag, bit);
     return f;
   }
 }
@@ -101,8 +101,8 @@ __global__ void __launch_bounds__(TILE)
 score_kernel(const uint8_t *__restrict__ image, const TreeRef *__restrict__ trees,
              const ChunkRef *__restrict__ chunks, int n_chunks,
              const uint32_t *__restrict__ cat_bits, const double *__restrict__ X, int rows, int cols,
-             double base, double *__restrict__ out, int *__restrict__ flag, uint32_t chunk_cap,
-             uint32_t ref_cap) {
+             double base, double *__restrict__ out, int *__restrict__ flag,
+             const uint32_t *__restrict__ row_req, uint32_t chunk_cap, uint32_t ref_cap) {
   using row_t = typename RowT<F64>::type;
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t *s_chunk = smem;                                   // chunk_cap bytes
@@ -121,7 +121,8 @@ score_kernel(const uint8_t *__restrict__ image, const TreeRef *__restrict__ tree
     for (long long e = tid; e < total; e += TILE) {
       int r = (int)(e / cols);
       int c = (int)(e - (long long)r * cols);
-      s_rows[c * TILE + r] = prep<F64>(src[e], flag);
+      // row_req != null: per-request status words (bit 32 = inf met), else one flag word (bit 1)
+      s_rows[c * TILE + r] = row_req ? prep<F64>(src[e], flag + row_req[row0 + r], 32) : prep<F64>(src[e], flag);
     }
     // tail lanes keep walking (uniform control flow); give them zeros
     for (int e = tile_rows + tid; e < TILE; e += TILE)
@@ -172,14 +173,16 @@ score_kernel(const uint8_t *__restrict__ image, const TreeRef *__restrict__ tree
             const uint32_t feat = walking ? (nd.w2 & 0xffffu) : 0u;
             double v;
             if constexpr (ROWS_LDS) v = s_rows[feat * TILE + tid];
-            else v = (walking && row < rows) ? prep<true>(X[row * cols + feat], flag) : 0.0;
+            else v = (walking && row < rows) ? (row_req ? prep<true>(X[row * cols + feat], flag + row_req[row], 32)
+                                                        : prep<true>(X[row * cols + feat], flag)) : 0.0;
             const bool left = decide64(nd.w0, nd.w1, nd.w2, v, cat_bits);
             next = left ? (int)(short)(nd.w3 & 0xffffu) : (int)(short)(nd.w3 >> 16);
           } else {
             const uint32_t feat = walking ? (nd.w1 & 0xffffu) : 0u;
             float v;
             if constexpr (ROWS_LDS) v = s_rows[feat * TILE + tid];
-            else v = (walking && row < rows) ? prep<false>(X[row * cols + feat], flag) : 0.f;
+            else v = (walking && row < rows) ? (row_req ? prep<false>(X[row * cols + feat], flag + row_req[row], 32)
+                                                        : prep<false>(X[row * cols + feat], flag)) : 0.f;
             const bool left = decide32(nd.w0, nd.w1, nd.w3, v, cat_bits);
             next = left ? (int)(short)(nd.w2 & 0xffffu) : (int)(short)(nd.w2 >> 16);
           }
@@ -202,7 +205,7 @@ score_kernel(const uint8_t *__restrict__ image, const TreeRef *__restrict__ tree
 
 template <bool F64, int TILE, bool ROWS_LDS>
 void launch_t(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
-              int *d_flag, uint32_t chunk_cap, uint32_t ref_cap, size_t smem) {
+              int *d_flag, const uint32_t *d_row_req, uint32_t chunk_cap, uint32_t ref_cap, size_t smem) {
   auto kern = score_kernel<F64, TILE, ROWS_LDS>;
   static thread_local const void *configured = nullptr;
   if (configured != (const void *)kern) {
@@ -212,13 +215,14 @@ void launch_t(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols,
   const int grid = (rows + TILE - 1) / TILE;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), smem, ctx->stream, m->d_image.as<uint8_t>(),
                      m->d_trees.as<TreeRef>(), m->d_chunks.as<ChunkRef>(), (int)m->packed.chunks.size(),
-                     m->d_cat.as<uint32_t>(), d_x, rows, cols, m->forest.base_score, d_out, d_flag,
+                     m->d_cat.as<uint32_t>(), d_x, rows, cols, m->forest.base_score, d_out, d_flag, d_row_req,
                      chunk_cap, ref_cap);
   MRK_HIP(hipGetLastError());
 }
 
 template <bool F64>
-void launch_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag) {
+void launch_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
+              const uint32_t *d_row_req) {
   const uint32_t chunk_cap = (m->packed.max_chunk_bytes + 15u) & ~15u;
   const uint32_t ref_cap = ((uint32_t)m->packed.max_chunk_trees * (uint32_t)sizeof(TreeRef) + 15u) & ~15u;
   const size_t esz = F64 ? 8 : 4;
@@ -228,25 +232,30 @@ void launch_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols,
   // Prefer the tile that still leaves room for two workgroups per CU (more waves to hide LDS
   // latency); fall back to smaller tiles, then to reading rows from global memory.
   const size_t half = 78 * 1024;
-  if (rows > 128 && smem(256) <= half) launch_t<F64, 256, true>(ctx, m, d_x, rows, cols, d_out, d_flag, chunk_cap, ref_cap, smem(256));
-  else if (rows > 64 && smem(128) <= half) launch_t<F64, 128, true>(ctx, m, d_x, rows, cols, d_out, d_flag, chunk_cap, ref_cap, smem(128));
-  else if (smem(64) <= half) launch_t<F64, 64, true>(ctx, m, d_x, rows, cols, d_out, d_flag, chunk_cap, ref_cap, smem(64));
-  else if (fits(256) && rows > 128) launch_t<F64, 256, true>(ctx, m, d_x, rows, cols, d_out, d_flag, chunk_cap, ref_cap, smem(256));
-  else if (fits(128) && rows > 64) launch_t<F64, 128, true>(ctx, m, d_x, rows, cols, d_out, d_flag, chunk_cap, ref_cap, smem(128));
-  else if (fits(64)) launch_t<F64, 64, true>(ctx, m, d_x, rows, cols, d_out, d_flag, chunk_cap, ref_cap, smem(64));
-  else launch_t<F64, 256, false>(ctx, m, d_x, rows, cols, d_out, d_flag, chunk_cap, ref_cap, (size_t)chunk_cap + ref_cap);
+  if (rows > 128 && smem(256) <= half) launch_t<F64, 256, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(256));
+  else if (rows > 64 && smem(128) <= half) launch_t<F64, 128, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(128));
+  else if (smem(64) <= half) launch_t<F64, 64, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(64));
+  else if (fits(256) && rows > 128) launch_t<F64, 256, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(256));
+  else if (fits(128) && rows > 64) launch_t<F64, 128, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(128));
+  else if (fits(64)) launch_t<F64, 64, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(64));
+  else launch_t<F64, 256, false>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, (size_t)chunk_cap + ref_cap);
 }
 
 }  // namespace
 
 uint32_t score_chunk_budget() { return 24 * 1024; }
 
-void launch_score(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
-                  int *d_flag) {
+void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
+                        int *d_status, const uint32_t *d_row_req) {
   if (rows <= 0) return;
   ScopedKernelTimer timer(ctx, "score");
-  if (m->forest.backend == Backend::LightGBM) launch_b<true>(ctx, m, d_x, rows, cols, d_out, d_flag);
-  else launch_b<false>(ctx, m, d_x, rows, cols, d_out, d_flag);
+  if (m->forest.backend == Backend::LightGBM) launch_b<true>(ctx, m, d_x, rows, cols, d_out, d_status, d_row_req);
+  else launch_b<false>(ctx, m, d_x, rows, cols, d_out, d_status, d_row_req);
+}
+
+void launch_score(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
+                  int *d_flag) {
+  launch_score_batch(ctx, m, d_x, rows, cols, d_out, d_flag, nullptr);
 }
 
 }  // namespace mrk

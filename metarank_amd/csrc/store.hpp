@@ -1,0 +1,141 @@
+// Device-resident feature store: the mirror of KVStore[Key, FeatureValue] (reference:
+// fstore/Persistence.scala:85-89, fed by flow/FeatureValueSink.scala:10-14).
+//
+// Layout in HBM.  One table per scope type (item, user, session, global, ranking, field, irf);
+// a table is an array of fixed-stride RECORDS, one per scope instance ("slot"), so that the
+// gather of one candidate item touches a single contiguous record (a few 128-B lines) instead of
+// one line per feature column.  A record is
+//     [tag bytes: one per column][8-byte value cells, one per column (P cells for a P-period counter)]
+// Variable-length values (string lists as interned token ids, double lists, bounded lists as item
+// slots) live in three append-only pools addressed by {offset, length} cells.
+// Strings are interned host-side (one dictionary for the whole store); the second key hop of the
+// item-field-scoped `rate` (item -> "field=<name>:<value>") is resolved at put time into a direct
+// slot reference.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "runtime.hpp"
+
+namespace mrk {
+
+enum ScopeId : int {
+  SC_GLOBAL = 0, SC_ITEM = 1, SC_USER = 2, SC_SESSION = 3, SC_RANKING = 4, SC_FIELD = 5, SC_IRF = 6, SC_COUNT = 7
+};
+
+enum ColKind : uint8_t { COL_SCALAR = 0, COL_COUNTER = 1, COL_PERIODIC = 2, COL_BOUNDED_LIST = 3 };
+
+// tag byte of a record cell
+enum Tag : uint8_t {
+  TAG_MISSING = 0,
+  TAG_DOUBLE = 1,       // ScalarValue(SDouble): cell = f64
+  TAG_BOOL = 2,         // ScalarValue(SBoolean): cell = f64 0/1
+  TAG_STRING = 3,       // ScalarValue(SString): cell = {u32 token, u32 linked field slot + 1 (0 = none)}
+  TAG_STRING_LIST = 4,  // ScalarValue(SStringList): cell = {u32 offset into token pool, u32 length}
+  TAG_DOUBLE_LIST = 5,  // ScalarValue(SDoubleList): cell = {u32 offset into f64 pool, u32 length}
+  TAG_PRESENT = 1,      // counter / bounded list present; periodic: tag = 1 + min(len, 250)
+};
+
+struct Column {
+  std::string name;
+  ColKind kind = COL_SCALAR;
+  int periods = 0;           // COL_PERIODIC: number of i64 cells
+  int tag_index = 0;         // byte index of the tag inside the record
+  int val_off = 0;           // byte offset of the first value cell inside the record
+  std::string link_field;    // SString scalar whose value is also a key into the FIELD table ("field=<link_field>:<value>")
+};
+
+struct Table {
+  ScopeId scope;
+  std::vector<Column> cols;
+  std::unordered_map<std::string, int> col_of;
+  uint32_t stride = 16;
+  std::unordered_map<std::string, uint32_t> slot_of;
+  std::vector<uint8_t> rows;      // host mirror, n_slots * stride
+  uint32_t n_slots = 0;
+  // device side
+  DevBuf d_rows;
+  uint32_t d_slots_cap = 0;       // slots allocated on device
+  uint32_t dirty_lo = UINT32_MAX, dirty_hi = 0;  // slot range to upload
+  bool dirty_all = false;
+  void mark(uint32_t slot) {
+    if (slot < dirty_lo) dirty_lo = slot;
+    if (slot + 1 > dirty_hi) dirty_hi = slot + 1;
+  }
+};
+
+template <typename T>
+struct Pool {
+  std::vector<T> host;
+  DevBuf dev;
+  size_t uploaded = 0;   // elements already on device
+  size_t dev_cap = 0;    // elements allocated on device
+};
+
+struct TableDev {          // what kernels see
+  const uint8_t *rows;
+  uint32_t stride;
+  uint32_t n_slots;
+};
+
+struct StoreDev {
+  TableDev tab[SC_COUNT];
+  const uint32_t *tok_pool;
+  const double *f64_pool;
+  const uint32_t *slot_pool;
+};
+
+struct Store {
+  Table tables[SC_COUNT];
+  Pool<uint32_t> tok_pool;   // interned token ids of string lists
+  Pool<double> f64_pool;
+  Pool<uint32_t> slot_pool;  // item slots of bounded lists
+  std::unordered_map<std::string, uint32_t> token_of;  // string -> token id (>= 1)
+  bool frozen = false;       // layout frozen after the first slot is created
+  uint64_t version = 0;      // bumped on every put
+
+  Store();
+  // layout (called by the registry while loading the config)
+  int add_column(ScopeId scope, const std::string &name, ColKind kind, int periods, const std::string &link_field = "");
+  void freeze_layout();
+
+  uint32_t intern(const std::string &s);
+  uint32_t find_token(const std::string &s) const;  // 0 if never seen
+  uint32_t slot(ScopeId scope, const std::string &id, bool create);
+  static constexpr uint32_t NO_SLOT = 0xffffffffu;
+
+  // Key.encode -> (scope, scope id, feature); false if malformed
+  static bool split_key(const char *key, ScopeId &scope, std::string &id, std::string &feature);
+
+  // puts: return false when the key does not belong to any configured column (ignored)
+  bool put_double(const char *key, double v);
+  bool put_bool(const char *key, bool v);
+  bool put_string(const char *key, const char *v);
+  bool put_string_list(const char *key, const char *const *v, int n);
+  bool put_double_list(const char *key, const double *v, int n);
+  bool put_counter(const char *key, int64_t v);
+  bool put_periodic(const char *key, const int64_t *v, int n);
+  bool put_bounded_list(const char *key, const char *const *v, int n);
+  bool erase(const char *key);
+
+  // host-side readers (used to size per-request scratch; never to compute features)
+  const uint8_t *record(ScopeId scope, uint32_t slot) const {
+    return tables[scope].rows.data() + (size_t)slot * tables[scope].stride;
+  }
+
+  // copies everything that changed since the last call to the device (async on stream)
+  void flush(hipStream_t stream);
+  StoreDev device_view() const;
+  size_t device_bytes() const;
+
+ private:
+  struct Cell { Table *t; Column *c; uint32_t slot; uint8_t *rec; };
+  bool locate(const char *key, Cell &out);
+  void set_tag(Cell &c, uint8_t tag) { c.rec[c.c->tag_index] = tag; }
+  template <typename T> void set_val(Cell &c, int idx, T v) { memcpy(c.rec + c.c->val_off + idx * 8, &v, sizeof(T)); }
+};
+
+}  // namespace mrk

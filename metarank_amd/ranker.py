@@ -1,0 +1,142 @@
+"""Host-side mirror of ml/Ranker.scala for the device path.
+
+    ranker = HipRanker(config)                 # FeatureMapping.fromFeatureSchema (config = features + models)
+    ranker.put_double("item=42/popularity", 7) # KVStore.put(Key, FeatureValue)   (Key.encode strings)
+    m, scores, order = ranker.rerank("xgboost", ranking_event, booster, explain=True)   # Ranker.rerank
+
+Everything is computed by libmrk_hip.so on the GPU; this class only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _native as N
+from .booster import Context, HipBooster, default_context
+from .request import Request, request_array
+
+
+def _strs(vals):
+    bs = [v.encode() for v in vals]
+    return (C.c_char_p * max(len(bs), 1))(*bs), bs
+
+
+class Batch:
+    """mrk_batch: a prepared, device-resident batch of requests."""
+
+    def __init__(self, ranker: "HipRanker", model_name: str, events):
+        self.ranker = ranker
+        self.requests = [e if isinstance(e, Request) else Request(e) for e in events]
+        arr = request_array(self.requests)
+        self._h = C.c_void_p()
+        N.check(N.lib().mrk_batch_prepare(ranker.ctx.handle, model_name.encode(), arr, len(self.requests), C.byref(self._h)))
+        self.n_req = len(self.requests)
+        self.total_items = N.lib().mrk_batch_total_items(self._h)
+        self.dim = ranker.dim(model_name)
+        self.offsets = np.concatenate([[0], np.cumsum([r.n_items for r in self.requests])]).astype(np.int64)
+
+    def run(self, booster: HipBooster | None):
+        N.check(N.lib().mrk_batch_run(self._h, booster.handle if booster is not None else None))
+
+    def device_outputs(self):
+        s, o, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(N.lib().mrk_batch_device_outputs(self._h, C.byref(s), C.byref(o), C.byref(m)))
+        return s.value, o.value, m.value
+
+    def fetch(self, matrix: bool = False):
+        scores = np.empty(self.total_items, dtype=np.float64)
+        order = np.empty(self.total_items, dtype=np.int32)
+        mat = np.empty((self.total_items, self.dim), dtype=np.float64) if matrix else None
+        N.check(N.lib().mrk_batch_fetch(self._h, scores.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p),
+                                        mat.ctypes.data_as(C.c_void_p) if matrix else None))
+        return scores, order, mat
+
+    def status(self) -> np.ndarray:
+        st = np.zeros(max(self.n_req, 1), dtype=np.int32)
+        N.check(N.lib().mrk_batch_status(self._h, st.ctypes.data_as(C.c_void_p)))
+        return st[:self.n_req]
+
+    def close(self):
+        if self._h:
+            N.lib().mrk_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipRanker:
+    def __init__(self, config: dict, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self._own_ctx = False
+        if getattr(self.ctx, "_configured", False):
+            # one configuration per mrk_ctx: give this ranker a private context on the same device
+            self.ctx = Context(self.ctx.device)
+            self._own_ctx = True
+        self.config = config
+        blob = json.dumps({"features": config["features"], "models": config.get("models", {})}).encode()
+        N.check(N.lib().mrk_config_load_json(self.ctx.handle, blob, len(blob)))
+        self.ctx._configured = True
+
+    # ---- KVStore.put
+    def _k(self, key): return key.encode()
+    def put_double(self, key, v): N.check(N.lib().mrk_store_put_double(self.ctx.handle, self._k(key), float(v)))
+    def put_bool(self, key, v): N.check(N.lib().mrk_store_put_bool(self.ctx.handle, self._k(key), 1 if v else 0))
+    def put_string(self, key, v): N.check(N.lib().mrk_store_put_string(self.ctx.handle, self._k(key), v.encode()))
+
+    def put_string_list(self, key, v):
+        arr, _keep = _strs(v)
+        N.check(N.lib().mrk_store_put_string_list(self.ctx.handle, self._k(key), arr, len(v)))
+
+    def put_double_list(self, key, v):
+        a = np.ascontiguousarray(v, dtype=np.float64)
+        N.check(N.lib().mrk_store_put_double_list(self.ctx.handle, self._k(key), a.ctypes.data_as(C.c_void_p), len(a)))
+
+    def put_counter(self, key, v): N.check(N.lib().mrk_store_put_counter(self.ctx.handle, self._k(key), int(v)))
+
+    def put_periodic(self, key, v):
+        a = np.ascontiguousarray(v, dtype=np.int64)
+        N.check(N.lib().mrk_store_put_periodic(self.ctx.handle, self._k(key), a.ctypes.data_as(C.c_void_p), len(a)))
+
+    def put_bounded_list(self, key, v):
+        arr, _keep = _strs(v)
+        N.check(N.lib().mrk_store_put_bounded_list(self.ctx.handle, self._k(key), arr, len(v)))
+
+    def delete(self, key): N.check(N.lib().mrk_store_delete(self.ctx.handle, self._k(key)))
+    def flush(self): N.check(N.lib().mrk_store_flush(self.ctx.handle))
+
+    def dim(self, model_name: str) -> int:
+        d = N.lib().mrk_model_dim(self.ctx.handle, model_name.encode())
+        if d < 0:
+            N.check(d)
+        return d
+
+    def load_model(self, blob: bytes, backend: int) -> HipBooster:
+        return HipBooster(blob, backend, self.ctx)
+
+    # ---- Ranker.rerank
+    def rerank(self, model_name: str, event, booster: HipBooster | None = None, explain: bool = False):
+        """-> (matrix | None, scores, order); order[k] = request index of the k-th response item."""
+        req = event if isinstance(event, Request) else Request(event)
+        n = req.n_items
+        dim = self.dim(model_name)
+        scores = np.empty(n, dtype=np.float64)
+        order = np.empty(n, dtype=np.int32)
+        mat = np.empty((n, dim), dtype=np.float64) if explain else None
+        N.check(N.lib().mrk_rank(self.ctx.handle, booster.handle if booster is not None else None, model_name.encode(),
+                                 C.byref(req.c), scores.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p),
+                                 mat.ctypes.data_as(C.c_void_p) if explain else None))
+        return mat, scores, order
+
+    def prepare(self, model_name: str, events) -> Batch:
+        return Batch(self, model_name, events)
+
+    def close(self):
+        if self._own_ctx:
+            self.ctx.close()
+            self._own_ctx = False
