@@ -40,6 +40,18 @@ void drain_profile_events(mrk_ctx *ctx) {
   ctx->pending_events.clear();
 }
 
+void ctx_retain(mrk_ctx *ctx) { ctx->refs.fetch_add(1); }
+void ctx_release(mrk_ctx *ctx) {
+  if (ctx->refs.fetch_sub(1) != 1) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_profile_events(ctx);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+}
+
 template <typename F>
 static int guard(F &&f) {
   try {
@@ -81,7 +93,9 @@ static mrk_model *make_model(mrk_ctx *ctx, int backend, const uint8_t *bytes, si
   if (m->forest.average_output)
     throw StatusError(MRK_ERR_UNSUPPORTED, "lightgbm: average_output (random forest) models are not supported");
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (ctx->closed) throw StatusError(MRK_ERR_INVALID_ARG, "context is shut down");
   upload_model(ctx, m.get());
+  ctx_retain(ctx);
   return m.release();
 }
 
@@ -125,13 +139,12 @@ int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out) {
 
 void mrk_shutdown(mrk_ctx *ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
-  if (ctx->stream) {
-    (void)hipStreamSynchronize(ctx->stream);
-    drain_profile_events(ctx);
-    (void)hipStreamDestroy(ctx->stream);
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->closed) return;
+    ctx->closed = true;
   }
-  delete ctx;
+  ctx_release(ctx);  // freed once the last model / batch handle is gone
 }
 
 int mrk_model_load(mrk_ctx *ctx, int backend, const uint8_t *bytes, size_t len, mrk_model **out) {
@@ -240,10 +253,13 @@ void mrk_model_free(mrk_model *model) {
   if (model->refs.fetch_sub(1) == 1) {
     mrk_ctx *ctx = model->ctx;
     if (ctx) {
-      std::lock_guard<std::mutex> lk(ctx->mu);
-      (void)hipSetDevice(ctx->device);
-      (void)hipStreamSynchronize(ctx->stream);
-      delete model;
+      {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        delete model;
+      }
+      ctx_release(ctx);
     } else {
       delete model;
     }

@@ -266,9 +266,11 @@ int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *r
     if (!ctx || n_req < 0 || (n_req > 0 && !reqs)) throw StatusError(MRK_ERR_INVALID_ARG, "bad arguments");
     std::lock_guard<std::mutex> lk(ctx->mu);
     const Program &prog = program_of(ctx, model_name);
+    if (ctx->closed) throw StatusError(MRK_ERR_INVALID_ARG, "context is shut down");
     std::unique_ptr<mrk_batch> b(new mrk_batch());
     build_batch(ctx, prog, reqs, n_req, *b);
     MRK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx_retain(ctx);
     *out = b.release();
   });
 }
@@ -317,10 +319,13 @@ void mrk_batch_free(mrk_batch *batch) {
   if (!batch) return;
   mrk_ctx *ctx = batch->ctx;
   if (ctx) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    delete batch;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      (void)hipSetDevice(ctx->device);
+      (void)hipStreamSynchronize(ctx->stream);
+      delete batch;
+    }
+    ctx_release(ctx);
   } else {
     delete batch;
   }

@@ -90,6 +90,9 @@ struct Registry;  // features.hpp
 }  // namespace mrk
 
 struct mrk_ctx {
+  // owner reference (dropped by mrk_shutdown) + one per live model / batch: the context outlives its handles
+  std::atomic<int> refs{1};
+  bool closed = false;
   int device = 0;
   hipStream_t stream = nullptr;
   int n_cus = 0;
@@ -129,6 +132,9 @@ struct ScopedKernelTimer {
   ~ScopedKernelTimer();
 };
 void drain_profile_events(mrk_ctx *ctx);
+
+void ctx_retain(mrk_ctx *ctx);
+void ctx_release(mrk_ctx *ctx);
 
 // capi_rank.cpp: releases ctx->registry / ctx->store
 void free_rank_state(mrk_ctx *ctx);
