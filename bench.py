@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""Benchmark of the /rank hot path (feature assembly + LambdaMART scoring + ordering) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic Ranklens-shaped requests that is
+already resident in HBM: pre-pass -> assemble -> score -> sort for `--requests` requests of
+`--items` candidate items each (default 4096 x 100 = 409 600 items per GPU per step).  Workload =
+the configuration BASELINE.json's metric is quoted on: 100-item requests, the 24 Ranklens columns
+(stock Ranklens model), 500-tree LightGBM-format LambdaMART.  Weak scaling: every rank owns a
+replica of the feature store and its own requests; for N > 1 the per-step scores are merged with
+one RCCL all-gather (the only exchange the path has).
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+  roofline     dominant kernel, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (a scalar port of the reference's read path) on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--requests", type=int, default=4096, help="requests per step per GPU")
+    ap.add_argument("--items", type=int, default=100, help="candidate items per request")
+    ap.add_argument("--catalogue", type=int, default=100_000)
+    ap.add_argument("--sessions", type=int, default=10_000)
+    ap.add_argument("--trees", type=int, default=500)
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="requests timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--latency-requests", type=int, default=300, help="single-request latency samples (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        log(f"WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+    n_gpus = max(world, 1)
+
+    torch = dist = None
+    if n_gpus > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import metarank_amd as M
+    from metarank_amd import ranklens, synth
+
+    ctx = M.Context(local_rank)
+    cfg = ranklens.ranklens_config()
+    ranker = M.HipRanker(cfg, ctx)
+    model_name = "xgboost"
+    dim = ranker.dim(model_name)
+
+    # ---- state: one generation pass feeds the device store (and the CPU oracle on rank 0, N=1)
+    oracle = None
+    do_cpu = rank == 0 and n_gpus == 1 and args.cpu_sample > 0
+    if do_cpu:
+        from oracle.assembly import OraclePlan, OracleStore, sort_order
+        from oracle.forest import OracleForest
+
+        class _O:
+            pass
+
+        oracle = _O()
+        oracle.store = OracleStore()
+        oracle.plan = OraclePlan(cfg, model_name)
+    t0 = time.perf_counter()
+    n_puts = 0
+    fn_h = {"double": ranker.put_double, "string": ranker.put_string, "string_list": ranker.put_string_list,
+            "double_list": ranker.put_double_list, "counter": ranker.put_counter, "periodic": ranker.put_periodic,
+            "bounded_list": ranker.put_bounded_list}
+    if oracle is not None:
+        s = oracle.store
+        fn_o = {"double": s.put_double, "string": s.put_string, "string_list": s.put_string_list,
+                "double_list": s.put_double_list, "counter": s.put_counter, "periodic": s.put_periodic,
+                "bounded_list": s.put_bounded_list}
+    for kind, key, value in ranklens.generate_state(args.catalogue, args.sessions):
+        fn_h[kind](key, value)
+        if oracle is not None:
+            fn_o[kind](key, value)
+        n_puts += 1
+    ranker.flush()
+    log(f"state: {n_puts} feature values for {args.catalogue} items / {args.sessions} sessions in {time.perf_counter() - t0:.1f}s")
+
+    # ---- requests (per-rank seeds) and the model
+    events = ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions, seed=ranklens.SEED + 1 + rank)
+    sample = ranker.prepare(model_name, events[:64])
+    sample.run(None)
+    _, _, sm = sample.fetch(matrix=True)
+    sample.close()
+    blob = synth.synthetic_lgbm_model(n_trees=args.trees, n_features=dim, num_leaves=16, max_depth=8,
+                                      quantiles=ranklens.column_quantiles(sm), cat_features=[7], cat_prob=0.007)  # ~ one categorical split per 10 trees
+    booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
+    info = booster.info()
+    t0 = time.perf_counter()
+    batch = ranker.prepare(model_name, events)
+    total_items = batch.total_items
+    log(f"batch: {args.requests} requests x {args.items} items resolved + uploaded in {time.perf_counter() - t0:.2f}s; "
+        f"model {info['n_trees']} trees, {info['n_nodes']} nodes, {info['device_bytes']} B on device")
+
+    # ---- multi-GPU merge buffers (scores of every rank) ----
+    gather = None
+    if n_gpus > 1:
+        d_scores, _, _ = batch.device_outputs()
+
+        class _Arr:  # __cuda_array_interface__ view of the library-owned score buffer
+            __cuda_array_interface__ = {"shape": (total_items,), "typestr": "<f8", "data": (d_scores, False), "version": 3}
+
+        scores_t = torch.as_tensor(_Arr(), device=f"cuda:{local_rank}")
+        merged = torch.empty(n_gpus * total_items, dtype=torch.float64, device=f"cuda:{local_rank}")
+        ext = torch.cuda.ExternalStream(M._native.lib().mrk_stream(ctx.handle), device=f"cuda:{local_rank}")
+
+        def gather():
+            with torch.cuda.stream(ext):
+                dist.all_gather_into_tensor(merged, scores_t)
+
+    def sync_all():
+        ctx.sync()
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        batch.run(booster)
+        if gather is not None:
+            gather()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    st = batch.status()
+    assert (st == 0).all(), f"requests failed: {st[st != 0][:5]}"
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_items * n_gpus * args.steps / elapsed
+
+    # ---- per-kernel HIP-event timing (outside the timed region: the events add a little overhead)
+    ctx.profile_enable(True)
+    prof_steps = max(5, min(args.steps, 20))
+    for _ in range(prof_steps):
+        batch.run(booster)
+    ctx.sync()
+    kernels = {}
+    for k in ("prepass", "assemble", "override", "score", "sort"):
+        ms, n = ctx.profile_get(k)
+        if n:
+            kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / prof_steps}
+    ctx.profile_enable(False)
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+    # algorithmic bytes per launch of the dominant kernel (DESIGN.md "Roofline accounting")
+    store_bytes_item = 8 * dim + 48           # one record worth of cells + ~12 list tokens
+    alg = {
+        "score": total_items * (8 * dim + 8) + info["device_bytes"],
+        "assemble": total_items * (store_bytes_item + 8 + 8 * dim),
+        "prepass": args.requests * (100 * 12 * 4 + 20 * 11 * 4),
+        "sort": total_items * (8 + 4),
+        "override": 0,
+    }
+    dur_s = kernels[dominant]["avg_ms"] * 1e-3
+    achieved = alg[dominant] / dur_s / 1e9
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg[dominant],
+                "avg_launch_ms": kernels[dominant]["avg_ms"],
+                "note": "tree walk is LDS/VALU-issue bound, not HBM bound (SURVEY.md 8d): "
+                        f"{total_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G tree-walks/s"}
+
+    # ---- single-request latency (p50 of mrk_rank: host marshalling + 4 launches + copies)
+    latency = None
+    if rank == 0 and args.latency_requests > 0:
+        reqs = [M.Request(e) for e in events[:args.latency_requests]]
+        for r in reqs[:20]:
+            ranker.rerank(model_name, r, booster)
+        lat = []
+        for r in reqs:
+            t1 = time.perf_counter()
+            ranker.rerank(model_name, r, booster)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        latency = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "n": len(lat),
+                   "items": args.items}
+
+    # ---- CPU baseline: the oracle (scalar C++ port of the reference read path + forest walk), 1 thread
+    cpu = None
+    if do_cpu:
+        forest = OracleForest.from_lightgbm_text(blob)
+        n = min(args.cpu_sample, len(events))
+        reqs = [M.Request(e) for e in events[:n]]
+        for r in reqs[:3]:
+            forest.predict(oracle.plan.assemble(oracle.store, r))
+        t1 = time.perf_counter()
+        parts = [0.0, 0.0, 0.0]
+        chk = []
+        for r in reqs:
+            a = time.perf_counter()
+            m = oracle.plan.assemble(oracle.store, r)
+            b = time.perf_counter()
+            s = forest.predict(m)
+            c = time.perf_counter()
+            o = sort_order(s)
+            d = time.perf_counter()
+            parts[0] += b - a
+            parts[1] += c - b
+            parts[2] += d - c
+            chk.append((s, o))
+        cpu_s = time.perf_counter() - t1
+        cpu = {"value": n * args.items / cpu_s, "unit": "items/s", "cores": 1, "kind": "port",
+               "sample": f"{n} requests x {args.items} items of the same workload, assemble+score+sort, single thread",
+               "host_cores": os.cpu_count(), "seconds": cpu_s,
+               "split_s": {"assemble": parts[0], "score": parts[1], "sort": parts[2]}}
+        # the GPU results of those requests equal the oracle's (parity inside the bench)
+        scores, order, _ = batch.fetch()
+        for r in range(n):
+            lo, hi = batch.offsets[r], batch.offsets[r + 1]
+            assert np.array_equal(scores[lo:hi], chk[r][0]) and np.array_equal(order[lo:hi], chk[r][1]), f"parity broke at request {r}"
+
+    if rank == 0:
+        out = {
+            "metric": "ranked items/sec (feature assembly + 500-tree LambdaMART + ordering), Ranklens-shaped 100-item requests",
+            "value": value, "unit": "items/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-lightgbm", "requests_per_step_per_gpu": args.requests,
+                       "items_per_request": args.items, "items_per_step_per_gpu": total_items, "catalogue_items": args.catalogue,
+                       "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16,
+                       "parallelism": f"request-sharded x{n_gpus}" + (", RCCL all-gather of scores" if n_gpus > 1 else "")},
+            "latency": latency,
+            "kernels": kernels,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    batch.close()
+    booster.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

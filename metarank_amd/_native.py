@@ -42,7 +42,7 @@ def build(force: bool = False) -> str:
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
            "-ffp-contract=off",  # the JVM never fuses a*b+c; parity with the reference is bit-exact
-           "-o", LIB_PATH] + srcs
+           "-o", LIB_PATH] + [f"-D{d}" for d in os.environ.get("MRK_DEFINES", "").split()] + srcs
     subprocess.check_call(cmd)
     return LIB_PATH
 

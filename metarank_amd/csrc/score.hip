@@ -23,7 +23,10 @@ namespace mrk {
 
 namespace {
 
-constexpr int U = 4;  // trees walked concurrently per lane
+#ifndef MRK_SCORE_U
+#define MRK_SCORE_U 4
+#endif
+constexpr int U = MRK_SCORE_U;  // trees walked concurrently per lane
 
 struct alignas(16) Node16 {
   uint32_t w0, w1;  // thr (f64) | thr (f32) + feat/flags
@@ -163,30 +166,74 @@ score_kernel(const uint8_t *__restrict__ image, const TreeRef *__restrict__ tree
         maxd = max(maxd, live ? (int)tr.depth : 0);
       }
       for (int d = 0; d < maxd; ++d) {
+        // Phase-structured so that the U dependency chains overlap: all node reads are issued
+        // back to back, then all feature gathers, then the (branch-free) numerical decisions.
+        // Categorical nodes are rare and fixed up afterwards under one wave-level branch.
+        Node16 nd[U];
+        bool walking[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int n = max(node[u], 0);
-          const Node16 nd = *(const Node16 *)(s_chunk + nbase[u] + (uint32_t)n * 16u);
-          int next;
-          const bool walking = node[u] >= 0;  // finished lanes re-read node 0; keep their gather in range
-          if constexpr (F64) {
-            const uint32_t feat = walking ? (nd.w2 & 0xffffu) : 0u;
-            double v;
-            if constexpr (ROWS_LDS) v = s_rows[feat * TILE + tid];
-            else v = (walking && row < rows) ? (row_req ? prep<true>(X[row * cols + feat], flag + row_req[row], 32)
-                                                        : prep<true>(X[row * cols + feat], flag)) : 0.0;
-            const bool left = decide64(nd.w0, nd.w1, nd.w2, v, cat_bits);
-            next = left ? (int)(short)(nd.w3 & 0xffffu) : (int)(short)(nd.w3 >> 16);
-          } else {
-            const uint32_t feat = walking ? (nd.w1 & 0xffffu) : 0u;
-            float v;
-            if constexpr (ROWS_LDS) v = s_rows[feat * TILE + tid];
-            else v = (walking && row < rows) ? (row_req ? prep<false>(X[row * cols + feat], flag + row_req[row], 32)
-                                                        : prep<false>(X[row * cols + feat], flag)) : 0.f;
-            const bool left = decide32(nd.w0, nd.w1, nd.w3, v, cat_bits);
-            next = left ? (int)(short)(nd.w2 & 0xffffu) : (int)(short)(nd.w2 >> 16);
+          walking[u] = node[u] >= 0;  // finished lanes re-read node 0; keep their gather in range
+          nd[u] = *(const Node16 *)(s_chunk + nbase[u] + (uint32_t)max(node[u], 0) * 16u);
+        }
+        bool left[U];
+        uint32_t any_flags = 0;
+        if constexpr (F64) {
+          double v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t feat = walking[u] ? (nd[u].w2 & 0xffffu) : 0u;
+            if constexpr (ROWS_LDS) v[u] = s_rows[feat * TILE + tid];
+            else v[u] = (walking[u] && row < rows) ? (row_req ? prep<true>(X[row * cols + feat], flag + row_req[row], 32)
+                                                              : prep<true>(X[row * cols + feat], flag)) : 0.0;
           }
-          node[u] = walking ? next : node[u];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t flags = (nd[u].w2 >> 16) & 0xffu;
+            any_flags |= walking[u] ? flags : 0u;
+            const double thr = __hiloint2double((int)nd[u].w1, (int)nd[u].w0);
+            bool l = v[u] <= thr;
+            if ((flags & NF_MISS_ZERO) && v[u] == 0.0) l = (flags & NF_DEFAULT_LEFT) != 0;
+            left[u] = (v[u] != v[u]) ? (((nd[u].w2 >> 24) & 1u) != 0) : l;
+          }
+          if (__builtin_expect((any_flags & NF_CATEGORICAL) != 0, 0)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (walking[u] && (((nd[u].w2 >> 16) & NF_CATEGORICAL) != 0))
+                left[u] = decide64(nd[u].w0, nd[u].w1, nd[u].w2, v[u], cat_bits);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int next = left[u] ? (int)(short)(nd[u].w3 & 0xffffu) : (int)(short)(nd[u].w3 >> 16);
+            node[u] = walking[u] ? next : node[u];
+          }
+        } else {
+          float v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t feat = walking[u] ? (nd[u].w1 & 0xffffu) : 0u;
+            if constexpr (ROWS_LDS) v[u] = s_rows[feat * TILE + tid];
+            else v[u] = (walking[u] && row < rows) ? (row_req ? prep<false>(X[row * cols + feat], flag + row_req[row], 32)
+                                                              : prep<false>(X[row * cols + feat], flag)) : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t flags = (nd[u].w1 >> 16) & 0xffu;
+            any_flags |= walking[u] ? flags : 0u;
+            const bool l = v[u] < __uint_as_float(nd[u].w0);
+            left[u] = (v[u] != v[u]) ? ((flags & NF_DEFAULT_LEFT) != 0) : l;
+          }
+          if (__builtin_expect((any_flags & NF_CATEGORICAL) != 0, 0)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (walking[u] && (((nd[u].w1 >> 16) & NF_CATEGORICAL) != 0))
+                left[u] = decide32(nd[u].w0, nd[u].w1, nd[u].w3, v[u], cat_bits);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int next = left[u] ? (int)(short)(nd[u].w2 & 0xffffu) : (int)(short)(nd[u].w2 >> 16);
+            node[u] = walking[u] ? next : node[u];
+          }
         }
       }
       // leaves are added strictly in tree order

@@ -1,0 +1,36 @@
+"""Multi-GPU plumbing for the rank path: the path shards by request (or by the
+candidate items of one big request) with a replicated store; the only exchange is one all-gather
+of the scores.  torch.distributed is used as the RCCL binding ("nccl" backend on ROCm) — and with
+"gloo" on CPU in the tests."""
+from __future__ import annotations
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """contiguous, balanced [lo, hi) chunk of n units for `rank` (first n % world ranks get one more)"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_scores(local, sizes=None, group=None):
+    """Merge per-rank score shards (1-D tensors) into the full list on every rank.
+    sizes: number of scores of every rank (exchanged first when not given)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if sizes is None:
+        mine = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+        allsz = torch.empty(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(allsz, mine, group=group)
+        sizes = [int(x) for x in allsz.tolist()]
+    if len(set(sizes)) == 1:
+        out = torch.empty(sum(sizes), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    pad = max(sizes)
+    buf = torch.zeros(pad, dtype=local.dtype, device=local.device)
+    buf[:local.numel()] = local
+    parts = [torch.empty(pad, dtype=local.dtype, device=local.device) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)])

@@ -1,0 +1,50 @@
+"""Worker for tests/test_dist_cpu.py: launched as 2 gloo ranks.  No GPU: the per-shard compute is
+the CPU oracle; what is under test is the sharding + all-gather merge used by bench.py --gpus N."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+from backends import OracleBackend  # noqa: E402
+from metarank_amd import ranklens, synth  # noqa: E402
+from metarank_amd.dist import all_gather_scores, shard_range  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cfg = ranklens.ranklens_config()
+    b = OracleBackend(cfg, "xgboost")
+    ranklens.load_state(b, ranklens.generate_state(600, 60))  # replicated store
+    reqs = ranklens.generate_requests(7, 50, 600, 60, seed=9)  # 7 requests: uneven shards
+    blob = synth.synthetic_lgbm_model(n_trees=40, n_features=24, seed=4)
+    b.load_model(blob, 0)
+    # (1) request sharding: every rank ranks its own requests, scores are merged
+    lo, hi = shard_range(len(reqs), rank, world)
+    local = np.concatenate([b.rerank(ev)[1] for ev in reqs[lo:hi]]) if hi > lo else np.zeros(0)
+    # requests have equal sizes here, so item counts follow request counts
+    merged = all_gather_scores(torch.from_numpy(local))  # uneven shards: sizes are exchanged first
+    # (2) item sharding of ONE request (C4): assemble once (request-level reductions need all items),
+    #     score a contiguous chunk of rows per rank, merge
+    big = ranklens.generate_requests(1, 333, 600, 60, seed=10)[0]
+    m = b.matrix(big)
+    lo2, hi2 = shard_range(len(m), rank, world)
+    part = b.forest.predict(m[lo2:hi2])
+    merged2 = all_gather_scores(torch.from_numpy(part), [shard_range(len(m), r, world)[1] - shard_range(len(m), r, world)[0] for r in range(world)])
+    if rank == 0:
+        full = np.concatenate([b.rerank(ev)[1] for ev in reqs])
+        assert np.array_equal(merged.numpy(), full)
+        assert np.array_equal(merged2.numpy(), b.forest.predict(m))
+        print("DIST_OK", world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
