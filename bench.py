@@ -58,7 +58,8 @@ def main():
     n_gpus = max(world, 1)
 
     torch = dist = None
-    if n_gpus > 1:
+    use_dist = n_gpus > 1 or bool(os.environ.get("MRK_BENCH_FORCE_DIST"))  # the env var exercises the RCCL leg on 1 GPU
+    if use_dist:
         import torch
         import torch.distributed as dist
 
@@ -124,7 +125,7 @@ def main():
 
     # ---- multi-GPU merge buffers (scores of every rank) ----
     gather = None
-    if n_gpus > 1:
+    if use_dist:
         d_scores, _, _ = batch.device_outputs()
 
         class _Arr:  # __cuda_array_interface__ view of the library-owned score buffer

@@ -80,6 +80,16 @@ static void upload_model(mrk_ctx *ctx, mrk_model *m) {
   up(m->d_trees, m->packed.trees.data(), m->packed.trees.size() * sizeof(TreeRef));
   up(m->d_chunks, m->packed.chunks.data(), m->packed.chunks.size() * sizeof(ChunkRef));
   up(m->d_cat, m->forest.cat_bits.data(), m->forest.cat_bits.size() * 4);
+  m->qs = pack_forest_qs(m->forest, m->forest.n_features);
+  if (m->qs.ok) {
+    up(m->d_qs_nodes, m->qs.nodes.data(), m->qs.nodes.size() * 4);
+    up(m->d_qs_leaves, m->qs.leaves.data(), m->qs.leaves.size());
+    up(m->d_qs_thr, m->qs.thr.data(), m->qs.thr.size() * 8);
+    up(m->d_qs_feats, m->qs.feats.data(), m->qs.feats.size() * sizeof(QsFeature));
+    up(m->d_qs_views, m->qs.views.data(), m->qs.views.size() * sizeof(QsView));
+    up(m->d_qs_catnodes, m->qs.cat_nodes.data(), m->qs.cat_nodes.size() * sizeof(QsCatNode));
+    up(m->d_qs_cat, m->qs.cat_bits.data(), m->qs.cat_bits.size() * 4);
+  }
 }
 
 static mrk_model *make_model(mrk_ctx *ctx, int backend, const uint8_t *bytes, size_t len) {

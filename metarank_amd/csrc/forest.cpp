@@ -519,4 +519,142 @@ PackedForest pack_forest(const Forest &f, uint32_t chunk_bytes) {
   return pf;
 }
 
+// ------------------------------------------------------------------ bit-vector image (scorer "qs")
+
+PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
+  PackedForestQS pf;
+  auto fail = [&](const std::string &why) { pf.ok = false; pf.why = why; return pf; };
+  const bool f64 = f.backend == Backend::LightGBM;
+  pf.f64 = f64;
+  pf.n_trees = (int)f.trees.size();
+  const uint32_t leaf_sz = f64 ? 8 : 4;
+  int nf = std::max(n_cols, 0);
+  for (auto &t : f.trees) {
+    if (t.leaf.size() > (size_t)QS_LEAVES) return fail("a tree has more than 16 leaves");
+    if (t.feat.size() > (size_t)QS_SLOTS - 1) return fail("a tree has more than 15 internal nodes");
+    for (auto ft : t.feat) nf = std::max(nf, ft + 1);
+  }
+  if (f.trees.empty()) return fail("empty forest");
+  if (nf > 4096) return fail("more than 4096 columns");
+
+  // which view of its column a node reads
+  auto node_kind = [&](const Tree &t, size_t i) -> int {
+    const uint8_t fl = t.flags[i];
+    if (fl & NF_CATEGORICAL) return QV_CAT;
+    const bool dl = (fl & NF_DEFAULT_LEFT) != 0;
+    if (!f64) return dl ? QV_NAN_LEFT : QV_NAN_RIGHT;  // XGBoost: NaN is "missing"
+    // LightGBM Tree::NumericalDecision: MissingType None compares NaN as 0.0; Zero sends NaN and
+    // |x| <= kZeroThreshold to the default side; NaN sends NaN to the default side.
+    if (fl & NF_MISS_ZERO) return dl ? QV_MISS_LEFT : QV_MISS_RIGHT;
+    if (fl & NF_MISS_NAN) return dl ? QV_NAN_LEFT : QV_NAN_RIGHT;
+    return (0.0 <= t.thr[i]) ? QV_NAN_LEFT : QV_NAN_RIGHT;
+  };
+  std::vector<std::vector<double>> tabs(nf);
+  std::map<std::pair<int, int>, int> view_ids;  // (feature, kind) -> tile column; ordered => grouped by feature
+  for (auto &t : f.trees)
+    for (size_t i = 0; i < t.feat.size(); ++i) {
+      if (!(t.flags[i] & NF_CATEGORICAL)) {
+        if (t.thr[i] != t.thr[i]) return fail("NaN threshold");
+        tabs[t.feat[i]].push_back(t.thr[i]);
+      } else if ((uint64_t)t.cat_words[i] * 32 > QS_CAT_BEYOND) {
+        return fail("categorical bitset with more than 32765 categories");
+      }
+      view_ids.emplace(std::make_pair(t.feat[i], node_kind(t, i)), 0);
+    }
+  pf.feats.assign(nf, QsFeature{0, 0, 0, 0});
+  for (int ft = 0; ft < nf; ++ft) {
+    auto &v = tabs[ft];
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());  // -0.0 == +0.0: one entry, compared numerically on the device too
+    if (v.size() > 32766) return fail("more than 32766 distinct thresholds on one column");
+    pf.feats[ft].thr_off = (uint32_t)pf.thr.size();
+    pf.feats[ft].thr_len = (uint32_t)v.size();
+    pf.thr.insert(pf.thr.end(), v.begin(), v.end());
+  }
+  {
+    int id = 0, cur = -1;
+    for (auto &kv : view_ids) {
+      kv.second = id;
+      pf.views.push_back(QsView{(uint16_t)kv.first.first, (uint8_t)kv.first.second, 0});
+      if (kv.first.first != cur) {
+        pf.feats[kv.first.first].view_begin = (uint32_t)id;
+        cur = kv.first.first;
+      }
+      pf.feats[kv.first.first].view_end = (uint32_t)id + 1;
+      ++id;
+    }
+  }
+
+  if (pf.views.size() > (size_t)QS_MAX_VIEWS) return fail("more than 255 tile columns");
+  pf.nodes.assign((size_t)(pf.n_trees + 1) * QS_TREE_WORDS, 0);
+  pf.leaves.assign((size_t)pf.n_trees * QS_LEAVES * leaf_sz, 0);
+  std::vector<int> lo, hi;  // per internal node: leaf positions [lo, hi) of its left subtree
+  for (size_t ti = 0; ti < f.trees.size(); ++ti) {
+    const Tree &t = f.trees[ti];
+    const size_t ni = t.feat.size();
+    uint32_t *nd = pf.nodes.data() + ti * QS_TREE_WORDS;  // zero: mask 0 never changes the bit vector
+    uint8_t *lv = pf.leaves.data() + ti * QS_LEAVES * leaf_sz;
+    auto put_leaf = [&](int pos, double v) {
+      if (f64) memcpy(lv + (size_t)pos * 8, &v, 8);
+      else { float x = (float)v; memcpy(lv + (size_t)pos * 4, &x, 4); }
+    };
+    const uint32_t cat_first = (uint32_t)pf.cat_nodes.size();  // first categorical node of this tree
+    if (cat_first >= (1u << 24)) return fail("more than 2^24 categorical nodes");
+    nd[QS_SLOTS - 1] = cat_first;
+    if (ni == 0) {
+      put_leaf(0, t.leaf.empty() ? 0.0 : t.leaf[0]);
+      continue;
+    }
+    // left-to-right leaf positions by an explicit in-order walk (left subtree first)
+    lo.assign(ni, 0);
+    hi.assign(ni, 0);
+    int pos = 0;
+    std::vector<std::pair<int, int>> st{{0, 0}};  // (node, stage)
+    while (!st.empty()) {
+      const int n = st.back().first;
+      const int stage = st.back().second++;
+      if (stage == 0) {
+        lo[n] = pos;
+        const int c = t.left[n];
+        if (c >= 0) st.push_back({c, 0});
+        else put_leaf(pos++, t.leaf[~c]);
+      } else if (stage == 1) {
+        hi[n] = pos;
+        const int c = t.right[n];
+        if (c >= 0) st.push_back({c, 0});
+        else put_leaf(pos++, t.leaf[~c]);
+      } else {
+        st.pop_back();
+      }
+    }
+    uint32_t slot = 0, n_cat = 0;
+    for (size_t i = 0; i < ni; ++i) {
+      const int kind = node_kind(t, i);
+      const uint32_t view = (uint32_t)view_ids.at({t.feat[i], kind});
+      const uint32_t m = ((1u << hi[i]) - 1u) ^ ((1u << lo[i]) - 1u);
+      if (kind == QV_CAT) {
+        QsCatNode cn{};
+        cn.view_dl = view | (((t.flags[i] & NF_DEFAULT_LEFT) ? 1u : 0u) << 16);
+        cn.mm = m | (m << 16);
+        cn.bits_begin = (uint32_t)pf.cat_bits.size();
+        cn.bits_words = t.cat_words[i];
+        pf.cat_bits.insert(pf.cat_bits.end(), f.cat_bits.begin() + t.cat_begin[i],
+                           f.cat_bits.begin() + t.cat_begin[i] + t.cat_words[i]);
+        pf.cat_nodes.push_back(cn);
+        ++n_cat;
+        continue;
+      }
+      const double *t0 = pf.thr.data() + pf.feats[t.feat[i]].thr_off;
+      const double *t1 = t0 + pf.feats[t.feat[i]].thr_len;
+      const uint32_t kbin = (uint32_t)(std::lower_bound(t0, t1, t.thr[i]) - t0);
+      nd[slot] = kbin | (kbin << 16);
+      nd[QS_SLOTS + slot] = m | (view << 24);
+      ++slot;
+    }
+    nd[QS_SLOTS - 1] = cat_first | (n_cat << 24);
+  }
+  pf.ok = true;
+  return pf;
+}
+
 }  // namespace mrk

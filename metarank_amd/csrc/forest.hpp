@@ -104,4 +104,78 @@ struct PackedForest {
 
 PackedForest pack_forest(const Forest &f, uint32_t chunk_bytes);
 
+// --- bit-vector device image (scorer "qs") ---------------------------------------------------
+// For forests of small trees (<= 16 leaves: LightGBM's numLeaves default in Metarank,
+// config/BoosterConfig.scala:19-28) the scorer does not walk trees.  It evaluates EVERY internal
+// node of a tree with data that is uniform across the wavefront (thresholds and masks live in
+// scalar registers) and finds the exit leaf with the QuickScorer bit-vector rule
+// (Lucchese et al., SIGIR'15): leaves are numbered left to right, a node whose test is false
+// removes the leaves of its left subtree, and the exit leaf is the lowest leaf left.
+//
+// Binning makes every test one 16-bit integer compare.  With T_f the sorted distinct thresholds
+// the forest uses on feature f and bin(x) = #{t in T_f : t < x} (LightGBM, `x <= t` goes left) or
+// #{t : t <= x} (XGBoost, `x < t` goes left):   x (<=|<) T_f[k]  <=>  bin(x) <= k,  exactly.
+// Missing values are folded into the cell by giving a feature up to four "views" (columns of the
+// binned tile), one per way a node can treat a missing value; a node reads the view that matches
+// its own rule, so the kernel has no special cases:
+//   QV_NAN_RIGHT   NaN -> 0x7FFF (greater than every k: right)   else bin
+//   QV_NAN_LEFT    NaN -> 0      (<= every k: left)              else bin
+//   QV_MISS_RIGHT  NaN or 0.0 -> 0x7FFF   (LightGBM MissingType::Zero, default right)
+//   QV_MISS_LEFT   NaN or 0.0 -> 0        (LightGBM MissingType::Zero, default left)
+//   QV_CAT         the category id itself (one view per categorical column): 0..0x7FFC, 0x7FFD = a valid
+//                  category beyond every bitset, 0x7FFE = invalid (XGBoost: negative or >= 2^24),
+//                  0x7FFF = NaN (and, for LightGBM, negative)
+// Numerical node (2 dwords, read with scalar loads): {k | k << 16,  m | view << 24} where m (16 bits)
+// has bit p set for every leaf position p in the node's left subtree and the view index sits in
+// bits 24-31 (so that `word >> 16` is the view's byte offset in a tile of 128 rows).  A tree is two
+// arrays of QS_SLOTS dwords (all k words, all m/view words) and arrives in two s_load_dwordx16;
+// unused slots have m = 0 (no effect).  The last slot is never a node: its k word holds
+// `first categorical node | count << 24`.  Categorical nodes are rare (about one per
+// ten trees); they live in a side list {view | default_left << 16, m | m << 16, bitset begin, bitset
+// words} and are tested against their bitset one by one.  One all-zero tree is appended so that the
+// scorer's prefetch of "the next tree" never leaves the array.
+// Leaves are stored in left-to-right position order, QS_LEAVES per tree.
+constexpr int QS_SLOTS = 16;
+constexpr int QS_LEAVES = 16;
+constexpr int QS_TREE_WORDS = QS_SLOTS * 2;
+constexpr int QS_MAX_VIEWS = 255;
+constexpr uint16_t QS_RIGHT = 0x7FFF;
+enum QsViewKind : uint8_t { QV_NAN_RIGHT = 0, QV_NAN_LEFT = 1, QV_MISS_RIGHT = 2, QV_MISS_LEFT = 3, QV_CAT = 4 };
+
+constexpr uint16_t QS_CAT_BEYOND = 0x7FFD, QS_CAT_INVALID = 0x7FFE, QS_CAT_NAN = 0x7FFF;
+struct QsView {        // 4 B, one per column of the binned tile; grouped by feature
+  uint16_t feature;
+  uint8_t kind;        // QsViewKind
+  uint8_t pad;
+};
+struct QsCatNode {     // 16 B
+  uint32_t view_dl;    // view index | default_left << 16 (XGBoost: where NaN goes)
+  uint32_t mm;         // m | m << 16
+  uint32_t bits_begin; // first word of the bitset in PackedForestQS::cat_bits
+  uint32_t bits_words;
+};
+struct QsFeature {     // 16 B, one per matrix column
+  uint32_t thr_off, thr_len;       // sorted distinct thresholds of this column in PackedForestQS::thr
+  uint32_t view_begin, view_end;   // its views
+};
+
+struct PackedForestQS {
+  bool ok = false;   // false: the forest does not fit this format; the tree-walk kernel is used
+  std::string why;
+  bool f64 = true;
+  int n_trees = 0;
+  std::vector<uint32_t> nodes;   // (n_trees + 1) * QS_SLOTS * 2
+  std::vector<uint8_t> leaves;   // n_trees * QS_LEAVES * (8 | 4)
+  std::vector<double> thr;
+  std::vector<QsFeature> feats;  // n_features
+  std::vector<QsView> views;
+  std::vector<QsCatNode> cat_nodes;
+  std::vector<uint32_t> cat_bits;
+  size_t device_bytes() const {
+    return nodes.size() * 4 + leaves.size() + thr.size() * 8 + feats.size() * 16 + views.size() * 4 + cat_nodes.size() * 16 + cat_bits.size() * 4;
+  }
+};
+
+PackedForestQS pack_forest_qs(const Forest &f, int n_cols);
+
 }  // namespace mrk

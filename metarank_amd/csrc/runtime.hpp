@@ -100,6 +100,7 @@ struct mrk_ctx {
   std::mutex mu;  // serialises stream use + scratch buffers (one in-flight call per ctx)
   // scratch for predict_f64
   mrk::DevBuf d_x, d_out, d_flag;
+  mrk::DevBuf d_cells;  // binned tile of the bit-vector scorer (score_qs.hip), grow-only
   mrk::PinBuf h_flag;
   // profiling
   bool profile = false;
@@ -119,6 +120,9 @@ struct mrk_model {
   mrk::PackedForest packed;
   std::vector<std::string> container_features;
   mrk::DevBuf d_image, d_trees, d_chunks, d_cat;
+  // bit-vector image (forests of <= 16-leaf trees); qs.ok == false => tree-walk kernel only
+  mrk::PackedForestQS qs;
+  mrk::DevBuf d_qs_nodes, d_qs_leaves, d_qs_thr, d_qs_feats, d_qs_views, d_qs_catnodes, d_qs_cat;
 };
 
 namespace mrk {
@@ -143,5 +147,8 @@ void free_rank_state(mrk_ctx *ctx);
 void launch_score(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                   int *d_flag);
 uint32_t score_chunk_budget();
+// score_qs.hip: false => not applicable, use the tree-walk kernel
+bool launch_score_qs(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
+                     const uint32_t *d_row_req);
 
 }  // namespace mrk

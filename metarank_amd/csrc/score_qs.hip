@@ -1,0 +1,461 @@
+// Bit-vector forest scorer for gfx950 (CDNA4): Booster.predictMat for forests of small trees
+// (<= 16 leaves, LightGBM's numLeaves default in Metarank, config/BoosterConfig.scala:19-28).
+// Reference call site: ml/rank/LambdaMARTRanker.scala:348; arithmetic: lib_lightgbm / libxgboost
+// (SURVEY.md §8c).  Format and the exactness argument: forest.hpp ("qs" image).
+//
+// Two kernels:
+//   qs_bin_kernel    f64 matrix -> u16 cells, one column ("view") per (column, missing rule) pair,
+//                    laid out [wave tile][view][row] so that the scorer's tile is one contiguous slab.
+//   qs_score_kernel  one wavefront owns R*64 rows; its slab sits in LDS.  For every tree ALL node
+//                    tests are evaluated: node constants come from scalar loads (they are uniform
+//                    across the wave), the cells of R rows per lane come from one conflict-free LDS
+//                    read, and two rows share each VALU op (v_pk_sub_i16 / v_pk_ashrrev_i16 /
+//                    v_and_or_b32 on 16-bit halves).  No branches, no dependent loads: the tree walk's
+//                    latency chain is gone.  Leaves are added in tree order in f64 (LightGBM) / f32
+//                    (XGBoost), the same additions the libraries make: scores are bit-identical.
+//
+// No MFMA: compare/index work.  Bound: VALU issue (about 1.75 ops per row-node), then LDS reads.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "runtime.hpp"
+
+namespace mrk {
+
+namespace {
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+constexpr int QS_WAVES = 4;  // wavefronts per workgroup (they share the staged leaf values)
+
+// ---------------------------------------------------------------------------------- binning
+
+template <bool F64>
+__global__ void __launch_bounds__(256)
+qs_bin_kernel(const double *__restrict__ X, int rows, int cols, const QsFeature *__restrict__ feats, int n_feats,
+              const QsView *__restrict__ views, const double *__restrict__ thr,
+              uint16_t *__restrict__ cells, int V, int tile_rows, long long padded_rows, int *__restrict__ flag,
+              const uint32_t *__restrict__ row_req) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= padded_rows) return;
+  const long long tile = row / tile_rows;
+  const int r = (int)(row - tile * tile_rows);
+  uint16_t *dst = cells + (size_t)tile * V * tile_rows + r;
+  const bool valid = row < rows;
+  const double *xr = X + (valid ? row : 0) * cols;
+  const int nf = n_feats < cols ? n_feats : cols;
+  for (int c = 0; c < nf; ++c) {
+    const QsFeature ft = feats[c];  // uniform: scalar loads
+    if (ft.view_begin == ft.view_end) continue;
+    double x = xr[c];
+    if constexpr (F64) {
+      // LightGBM RowFunctionFromDenseMatric keeps a cell only if |x| > kZeroThreshold (1e-35f) or NaN
+      const double kZero = (double)1e-35f;
+      x = (fabs(x) > kZero || x != x) ? x : 0.0;
+    } else {
+      // ltrlib narrows Double -> Float before DMatrix; XGBoost rejects +-inf ("Input data contains `inf`")
+      const float f = (float)x;
+      if (valid && __builtin_isinf(f)) {
+        if (row_req) atomicOr(flag + row_req[row], 32);
+        else atomicOr(flag, 1);
+      }
+      x = (double)f;
+    }
+    const bool isn = x != x;
+    const bool isz = x == 0.0;
+    // bin = number of thresholds strictly below x (LightGBM) / not above x (XGBoost)
+    uint32_t pos = 0;
+    if (ft.thr_len) {
+      const double *T = thr + ft.thr_off;
+      uint32_t step = 1u << (31 - __builtin_clz(ft.thr_len));
+      for (; step > 0; step >>= 1) {
+        const uint32_t p = pos + step;
+        if (p <= ft.thr_len) {
+          const double t = T[p - 1];
+          const bool below = F64 ? (t < x) : (t <= x);
+          pos = below ? p : pos;
+        }
+      }
+    }
+    for (uint32_t v = ft.view_begin; v < ft.view_end; ++v) {
+      const QsView vw = views[v];
+      uint32_t cell;
+      if (vw.kind == QV_CAT) {
+        // the category id; the node's bitset is consulted by the scorer
+        if (isn) cell = QS_CAT_NAN;
+        else if constexpr (F64) {
+          // LightGBM Tree::CategoricalDecision: int(fval) < 0 goes right, like NaN
+          const int iv = (int)x;  // v_cvt_i32_f64 saturates
+          cell = iv < 0 ? (uint32_t)QS_CAT_NAN : (iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv);
+        } else {
+          // XGBoost common::Decision: negative or >= 2^24 is an invalid category (goes left)
+          if (x < 0.0 || x >= 16777216.0) cell = QS_CAT_INVALID;
+          else {
+            const int iv = (int)x;
+            cell = iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv;
+          }
+        }
+      } else {
+        const bool miss = (vw.kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
+        const uint32_t mval = (vw.kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
+        cell = miss ? mval : pos;
+      }
+      dst[(size_t)v * tile_rows] = valid ? (uint16_t)cell : (uint16_t)0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- scoring
+
+// categorical nodes of one tree (rare path): the cell is the category id, tested against the node's bitset
+template <bool F64>
+__device__ __forceinline__ uint32_t qs_cat_pair(const QsCatNode &cn, uint32_t cc, const uint32_t *__restrict__ cat_bits) {
+  const bool dl = (cn.view_dl >> 16) != 0;
+  uint32_t removed = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t cat = (cc >> (16 * h)) & 0xffffu;
+    const uint32_t w = cat >> 5;
+    bool in = false;
+    if (cat < QS_CAT_BEYOND && w < cn.bits_words) in = (cat_bits[cn.bits_begin + w] >> (cat & 31)) & 1u;
+    bool right;
+    if constexpr (F64) right = !in;  // LightGBM: member -> left; NaN / negative / unknown -> right
+    else right = cat == QS_CAT_NAN ? !dl : in;  // XGBoost: member -> right; invalid / unknown -> left
+    if (right) removed |= cn.mm & (0xffffu << (16 * h));
+  }
+  return removed;
+}
+
+// Generic kernel: QS_WAVES wavefronts per workgroup share LDS-staged leaf chunks; R = 2, 4 or 8 rows per lane.
+template <bool F64, int R>
+__global__ void __launch_bounds__(QS_WAVES * 64)
+qs_score_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restrict__ leaves,
+                const QsCatNode *__restrict__ cat_nodes, const uint32_t *__restrict__ cat_bits,
+                const uint16_t *__restrict__ cells, int n_trees, int V, int rows, long long n_tiles, double base,
+                double *__restrict__ out, int chunk_trees) {
+  constexpr int LS = F64 ? 8 : 4;               // bytes per leaf
+  constexpr int TREE_LEAF_BYTES = QS_LEAVES * LS;
+  constexpr int VIEW_BYTES = R * 64 * 2;        // one view of one wave tile
+  constexpr int VIEW_SHIFT = R == 8 ? 2 : (R == 4 ? 1 : 0);  // the node word carries view * 256
+  static_assert(R == 2 || R == 4 || R == 8, "rows per lane");
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t leaf_cap = (uint32_t)chunk_trees * TREE_LEAF_BYTES;
+  const long long tile = (long long)blockIdx.x * QS_WAVES + wave;
+  const uint32_t tile_off = leaf_cap + (uint32_t)wave * (uint32_t)V * VIEW_BYTES;
+
+  // stage this wave's slab: V views x R*64 cells, contiguous in HBM
+  if (tile < n_tiles) {
+    const uint4 *src = (const uint4 *)(cells + (size_t)tile * V * (R * 64));
+    uint4 *dst = (uint4 *)(smem + tile_off);
+    const int n16 = V * (VIEW_BYTES / 16);
+    for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+  }
+
+  const uint32_t lane_off = tile_off + (uint32_t)lane * (R * 2);
+  double acc64[R];
+  float acc32[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) { acc64[j] = 0.0; acc32[j] = (float)base; }
+
+  for (int t0 = 0; t0 < n_trees; t0 += chunk_trees) {
+    const int nt = min(chunk_trees, n_trees - t0);
+    __syncthreads();  // previous leaf chunk consumed
+    {
+      const uint4 *src = (const uint4 *)(leaves + (size_t)t0 * TREE_LEAF_BYTES);
+      uint4 *dst = (uint4 *)smem;
+      const int n16 = nt * (TREE_LEAF_BYTES / 16);
+      for (int i = tid; i < n16; i += QS_WAVES * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t *nd = nodes + (size_t)t0 * QS_TREE_WORDS;
+    for (int t = 0; t < nt; ++t, nd += QS_TREE_WORDS) {
+      uint32_t accn[R / 2];
+#pragma unroll
+      for (int p = 0; p < R / 2; ++p) accn[p] = 0;
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; ++s) {
+        const uint32_t kk = nd[s];             // k | k << 16        (scalar)
+        const uint32_t mv = nd[QS_SLOTS + s];  // m | view << 24     (scalar)
+        const uint32_t mm = (mv & 0xffffu) * 0x10001u;
+        const uint32_t addr = ((mv >> 16) << VIEW_SHIFT) + lane_off;  // v_lshl_add_u32
+        uint32_t c[R / 2];
+        if constexpr (R == 2) {
+          c[0] = *(const uint32_t *)(smem + addr);
+        } else if constexpr (R == 4) {
+          const uint2 q = *(const uint2 *)(smem + addr);
+          c[0] = q.x; c[1] = q.y;
+        } else {
+          const uint4 q = *(const uint4 *)(smem + addr);
+          c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
+        }
+#pragma unroll
+        for (int p = 0; p < R / 2; ++p) {
+          const short2v d = __builtin_bit_cast(short2v, kk) - __builtin_bit_cast(short2v, c[p]);  // < 0 <=> cell > k
+          const short2v sg = d >> 15;                                                            // 0xFFFF where the test is false
+          accn[p] |= __builtin_bit_cast(uint32_t, sg) & mm;
+        }
+      }
+      const uint32_t catw = nd[QS_SLOTS - 1];
+      if (catw >> 24) {
+        const QsCatNode *cn = cat_nodes + (catw & 0xffffffu);
+        for (uint32_t j = 0; j < (catw >> 24); ++j) {
+          const QsCatNode c = cn[j];  // scalar
+          const uint32_t addr = ((c.view_dl & 0xffffu) << (8 + VIEW_SHIFT)) + lane_off;
+#pragma unroll
+          for (int p = 0; p < R / 2; ++p) accn[p] |= qs_cat_pair<F64>(c, *(const uint32_t *)(smem + addr + 4 * p), cat_bits);
+        }
+      }
+      // exit leaf = lowest position not removed; position nl-1 is in no left subtree, so a zero bit exists
+      const uint32_t lbase = (uint32_t)t * TREE_LEAF_BYTES;
+#pragma unroll
+      for (int p = 0; p < R / 2; ++p) {
+        const uint32_t inv = ~accn[p];
+        const uint32_t l0 = (uint32_t)__builtin_ctz(inv);
+        const uint32_t l1 = (uint32_t)__builtin_ctz(inv >> 16);
+        if constexpr (F64) {
+          acc64[2 * p] += *(const double *)(smem + lbase + l0 * 8u);
+          acc64[2 * p + 1] += *(const double *)(smem + lbase + l1 * 8u);
+        } else {
+          acc32[2 * p] += *(const float *)(smem + lbase + l0 * 4u);
+          acc32[2 * p + 1] += *(const float *)(smem + lbase + l1 * 4u);
+        }
+      }
+    }
+  }
+  if (tile < n_tiles) {
+    const long long row0 = tile * (R * 64) + (long long)lane * R;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (row0 + j < rows) out[row0 + j] = F64 ? acc64[j] : (double)acc32[j];
+  }
+}
+
+// One-wavefront workgroups, two rows per lane (the default).  Scalar (SMEM) loads and LDS reads share one
+// counter (lgkmcnt) and SMEM returns out of order, so any wait for an LDS result while a scalar load is in
+// flight drains the scalar load too.  The loop keeps the two apart:
+//   A  issue the 15 cell reads of tree t: `ds_read_addtid_b32` (LDS address = M0 + 4 * lane), M0 set by the
+//      scalar unit, so a read costs no VALU op and no address VGPR
+//   B  wait for them (the one explicit s_waitcnt: the reads are inline asm, invisible to the compiler's
+//      wait-count pass - cdna_hip_programming.md §5.7)
+//   C  issue the scalar loads of tree t+1's node constants          <- nothing else outstanding
+//   D  pure VALU: 15 x {v_pk_sub_i16, v_pk_ashrrev_i16, v_and_or_b32}, the exit leaf, the leaf adds of
+//      tree t-2; then the global loads of tree t's two leaf values (L1/L2 resident, on vmcnt)
+// so the scalar-load latency of the next tree hides behind D and behind the other waves of the SIMD.
+// No LDS leaf chunks and no barriers: a workgroup's LDS footprint is its V x 256 B slab, so occupancy is
+// 160 KB / (V x 256 B) waves per CU at wave granularity.
+struct QsNodeRegs {
+  uint32_t kk[QS_SLOTS], mv[QS_SLOTS];  // kk[QS_SLOTS-1] = categorical word
+};
+
+__device__ __forceinline__ void qs_load_nodes(QsNodeRegs &r, const uint32_t *__restrict__ nd) {
+#pragma unroll
+  for (int s = 0; s < QS_SLOTS; ++s) {
+    r.kk[s] = nd[s];
+    r.mv[s] = nd[QS_SLOTS + s];
+  }
+}
+
+template <bool F64>
+__global__ void __launch_bounds__(64)
+qs_score_wave_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restrict__ leaves,
+                     const QsCatNode *__restrict__ cat_nodes, const uint32_t *__restrict__ cat_bits,
+                     const uint16_t *__restrict__ cells, int n_trees, int V, int rows, double base,
+                     double *__restrict__ out) {
+  constexpr int R = 2;
+  constexpr int LS = F64 ? 8 : 4;
+  constexpr int TREE_LEAF_BYTES = QS_LEAVES * LS;
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const long long tile = blockIdx.x;
+  {
+    const uint4 *src = (const uint4 *)(cells + (size_t)tile * V * (R * 64));
+    uint4 *dst = (uint4 *)smem;
+    const int n16 = V * 16;
+    for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // slab written (one wave: its LDS ops complete in order)
+  double acc64[R] = {0.0, 0.0};
+  float acc32[R] = {(float)base, (float)base};
+
+  // one pipeline step for tree t: `cur` holds its node constants, `nxt` receives tree t+1's; `lv*` holds
+  // the leaf values of tree t-2 (added here) and then receives those of tree t
+  auto step = [&](QsNodeRegs &cur, QsNodeRegs &nxt, const uint32_t *__restrict__ nd_next, const uint8_t *__restrict__ lv_tree,
+                  double (&lv64)[R], float (&lv32)[R]) {
+    // A: cell reads, M0 = view * 256.  A DS add-TID instruction needs one wait state after an M0 write;
+    // the slot is filled with the s_pack_ll_b32_b16 that replicates the node's mask for phase D.
+    uint32_t c[QS_SLOTS - 1], mm[QS_SLOTS - 1];
+#pragma unroll
+    for (int s = 0; s < QS_SLOTS - 1; ++s)
+      asm volatile("s_lshr_b32 m0, %2, 16\n\ts_pack_ll_b32_b16 %1, %2, %2\n\tds_read_addtid_b32 %0"
+                   : "=v"(c[s]), "=s"(mm[s]) : "s"(cur.mv[s]) : "memory");
+    // B
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    // C
+    qs_load_nodes(nxt, nd_next);
+    __builtin_amdgcn_sched_barrier(0);
+    // D
+    // (all subtracts, then all shifts, then the mask accumulate on two chains: no VALU op waits on its predecessor)
+#pragma unroll
+    for (int s = 0; s < QS_SLOTS - 1; ++s)
+      c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, cur.kk[s]) - __builtin_bit_cast(short2v, c[s]));  // < 0 <=> cell > k
+#pragma unroll
+    for (int s = 0; s < QS_SLOTS - 1; ++s)
+      c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, c[s]) >> 15);  // 0xFFFF where the test is false
+    uint32_t acc_a = 0, acc_b = 0;
+#pragma unroll
+    for (int s = 0; s < QS_SLOTS - 1; s += 2) {
+      asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_a) : "v"(c[s]), "s"(mm[s]));
+      if (s + 1 < QS_SLOTS - 1) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_b) : "v"(c[s + 1]), "s"(mm[s + 1]));
+    }
+    uint32_t accn = acc_a | acc_b;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // tree t-2's leaves (-0.0 for the first two trees: x + -0.0 == x, bit for bit)
+      if constexpr (F64) acc64[j] += lv64[j];
+      else acc32[j] += lv32[j];
+    }
+    const uint32_t catw = cur.kk[QS_SLOTS - 1];
+    if (catw >> 24) {
+      const QsCatNode *cn = cat_nodes + (catw & 0xffffffu);
+      for (uint32_t j = 0; j < (catw >> 24); ++j) {
+        const QsCatNode cnode = cn[j];
+        accn |= qs_cat_pair<F64>(cnode, *(const uint32_t *)(smem + ((cnode.view_dl & 0xffffu) << 8) + lane * 4), cat_bits);
+      }
+    }
+    // exit leaf = lowest position not removed; position nl-1 is in no left subtree, so a zero bit exists
+    const uint32_t inv = ~accn;
+    const uint32_t o0 = (uint32_t)__builtin_ctz(inv) * LS;
+    const uint32_t o1 = (uint32_t)__builtin_ctz(inv >> 16) * LS;
+    if constexpr (F64) {
+      lv64[0] = *(const double *)(lv_tree + o0);
+      lv64[1] = *(const double *)(lv_tree + o1);
+    } else {
+      lv32[0] = *(const float *)(lv_tree + o0);
+      lv32[1] = *(const float *)(lv_tree + o1);
+    }
+  };
+
+  QsNodeRegs ra, rb;
+  qs_load_nodes(ra, nodes);
+  double la64[R] = {-0.0, -0.0}, lb64[R] = {-0.0, -0.0};
+  float la32[R] = {-0.f, -0.f}, lb32[R] = {-0.f, -0.f};
+  const uint32_t *nd = nodes;      // the array ends with one all-zero tree: the last prefetch stays in bounds
+  const uint8_t *lt = leaves;
+  for (int t = 0; t < n_trees; t += 2) {
+    step(ra, rb, nd + QS_TREE_WORDS, lt, la64, la32);
+    if (t + 1 < n_trees) step(rb, ra, nd + 2 * QS_TREE_WORDS, lt + TREE_LEAF_BYTES, lb64, lb32);
+    nd += 2 * QS_TREE_WORDS;
+    lt += 2 * TREE_LEAF_BYTES;
+  }
+  // drain: the last two trees' leaves, in tree order
+  const bool odd = n_trees & 1;
+  if (odd) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) { if constexpr (F64) acc64[j] += lb64[j]; else acc32[j] += lb32[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) { if constexpr (F64) acc64[j] += la64[j]; else acc32[j] += la32[j]; }
+  if (!odd) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) { if constexpr (F64) acc64[j] += lb64[j]; else acc32[j] += lb32[j]; }
+  }
+  const long long row0 = tile * (R * 64) + (long long)lane * R;
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (row0 + j < rows) out[row0 + j] = F64 ? acc64[j] : (double)acc32[j];
+}
+
+template <bool F64, int R>
+void launch_qs_t(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
+                 const uint32_t *d_row_req, int chunk_trees, size_t smem) {
+  const PackedForestQS &q = m->qs;
+  const int V = (int)q.views.size();
+  const int tile_rows = R * 64;
+  const long long n_tiles = ((long long)rows + tile_rows - 1) / tile_rows;
+  const long long padded = n_tiles * tile_rows;
+  ctx->d_cells.reserve((size_t)padded * V * 2);
+  {
+    ScopedKernelTimer timer(ctx, "bin");
+    const int grid = (int)((padded + 255) / 256);
+    hipLaunchKernelGGL(qs_bin_kernel<F64>, dim3(grid), dim3(256), 0, ctx->stream, d_x, rows, cols,
+                       m->d_qs_feats.as<QsFeature>(), (int)q.feats.size(), m->d_qs_views.as<QsView>(),
+                       m->d_qs_thr.as<double>(), ctx->d_cells.as<uint16_t>(), V, tile_rows,
+                       padded, d_flag, d_row_req);
+    MRK_HIP(hipGetLastError());
+  }
+  static const int variant = [] { const char *e = getenv("MRK_QS_KERNEL"); return e ? atoi(e) : 1; }();
+  if (R == 2 && variant == 1) {
+    auto wk = qs_score_wave_kernel<F64>;
+    static thread_local const void *wconfigured = nullptr;
+    if (wconfigured != (const void *)wk) {
+      MRK_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      wconfigured = (const void *)wk;
+    }
+    ScopedKernelTimer timer(ctx, "score");
+    hipLaunchKernelGGL(wk, dim3((unsigned)n_tiles), dim3(64), (size_t)V * 256, ctx->stream, m->d_qs_nodes.as<uint32_t>(),
+                       m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(),
+                       ctx->d_cells.as<uint16_t>(), q.n_trees, V, rows, m->forest.base_score, d_out);
+    MRK_HIP(hipGetLastError());
+    return;
+  }
+  auto kern = qs_score_kernel<F64, R>;
+  static thread_local const void *configured = nullptr;
+  if (configured != (const void *)kern) {
+    MRK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    configured = (const void *)kern;
+  }
+  ScopedKernelTimer timer(ctx, "score");
+  const int grid = (int)((n_tiles + QS_WAVES - 1) / QS_WAVES);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(QS_WAVES * 64), smem, ctx->stream, m->d_qs_nodes.as<uint32_t>(),
+                     m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(),
+                     ctx->d_cells.as<uint16_t>(), q.n_trees, V, rows, n_tiles,
+                     m->forest.base_score, d_out, chunk_trees);
+  MRK_HIP(hipGetLastError());
+}
+
+template <bool F64>
+bool launch_qs_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
+                 const uint32_t *d_row_req) {
+  const PackedForestQS &q = m->qs;
+  const size_t V = q.views.size();
+  const int leaf_bytes = QS_LEAVES * (F64 ? 8 : 4);
+  static const int chunk_kb = [] { const char *e = getenv("MRK_QS_CHUNK_KB"); return e ? std::max(1, atoi(e)) : 8; }();
+  const int chunk_trees = std::min(q.n_trees, chunk_kb * 1024 / leaf_bytes);
+  const size_t leaf_cap = (size_t)chunk_trees * leaf_bytes;
+  auto smem = [&](int r) { return leaf_cap + (size_t)QS_WAVES * V * r * 128; };
+  const size_t budget = 160 * 1024;
+  static const int forced = [] { const char *e = getenv("MRK_QS_R"); return e ? atoi(e) : 0; }();
+  // More rows per lane amortise the address op and the LDS read; fewer rows per lane leave room for a
+  // second workgroup per CU and cut the tail when there are few rows.
+  int r = 0;
+  if (forced == 2 || forced == 4 || forced == 8) r = smem(forced) <= budget ? forced : 0;
+  if (!r) {
+    const long long cu_rows = (long long)ctx->n_cus * QS_WAVES * 64;
+    if (smem(4) <= budget / 2 && rows >= 4 * cu_rows) r = 4;
+    else if (smem(2) <= budget) r = 2;
+  }
+  if (!r) return false;
+  if (r == 8) launch_qs_t<F64, 8>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_trees, smem(8));
+  else if (r == 4) launch_qs_t<F64, 4>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_trees, smem(4));
+  else launch_qs_t<F64, 2>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_trees, smem(2));
+  return true;
+}
+
+}  // namespace
+
+// Returns false when the model has no bit-vector image or its tile does not fit LDS: the caller
+// falls back to the tree-walk kernel (score.hip).  Both produce identical bits.
+bool launch_score_qs(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
+                     const uint32_t *d_row_req) {
+  if (!m->qs.ok) return false;
+  if (m->forest.backend == Backend::LightGBM) return launch_qs_b<true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req);
+  return launch_qs_b<false>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req);
+}
+
+}  // namespace mrk

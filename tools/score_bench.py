@@ -1,5 +1,6 @@
 """Micro-benchmark of the scorer alone (device-resident matrix): items/s and node visits/s."""
 import ctypes as C
+import os
 import sys
 import time
 
@@ -19,7 +20,8 @@ X = rng.normal(size=(rows, cols))
 q = [np.quantile(X[:, j], np.linspace(0.02, 0.98, 49)) for j in range(cols)]
 ctx = M.Context(0)
 if kind == "lgbm":
-    b = M.HipBooster(synth.synthetic_lgbm_model(n_trees=ntrees, n_features=cols, quantiles=q), M.LIGHTGBM, ctx)
+    b = M.HipBooster(synth.synthetic_lgbm_model(n_trees=ntrees, n_features=cols, quantiles=q, missing=os.environ.get("MISSING", "per_feature"),
+                                                cat_features=[7], cat_prob=0.007), M.LIGHTGBM, ctx)
 else:
     b = M.HipBooster(synth.synthetic_xgb_model(n_trees=ntrees, n_features=cols, depth=6, quantiles=q), M.XGBOOST, ctx)
 print(b.info())
@@ -40,5 +42,6 @@ for _ in range(K):
 ctx.sync()
 dt = (time.perf_counter() - t0) / K
 ms, n = ctx.profile_get("score")
-print(f"rows={rows} cols={cols} {kind} trees={ntrees}: wall {dt*1e3:.3f} ms/launch, event {ms/n:.3f} ms/launch, "
-      f"{rows/dt/1e6:.1f} M items/s")
+bms, bn = ctx.profile_get("bin")
+print(f"rows={rows} cols={cols} {kind} trees={ntrees} R={os.environ.get('MRK_QS_R')} scorer={os.environ.get('MRK_SCORER')}: "
+      f"wall {dt*1e3:.3f} ms/launch, score {ms/n:.3f} ms, bin {bms/max(bn,1):.3f} ms, {rows/dt/1e6:.1f} M items/s")
