@@ -5,7 +5,8 @@
 
 A "step" is one pass of the hot path over one batch of synthetic Ranklens-shaped requests that is
 already resident in HBM: pre-pass -> assemble -> score -> sort for `--requests` requests of
-`--items` candidate items each (default 4096 x 100 = 409 600 items per GPU per step).  Workload =
+`--items` candidate items each (default 3840 x 100 = 384 000 items per GPU per step: 3000 scorer
+wavefronts of 128 items, one resident round on 256 CUs x 12 waves).  Workload =
 the configuration BASELINE.json's metric is quoted on: 100-item requests, the 24 Ranklens columns
 (stock Ranklens model), 500-tree LightGBM-format LambdaMART.  Weak scaling: every rank owns a
 replica of the feature store and its own requests; for N > 1 the per-step scores are merged with
@@ -41,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--requests", type=int, default=4096, help="requests per step per GPU")
+    ap.add_argument("--requests", type=int, default=3840, help="requests per step per GPU")
     ap.add_argument("--items", type=int, default=100, help="candidate items per request")
     ap.add_argument("--catalogue", type=int, default=100_000)
     ap.add_argument("--sessions", type=int, default=10_000)
@@ -114,7 +115,8 @@ def main():
     _, _, sm = sample.fetch(matrix=True)
     sample.close()
     blob = synth.synthetic_lgbm_model(n_trees=args.trees, n_features=dim, num_leaves=16, max_depth=8,
-                                      quantiles=ranklens.column_quantiles(sm), cat_features=[7], cat_prob=0.007)  # ~ one categorical split per 10 trees
+                                      quantiles=ranklens.column_quantiles(sm), cat_features=[7], cat_prob=0.007,  # ~ one categorical split per 10 trees
+                                      missing="per_feature")  # one missing type per column, as LightGBM's bin mappers produce
     booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
     info = booster.info()
     t0 = time.perf_counter()
@@ -181,7 +183,7 @@ def main():
         batch.run(booster)
     ctx.sync()
     kernels = {}
-    for k in ("prepass", "assemble", "override", "score", "sort"):
+    for k in ("prepass", "assemble", "override", "bin", "score", "sort"):
         ms, n = ctx.profile_get(k)
         if n:
             kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / prof_steps}
@@ -191,6 +193,7 @@ def main():
     store_bytes_item = 8 * dim + 48           # one record worth of cells + ~12 list tokens
     alg = {
         "score": total_items * (8 * dim + 8) + info["device_bytes"],
+        "bin": total_items * (8 * dim + 2 * 2 * dim),   # f64 row in, ~2 u16 views per column out
         "assemble": total_items * (store_bytes_item + 8 + 8 * dim),
         "prepass": args.requests * (100 * 12 * 4 + 20 * 11 * 4),
         "sort": total_items * (8 + 4),
@@ -201,8 +204,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg[dominant],
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
-                "note": "tree walk is LDS/VALU-issue bound, not HBM bound (SURVEY.md 8d): "
-                        f"{total_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G tree-walks/s"}
+                "note": "the forest scorer is VALU-issue bound, not HBM bound (SURVEY.md 8d): "
+                        f"{total_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G item-trees/s "
+                        f"in {kernels['score']['avg_ms']:.3f} ms"}
 
     # ---- single-request latency (p50 of mrk_rank: host marshalling + 4 launches + copies)
     latency = None
