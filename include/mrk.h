@@ -186,7 +186,11 @@ int mrk_batch_total_items(mrk_batch *batch);
 /* asynchronous on the context stream */
 int mrk_batch_run(mrk_batch *batch, mrk_model *model);
 /* device pointers of the batch outputs (valid until mrk_batch_free): scores f64[total_items],
- * order i32[total_items] (request-local indices), matrix f64[total_items*dim] */
+ * order i32[total_items] (request-local indices), matrix f64[total_items*dim].
+ * The f64 matrix (ClickthroughQuery's layout) is materialised on demand only: with a LightGBM /
+ * XGBoost model of <= 16-leaf trees the assembled values go straight into the scorer's binned
+ * tile.  Asking for d_matrix here makes every later mrk_batch_run of this batch write it;
+ * mrk_batch_fetch(out_matrix != NULL) and mrk_rank(out_matrix != NULL) materialise it for that call. */
 int mrk_batch_device_outputs(mrk_batch *batch, double **d_scores, int32_t **d_order, double **d_matrix);
 /* copy results to host (synchronises); any pointer may be NULL */
 int mrk_batch_fetch(mrk_batch *batch, double *out_scores, int32_t *out_order, double *out_matrix);

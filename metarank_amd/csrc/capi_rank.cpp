@@ -1,7 +1,10 @@
 // Feature store + rank entry points of the C ABI (include/mrk.h).
 #include <cstring>
 
+#include <cstdlib>
+
 #include "features.hpp"
+#include "qs_device.hpp"
 #include "rank.hpp"
 #include "runtime.hpp"
 
@@ -12,6 +15,13 @@ void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
 void launch_sort(mrk_ctx *ctx, const BatchDev &b);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
+void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
+                           uint16_t *cells, bool f64);
+void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
+                       int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64);
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap);
+int fused_max_prep();
+QsDev qs_device_view(const mrk_model *m);
 
 void free_rank_state(mrk_ctx *ctx) {
   delete ctx->registry;
@@ -62,10 +72,18 @@ struct mrk_batch {
   const Program *prog = nullptr;
   int n_req = 0, total_items = 0;
   DevBuf d_in, d_prep_out, d_arena, d_status, d_matrix, d_scores, d_order;
+  DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
   PinBuf h_in;
   BatchDev view{};
   std::vector<int32_t> h_status;
   bool ran = false;
+  // one-workgroup-per-request path (tables in LDS)
+  bool fused_ok = false;
+  uint32_t fused_entries = 0;
+  int fused_vals = 1, fused_threads = 64;
+  // the f64 matrix is materialised only on demand (explain / parity / models without a bit-vector image)
+  bool want_matrix = false;
+  bool matrix_valid = false;
 };
 
 namespace mrk {
@@ -131,6 +149,16 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   v.order = (int32_t *)b.d_order.p;
   b.h_status.assign(n_req, 0);
   b.ran = false;
+  b.matrix_valid = false;
+  // small requests: both phases in one workgroup, tables in LDS (<= 64 KB keeps two workgroups per CU)
+  uint32_t vals = 1;
+  while ((int)vals < hb.max_doubles) vals <<= 1;
+  b.fused_entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
+  b.fused_vals = (int)vals;
+  b.fused_threads = std::min(256, std::max(64, (hb.max_items + 63) / 64 * 64));
+  static const bool fused_enabled = [] { const char *e = getenv("MRK_RANK_FUSED"); return !e || atoi(e) != 0; }();
+  b.fused_ok = fused_enabled && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
+               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals) <= 64 * 1024;
 }
 
 static void check_model_fits(mrk_model *model, const Program &prog) {
@@ -144,6 +172,18 @@ static void check_model_fits(mrk_model *model, const Program &prog) {
                                                 "' has " + std::to_string(prog.dim) + " columns");
 }
 
+// pre-pass + assembly into the row-major f64 matrix (ClickthroughQuery's layout); ctx->mu must be held
+static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &pd) {
+  mrk_ctx *ctx = b.ctx;
+  if (b.fused_ok) {
+    launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, nullptr, nullptr, true);
+  } else {
+    launch_prepass(ctx, st, pd, b.view);
+    launch_assemble(ctx, st, pd, b.view);
+  }
+  b.matrix_valid = true;
+}
+
 // enqueue the whole pipeline on the context stream; ctx->mu must be held
 static void run_batch(mrk_batch &b, mrk_model *model) {
   mrk_ctx *ctx = b.ctx;
@@ -152,13 +192,37 @@ static void run_batch(mrk_batch &b, mrk_model *model) {
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
   MRK_HIP(hipMemsetAsync(b.d_status.p, 0, std::max<size_t>(b.n_req, 1) * 4, ctx->stream));
-  launch_prepass(ctx, st, pd, b.view);
-  launch_assemble(ctx, st, pd, b.view);
-  if (model) {
-    launch_score_batch(ctx, model, b.view.matrix, b.total_items, pd.dim, b.view.scores, b.view.status, b.view.item_req);
-  } else if (b.total_items > 0) {
-    // NoopModel (ml/rank/NoopRanker.scala:22-26): every score is 0.0
-    MRK_HIP(hipMemsetAsync(b.d_scores.p, 0, (size_t)b.total_items * 8, ctx->stream));
+  // MRK_RANK_CELLS=0 / MRK_SCORER=walk keep the f64 matrix between assembly and scoring (A/B measurements)
+  static const bool cells_enabled = [] {
+    const char *e = getenv("MRK_RANK_CELLS"), *w = getenv("MRK_SCORER");
+    return (!e || atoi(e) != 0) && !(w && std::string(w) == "walk");
+  }();
+  const bool cells = cells_enabled && model && model->qs.ok && !b.want_matrix && b.total_items > 0;
+  if (cells) {
+    // hot path: the assembled values go straight into the scorer's binned tile; no f64 matrix
+    const QsDev q = qs_device_view(model);
+    const size_t tile_bytes = (size_t)q.n_views * QS_TILE_ROWS * 2;
+    const size_t n_tiles = ((size_t)b.total_items + QS_TILE_ROWS - 1) / QS_TILE_ROWS;
+    b.d_cells.reserve(n_tiles * tile_bytes);
+    if (b.total_items % QS_TILE_ROWS)  // rows past the last item of the last tile
+      MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (n_tiles - 1) * tile_bytes, 0, tile_bytes, ctx->stream));
+    const bool f64 = model->forest.backend == Backend::LightGBM;
+    if (b.fused_ok) {
+      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64);
+    } else {
+      launch_prepass(ctx, st, pd, b.view);
+      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64);
+    }
+    b.matrix_valid = false;
+    launch_score_qs_cells(ctx, model, b.d_cells.as<uint16_t>(), b.total_items, b.view.scores);
+  } else {
+    assemble_matrix(b, st, pd);
+    if (model) {
+      launch_score_batch(ctx, model, b.view.matrix, b.total_items, pd.dim, b.view.scores, b.view.status, b.view.item_req);
+    } else if (b.total_items > 0) {
+      // NoopModel (ml/rank/NoopRanker.scala:22-26): every score is 0.0
+      MRK_HIP(hipMemsetAsync(b.d_scores.p, 0, (size_t)b.total_items * 8, ctx->stream));
+    }
   }
   launch_sort(ctx, b.view);
   b.ran = true;
@@ -168,6 +232,10 @@ static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *ma
   mrk_ctx *ctx = b.ctx;
   MRK_HIP(hipSetDevice(ctx->device));
   const size_t T = (size_t)b.total_items;
+  if (matrix && T && b.prog->dim && !b.matrix_valid) {
+    // the last run assembled straight into the scorer's tile: materialise the f64 matrix now
+    assemble_matrix(b, ctx->store->device_view(), b.prog->device_view());
+  }
   if (scores && T) MRK_HIP(hipMemcpyAsync(scores, b.d_scores.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (order && T) MRK_HIP(hipMemcpyAsync(order, b.d_order.p, T * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (matrix && T && b.prog->dim) MRK_HIP(hipMemcpyAsync(matrix, b.d_matrix.p, T * b.prog->dim * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -251,6 +319,7 @@ int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_r
     const Program &prog = program_of(ctx, model_name);
     mrk_batch b;
     build_batch(ctx, prog, req, 1, b);
+    b.want_matrix = out_matrix != nullptr;
     run_batch(b, model);
     fetch_batch(b, out_scores, out_order, out_matrix);
     std::string msg;
@@ -291,7 +360,11 @@ int mrk_batch_device_outputs(mrk_batch *batch, double **d_scores, int32_t **d_or
     if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
     if (d_scores) *d_scores = batch->view.scores;
     if (d_order) *d_order = batch->view.order;
-    if (d_matrix) *d_matrix = batch->view.matrix;
+    if (d_matrix) {  // from now on every run materialises the f64 matrix
+      std::lock_guard<std::mutex> lk(batch->ctx->mu);
+      batch->want_matrix = true;
+      *d_matrix = batch->view.matrix;
+    }
   });
 }
 

@@ -676,7 +676,9 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
     rd.user_slot = slot_or(SC_USER, rq.user);
     rd.session_slot = slot_or(SC_SESSION, rq.session);
     rd.ranking_slot = slot_or(SC_RANKING, rq.id ? rq.id : "");
-    rd.pad = 0;
+    rd.arena_begin = (uint32_t)arena;
+    const uint64_t arena_at_start = arena;
+    hb.max_items = std::max(hb.max_items, rq.n_items);
     rd.ts_ms = rq.timestamp_ms;
     for (int i = 0; i < rq.n_items; ++i) {
       hb.item_slot[begin + i] = slot_or(SC_ITEM, rq.item_ids[i] ? rq.item_ids[i] : "");
@@ -787,6 +789,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
           else if (mode == 1 && c.tag == TAG_STRING_LIST) { tokens += (uint32_t)(c.bits >> 32); ++taken; }
           else if (mode == 2 && c.tag == TAG_DOUBLE) { ++doubles; ++taken; }
         }
+        hb.max_doubles = std::max(hb.max_doubles, doubles);
         if (doubles > PREP_MAX_VALUES)
           throw StatusError(MRK_ERR_UNSUPPORTED, "diversity feature '" + f.name + "' over more than " + std::to_string(PREP_MAX_VALUES) + " values: set `top`");
         PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base];
@@ -837,6 +840,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
         }
       }
     }
+    hb.max_req_entries = std::max(hb.max_req_entries, arena - arena_at_start);
     begin += rq.n_items;
   }
   if (arena > 0xffffffffull) throw StatusError(MRK_ERR_UNSUPPORTED, "batch needs more than 2^32 hash-table entries");

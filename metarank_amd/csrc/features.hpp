@@ -81,6 +81,9 @@ struct HostBatch {
   std::vector<Override> overrides;
   std::vector<PrepOut> prep_out;
   uint64_t arena_entries = 0;
+  uint64_t max_req_entries = 0;   // largest per-request table total (fused kernel: LDS sizing)
+  int max_doubles = 0;            // most numeric diversity values of any (request, feature)
+  int max_items = 0;              // largest request
   int total_items = 0;
 };
 

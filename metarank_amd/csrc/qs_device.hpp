@@ -1,0 +1,82 @@
+// Device-side helpers of the bit-vector scorer shared by score_qs.hip (standalone binning of an f64
+// matrix) and rank.hip (feature assembly writing binned cells directly).  Format: forest.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "forest.hpp"
+
+namespace mrk {
+
+constexpr int QS_TILE_ROWS = 128;  // rows of one scorer wavefront (two per lane)
+
+struct QsDev {             // what a kernel needs to bin a value of any matrix column
+  const QsFeature *feats;  // n_feats
+  const QsView *views;
+  const double *thr;
+  int32_t n_feats;
+  int32_t n_views;
+};
+
+// Bins one matrix value `x` of a column described by `ft` into every view of that column and hands
+// (view index, cell) to `emit`.  F64: LightGBM semantics, else XGBoost.  Returns false iff the value
+// is one XGBoost rejects (+-inf after the Double -> Float narrowing ltrlib performs).
+template <bool F64, typename Emit>
+__device__ __forceinline__ bool qs_bin_column(double x, const QsFeature ft, const QsView *__restrict__ views,
+                                              const double *__restrict__ thr, Emit emit) {
+  bool ok = true;
+  if constexpr (F64) {
+    // LightGBM RowFunctionFromDenseMatric keeps a cell only if |x| > kZeroThreshold (1e-35f) or NaN
+    const double kZero = (double)1e-35f;
+    x = (fabs(x) > kZero || x != x) ? x : 0.0;
+  } else {
+    // ltrlib narrows Double -> Float before DMatrix; XGBoost rejects +-inf ("Input data contains `inf`")
+    const float f = (float)x;
+    ok = !__builtin_isinf(f);
+    x = (double)f;
+  }
+  const bool isn = x != x;
+  const bool isz = x == 0.0;
+  // bin = number of thresholds strictly below x (LightGBM: x <= t goes left) / not above x (XGBoost: x < t)
+  uint32_t pos = 0;
+  if (ft.thr_len) {
+    const double *T = thr + ft.thr_off;
+    for (uint32_t step = 1u << (31 - __builtin_clz(ft.thr_len)); step > 0; step >>= 1) {
+      const uint32_t p = pos + step;
+      if (p <= ft.thr_len) {
+        const double t = T[p - 1];
+        const bool below = F64 ? (t < x) : (t <= x);
+        pos = below ? p : pos;
+      }
+    }
+  }
+  for (uint32_t v = ft.view_begin; v < ft.view_end; ++v) {
+    const QsView vw = views[v];
+    uint32_t cell;
+    if (vw.kind == QV_CAT) {
+      // the category id; the node's bitset is consulted by the scorer
+      if (isn) cell = QS_CAT_NAN;
+      else if constexpr (F64) {
+        // LightGBM Tree::CategoricalDecision: int(fval) < 0 goes right, like NaN
+        const int iv = (int)x;  // v_cvt_i32_f64 saturates
+        cell = iv < 0 ? (uint32_t)QS_CAT_NAN : (iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv);
+      } else {
+        // XGBoost common::Decision: negative or >= 2^24 is an invalid category (goes left)
+        if (x < 0.0 || x >= 16777216.0) cell = QS_CAT_INVALID;
+        else {
+          const int iv = (int)x;
+          cell = iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv;
+        }
+      }
+    } else {
+      const bool miss = (vw.kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
+      const uint32_t mval = (vw.kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
+      cell = miss ? mval : pos;
+    }
+    emit(v, cell);
+  }
+  return ok;
+}
+
+}  // namespace mrk

@@ -3,19 +3,25 @@
 //   Ranker.rerank's   sortBy(-_.score)
 // Reference: ml/Ranker.scala:27-83,97-106; feature/*.scala (cited per op in rank.hpp).
 //
-// Three launches per batch of requests (the scorer of score.hip runs between assemble and sort):
-//   prepass_kernel   one workgroup per request: the cross-item reductions (session-profile token
-//                    histograms for interacted_with, token histogram / median over the first `top`
-//                    present items for diversity) -> small open-addressing tables in HBM/L2
-//   assemble_kernel  one lane per candidate item: gathers the item's record (one contiguous
-//                    record per item, see store.hpp), evaluates every op of the model program and
-//                    writes its row of the dense f64 matrix
+// Two phases per request, then the scorer (score_qs.hip / score.hip), then the ordering:
+//   pre-pass   the cross-item reductions (session-profile token histograms for interacted_with, token
+//              histogram / median over the first `top` present items for diversity) -> small
+//              open-addressing tables
+//   assemble   one lane per candidate item: gathers the item's record (one contiguous record per
+//              item, see store.hpp) and evaluates every op of the model program; each value goes to a
+//              *sink*: the row-major f64 matrix (ClickthroughQuery's layout: explain / parity / models
+//              without a bit-vector image) or, for the hot path, straight into the scorer's binned
+//              u16 tile (qs_device.hpp) - the f64 matrix is then never written or read
+// Small requests run both phases in ONE workgroup with the tables in LDS (rank_fused_kernel); large
+// requests (more candidates than one workgroup should loop over, or tables that do not fit LDS) use
+// prepass_kernel -> tables in HBM -> assemble_kernel across many workgroups.
 //   sort_kernel      one workgroup per request: stable descending order, java.lang.Double.compare
 // Compiled with -ffp-contract=off: the JVM never fuses a*b+c, and parity is bit-exact.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 
+#include "qs_device.hpp"
 #include "rank.hpp"
 #include "runtime.hpp"
 
@@ -97,18 +103,27 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
 
 // ---------------------------------------------------------------- pre-pass
 constexpr int PREP_THREADS = 256;
+constexpr int FUSED_MAX_PREP = 32;  // pre-pass entries a fused workgroup keeps in LDS
 
-// exclusive prefix sum of a 0/1 flag over the workgroup + total (PREP_THREADS = 4 waves of 64)
+struct PrepScratch {   // LDS scratch of one workgroup
+  double *vals;        // vals_cap doubles: diversity median
+  int vals_cap;
+  int *wave_tot;       // 4
+  int *first;          // 1
+  int *misc;           // 4
+};
+
+// exclusive prefix sum of a 0/1 flag over the workgroup + total (blockDim.x <= 256 = 4 waves of 64)
 __device__ __forceinline__ int block_scan_flag(bool flag, int *s_wave_tot, int &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_waves = (blockDim.x + 63) >> 6;
   const unsigned long long ball = __ballot(flag);
   const int within = __popcll(ball & ((1ull << lane) - 1ull));
   if (lane == 0) s_wave_tot[wave] = __popcll(ball);
   __syncthreads();
   int before = 0;
   total = 0;
-#pragma unroll
-  for (int w = 0; w < PREP_THREADS / 64; ++w) {
+  for (int w = 0; w < n_waves; ++w) {
     int t = s_wave_tot[w];
     if (w < wave) before += t;
     total += t;
@@ -117,23 +132,21 @@ __device__ __forceinline__ int block_scan_flag(bool flag, int *s_wave_tot, int &
   return before + within;
 }
 
-__global__ void __launch_bounds__(PREP_THREADS)
-prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
-  __shared__ double s_vals[PREP_MAX_VALUES];
-  __shared__ int s_wave_tot[PREP_THREADS / 64];
-  __shared__ int s_first;
-  __shared__ int s_misc[4];
-  const int r = blockIdx.x;
+// The pre-pass of request r, run by one whole workgroup.  Tables live at tab_base + (po.tab_off - tab_sub)
+// (HBM arena: tab_sub = 0; LDS: tab_sub = the request's first arena entry); mode / scalar go to po_out[e].
+__device__ void prepass_request(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, int r, const ReqDev &rq,
+                                unsigned long long *tab_base, uint32_t tab_sub, PrepOut *po_out, const PrepScratch &sc) {
   const int tid = threadIdx.x;
-  const ReqDev rq = b.reqs[r];
-
+  const int nthr = blockDim.x;
+  double *s_vals = sc.vals;
+  int *s_misc = sc.misc;
   for (int e = 0; e < prog.n_prep; ++e) {
     const PrepEntry pe = prog.prep[e];
-    PrepOut *po = &b.prep_out[(size_t)r * prog.n_prep + e];
-    unsigned long long *tab = b.arena + po->tab_off;
+    PrepOut *po = &po_out[e];
+    unsigned long long *tab = tab_base + (po->tab_off - tab_sub);
     const uint32_t mask = po->tab_mask;
-    for (uint32_t i = tid; i <= mask; i += PREP_THREADS) tab[i] = 0ull;
-    if (tid == 0) { s_first = 0x7fffffff; s_misc[0] = 0; s_misc[1] = 0; s_misc[2] = 0; }
+    for (uint32_t i = tid; i <= mask; i += nthr) tab[i] = 0ull;
+    if (tid == 0) { *sc.first = 0x7fffffff; s_misc[0] = 0; s_misc[1] = 0; s_misc[2] = 0; }
     __syncthreads();
 
     if (pe.kind == PREP_IW_FIELD) {
@@ -142,7 +155,7 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
       const Cell lc = load_cell(record(st, pe.list_scope, vslot), pe.list_col);
       if (lc.tag != TAG_MISSING) {
         const uint32_t off = lc.lo(), len = lc.hi();
-        for (uint32_t k = tid; k < len; k += PREP_THREADS) {
+        for (uint32_t k = tid; k < len; k += nthr) {
           const int islot = (int)st.slot_pool[off + k];
           const Cell ic = load_cell(record(st, SC_ITEM, islot), pe.item_col);
           if (ic.tag == TAG_STRING_LIST) {
@@ -158,20 +171,21 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
 
     // ---- PREP_DIVERSITY (DiversityFeature.scala:72-103) ----
     // (a) the first candidate that has a ScalarValue decides string vs number
-    for (int base = 0; base < rq.n_items; base += PREP_THREADS) {
+    for (int base = 0; base < rq.n_items; base += nthr) {
       const int i = base + tid;
       if (i < rq.n_items) {
         const Cell c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), pe.item_col);
-        if (c.tag != TAG_MISSING) atomicMin(&s_first, i);
+        if (c.tag != TAG_MISSING) atomicMin(sc.first, i);
       }
       __syncthreads();
-      const int found = s_first;
+      const int found = *sc.first;
       __syncthreads();  // nobody may start the next round's atomicMin before everyone has read
       if (found != 0x7fffffff) break;
     }
+    const int first = *sc.first;
     int mode = DIV_EMPTY;
-    if (s_first != 0x7fffffff) {
-      const Cell h = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + s_first]), pe.item_col);
+    if (first != 0x7fffffff) {
+      const Cell h = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + first]), pe.item_col);
       if (h.tag == TAG_STRING || h.tag == TAG_STRING_LIST) mode = DIV_STRING;
       else if (h.tag == TAG_DOUBLE) mode = DIV_DOUBLE;
     }
@@ -179,7 +193,7 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
     if (mode != DIV_EMPTY) {
       // (b) the first `top` candidates of that type, in request order
       int running = 0;
-      for (int base = 0; base < rq.n_items && running < pe.top; base += PREP_THREADS) {
+      for (int base = 0; base < rq.n_items && running < pe.top; base += nthr) {
         const int i = base + tid;
         Cell c;
         c.tag = TAG_MISSING;
@@ -187,7 +201,7 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
         if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), pe.item_col);
         const bool cand = mode == DIV_STRING ? (c.tag == TAG_STRING || c.tag == TAG_STRING_LIST) : (c.tag == TAG_DOUBLE);
         int total;
-        const int rank = running + block_scan_flag(cand, s_wave_tot, total);
+        const int rank = running + block_scan_flag(cand, sc.wave_tot, total);
         if (cand && rank < pe.top) {
           if (mode == DIV_STRING) {
             if (c.tag == TAG_STRING) {
@@ -200,7 +214,7 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
               atomicAdd(&s_misc[0], (int)tlen);
             }
           } else {
-            if (rank < PREP_MAX_VALUES) s_vals[rank] = c.f64();
+            if (rank < sc.vals_cap) s_vals[rank] = c.f64();
             else atomicOr(&b.status[r], ST_TOO_MANY);
           }
         }
@@ -211,22 +225,22 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
         scalar = (double)s_misc[0];  // stringCounts.values.foldLeft(0.0)(_ + _): integers, exact in f64
       } else {
         // commons-math Percentile (LEGACY, NaN removed) .evaluate(50)
-        int n_raw = min(min(running, pe.top), PREP_MAX_VALUES);
+        int n_raw = min(min(running, pe.top), sc.vals_cap);
         if (n_raw == 1) {
           scalar = s_vals[0];
         } else {
           // NaN -> +inf placeholder (sorts last), counted
-          for (int i = tid; i < n_raw; i += PREP_THREADS) {
+          for (int i = tid; i < n_raw; i += nthr) {
             double v = s_vals[i];
             if (v != v) { s_vals[i] = __longlong_as_double(0x7ff0000000000000LL); atomicAdd(&s_misc[1], 1); }
           }
           int p2 = 1;
           while (p2 < n_raw) p2 <<= 1;
-          for (int i = n_raw + tid; i < p2; i += PREP_THREADS) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
+          for (int i = n_raw + tid; i < p2; i += nthr) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
           __syncthreads();
           for (int k = 2; k <= p2; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-              for (int i = tid; i < p2; i += PREP_THREADS) {
+              for (int i = tid; i < p2; i += nthr) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                   const double a = s_vals[i], c2 = s_vals[ixj];
@@ -263,6 +277,18 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
   }
 }
 
+__global__ void __launch_bounds__(PREP_THREADS)
+prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
+  __shared__ double s_vals[PREP_MAX_VALUES];
+  __shared__ int s_wave_tot[PREP_THREADS / 64];
+  __shared__ int s_first;
+  __shared__ int s_misc[4];
+  const int r = blockIdx.x;
+  const ReqDev rq = b.reqs[r];
+  PrepScratch sc{s_vals, PREP_MAX_VALUES, s_wave_tot, &s_first, s_misc};
+  prepass_request(st, prog, b, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sc);
+}
+
 // ---------------------------------------------------------------- assemble
 constexpr int ASM_THREADS = 256;
 
@@ -282,38 +308,57 @@ __device__ __forceinline__ long long long_div(long long a, long long b) {
   return a / b;
 }
 
-__global__ void __launch_bounds__(ASM_THREADS)
-assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
-  const int gi = blockIdx.x * ASM_THREADS + threadIdx.x;
-  if (gi >= b.total_items) return;
-  const int r = (int)b.item_req[gi];
-  const ReqDev rq = b.reqs[r];
+// ---- sinks: where an assembled value goes
+struct MatrixSink {   // row-major f64 matrix, ClickthroughQuery's layout
+  double *row;
+  __device__ __forceinline__ void put(int col, double v) const { row[col] = v; }
+};
+
+template <bool F64>
+struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row] u16
+  QsDev q;
+  uint16_t *dst;      // &cells[tile][0][row]
+  int32_t *status;    // the request's status word
+  __device__ __forceinline__ void put(int col, double v) const {
+    if (col >= q.n_feats) return;
+    const QsFeature ft = q.feats[col];  // col is uniform across the wave: scalar loads
+    if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
+    uint16_t *d = dst;
+    const bool ok = qs_bin_column<F64>(v, ft, q.views, q.thr, [d](uint32_t view, uint32_t cell) { d[view * QS_TILE_ROWS] = (uint16_t)cell; });
+    if (!ok) atomicOr(status, 32);
+  }
+};
+
+// Evaluates the model program for batch item gi of request r.  Hash tables: tab_base + (po.tab_off - tab_sub).
+template <typename Sink>
+__device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, int gi, int r,
+                                              const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
+                                              const PrepOut *pos, const Sink &sink) {
   const int islot = b.item_slot[gi];
   const uint8_t *irec = record(st, SC_ITEM, islot);
-  double *row = b.matrix + (size_t)gi * prog.dim;
   const double NaN = d_nan();
 
   for (int oi = 0; oi < prog.n_ops; ++oi) {
     const Op op = prog.ops[oi];
-    double *out = row + op.dst;
+    const int dst = op.dst;
     switch (op.kind) {
       case OP_SCALAR_DOUBLE: {
         const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
-        out[0] = c.tag == TAG_DOUBLE ? c.f64() : NaN;
+        sink.put(dst + 0, c.tag == TAG_DOUBLE ? c.f64() : NaN);
         break;
       }
       case OP_SCALAR_BOOL: {
         const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
-        out[0] = c.tag == TAG_BOOL ? c.f64() : NaN;
+        sink.put(dst + 0, c.tag == TAG_BOOL ? c.f64() : NaN);
         break;
       }
       case OP_VECTOR: {
         const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
         if (c.tag == TAG_DOUBLE_LIST) {
           const uint32_t off = c.lo(), len = c.hi();
-          for (int k = 0; k < op.dim; ++k) out[k] = (uint32_t)k < len ? st.f64_pool[off + k] : 0.0;
+          for (int k = 0; k < op.dim; ++k) sink.put(dst + k, (uint32_t)k < len ? st.f64_pool[off + k] : 0.0);
         } else {
-          for (int k = 0; k < op.dim; ++k) out[k] = NaN;
+          for (int k = 0; k < op.dim; ++k) sink.put(dst + k, NaN);
         }
         break;
       }
@@ -325,36 +370,41 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
           for (int k = 0; k < op.i1; ++k)
             if (prog.aux[op.i0 + k] == first) idx = (double)(k + 1);  // zipWithIndex.toMap: last duplicate wins
         }
-        out[0] = idx;
+        sink.put(dst + 0, idx);
         break;
       }
       case OP_STRING_ONEHOT: {
+        // OneHotEncoder.fromValues: every token sets the FIRST position whose value equals it (indexOf)
         const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
-        for (int k = 0; k < op.dim; ++k) out[k] = 0.0;
-        if (c.tag == TAG_STRING_LIST) {
-          const uint32_t off = c.lo(), len = c.hi();
-          for (uint32_t j = 0; j < len; ++j) {
-            const uint32_t tok = st.tok_pool[off + j];
-            for (int k = 0; k < op.i1; ++k)
-              if (prog.aux[op.i0 + k] == tok) { out[k] = 1.0; break; }  // indexOf: first match
+        const bool has = c.tag == TAG_STRING_LIST;
+        const uint32_t off = c.lo(), len = has ? c.hi() : 0u;
+        for (int k = 0; k < op.dim; ++k) {
+          double v = 0.0;
+          if (k < op.i1) {
+            const uint32_t want = prog.aux[op.i0 + k];
+            bool first = true;  // a duplicate possible value is never reached by indexOf
+            for (int k2 = 0; k2 < k; ++k2) first = first && prog.aux[op.i0 + k2] != want;
+            if (first)
+              for (uint32_t j = 0; j < len; ++j)
+                if (st.tok_pool[off + j] == want) { v = 1.0; break; }
           }
+          sink.put(dst + k, v);
         }
         break;
       }
       case OP_COUNTER: {
         const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
-        out[0] = c.tag != TAG_MISSING ? (double)c.i64() : 0.0;
+        sink.put(dst + 0, c.tag != TAG_MISSING ? (double)c.i64() : 0.0);
         break;
       }
       case OP_WINDOW: {
         const uint8_t *rec = record(st, op.scope, scoped_slot(rq, op.scope, islot));
         const Cell c = load_cell(rec, op.c0);
         const bool ok = c.tag != TAG_MISSING && (int)c.tag - 1 == op.dim;
-        for (int k = 0; k < op.dim; ++k) out[k] = ok ? (double)load_cell(rec, op.c0, k).i64() : NaN;
+        for (int k = 0; k < op.dim; ++k) sink.put(dst + k, ok ? (double)load_cell(rec, op.c0, k).i64() : NaN);
         break;
       }
       case OP_RATE: {
-        for (int k = 0; k < op.dim; ++k) out[k] = NaN;
         const uint8_t *trec = nullptr;  // record holding the target-scope counters
         ColRef top = op.c0, bot = op.c1;
         if (op.i0 == RATE_ITEM) {
@@ -370,30 +420,38 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
           top = op.c4;
           bot = op.c5;
         }
-        if (trec == nullptr) break;
-        const Cell t0 = load_cell(trec, top), b0 = load_cell(trec, bot);
-        if (t0.tag == TAG_MISSING || b0.tag == TAG_MISSING) break;
-        const bool len_ok = (int)t0.tag - 1 == op.dim && (int)b0.tag - 1 == op.dim;
-        if (op.i3 == 0) {
-          if (!len_ok) break;
-          for (int k = 0; k < op.dim; ++k)
-            out[k] = (double)load_cell(trec, top, k).i64() / (double)load_cell(trec, bot, k).i64();
-        } else {
-          const uint8_t *grec = record(st, SC_GLOBAL, 0);
+        // every value present with exactly `dim` periods, else NaN x dim (RateFeature.scala:318-350)
+        bool valid = trec != nullptr;
+        if (valid) {
+          const Cell t0 = load_cell(trec, top), b0 = load_cell(trec, bot);
+          valid = t0.tag != TAG_MISSING && b0.tag != TAG_MISSING && (int)t0.tag - 1 == op.dim && (int)b0.tag - 1 == op.dim;
+        }
+        const uint8_t *grec = nullptr;
+        if (valid && op.i3 != 0) {
+          grec = record(st, SC_GLOBAL, 0);
           const Cell gt = load_cell(grec, op.c2), gb = load_cell(grec, op.c3);
-          if (gt.tag == TAG_MISSING || gb.tag == TAG_MISSING) break;
-          if (!len_ok || (int)gt.tag - 1 != op.dim || (int)gb.tag - 1 != op.dim) break;
-          for (int k = 0; k < op.dim; ++k) {
-            const long long tg = load_cell(grec, op.c2, k).i64(), bg = load_cell(grec, op.c3, k).i64();
-            if (tg == 0) {  // java.lang.ArithmeticException: / by zero
-              atomicOr(&b.status[r], ST_ARITHMETIC);
-              break;
+          valid = gt.tag != TAG_MISSING && gb.tag != TAG_MISSING && (int)gt.tag - 1 == op.dim && (int)gb.tag - 1 == op.dim;
+        }
+        bool thrown = false;  // java.lang.ArithmeticException: / by zero aborts the request
+        for (int k = 0; k < op.dim; ++k) {
+          double v = NaN;
+          if (valid && !thrown) {
+            if (op.i3 == 0) {
+              v = (double)load_cell(trec, top, k).i64() / (double)load_cell(trec, bot, k).i64();
+            } else {
+              const long long tg = load_cell(grec, op.c2, k).i64(), bg = load_cell(grec, op.c3, k).i64();
+              if (tg == 0) {
+                atomicOr(&b.status[r], ST_ARITHMETIC);
+                thrown = true;
+              } else {
+                const double ratio = (double)long_div(bg, tg);
+                const double num = __dadd_rn(op.d0, (double)load_cell(trec, top, k).i64());
+                const double den = __dadd_rn(__dmul_rn(op.d0, ratio), (double)load_cell(trec, bot, k).i64());
+                v = num / den;
+              }
             }
-            const double ratio = (double)long_div(bg, tg);
-            const double num = __dadd_rn(op.d0, (double)load_cell(trec, top, k).i64());
-            const double den = __dadd_rn(__dmul_rn(op.d0, ratio), (double)load_cell(trec, bot, k).i64());
-            out[k] = num / den;
           }
+          sink.put(dst + k, v);
         }
         break;
       }
@@ -403,38 +461,38 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
           ColRef col;
           col.tag = (int32_t)prog.aux[op.i0 + 2 * f];
           col.val = (int32_t)prog.aux[op.i0 + 2 * f + 1];
-          const PrepOut po = b.prep_out[(size_t)r * prog.n_prep + op.i1 + f];
-          const unsigned long long *tab = b.arena + po.tab_off;
+          const PrepOut po = pos[op.i1 + f];
+          const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
           const Cell c = load_cell(irec, col);
           double cnt = 0.0;
           if (c.tag == TAG_STRING_LIST) {
             const uint32_t off = c.lo(), len = c.hi();
             for (uint32_t j = 0; j < len; ++j) cnt = cnt + (double)table_get(tab, po.tab_mask, st.tok_pool[off + j]);
           }
-          out[f] = cnt;
+          sink.put(dst + f, cnt);
         }
         break;
       }
       case OP_DIVERSITY: {
-        const PrepOut po = b.prep_out[(size_t)r * prog.n_prep + op.i1];
+        const PrepOut po = pos[op.i1];
         const Cell c = load_cell(irec, op.c0);
+        double v = NaN;
         if (po.mode == DIV_EMPTY) {
-          out[0] = 0.0;
+          v = 0.0;
         } else if (po.mode == DIV_DOUBLE) {
-          out[0] = c.tag == TAG_DOUBLE ? c.f64() - po.scalar : NaN;
+          if (c.tag == TAG_DOUBLE) v = c.f64() - po.scalar;
         } else {
-          const unsigned long long *tab = b.arena + po.tab_off;
+          const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
           if (c.tag == TAG_STRING) {
-            out[0] = (0.0 + (double)table_get(tab, po.tab_mask, c.lo())) / po.scalar;
+            v = (0.0 + (double)table_get(tab, po.tab_mask, c.lo())) / po.scalar;
           } else if (c.tag == TAG_STRING_LIST) {
             const uint32_t off = c.lo(), len = c.hi();
             double w = 0.0;
             for (uint32_t j = 0; j < len; ++j) w = w + (double)table_get(tab, po.tab_mask, st.tok_pool[off + j]);
-            out[0] = w / po.scalar;
-          } else {
-            out[0] = NaN;
+            v = w / po.scalar;
           }
         }
+        sink.put(dst + 0, v);
         break;
       }
       case OP_ITEM_AGE: {
@@ -447,16 +505,16 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
           if (diff < 0 || diff > 9223372036854LL) atomicOr(&b.status[r], ST_ILLEGAL_ARG);  // FiniteDuration bound
           else v = (double)(diff / 1000);
         }
-        out[0] = v;
+        sink.put(dst + 0, v);
         break;
       }
       case OP_CONST: {
         const double *cs = b.consts + (size_t)r * prog.n_consts + op.i0;
-        for (int k = 0; k < op.dim; ++k) out[k] = cs[k];
+        for (int k = 0; k < op.dim; ++k) sink.put(dst + k, cs[k]);
         break;
       }
       case OP_FILL_NAN: {
-        for (int k = 0; k < op.dim; ++k) out[k] = NaN;
+        for (int k = 0; k < op.dim; ++k) sink.put(dst + k, NaN);
         break;
       }
       case OP_BIENCODER: {
@@ -480,7 +538,7 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
             v = top / (sqrt(a) * sqrt(bs));
           }
         }
-        out[0] = v;
+        sink.put(dst + 0, v);
         break;
       }
       default: break;
@@ -488,11 +546,79 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
   }
 }
 
+__global__ void __launch_bounds__(ASM_THREADS)
+assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
+  const int gi = blockIdx.x * ASM_THREADS + threadIdx.x;
+  if (gi >= b.total_items) return;
+  const int r = (int)b.item_req[gi];
+  const ReqDev rq = b.reqs[r];
+  MatrixSink sink{b.matrix + (size_t)gi * prog.dim};
+  assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
+}
+
+template <bool F64>
+__global__ void __launch_bounds__(ASM_THREADS)
+assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_t *cells) {
+  const int gi = blockIdx.x * ASM_THREADS + threadIdx.x;
+  if (gi >= b.total_items) return;
+  const int r = (int)b.item_req[gi];
+  const ReqDev rq = b.reqs[r];
+  CellSink<F64> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r]};
+  assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
+}
+
+// Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
+// Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x n_prep][ints]
+template <typename SinkMaker>
+__device__ __forceinline__ void rank_fused_body(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
+                                                int vals_cap, const SinkMaker &make_sink) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  unsigned long long *s_tab = (unsigned long long *)smem;
+  double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
+  PrepOut *s_po = (PrepOut *)(smem + (size_t)tab_entries * 8 + (size_t)vals_cap * 8);
+  int *s_int = (int *)(s_po + FUSED_MAX_PREP);
+  const int r = blockIdx.x;
+  const ReqDev rq = b.reqs[r];
+  for (int e = threadIdx.x; e < prog.n_prep; e += blockDim.x) s_po[e] = b.prep_out[(size_t)r * prog.n_prep + e];
+  __syncthreads();
+  PrepScratch sc{s_vals, vals_cap, s_int, s_int + 4, s_int + 8};
+  prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
+  for (int i = threadIdx.x; i < rq.n_items; i += blockDim.x) {
+    const int gi = rq.item_begin + i;
+    assemble_item(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r));
+  }
+}
+
+__global__ void __launch_bounds__(256)
+rank_fused_matrix_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap) {
+  rank_fused_body(st, prog, b, tab_entries, vals_cap,
+                  [&](int gi, int) { return MatrixSink{b.matrix + (size_t)gi * prog.dim}; });
+}
+
+template <bool F64>
+__global__ void __launch_bounds__(256)
+rank_fused_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, QsDev q, uint16_t *cells) {
+  rank_fused_body(st, prog, b, tab_entries, vals_cap, [&](int gi, int r) {
+    return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r]};
+  });
+}
+
 __global__ void override_kernel(BatchDev b, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n_overrides) return;
   const Override o = b.overrides[i];
   b.matrix[(size_t)o.item * dim + o.col] = o.value;
+}
+
+// the same for the binned tile: re-bin the overriding value into every view of its column
+template <bool F64>
+__global__ void override_cells_kernel(BatchDev b, QsDev q, uint16_t *cells) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n_overrides) return;
+  const Override o = b.overrides[i];
+  CellSink<F64> sink{q, cells + (size_t)(o.item / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (o.item % QS_TILE_ROWS),
+                     &b.status[b.item_req[o.item]]};
+  sink.put((int)o.col, o.value);
 }
 
 // ---------------------------------------------------------------- ordering
@@ -562,6 +688,65 @@ void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
     ScopedKernelTimer timer(ctx, "override");
     hipLaunchKernelGGL(override_kernel, dim3((b.n_overrides + 255) / 256), dim3(256), 0, ctx->stream, b, prog.dim);
     MRK_HIP(hipGetLastError());
+  }
+}
+
+static void launch_override_cells(mrk_ctx *ctx, const BatchDev &b, const QsDev &q, uint16_t *cells, bool f64) {
+  if (b.n_overrides <= 0) return;
+  ScopedKernelTimer timer(ctx, "override");
+  const dim3 grid((b.n_overrides + 255) / 256);
+  if (f64) hipLaunchKernelGGL(override_cells_kernel<true>, grid, dim3(256), 0, ctx->stream, b, q, cells);
+  else hipLaunchKernelGGL(override_cells_kernel<false>, grid, dim3(256), 0, ctx->stream, b, q, cells);
+  MRK_HIP(hipGetLastError());
+}
+
+// assembly straight into the scorer's binned tile (tables from a previous launch_prepass)
+void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
+                           uint16_t *cells, bool f64) {
+  if (b.total_items <= 0) return;
+  {
+    ScopedKernelTimer timer(ctx, "assemble");
+    const dim3 grid((b.total_items + ASM_THREADS - 1) / ASM_THREADS);
+    if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), 0, ctx->stream, st, prog, b, q, cells);
+    else hipLaunchKernelGGL(assemble_cells_kernel<false>, grid, dim3(ASM_THREADS), 0, ctx->stream, st, prog, b, q, cells);
+    MRK_HIP(hipGetLastError());
+  }
+  launch_override_cells(ctx, b, q, cells, f64);
+}
+
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap) {
+  return (size_t)tab_entries * 8 + (size_t)vals_cap * 8 + FUSED_MAX_PREP * sizeof(PrepOut) + 16 * sizeof(int);
+}
+int fused_max_prep() { return FUSED_MAX_PREP; }
+
+// pre-pass + assembly of every request in one launch (one workgroup per request, tables in LDS).
+// cells == nullptr: write the f64 matrix; else write the binned tile.
+void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
+                       int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64) {
+  if (b.n_req <= 0) return;
+  const size_t lds = fused_lds_bytes(tab_entries, vals_cap);
+  {
+    ScopedKernelTimer timer(ctx, "assemble");
+    static thread_local bool configured = false;
+    if (!configured) {
+      MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      configured = true;
+    }
+    if (!cells) hipLaunchKernelGGL(rank_fused_matrix_kernel, dim3(b.n_req), dim3(threads), lds, ctx->stream, st, prog, b, tab_entries, vals_cap);
+    else if (f64) hipLaunchKernelGGL(rank_fused_cells_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->stream, st, prog, b, tab_entries, vals_cap, *q, cells);
+    else hipLaunchKernelGGL(rank_fused_cells_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->stream, st, prog, b, tab_entries, vals_cap, *q, cells);
+    MRK_HIP(hipGetLastError());
+  }
+  if (!cells) {
+    if (b.n_overrides > 0) {
+      ScopedKernelTimer timer(ctx, "override");
+      hipLaunchKernelGGL(override_kernel, dim3((b.n_overrides + 255) / 256), dim3(256), 0, ctx->stream, b, prog.dim);
+      MRK_HIP(hipGetLastError());
+    }
+  } else {
+    launch_override_cells(ctx, b, *q, cells, f64);
   }
 }
 

@@ -69,7 +69,8 @@ struct PrepOut {
 
 struct ReqDev {
   int32_t item_begin, n_items;
-  int32_t user_slot, session_slot, ranking_slot, pad;
+  int32_t user_slot, session_slot, ranking_slot;
+  uint32_t arena_begin;  // first hash-table entry of this request in the arena (its tables are contiguous)
   int64_t ts_ms;
 };
 

@@ -150,5 +150,6 @@ uint32_t score_chunk_budget();
 // score_qs.hip: false => not applicable, use the tree-walk kernel
 bool launch_score_qs(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
                      const uint32_t *d_row_req);
+void launch_score_qs_cells(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, double *d_out);
 
 }  // namespace mrk

@@ -20,9 +20,12 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "qs_device.hpp"
 #include "runtime.hpp"
 
 namespace mrk {
+
+QsDev qs_device_view(const mrk_model *m);
 
 namespace {
 
@@ -34,75 +37,25 @@ constexpr int QS_WAVES = 4;  // wavefronts per workgroup (they share the staged 
 
 template <bool F64>
 __global__ void __launch_bounds__(256)
-qs_bin_kernel(const double *__restrict__ X, int rows, int cols, const QsFeature *__restrict__ feats, int n_feats,
-              const QsView *__restrict__ views, const double *__restrict__ thr,
-              uint16_t *__restrict__ cells, int V, int tile_rows, long long padded_rows, int *__restrict__ flag,
-              const uint32_t *__restrict__ row_req) {
+qs_bin_kernel(const double *__restrict__ X, int rows, int cols, QsDev q, uint16_t *__restrict__ cells, int tile_rows,
+              long long padded_rows, int *__restrict__ flag, const uint32_t *__restrict__ row_req) {
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
   if (row >= padded_rows) return;
   const long long tile = row / tile_rows;
   const int r = (int)(row - tile * tile_rows);
-  uint16_t *dst = cells + (size_t)tile * V * tile_rows + r;
+  uint16_t *dst = cells + (size_t)tile * q.n_views * tile_rows + r;
   const bool valid = row < rows;
   const double *xr = X + (valid ? row : 0) * cols;
-  const int nf = n_feats < cols ? n_feats : cols;
+  const int nf = q.n_feats < cols ? q.n_feats : cols;
   for (int c = 0; c < nf; ++c) {
-    const QsFeature ft = feats[c];  // uniform: scalar loads
+    const QsFeature ft = q.feats[c];  // uniform: scalar loads
     if (ft.view_begin == ft.view_end) continue;
-    double x = xr[c];
-    if constexpr (F64) {
-      // LightGBM RowFunctionFromDenseMatric keeps a cell only if |x| > kZeroThreshold (1e-35f) or NaN
-      const double kZero = (double)1e-35f;
-      x = (fabs(x) > kZero || x != x) ? x : 0.0;
-    } else {
-      // ltrlib narrows Double -> Float before DMatrix; XGBoost rejects +-inf ("Input data contains `inf`")
-      const float f = (float)x;
-      if (valid && __builtin_isinf(f)) {
-        if (row_req) atomicOr(flag + row_req[row], 32);
-        else atomicOr(flag, 1);
-      }
-      x = (double)f;
-    }
-    const bool isn = x != x;
-    const bool isz = x == 0.0;
-    // bin = number of thresholds strictly below x (LightGBM) / not above x (XGBoost)
-    uint32_t pos = 0;
-    if (ft.thr_len) {
-      const double *T = thr + ft.thr_off;
-      uint32_t step = 1u << (31 - __builtin_clz(ft.thr_len));
-      for (; step > 0; step >>= 1) {
-        const uint32_t p = pos + step;
-        if (p <= ft.thr_len) {
-          const double t = T[p - 1];
-          const bool below = F64 ? (t < x) : (t <= x);
-          pos = below ? p : pos;
-        }
-      }
-    }
-    for (uint32_t v = ft.view_begin; v < ft.view_end; ++v) {
-      const QsView vw = views[v];
-      uint32_t cell;
-      if (vw.kind == QV_CAT) {
-        // the category id; the node's bitset is consulted by the scorer
-        if (isn) cell = QS_CAT_NAN;
-        else if constexpr (F64) {
-          // LightGBM Tree::CategoricalDecision: int(fval) < 0 goes right, like NaN
-          const int iv = (int)x;  // v_cvt_i32_f64 saturates
-          cell = iv < 0 ? (uint32_t)QS_CAT_NAN : (iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv);
-        } else {
-          // XGBoost common::Decision: negative or >= 2^24 is an invalid category (goes left)
-          if (x < 0.0 || x >= 16777216.0) cell = QS_CAT_INVALID;
-          else {
-            const int iv = (int)x;
-            cell = iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv;
-          }
-        }
-      } else {
-        const bool miss = (vw.kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
-        const uint32_t mval = (vw.kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
-        cell = miss ? mval : pos;
-      }
+    const bool ok = qs_bin_column<F64>(xr[c], ft, q.views, q.thr, [&](uint32_t v, uint32_t cell) {
       dst[(size_t)v * tile_rows] = valid ? (uint16_t)cell : (uint16_t)0;
+    });
+    if (!ok && valid) {
+      if (row_req) atomicOr(flag + row_req[row], 32);
+      else atomicOr(flag, 1);
     }
   }
 }
@@ -371,39 +324,29 @@ qs_score_wave_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restri
     if (row0 + j < rows) out[row0 + j] = F64 ? acc64[j] : (double)acc32[j];
 }
 
-template <bool F64, int R>
-void launch_qs_t(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
-                 const uint32_t *d_row_req, int chunk_trees, size_t smem) {
+template <bool F64>
+void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, double *d_out) {
   const PackedForestQS &q = m->qs;
   const int V = (int)q.views.size();
-  const int tile_rows = R * 64;
-  const long long n_tiles = ((long long)rows + tile_rows - 1) / tile_rows;
-  const long long padded = n_tiles * tile_rows;
-  ctx->d_cells.reserve((size_t)padded * V * 2);
-  {
-    ScopedKernelTimer timer(ctx, "bin");
-    const int grid = (int)((padded + 255) / 256);
-    hipLaunchKernelGGL(qs_bin_kernel<F64>, dim3(grid), dim3(256), 0, ctx->stream, d_x, rows, cols,
-                       m->d_qs_feats.as<QsFeature>(), (int)q.feats.size(), m->d_qs_views.as<QsView>(),
-                       m->d_qs_thr.as<double>(), ctx->d_cells.as<uint16_t>(), V, tile_rows,
-                       padded, d_flag, d_row_req);
-    MRK_HIP(hipGetLastError());
+  const long long n_tiles = ((long long)rows + QS_TILE_ROWS - 1) / QS_TILE_ROWS;
+  auto wk = qs_score_wave_kernel<F64>;
+  static thread_local const void *configured = nullptr;
+  if (configured != (const void *)wk) {
+    MRK_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    configured = (const void *)wk;
   }
-  static const int variant = [] { const char *e = getenv("MRK_QS_KERNEL"); return e ? atoi(e) : 1; }();
-  if (R == 2 && variant == 1) {
-    auto wk = qs_score_wave_kernel<F64>;
-    static thread_local const void *wconfigured = nullptr;
-    if (wconfigured != (const void *)wk) {
-      MRK_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      wconfigured = (const void *)wk;
-    }
-    ScopedKernelTimer timer(ctx, "score");
-    hipLaunchKernelGGL(wk, dim3((unsigned)n_tiles), dim3(64), (size_t)V * 256, ctx->stream, m->d_qs_nodes.as<uint32_t>(),
-                       m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(),
-                       ctx->d_cells.as<uint16_t>(), q.n_trees, V, rows, m->forest.base_score, d_out);
-    MRK_HIP(hipGetLastError());
-    return;
-  }
+  ScopedKernelTimer timer(ctx, "score");
+  hipLaunchKernelGGL(wk, dim3((unsigned)n_tiles), dim3(64), (size_t)V * 256, ctx->stream, m->d_qs_nodes.as<uint32_t>(),
+                     m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(), d_cells,
+                     q.n_trees, V, rows, m->forest.base_score, d_out);
+  MRK_HIP(hipGetLastError());
+}
+
+template <bool F64, int R>
+void launch_generic(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, double *d_out, int chunk_trees, size_t smem) {
+  const PackedForestQS &q = m->qs;
+  const int V = (int)q.views.size();
+  const long long n_tiles = ((long long)rows + R * 64 - 1) / (R * 64);
   auto kern = qs_score_kernel<F64, R>;
   static thread_local const void *configured = nullptr;
   if (configured != (const void *)kern) {
@@ -413,49 +356,73 @@ void launch_qs_t(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int co
   ScopedKernelTimer timer(ctx, "score");
   const int grid = (int)((n_tiles + QS_WAVES - 1) / QS_WAVES);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(QS_WAVES * 64), smem, ctx->stream, m->d_qs_nodes.as<uint32_t>(),
-                     m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(),
-                     ctx->d_cells.as<uint16_t>(), q.n_trees, V, rows, n_tiles,
-                     m->forest.base_score, d_out, chunk_trees);
+                     m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(), d_cells,
+                     q.n_trees, V, rows, n_tiles, m->forest.base_score, d_out, chunk_trees);
+  MRK_HIP(hipGetLastError());
+}
+
+template <bool F64>
+void launch_bin(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, int tile_rows, int *d_flag,
+                const uint32_t *d_row_req) {
+  const long long n_tiles = ((long long)rows + tile_rows - 1) / tile_rows;
+  const long long padded = n_tiles * tile_rows;
+  ctx->d_cells.reserve((size_t)padded * m->qs.views.size() * 2);
+  ScopedKernelTimer timer(ctx, "bin");
+  const int grid = (int)((padded + 255) / 256);
+  hipLaunchKernelGGL(qs_bin_kernel<F64>, dim3(grid), dim3(256), 0, ctx->stream, d_x, rows, cols, qs_device_view(m),
+                     ctx->d_cells.as<uint16_t>(), tile_rows, padded, d_flag, d_row_req);
   MRK_HIP(hipGetLastError());
 }
 
 template <bool F64>
 bool launch_qs_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
                  const uint32_t *d_row_req) {
-  const PackedForestQS &q = m->qs;
-  const size_t V = q.views.size();
-  const int leaf_bytes = QS_LEAVES * (F64 ? 8 : 4);
-  static const int chunk_kb = [] { const char *e = getenv("MRK_QS_CHUNK_KB"); return e ? std::max(1, atoi(e)) : 8; }();
-  const int chunk_trees = std::min(q.n_trees, chunk_kb * 1024 / leaf_bytes);
-  const size_t leaf_cap = (size_t)chunk_trees * leaf_bytes;
-  auto smem = [&](int r) { return leaf_cap + (size_t)QS_WAVES * V * r * 128; };
-  const size_t budget = 160 * 1024;
-  static const int forced = [] { const char *e = getenv("MRK_QS_R"); return e ? atoi(e) : 0; }();
-  // More rows per lane amortise the address op and the LDS read; fewer rows per lane leave room for a
-  // second workgroup per CU and cut the tail when there are few rows.
-  int r = 0;
-  if (forced == 2 || forced == 4 || forced == 8) r = smem(forced) <= budget ? forced : 0;
-  if (!r) {
-    const long long cu_rows = (long long)ctx->n_cus * QS_WAVES * 64;
-    if (smem(4) <= budget / 2 && rows >= 4 * cu_rows) r = 4;
-    else if (smem(2) <= budget) r = 2;
+  // MRK_QS_KERNEL=0 selects the multi-wave generic kernel with MRK_QS_R rows per lane (A/B measurements)
+  static const int variant = [] { const char *e = getenv("MRK_QS_KERNEL"); return e ? atoi(e) : 1; }();
+  if (variant != 0) {
+    launch_bin<F64>(ctx, m, d_x, rows, cols, QS_TILE_ROWS, d_flag, d_row_req);
+    launch_wave<F64>(ctx, m, ctx->d_cells.as<uint16_t>(), rows, d_out);
+    return true;
   }
-  if (!r) return false;
-  if (r == 8) launch_qs_t<F64, 8>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_trees, smem(8));
-  else if (r == 4) launch_qs_t<F64, 4>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_trees, smem(4));
-  else launch_qs_t<F64, 2>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_trees, smem(2));
+  const size_t V = m->qs.views.size();
+  const int leaf_bytes = QS_LEAVES * (F64 ? 8 : 4);
+  const int chunk_trees = std::min(m->qs.n_trees, 8 * 1024 / leaf_bytes);
+  auto smem = [&](int r) { return (size_t)chunk_trees * leaf_bytes + (size_t)QS_WAVES * V * r * 128; };
+  static const int forced = [] { const char *e = getenv("MRK_QS_R"); return e ? atoi(e) : 2; }();
+  const int r = (forced == 4 || forced == 8) ? forced : 2;
+  if (smem(r) > 160 * 1024) return false;
+  launch_bin<F64>(ctx, m, d_x, rows, cols, r * 64, d_flag, d_row_req);
+  if (r == 8) launch_generic<F64, 8>(ctx, m, ctx->d_cells.as<uint16_t>(), rows, d_out, chunk_trees, smem(8));
+  else if (r == 4) launch_generic<F64, 4>(ctx, m, ctx->d_cells.as<uint16_t>(), rows, d_out, chunk_trees, smem(4));
+  else launch_generic<F64, 2>(ctx, m, ctx->d_cells.as<uint16_t>(), rows, d_out, chunk_trees, smem(2));
   return true;
 }
 
 }  // namespace
 
-// Returns false when the model has no bit-vector image or its tile does not fit LDS: the caller
-// falls back to the tree-walk kernel (score.hip).  Both produce identical bits.
+QsDev qs_device_view(const mrk_model *m) {
+  QsDev q;
+  q.feats = m->d_qs_feats.as<QsFeature>();
+  q.views = m->d_qs_views.as<QsView>();
+  q.thr = m->d_qs_thr.as<double>();
+  q.n_feats = (int32_t)m->qs.feats.size();
+  q.n_views = (int32_t)m->qs.views.size();
+  return q;
+}
+
+// Returns false when the model has no bit-vector image (trees with more than 16 leaves, ...): the
+// caller falls back to the tree-walk kernel (score.hip).  Both produce identical bits.
 bool launch_score_qs(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
                      const uint32_t *d_row_req) {
   if (!m->qs.ok) return false;
   if (m->forest.backend == Backend::LightGBM) return launch_qs_b<true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req);
   return launch_qs_b<false>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req);
+}
+
+// Scores rows whose binned cells ([tile of 128 rows][view][row] u16) were written by the assembly kernels.
+void launch_score_qs_cells(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, double *d_out) {
+  if (m->forest.backend == Backend::LightGBM) launch_wave<true>(ctx, m, d_cells, rows, d_out);
+  else launch_wave<false>(ctx, m, d_cells, rows, d_out);
 }
 
 }  // namespace mrk
