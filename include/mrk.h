@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MRK_ABI_VERSION 1
+#define MRK_ABI_VERSION 2
 
 typedef enum mrk_status {
   MRK_OK = 0,
@@ -100,6 +100,8 @@ typedef struct mrk_model_info {
   int64_t n_leaves;
   int64_t device_bytes;  /* packed forest bytes resident in HBM             */
   double base_score;     /* XGBoost base margin (0.0 for LightGBM)          */
+  int32_t bitvector;     /* 1: every tree has <= 16 leaves, the bit-vector scorer applies; 0: tree-walk scorer */
+  int32_t tile_columns;  /* bitvector: columns ("views") of the scorer's binned tile */
 } mrk_model_info;
 int mrk_model_get_info(mrk_model *model, mrk_model_info *out);
 
@@ -185,6 +187,16 @@ int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *r
 int mrk_batch_total_items(mrk_batch *batch);
 /* asynchronous on the context stream */
 int mrk_batch_run(mrk_batch *batch, mrk_model *model);
+/* Item-sharded execution (the reference has no counterpart - it scores a request on one
+ * JVM thread): shard `shard_index` of `shard_count` assembles and scores batch items
+ * [index * chunk, (index + 1) * chunk) only, chunk = mrk_batch_shard_chunk() (total / count rounded up to a
+ * whole number of 128-item scorer tiles), and does NOT sort.  Request-level reductions (diversity,
+ * interacted_with) are computed from the whole request on every shard.  The caller merges the score
+ * slices of all shards into the device score buffer (one all-gather of chunk * count f64; the buffer
+ * has room for the padded tail) and then calls mrk_batch_sort on the rank(s) that need the order. */
+int mrk_batch_shard_chunk(mrk_batch *batch, int shard_count);
+int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int shard_count);
+int mrk_batch_sort(mrk_batch *batch);
 /* device pointers of the batch outputs (valid until mrk_batch_free): scores f64[total_items],
  * order i32[total_items] (request-local indices), matrix f64[total_items*dim].
  * The f64 matrix (ClickthroughQuery's layout) is materialised on demand only: with a LightGBM /

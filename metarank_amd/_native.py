@@ -50,7 +50,7 @@ def build(force: bool = False) -> str:
 class mrk_model_info(C.Structure):
     _fields_ = [("backend", C.c_int32), ("n_trees", C.c_int32), ("max_depth", C.c_int32), ("n_features", C.c_int32),
                 ("is_f64", C.c_int32), ("n_categorical", C.c_int32), ("n_nodes", C.c_int64), ("n_leaves", C.c_int64),
-                ("device_bytes", C.c_int64), ("base_score", C.c_double)]
+                ("device_bytes", C.c_int64), ("base_score", C.c_double), ("bitvector", C.c_int32), ("tile_columns", C.c_int32)]
 
 
 class mrk_field(C.Structure):
@@ -95,6 +95,9 @@ SIGNATURES = {
     "mrk_batch_prepare": (_I, [_V, _S, C.POINTER(mrk_request), _I, C.POINTER(_V)]),
     "mrk_batch_total_items": (_I, [_V]),
     "mrk_batch_run": (_I, [_V, _V]),
+    "mrk_batch_shard_chunk": (_I, [_V, _I]),
+    "mrk_batch_run_shard": (_I, [_V, _V, _I, _I]),
+    "mrk_batch_sort": (_I, [_V]),
     "mrk_batch_device_outputs": (_I, [_V, C.POINTER(_V), C.POINTER(_V), C.POINTER(_V)]),
     "mrk_batch_fetch": (_I, [_V, _P, _P, _P]),
     "mrk_batch_status": (_I, [_V, _P]),

@@ -251,6 +251,8 @@ int mrk_model_get_info(mrk_model *model, mrk_model_info *out) {
     out->device_bytes = (int64_t)(model->packed.image.size() + model->packed.trees.size() * sizeof(TreeRef) +
                                   model->packed.chunks.size() * sizeof(ChunkRef) + f.cat_bits.size() * 4);
     out->base_score = f.base_score;
+    out->bitvector = model->qs.ok ? 1 : 0;
+    out->tile_columns = model->qs.ok ? (int32_t)model->qs.views.size() : 0;
   });
 }
 

@@ -13,6 +13,7 @@ namespace mrk {
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_sort(mrk_ctx *ctx, const BatchDev &b);
+void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
@@ -73,6 +74,8 @@ struct mrk_batch {
   int n_req = 0, total_items = 0;
   DevBuf d_in, d_prep_out, d_arena, d_status, d_matrix, d_scores, d_order;
   DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
+  DevBuf d_sort_keys, d_sort_idx;       // scratch of the multi-workgroup sort
+  std::vector<std::pair<int, int>> big; // (request, n_items) with n_items > SORT_MAX_ITEMS
   PinBuf h_in;
   BatchDev view{};
   std::vector<int32_t> h_status;
@@ -128,13 +131,15 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.d_arena.reserve(std::max<size_t>(hb.arena_entries, 1) * 8);
   b.d_status.reserve(std::max<size_t>(n_req, 1) * 4);
   b.d_matrix.reserve(std::max<size_t>((size_t)T * prog.dim, 1) * 8);
-  b.d_scores.reserve(std::max<size_t>(T, 1) * 8);
+  b.d_scores.reserve(((size_t)T + 256 * QS_TILE_ROWS) * 8);  // room for the padded chunks of an item-sharded all-gather
   b.d_order.reserve(std::max<size_t>(T, 1) * 4);
   uint8_t *d = b.d_in.as<uint8_t>();
   BatchDev &v = b.view;
   v.reqs = (const ReqDev *)(d + o_reqs);
   v.n_req = n_req;
   v.total_items = T;
+  v.item_lo = 0;
+  v.item_hi = T;
   v.item_slot = (const int32_t *)(d + o_slot);
   v.item_req = (const uint32_t *)(d + o_ireq);
   v.consts = (const double *)(d + o_consts);
@@ -150,13 +155,26 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.h_status.assign(n_req, 0);
   b.ran = false;
   b.matrix_valid = false;
+  b.big.clear();
+  size_t big_p2 = 0;
+  for (int r = 0; r < n_req; ++r)
+    if (hb.reqs[r].n_items > SORT_MAX_ITEMS) {
+      b.big.emplace_back(r, hb.reqs[r].n_items);
+      size_t p2 = SORT_MAX_ITEMS;
+      while (p2 < (size_t)hb.reqs[r].n_items) p2 <<= 1;
+      big_p2 = std::max(big_p2, p2);
+    }
+  if (big_p2) {
+    b.d_sort_keys.reserve(big_p2 * 8);
+    b.d_sort_idx.reserve(big_p2 * 4);
+  }
   // small requests: both phases in one workgroup, tables in LDS (<= 64 KB keeps two workgroups per CU)
   uint32_t vals = 1;
   while ((int)vals < hb.max_doubles) vals <<= 1;
   b.fused_entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
   b.fused_vals = (int)vals;
   b.fused_threads = std::min(256, std::max(64, (hb.max_items + 63) / 64 * 64));
-  static const bool fused_enabled = [] { const char *e = getenv("MRK_RANK_FUSED"); return !e || atoi(e) != 0; }();
+  const bool fused_enabled = [] { const char *e = getenv("MRK_RANK_FUSED"); return !e || atoi(e) != 0; }();
   b.fused_ok = fused_enabled && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
                hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals) <= 64 * 1024;
 }
@@ -184,28 +202,43 @@ static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &
   b.matrix_valid = true;
 }
 
-// enqueue the whole pipeline on the context stream; ctx->mu must be held
-static void run_batch(mrk_batch &b, mrk_model *model) {
+// items per shard of an item-sharded run: ceil(total / count) rounded up to whole scorer tiles
+static int shard_chunk(const mrk_batch &b, int count) {
+  const long long per = ((long long)b.total_items + count - 1) / count;
+  return (int)((per + QS_TILE_ROWS - 1) / QS_TILE_ROWS * QS_TILE_ROWS);
+}
+
+static void sort_batch(mrk_batch &b) {
+  mrk_ctx *ctx = b.ctx;
+  launch_sort(ctx, b.view);
+  for (auto &br : b.big) launch_big_sort(ctx, b.view, br.first, br.second, b.d_sort_keys.as<unsigned long long>(), b.d_sort_idx.as<int>());
+}
+
+// enqueue the pipeline on the context stream for batch items [lo, hi); ctx->mu must be held
+static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort) {
   mrk_ctx *ctx = b.ctx;
   MRK_HIP(hipSetDevice(ctx->device));
   check_model_fits(model, *b.prog);
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
   MRK_HIP(hipMemsetAsync(b.d_status.p, 0, std::max<size_t>(b.n_req, 1) * 4, ctx->stream));
+  b.view.item_lo = lo;
+  b.view.item_hi = hi;
+  const int rows = hi - lo;
   // MRK_RANK_CELLS=0 / MRK_SCORER=walk keep the f64 matrix between assembly and scoring (A/B measurements)
-  static const bool cells_enabled = [] {
+  const bool cells_enabled = [] {
     const char *e = getenv("MRK_RANK_CELLS"), *w = getenv("MRK_SCORER");
     return (!e || atoi(e) != 0) && !(w && std::string(w) == "walk");
   }();
-  const bool cells = cells_enabled && model && model->qs.ok && !b.want_matrix && b.total_items > 0;
+  const bool cells = cells_enabled && model && model->qs.ok && !b.want_matrix && rows > 0;
   if (cells) {
     // hot path: the assembled values go straight into the scorer's binned tile; no f64 matrix
     const QsDev q = qs_device_view(model);
     const size_t tile_bytes = (size_t)q.n_views * QS_TILE_ROWS * 2;
     const size_t n_tiles = ((size_t)b.total_items + QS_TILE_ROWS - 1) / QS_TILE_ROWS;
-    b.d_cells.reserve(n_tiles * tile_bytes);
-    if (b.total_items % QS_TILE_ROWS)  // rows past the last item of the last tile
-      MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (n_tiles - 1) * tile_bytes, 0, tile_bytes, ctx->stream));
+    b.d_cells.reserve(std::max<size_t>(n_tiles * tile_bytes, 16));
+    if (hi % QS_TILE_ROWS && tile_bytes)  // rows past the last item of the last tile of this range
+      MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (size_t)(hi / QS_TILE_ROWS) * tile_bytes, 0, tile_bytes, ctx->stream));
     const bool f64 = model->forest.backend == Backend::LightGBM;
     if (b.fused_ok) {
       launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64);
@@ -214,19 +247,25 @@ static void run_batch(mrk_batch &b, mrk_model *model) {
       launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64);
     }
     b.matrix_valid = false;
-    launch_score_qs_cells(ctx, model, b.d_cells.as<uint16_t>(), b.total_items, b.view.scores);
+    // lo is a multiple of the tile size: the scorer sees rows [lo, hi) as its rows [0, hi - lo)
+    launch_score_qs_cells(ctx, model, b.d_cells.as<uint16_t>() + (size_t)(lo / QS_TILE_ROWS) * (tile_bytes / 2), rows, b.view.scores + lo);
   } else {
     assemble_matrix(b, st, pd);
-    if (model) {
-      launch_score_batch(ctx, model, b.view.matrix, b.total_items, pd.dim, b.view.scores, b.view.status, b.view.item_req);
-    } else if (b.total_items > 0) {
+    b.matrix_valid = lo == 0 && hi == b.total_items;
+    if (model && rows > 0) {
+      launch_score_batch(ctx, model, b.view.matrix + (size_t)lo * pd.dim, rows, pd.dim, b.view.scores + lo, b.view.status, b.view.item_req + lo);
+    } else if (rows > 0) {
       // NoopModel (ml/rank/NoopRanker.scala:22-26): every score is 0.0
-      MRK_HIP(hipMemsetAsync(b.d_scores.p, 0, (size_t)b.total_items * 8, ctx->stream));
+      MRK_HIP(hipMemsetAsync(b.view.scores + lo, 0, (size_t)rows * 8, ctx->stream));
     }
   }
-  launch_sort(ctx, b.view);
+  b.view.item_lo = 0;
+  b.view.item_hi = b.total_items;
+  if (sort) sort_batch(b);
   b.ran = true;
 }
+
+static void run_batch(mrk_batch &b, mrk_model *model) { run_batch(b, model, 0, b.total_items, true); }
 
 static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *matrix) {
   mrk_ctx *ctx = b.ctx;
@@ -352,6 +391,34 @@ int mrk_batch_run(mrk_batch *batch, mrk_model *model) {
     if (model && model->ctx != batch->ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
     std::lock_guard<std::mutex> lk(batch->ctx->mu);
     run_batch(*batch, model);
+  });
+}
+
+int mrk_batch_shard_chunk(mrk_batch *batch, int shard_count) {
+  if (!batch || shard_count < 1) return MRK_ERR_INVALID_ARG;
+  return shard_chunk(*batch, shard_count);
+}
+
+int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int shard_count) {
+  return guard([&] {
+    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    if (shard_count < 1 || shard_count > 256 || shard_index < 0 || shard_index >= shard_count)
+      throw StatusError(MRK_ERR_INVALID_ARG, "bad shard index / count (1..256 shards)");
+    if (model && model->ctx != batch->ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
+    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    const int chunk = shard_chunk(*batch, shard_count);
+    const int lo = std::min<long long>((long long)chunk * shard_index, batch->total_items);
+    const int hi = std::min<long long>((long long)chunk * (shard_index + 1), batch->total_items);
+    run_batch(*batch, model, lo, hi, false);
+  });
+}
+
+int mrk_batch_sort(mrk_batch *batch) {
+  return guard([&] {
+    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    MRK_HIP(hipSetDevice(batch->ctx->device));
+    sort_batch(*batch);
   });
 }
 

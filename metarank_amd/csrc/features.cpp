@@ -649,8 +649,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
   int total = 0;
   for (int r = 0; r < n_req; ++r) {
     if (reqs[r].n_items < 0 || (reqs[r].n_items > 0 && !reqs[r].item_ids)) throw StatusError(MRK_ERR_INVALID_ARG, "bad item list");
-    if (reqs[r].n_items > SORT_MAX_ITEMS)
-      throw StatusError(MRK_ERR_UNSUPPORTED, "requests with more than " + std::to_string(SORT_MAX_ITEMS) + " items are not supported yet");
+    if (reqs[r].n_items > (1 << 27)) throw StatusError(MRK_ERR_UNSUPPORTED, "requests with more than 2^27 items are not supported");
     total += reqs[r].n_items;
   }
   hb.total_items = total;

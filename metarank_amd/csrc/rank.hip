@@ -285,6 +285,7 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
   __shared__ int s_misc[4];
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
+  if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
   PrepScratch sc{s_vals, PREP_MAX_VALUES, s_wave_tot, &s_first, s_misc};
   prepass_request(st, prog, b, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sc);
 }
@@ -548,8 +549,8 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
 
 __global__ void __launch_bounds__(ASM_THREADS)
 assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
-  const int gi = blockIdx.x * ASM_THREADS + threadIdx.x;
-  if (gi >= b.total_items) return;
+  const int gi = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
+  if (gi >= b.item_hi) return;
   const int r = (int)b.item_req[gi];
   const ReqDev rq = b.reqs[r];
   MatrixSink sink{b.matrix + (size_t)gi * prog.dim};
@@ -559,8 +560,8 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
 template <bool F64>
 __global__ void __launch_bounds__(ASM_THREADS)
 assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_t *cells) {
-  const int gi = blockIdx.x * ASM_THREADS + threadIdx.x;
-  if (gi >= b.total_items) return;
+  const int gi = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
+  if (gi >= b.item_hi) return;
   const int r = (int)b.item_req[gi];
   const ReqDev rq = b.reqs[r];
   CellSink<F64> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r]};
@@ -579,12 +580,14 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Progra
   int *s_int = (int *)(s_po + FUSED_MAX_PREP);
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
+  if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
   for (int e = threadIdx.x; e < prog.n_prep; e += blockDim.x) s_po[e] = b.prep_out[(size_t)r * prog.n_prep + e];
   __syncthreads();
   PrepScratch sc{s_vals, vals_cap, s_int, s_int + 4, s_int + 8};
   prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
   for (int i = threadIdx.x; i < rq.n_items; i += blockDim.x) {
     const int gi = rq.item_begin + i;
+    if (gi < b.item_lo || gi >= b.item_hi) continue;
     assemble_item(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r));
   }
 }
@@ -607,6 +610,7 @@ __global__ void override_kernel(BatchDev b, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n_overrides) return;
   const Override o = b.overrides[i];
+  if ((int)o.item < b.item_lo || (int)o.item >= b.item_hi) return;
   b.matrix[(size_t)o.item * dim + o.col] = o.value;
 }
 
@@ -616,6 +620,7 @@ __global__ void override_cells_kernel(BatchDev b, QsDev q, uint16_t *cells) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n_overrides) return;
   const Override o = b.overrides[i];
+  if ((int)o.item < b.item_lo || (int)o.item >= b.item_hi) return;
   CellSink<F64> sink{q, cells + (size_t)(o.item / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (o.item % QS_TILE_ROWS),
                      &b.status[b.item_req[o.item]]};
   sink.put((int)o.col, o.value);
@@ -640,7 +645,7 @@ sort_kernel(BatchDev b) {
   const int tid = threadIdx.x;
   const ReqDev rq = b.reqs[r];
   const int n = rq.n_items;
-  if (n <= 0) return;
+  if (n <= 0 || n > SORT_MAX_ITEMS) return;  // larger requests: the multi-workgroup sort below
   int p2 = 1;
   while (p2 < n) p2 <<= 1;
   for (int i = tid; i < p2; i += SORT_THREADS) {
@@ -667,6 +672,67 @@ sort_kernel(BatchDev b) {
   for (int i = tid; i < n; i += SORT_THREADS) b.order[rq.item_begin + i] = s_idx[i];
 }
 
+// ---- requests with more than SORT_MAX_ITEMS candidates (C4: 100 000): bitonic network over global memory.
+// Chunks of SORT_MAX_ITEMS elements are sorted / merged in LDS; only the compare distances >= one chunk
+// run as global steps.  (key, index) pairs are distinct, so the result is the stable order.
+__device__ __forceinline__ bool pair_gt(unsigned long long ka, int ia, unsigned long long kb, int ib) {
+  return ka > kb || (ka == kb && ia > ib);
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+bigsort_init_kernel(BatchDev b, int r, unsigned long long *keys, int *idx, int p2) {
+  const ReqDev rq = b.reqs[r];
+  const int i = blockIdx.x * SORT_THREADS + threadIdx.x;
+  if (i >= p2) return;
+  keys[i] = i < rq.n_items ? sort_key(b.scores[rq.item_begin + i]) : ~0ull;
+  idx[i] = i < rq.n_items ? i : 0x7fffffff;
+}
+
+// one chunk per workgroup: every stage (k, j) with j < SORT_MAX_ITEMS of the sizes k in [k_lo, k_hi]
+__global__ void __launch_bounds__(SORT_THREADS)
+bigsort_local_kernel(unsigned long long *keys, int *idx, int k_lo, int k_hi) {
+  __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
+  __shared__ int s_idx[SORT_MAX_ITEMS];
+  const int base = blockIdx.x * SORT_MAX_ITEMS;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) { s_key[i] = keys[base + i]; s_idx[i] = idx[base + i]; }
+  __syncthreads();
+  for (int k = k_lo; k <= k_hi; k <<= 1) {
+    for (int j = min(k >> 1, SORT_MAX_ITEMS >> 1); j > 0; j >>= 1) {
+      for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long ka = s_key[i], kb = s_key[ixj];
+          const int ia = s_idx[i], ib = s_idx[ixj];
+          const bool up = ((base + i) & k) == 0;
+          if (pair_gt(ka, ia, kb, ib) == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) { keys[base + i] = s_key[i]; idx[base + i] = s_idx[i]; }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+bigsort_global_kernel(unsigned long long *keys, int *idx, int p2, int k, int j) {
+  const int t = blockIdx.x * SORT_THREADS + threadIdx.x;  // one compare-exchange per thread
+  if (t >= (p2 >> 1)) return;
+  const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // the lower index of the pair: bit j clear
+  const int ixj = i | j;
+  const unsigned long long ka = keys[i], kb = keys[ixj];
+  const int ia = idx[i], ib = idx[ixj];
+  const bool up = (i & k) == 0;
+  if (pair_gt(ka, ia, kb, ib) == up) { keys[i] = kb; keys[ixj] = ka; idx[i] = ib; idx[ixj] = ia; }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+bigsort_store_kernel(BatchDev b, int r, const int *idx) {
+  const ReqDev rq = b.reqs[r];
+  const int i = blockIdx.x * SORT_THREADS + threadIdx.x;
+  if (i < rq.n_items) b.order[rq.item_begin + i] = idx[i];
+}
+
 }  // namespace
 
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b) {
@@ -677,10 +743,10 @@ void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, co
 }
 
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b) {
-  if (b.total_items <= 0) return;
+  if (b.item_hi <= b.item_lo) return;
   {
     ScopedKernelTimer timer(ctx, "assemble");
-    const int grid = (b.total_items + ASM_THREADS - 1) / ASM_THREADS;
+    const int grid = (b.item_hi - b.item_lo + ASM_THREADS - 1) / ASM_THREADS;
     hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(ASM_THREADS), 0, ctx->stream, st, prog, b);
     MRK_HIP(hipGetLastError());
   }
@@ -703,10 +769,10 @@ static void launch_override_cells(mrk_ctx *ctx, const BatchDev &b, const QsDev &
 // assembly straight into the scorer's binned tile (tables from a previous launch_prepass)
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
                            uint16_t *cells, bool f64) {
-  if (b.total_items <= 0) return;
+  if (b.item_hi <= b.item_lo) return;
   {
     ScopedKernelTimer timer(ctx, "assemble");
-    const dim3 grid((b.total_items + ASM_THREADS - 1) / ASM_THREADS);
+    const dim3 grid((b.item_hi - b.item_lo + ASM_THREADS - 1) / ASM_THREADS);
     if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), 0, ctx->stream, st, prog, b, q, cells);
     else hipLaunchKernelGGL(assemble_cells_kernel<false>, grid, dim3(ASM_THREADS), 0, ctx->stream, st, prog, b, q, cells);
     MRK_HIP(hipGetLastError());
@@ -754,6 +820,24 @@ void launch_sort(mrk_ctx *ctx, const BatchDev &b) {
   if (b.n_req <= 0) return;
   ScopedKernelTimer timer(ctx, "sort");
   hipLaunchKernelGGL(sort_kernel, dim3(b.n_req), dim3(SORT_THREADS), 0, ctx->stream, b);
+  MRK_HIP(hipGetLastError());
+}
+
+// one request with n_items > SORT_MAX_ITEMS; keys / idx hold p2 = next power of two >= n_items elements
+void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx) {
+  int p2 = SORT_MAX_ITEMS;
+  while (p2 < n_items) p2 <<= 1;
+  ScopedKernelTimer timer(ctx, "sort");
+  const dim3 blk(SORT_THREADS);
+  hipLaunchKernelGGL(bigsort_init_kernel, dim3(p2 / SORT_THREADS), blk, 0, ctx->stream, b, r, keys, idx, p2);
+  const int chunks = p2 / SORT_MAX_ITEMS;
+  hipLaunchKernelGGL(bigsort_local_kernel, dim3(chunks), blk, 0, ctx->stream, keys, idx, 2, SORT_MAX_ITEMS);
+  for (int k = SORT_MAX_ITEMS << 1; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j >= SORT_MAX_ITEMS; j >>= 1)
+      hipLaunchKernelGGL(bigsort_global_kernel, dim3((p2 / 2 + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->stream, keys, idx, p2, k, j);
+    hipLaunchKernelGGL(bigsort_local_kernel, dim3(chunks), blk, 0, ctx->stream, keys, idx, k, k);
+  }
+  hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->stream, b, r, idx);
   MRK_HIP(hipGetLastError());
 }
 

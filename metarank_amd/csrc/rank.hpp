@@ -103,6 +103,7 @@ struct BatchDev {
   const ReqDev *reqs;
   int32_t n_req;
   int32_t total_items;
+  int32_t item_lo, item_hi;   // the batch items this launch assembles (item-sharded runs; else 0, total_items)
   const int32_t *item_slot;   // ITEM table slot of every batch item (-1: unknown id)
   const uint32_t *item_req;   // request index of every batch item
   const double *consts;       // n_req * n_consts

@@ -297,8 +297,9 @@ uint32_t score_chunk_budget() { return 24 * 1024; }
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req) {
   if (rows <= 0) return;
-  // MRK_SCORER=walk forces the tree-walk kernel (A/B measurements, parity of both kernels)
-  static const bool walk_only = [] { const char *e = getenv("MRK_SCORER"); return e && std::string(e) == "walk"; }();
+  // MRK_SCORER=walk forces the tree-walk kernel (A/B measurements, parity of both kernels); read per call so
+  // that a test can flip it
+  const bool walk_only = [] { const char *e = getenv("MRK_SCORER"); return e && std::string(e) == "walk"; }();
   if (!walk_only && launch_score_qs(ctx, m, d_x, rows, cols, d_out, d_status, d_row_req)) return;
   ScopedKernelTimer timer(ctx, "score");
   if (m->forest.backend == Backend::LightGBM) launch_b<true>(ctx, m, d_x, rows, cols, d_out, d_status, d_row_req);

@@ -378,7 +378,7 @@ template <bool F64>
 bool launch_qs_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
                  const uint32_t *d_row_req) {
   // MRK_QS_KERNEL=0 selects the multi-wave generic kernel with MRK_QS_R rows per lane (A/B measurements)
-  static const int variant = [] { const char *e = getenv("MRK_QS_KERNEL"); return e ? atoi(e) : 1; }();
+  const int variant = [] { const char *e = getenv("MRK_QS_KERNEL"); return e ? atoi(e) : 1; }();
   if (variant != 0) {
     launch_bin<F64>(ctx, m, d_x, rows, cols, QS_TILE_ROWS, d_flag, d_row_req);
     launch_wave<F64>(ctx, m, ctx->d_cells.as<uint16_t>(), rows, d_out);
@@ -388,7 +388,7 @@ bool launch_qs_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int co
   const int leaf_bytes = QS_LEAVES * (F64 ? 8 : 4);
   const int chunk_trees = std::min(m->qs.n_trees, 8 * 1024 / leaf_bytes);
   auto smem = [&](int r) { return (size_t)chunk_trees * leaf_bytes + (size_t)QS_WAVES * V * r * 128; };
-  static const int forced = [] { const char *e = getenv("MRK_QS_R"); return e ? atoi(e) : 2; }();
+  const int forced = [] { const char *e = getenv("MRK_QS_R"); return e ? atoi(e) : 2; }();
   const int r = (forced == 4 || forced == 8) ? forced : 2;
   if (smem(r) > 160 * 1024) return false;
   launch_bin<F64>(ctx, m, d_x, rows, cols, r * 64, d_flag, d_row_req);

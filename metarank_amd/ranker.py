@@ -40,10 +40,24 @@ class Batch:
     def run(self, booster: HipBooster | None):
         N.check(N.lib().mrk_batch_run(self._h, booster.handle if booster is not None else None))
 
-    def device_outputs(self):
+    def run_shard(self, booster: HipBooster | None, shard_index: int, shard_count: int):
+        """assemble + score batch items [index * chunk, (index + 1) * chunk) only; no sort (mrk_batch_run_shard)"""
+        N.check(N.lib().mrk_batch_run_shard(self._h, booster.handle if booster is not None else None, shard_index, shard_count))
+
+    def shard_chunk(self, shard_count: int) -> int:
+        c = N.lib().mrk_batch_shard_chunk(self._h, shard_count)
+        if c < 0:
+            N.check(c)
+        return c
+
+    def sort(self):
+        N.check(N.lib().mrk_batch_sort(self._h))
+
+    def device_outputs(self, matrix: bool = False):
+        """device pointers (scores, order, matrix | None); asking for the matrix makes later runs write it"""
         s, o, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        N.check(N.lib().mrk_batch_device_outputs(self._h, C.byref(s), C.byref(o), C.byref(m)))
-        return s.value, o.value, m.value
+        N.check(N.lib().mrk_batch_device_outputs(self._h, C.byref(s), C.byref(o), C.byref(m) if matrix else None))
+        return s.value, o.value, (m.value if matrix else None)
 
     def fetch(self, matrix: bool = False):
         scores = np.empty(self.total_items, dtype=np.float64)

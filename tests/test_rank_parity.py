@@ -154,3 +154,112 @@ def test_store_updates_are_visible_and_batch_status_per_request():
         batch.close()
     finally:
         hip.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["lgbm", "xgb4"])
+def test_assembly_paths_agree(oracle_c2, kind):
+    """The four ways a batch can be assembled - {one fused workgroup per request with LDS tables,
+    pre-pass kernel + item-parallel kernel with HBM tables} x {straight into the scorer's binned tile,
+    f64 matrix + binning kernel} - give the oracle's scores and order; item-field overrides and a request
+    that throws are in the batch."""
+    import os
+
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS")}
+    try:
+        load(hip)
+        reqs = ranklens.generate_requests(30, 100, N_ITEMS, N_SESS, seed=21)
+        reqs += ranklens.generate_requests(2, 1, N_ITEMS, N_SESS, seed=22) + ranklens.generate_requests(2, 300, N_ITEMS, N_SESS, seed=23)
+        reqs.append({"id": "empty-ish", "timestamp": ranklens.TS, "user": None, "session": None, "fields": [], "items": [{"id": "nobody"}]})
+        # per-request inputs that win over the store (NumberFeature.scala:86-92, StringFeature.scala:96-99)
+        for ev in reqs[:6]:
+            ev["items"][0]["fields"] = [{"name": "popularity", "value": 77.5}, {"name": "genres", "value": ["drama", "comedy"]}]
+            ev["items"][3]["fields"] = [{"name": "vote_avg", "value": float("nan")}]
+        mats = [oracle_c2.matrix(ev) for ev in reqs]
+        q = ranklens.column_quantiles(np.concatenate(mats))
+        if kind == "lgbm":
+            blob, be = synth.synthetic_lgbm_model(n_trees=300, n_features=24, quantiles=q, cat_features=[7], cat_prob=0.03), 0
+        else:
+            blob, be = synth.synthetic_xgb_model(n_trees=200, n_features=24, depth=4, quantiles=q, cat_features=[7], cat_prob=0.05), 1
+        oracle_c2.load_model(blob, be)
+        hip.load_model(blob, be)
+        assert hip.booster.info()["bitvector"] == 1
+        expected = [oracle_c2.rerank(ev) for ev in reqs]
+        for fused in ("1", "0"):
+            for cells in ("1", "0"):
+                os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"] = fused, cells
+                batch = hip.ranker.prepare("xgboost", reqs)
+                batch.run(hip.booster)
+                scores, order, _ = batch.fetch()
+                assert (batch.status() == 0).all()
+                for r, (_, es, eo) in enumerate(expected):
+                    lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                    assert same(scores[lo:hi], es), (fused, cells, r)
+                    assert order[lo:hi].tolist() == eo.tolist(), (fused, cells, r)
+                # the matrix is materialised on demand and is the oracle's
+                _, _, mat = batch.fetch(matrix=True)
+                for r in range(len(reqs)):
+                    assert same(mat[batch.offsets[r]:batch.offsets[r + 1]], mats[r]), (fused, cells, r)
+                # and the next run (straight into the tile again) still gives the same scores
+                batch.run(hip.booster)
+                s2, o2, _ = batch.fetch()
+                assert same(s2, scores) and (o2 == order).all()
+                batch.close()
+        # single requests: mrk_rank without / with the explain matrix
+        os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"] = "1", "1"
+        for ev, (_, es, eo), m in list(zip(reqs, expected, mats))[:8]:
+            _, hs, ho = hip.ranker.rerank("xgboost", ev, hip.booster, explain=False)
+            assert same(hs, es) and ho.tolist() == eo.tolist()
+            hm, hs, ho = hip.ranker.rerank("xgboost", ev, hip.booster, explain=True)
+            assert same(hm, m) and same(hs, es) and ho.tolist() == eo.tolist()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        hip.close()
+
+
+@pytest.mark.gpu
+def test_c4_100k_candidates_sharded_and_sorted(oracle_c2):
+    """BASELINE config C4: one request with 100 000 candidates.  (a) whole on one GPU: multi-workgroup
+    assembly, HBM pre-pass tables, multi-workgroup sort; (b) item-sharded 2 and 8 ways the way 8 GPUs
+    would run it (each shard assembles + scores its slice, the slices are merged, then one sort):
+    same bytes as the oracle's rerank of the whole request."""
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        load(hip)
+        big = ranklens.generate_requests(1, 100_000, N_ITEMS, N_SESS, seed=41)[0]
+        small = ranklens.generate_requests(3, 100, N_ITEMS, N_SESS, seed=42)
+        reqs = [small[0], big, small[1], small[2]]
+        sample = np.concatenate([oracle_c2.matrix(ev) for ev in small])
+        blob = synth.synthetic_lgbm_model(n_trees=500, n_features=24, quantiles=ranklens.column_quantiles(sample),
+                                          cat_features=[7], cat_prob=0.01, missing="per_feature")
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        expected = [oracle_c2.rerank(ev) for ev in reqs]
+        batch = hip.ranker.prepare("xgboost", reqs)
+        batch.run(hip.booster)
+        scores, order, _ = batch.fetch()
+        assert (batch.status() == 0).all()
+        for r, (_, es, eo) in enumerate(expected):
+            lo, hi = batch.offsets[r], batch.offsets[r + 1]
+            assert same(scores[lo:hi], es), r
+            assert order[lo:hi].tolist() == eo.tolist(), r
+        # ties and NaN in a large sort: stable order == argsort(kind="stable") on the Double.compare key
+        assert len(np.unique(scores[batch.offsets[1]:batch.offsets[2]])) < 100_000  # duplicates exist: the tie-break matters
+        for world in (2, 8):
+            chunk = batch.shard_chunk(world)
+            assert chunk % 128 == 0 and chunk * world >= batch.total_items
+            b2 = hip.ranker.prepare("xgboost", reqs)
+            for rank in range(world):  # same device buffer: the slices land where an all-gather would put them
+                b2.run_shard(hip.booster, rank, world)
+            b2.sort()
+            s2, o2, _ = b2.fetch()
+            assert same(s2, scores) and (o2 == order).all(), world
+            b2.close()
+        batch.close()
+    finally:
+        hip.close()

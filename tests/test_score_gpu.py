@@ -149,3 +149,101 @@ def test_full_size_properties_100k(ctx):
     # (3) the oracle on a seeded sample
     idx = rng.choice(len(X), 2000, replace=False)
     assert np.array_equal(full[idx], OracleForest.from_lightgbm_text(blob).predict(X[idx]))
+
+
+# ---------------------------------------------------------------------------------------------
+# The two scorers: bit-vector (trees of <= 16 leaves, score_qs.hip) and tree-walk (score.hip).
+# Both must reproduce the oracle bit for bit on the same model; MRK_SCORER / MRK_QS_KERNEL are read
+# per call by the library, so a test can pin a kernel.
+@pytest.fixture
+def scorer_env():
+    saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R")}
+    yield
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _all_kernels(b, X):
+    out = {}
+    os.environ.pop("MRK_SCORER", None)
+    os.environ["MRK_QS_KERNEL"] = "1"
+    out["bitvector-wave"] = b.predict(X)
+    for r in ("2", "4", "8"):
+        os.environ["MRK_QS_KERNEL"] = "0"
+        os.environ["MRK_QS_R"] = r
+        out[f"bitvector-generic-r{r}"] = b.predict(X)
+    os.environ.pop("MRK_QS_KERNEL", None)
+    os.environ.pop("MRK_QS_R", None)
+    os.environ["MRK_SCORER"] = "walk"
+    out["walk"] = b.predict(X)
+    os.environ.pop("MRK_SCORER", None)
+    return out
+
+
+@pytest.mark.parametrize("rows", [1, 2, 127, 128, 129, 1000])
+@pytest.mark.parametrize("num_leaves,missing,cat_prob", [(16, "per_node", 0.02), (16, "per_feature", 0.0), (7, "per_node", 0.05),
+                                                         (2, "per_feature", 0.3), (1, "per_node", 0.0)])
+def test_bitvector_and_walk_kernels_lightgbm(ctx, scorer_env, rows, num_leaves, missing, cat_prob):
+    rng = np.random.default_rng(rows * 31 + num_leaves)
+    X = make_X(rng, rows, 24, cat_col=7, n_cats=40)
+    blob = synth.synthetic_lgbm_model(n_trees=120, n_features=24, num_leaves=num_leaves, quantiles=quantiles_of(X),
+                                      cat_features=[7], cat_prob=cat_prob, n_cats=40, missing=missing, seed=rows + num_leaves)
+    exp = OracleForest.from_lightgbm_text(blob).predict(X)
+    b = M.HipBooster(blob, M.LIGHTGBM, ctx)
+    assert b.info()["bitvector"] == 1 and (b.info()["tile_columns"] > 0) == (num_leaves > 1)
+    for name, got in _all_kernels(b, X).items():
+        assert np.array_equal(got, exp), name
+
+
+@pytest.mark.parametrize("rows", [1, 128, 333])
+@pytest.mark.parametrize("depth,complete", [(4, True), (4, False), (2, True)])
+def test_bitvector_and_walk_kernels_xgboost(ctx, scorer_env, rows, depth, complete):
+    rng = np.random.default_rng(rows + depth)
+    X = make_X(rng, rows, 17, cat_col=3)
+    blob = synth.synthetic_xgb_model(n_trees=90, n_features=17, depth=depth, quantiles=quantiles_of(X), cat_features=[3],
+                                     cat_prob=0.1, complete=complete, seed=rows)
+    exp = OracleForest.from_xgboost(blob).predict(X)
+    b = M.HipBooster(blob, M.XGBOOST, ctx)
+    assert b.info()["bitvector"] == 1
+    for name, got in _all_kernels(b, X).items():
+        assert np.array_equal(got, exp), name
+
+
+def test_large_trees_have_no_bitvector_image(ctx):
+    blob = synth.synthetic_xgb_model(n_trees=5, n_features=6, depth=6)
+    assert M.HipBooster(blob, M.XGBOOST, ctx).info()["bitvector"] == 0
+    blob = synth.synthetic_lgbm_model(n_trees=5, n_features=6, num_leaves=17, max_depth=10)
+    assert M.HipBooster(blob, M.LIGHTGBM, ctx).info()["bitvector"] == 0
+
+
+def test_bitvector_special_values(ctx, scorer_env):
+    """-0.0, +-1e-36 (LightGBM's zero flush), +-inf, huge categories, thresholds hit exactly."""
+    rng = np.random.default_rng(77)
+    X = make_X(rng, 600, 8, cat_col=2, n_cats=70)
+    q = quantiles_of(X)
+    specials = [0.0, -0.0, 1e-36, -1e-36, 1e-35, math.inf, -math.inf, NAN, 1e300, -1e300, 2.0 ** 31, -(2.0 ** 31), 16777216.0, 70000.0]
+    for i, v in enumerate(specials):
+        X[i, :] = v
+    for j in range(8):  # values equal to thresholds
+        X[100:100 + len(q[j]), j] = q[j]
+    blob = synth.synthetic_lgbm_model(n_trees=200, n_features=8, quantiles=q, cat_features=[2], cat_prob=0.1, n_cats=70, seed=5)
+    exp = OracleForest.from_lightgbm_text(blob).predict(X)
+    b = M.HipBooster(blob, M.LIGHTGBM, ctx)
+    for name, got in _all_kernels(b, X).items():
+        assert np.array_equal(got, exp), name
+    Xf = X.copy()
+    Xf[np.isinf(Xf)] = 3.0e38  # XGBoost rejects inf; keep a value that narrows to a finite float
+    Xf[np.abs(Xf) > 3.0e38] = 3.0e38
+    xb = synth.synthetic_xgb_model(n_trees=150, n_features=8, depth=4, quantiles=q, cat_features=[2], cat_prob=0.1, n_cats=70, seed=6)
+    expx = OracleForest.from_xgboost(xb).predict(Xf)
+    bx = M.HipBooster(xb, M.XGBOOST, ctx)
+    for name, got in _all_kernels(bx, Xf).items():
+        assert np.array_equal(got, expx), name
+    Xi = Xf.copy()
+    Xi[5, 1] = math.inf
+    with pytest.raises(M.MrkError) as e:
+        bx.predict(Xi)
+    assert "inf" in e.value.message
