@@ -4,13 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic Ranklens-shaped requests that is
-already resident in HBM: pre-pass -> assemble -> score -> sort for `--requests` requests of
-`--items` candidate items each (default 3840 x 100 = 384 000 items per GPU per step: 3000 scorer
-wavefronts of 128 items, one resident round on 256 CUs x 12 waves).  Workload =
-the configuration BASELINE.json's metric is quoted on: 100-item requests, the 24 Ranklens columns
-(stock Ranklens model), 500-tree LightGBM-format LambdaMART.  Weak scaling: every rank owns a
-replica of the feature store and its own requests; for N > 1 the per-step scores are merged with
-one RCCL all-gather (the only exchange the path has).
+already resident in HBM: assembly (pre-pass + gather, straight into the scorer's binned tile) ->
+score -> sort for `--requests` requests of `--items` candidate items each.
+
+--workload c2 (default)  the configuration BASELINE.json's metric is quoted on: 100-item requests, the
+             24 Ranklens columns (stock Ranklens model), 500-tree LightGBM-format LambdaMART;
+             3840 x 100 = 384 000 items per GPU per step (3000 scorer wavefronts of 128 items: one
+             resident round on 256 CUs x 12 waves).  Weak scaling: every rank owns a replica of the
+             feature store and its own requests; for N > 1 the per-step scores are merged with one RCCL
+             all-gather (the only exchange the path has).
+--workload c3   1000-item requests, 64 mixed columns (BASELINE config 3), 384 requests per GPU per step.
+--workload c4   ONE request with 100 000 candidates (BASELINE config 4), item-sharded over the ranks:
+             every rank assembles + scores its slice, one in-place RCCL all-gather of the f64 scores,
+             then the sort.  Strong scaling ("scaling": "strong").
 
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
   roofline     dominant kernel, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
@@ -42,14 +48,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--requests", type=int, default=3840, help="requests per step per GPU")
-    ap.add_argument("--items", type=int, default=100, help="candidate items per request")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--requests", type=int, default=None, help="requests per step per GPU (c2: 3840, c3: 384, c4: 1)")
+    ap.add_argument("--items", type=int, default=None, help="candidate items per request (c2: 100, c3: 1000, c4: 100000)")
     ap.add_argument("--catalogue", type=int, default=100_000)
     ap.add_argument("--sessions", type=int, default=10_000)
     ap.add_argument("--trees", type=int, default=500)
     ap.add_argument("--cpu-sample", type=int, default=4096, help="requests timed on the CPU oracle (0 = skip)")
     ap.add_argument("--latency-requests", type=int, default=300, help="single-request latency samples (0 = skip)")
     args = ap.parse_args()
+    wl = args.workload
+    if args.requests is None:
+        args.requests = {"c2": 3840, "c3": 384, "c4": 1}[wl]
+    if args.items is None:
+        args.items = {"c2": 100, "c3": 1000, "c4": 100_000}[wl]
+    sharded = wl == "c4"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -72,7 +85,7 @@ def main():
     from metarank_amd import ranklens, synth
 
     ctx = M.Context(local_rank)
-    cfg = ranklens.ranklens_config()
+    cfg = ranklens.c3_config() if wl == "c3" else ranklens.ranklens_config()
     ranker = M.HipRanker(cfg, ctx)
     model_name = "xgboost"
     dim = ranker.dim(model_name)
@@ -100,7 +113,7 @@ def main():
         fn_o = {"double": s.put_double, "string": s.put_string, "string_list": s.put_string_list,
                 "double_list": s.put_double_list, "counter": s.put_counter, "periodic": s.put_periodic,
                 "bounded_list": s.put_bounded_list}
-    for kind, key, value in ranklens.generate_state(args.catalogue, args.sessions):
+    for kind, key, value in ranklens.generate_state(args.catalogue, args.sessions, c3=(wl == "c3")):
         fn_h[kind](key, value)
         if oracle is not None:
             fn_o[kind](key, value)
@@ -109,8 +122,10 @@ def main():
     log(f"state: {n_puts} feature values for {args.catalogue} items / {args.sessions} sessions in {time.perf_counter() - t0:.1f}s")
 
     # ---- requests (per-rank seeds) and the model
-    events = ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions, seed=ranklens.SEED + 1 + rank)
-    sample = ranker.prepare(model_name, events[:64])
+    # item-sharded: every rank holds the same request; else per-rank requests
+    events = ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
+                                        seed=ranklens.SEED + 1 + (0 if sharded else rank))
+    sample = ranker.prepare(model_name, ranklens.generate_requests(64, 100, args.catalogue, args.sessions, seed=ranklens.SEED + 99))
     sample.run(None)
     _, _, sm = sample.fetch(matrix=True)
     sample.close()
@@ -127,19 +142,26 @@ def main():
 
     # ---- multi-GPU merge buffers (scores of every rank) ----
     gather = None
+    chunk = batch.shard_chunk(n_gpus) if sharded else total_items
     if use_dist:
+        from metarank_amd.dist import all_gather_padded
+
         d_scores, _, _ = batch.device_outputs()
+        n_view = chunk * n_gpus if sharded else total_items  # the library's score buffer has room for the padded chunks
 
         class _Arr:  # __cuda_array_interface__ view of the library-owned score buffer
-            __cuda_array_interface__ = {"shape": (total_items,), "typestr": "<f8", "data": (d_scores, False), "version": 3}
+            __cuda_array_interface__ = {"shape": (n_view,), "typestr": "<f8", "data": (d_scores, False), "version": 3}
 
         scores_t = torch.as_tensor(_Arr(), device=f"cuda:{local_rank}")
-        merged = torch.empty(n_gpus * total_items, dtype=torch.float64, device=f"cuda:{local_rank}")
+        merged = None if sharded else torch.empty(n_gpus * total_items, dtype=torch.float64, device=f"cuda:{local_rank}")
         ext = torch.cuda.ExternalStream(M._native.lib().mrk_stream(ctx.handle), device=f"cuda:{local_rank}")
 
         def gather():
             with torch.cuda.stream(ext):
-                dist.all_gather_into_tensor(merged, scores_t)
+                if sharded:
+                    all_gather_padded(scores_t, chunk)  # in place: every rank ends up with every slice
+                else:
+                    dist.all_gather_into_tensor(merged, scores_t)
 
     def sync_all():
         ctx.sync()
@@ -151,9 +173,15 @@ def main():
             dist.barrier()
 
     def step():
-        batch.run(booster)
-        if gather is not None:
-            gather()
+        if sharded:  # this rank's slice -> merge -> order
+            batch.run_shard(booster, rank, n_gpus)
+            if gather is not None:
+                gather()
+            batch.sort()
+        else:
+            batch.run(booster)
+            if gather is not None:
+                gather()
 
     for _ in range(args.warmup):
         step()
@@ -174,13 +202,17 @@ def main():
     st = batch.status()
     assert (st == 0).all(), f"requests failed: {st[st != 0][:5]}"
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_items * n_gpus * args.steps / elapsed
+    value = total_items * (1 if sharded else n_gpus) * args.steps / elapsed
 
     # ---- per-kernel HIP-event timing (outside the timed region: the events add a little overhead)
     ctx.profile_enable(True)
     prof_steps = max(5, min(args.steps, 20))
     for _ in range(prof_steps):
-        batch.run(booster)
+        if sharded:
+            batch.run_shard(booster, rank, n_gpus)
+            batch.sort()
+        else:
+            batch.run(booster)
     ctx.sync()
     kernels = {}
     for k in ("prepass", "assemble", "override", "bin", "score", "sort"):
@@ -191,11 +223,14 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
     # algorithmic bytes per launch of the dominant kernel (DESIGN.md "Roofline accounting")
     store_bytes_item = 8 * dim + 48           # one record worth of cells + ~12 list tokens
+    V = info["tile_columns"]                  # u16 cells per item in the scorer's tile
+    my_items = min(chunk, total_items) if sharded else total_items
+    prepass_bytes = args.requests * (100 * 12 * 4 + 20 * 11 * 4)  # session profile tokens + diversity head
     alg = {
-        "score": total_items * (8 * dim + 8) + info["device_bytes"],
-        "bin": total_items * (8 * dim + 2 * 2 * dim),   # f64 row in, ~2 u16 views per column out
-        "assemble": total_items * (store_bytes_item + 8 + 8 * dim),
-        "prepass": args.requests * (100 * 12 * 4 + 20 * 11 * 4),
+        "score": my_items * (2 * V + 8) + info["n_trees"] * 256,   # cells in, score out, node constants + leaves
+        "bin": my_items * (8 * dim + 2 * V),
+        "assemble": my_items * (store_bytes_item + 8 + 2 * V) + prepass_bytes,  # record + tokens + slot in, cells out
+        "prepass": prepass_bytes,
         "sort": total_items * (8 + 4),
         "override": 0,
     }
@@ -205,14 +240,14 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg[dominant],
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
                 "note": "the forest scorer is VALU-issue bound, not HBM bound (SURVEY.md 8d): "
-                        f"{total_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G item-trees/s "
+                        f"{my_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G item-trees/s "
                         f"in {kernels['score']['avg_ms']:.3f} ms"}
 
     # ---- single-request latency (p50 of mrk_rank: host marshalling + 4 launches + copies)
     latency = None
     if rank == 0 and args.latency_requests > 0:
-        reqs = [M.Request(e) for e in events[:args.latency_requests]]
-        for r in reqs[:20]:
+        reqs = [M.Request(e) for e in events[:min(args.latency_requests, max(3, 30_000 // args.items))]]
+        for r in reqs[:min(20, len(reqs))]:
             ranker.rerank(model_name, r, booster)
         lat = []
         for r in reqs:
@@ -226,7 +261,7 @@ def main():
     cpu = None
     if do_cpu:
         forest = OracleForest.from_lightgbm_text(blob)
-        n = min(args.cpu_sample, len(events))
+        n = min(args.cpu_sample, len(events), max(1, 400_000 // args.items))  # bounded: ~10 s of CPU work
         reqs = [M.Request(e) for e in events[:n]]
         for r in reqs[:3]:
             forest.predict(oracle.plan.assemble(oracle.store, r))
@@ -258,14 +293,16 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "ranked items/sec (feature assembly + 500-tree LambdaMART + ordering), Ranklens-shaped 100-item requests",
+            "metric": f"ranked items/sec (feature assembly + {args.trees}-tree LambdaMART + ordering), Ranklens-shaped {args.items}-item requests",
             "value": value, "unit": "items/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-lightgbm", "requests_per_step_per_gpu": args.requests,
                        "items_per_request": args.items, "items_per_step_per_gpu": total_items, "catalogue_items": args.catalogue,
                        "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16,
-                       "parallelism": f"request-sharded x{n_gpus}" + (", RCCL all-gather of scores" if n_gpus > 1 else "")},
+                       "tile_columns": V,
+                       "parallelism": (f"item-sharded x{n_gpus}" if sharded else f"request-sharded x{n_gpus}") +
+                                      (", RCCL all-gather of scores" if n_gpus > 1 else "")},
             "latency": latency,
             "kernels": kernels,
             "roofline": roofline,

@@ -626,6 +626,14 @@ double map_datetime(int mapper, const Civil &c) {
   }
 }
 
+// open-addressing capacity for a table that receives `tokens` insertions (distinct keys <= tokens): load
+// factor <= 0.75 in the worst case, usually far lower (tokens repeat); even => the 8-byte entries of
+// consecutive tables stay 16-byte aligned
+static uint32_t table_capacity(uint64_t tokens) {
+  uint64_t cap = tokens + tokens / 3 + 2;
+  return (uint32_t)((cap + 1) & ~1ull);
+}
+
 uint32_t pow2_at_least(uint64_t n) {
   uint32_t c = 1;
   while (c < n) c <<= 1;
@@ -769,9 +777,9 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
             }
           }
           PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base + fi];
-          const uint32_t cap = pow2_at_least(std::max<uint64_t>(1, 2 * count));
+          const uint32_t cap = table_capacity(count);
           po.tab_off = (uint32_t)arena;
-          po.tab_mask = cap - 1;
+          po.tab_cap = cap;
           arena += cap;
         }
       } else if (f.type == FType::Diversity) {
@@ -792,9 +800,9 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
         if (doubles > PREP_MAX_VALUES)
           throw StatusError(MRK_ERR_UNSUPPORTED, "diversity feature '" + f.name + "' over more than " + std::to_string(PREP_MAX_VALUES) + " values: set `top`");
         PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base];
-        const uint32_t cap = pow2_at_least(std::max<uint64_t>(1, 2 * tokens));
+        const uint32_t cap = table_capacity(tokens);
         po.tab_off = (uint32_t)arena;
-        po.tab_mask = cap - 1;
+        po.tab_cap = cap;
         arena += cap;
       }
     }

@@ -69,12 +69,15 @@ __device__ __forceinline__ int scoped_slot(const ReqDev &rq, int scope, int item
 }
 
 // ---------------------------------------------------------------- token -> count hash tables
-// entry = key (token id, >= 1) in the low 32 bits, count in the high 32 bits; 0 = empty.
-__device__ __forceinline__ uint32_t tok_hash(uint32_t tok) { return tok * 2654435761u; }
+// entry = key (token id, >= 1) in the low 32 bits, count in the high 32 bits; 0 = empty.  Open addressing
+// with linear probing; the capacity is any number > the number of tokens inserted (not a power of two:
+// the tables of a request live in LDS and their size sets the occupancy), the home slot is the
+// multiply-high range reduction of a multiplicative hash.
+__device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t cap) { return __umulhi(tok * 2654435761u, cap); }
 
-__device__ bool table_add(unsigned long long *tab, uint32_t mask, uint32_t tok) {
-  uint32_t idx = (tok_hash(tok) >> 7) & mask;
-  for (uint32_t probe = 0; probe <= mask; ++probe) {
+__device__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok) {
+  uint32_t idx = tok_home(tok, cap);
+  for (uint32_t probe = 0; probe < cap; ++probe) {
     unsigned long long cur = tab[idx];
     if (cur == 0ull) {
       unsigned long long prev = atomicCAS(&tab[idx], 0ull, (unsigned long long)tok | (1ull << 32));
@@ -85,18 +88,18 @@ __device__ bool table_add(unsigned long long *tab, uint32_t mask, uint32_t tok) 
       atomicAdd(&tab[idx], 1ull << 32);
       return true;
     }
-    idx = (idx + 1) & mask;
+    idx = idx + 1 == cap ? 0 : idx + 1;
   }
   return false;
 }
 
-__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t mask, uint32_t tok) {
-  uint32_t idx = (tok_hash(tok) >> 7) & mask;
-  for (uint32_t probe = 0; probe <= mask; ++probe) {
+__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok) {
+  uint32_t idx = tok_home(tok, cap);
+  for (uint32_t probe = 0; probe < cap; ++probe) {
     unsigned long long cur = tab[idx];
     if (cur == 0ull) return 0;
     if ((uint32_t)cur == tok) return (uint32_t)(cur >> 32);
-    idx = (idx + 1) & mask;
+    idx = idx + 1 == cap ? 0 : idx + 1;
   }
   return 0;
 }
@@ -144,8 +147,8 @@ __device__ void prepass_request(const StoreDev &st, const ProgramDev &prog, cons
     const PrepEntry pe = prog.prep[e];
     PrepOut *po = &po_out[e];
     unsigned long long *tab = tab_base + (po->tab_off - tab_sub);
-    const uint32_t mask = po->tab_mask;
-    for (uint32_t i = tid; i <= mask; i += nthr) tab[i] = 0ull;
+    const uint32_t mask = po->tab_cap;  // capacity
+    for (uint32_t i = tid; i < mask; i += nthr) tab[i] = 0ull;
     if (tid == 0) { *sc.first = 0x7fffffff; s_misc[0] = 0; s_misc[1] = 0; s_misc[2] = 0; }
     __syncthreads();
 
@@ -468,7 +471,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
           double cnt = 0.0;
           if (c.tag == TAG_STRING_LIST) {
             const uint32_t off = c.lo(), len = c.hi();
-            for (uint32_t j = 0; j < len; ++j) cnt = cnt + (double)table_get(tab, po.tab_mask, st.tok_pool[off + j]);
+            for (uint32_t j = 0; j < len; ++j) cnt = cnt + (double)table_get(tab, po.tab_cap, st.tok_pool[off + j]);
           }
           sink.put(dst + f, cnt);
         }
@@ -485,11 +488,11 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
         } else {
           const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
           if (c.tag == TAG_STRING) {
-            v = (0.0 + (double)table_get(tab, po.tab_mask, c.lo())) / po.scalar;
+            v = (0.0 + (double)table_get(tab, po.tab_cap, c.lo())) / po.scalar;
           } else if (c.tag == TAG_STRING_LIST) {
             const uint32_t off = c.lo(), len = c.hi();
             double w = 0.0;
-            for (uint32_t j = 0; j < len; ++j) w = w + (double)table_get(tab, po.tab_mask, st.tok_pool[off + j]);
+            for (uint32_t j = 0; j < len; ++j) w = w + (double)table_get(tab, po.tab_cap, st.tok_pool[off + j]);
             v = w / po.scalar;
           }
         }

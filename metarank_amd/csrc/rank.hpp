@@ -61,7 +61,7 @@ struct PrepEntry {
 enum DivMode : int32_t { DIV_EMPTY = 0, DIV_STRING = 1, DIV_DOUBLE = 2 };
 struct PrepOut {
   uint32_t tab_off;    // first entry of this hash table in the arena (host-sized)
-  uint32_t tab_mask;   // capacity - 1 (capacity is a power of two)
+  uint32_t tab_cap;    // capacity in entries (> number of tokens the host counted for it)
   double scalar;       // diversity: median (DOUBLE) or sum of counts (STRING)
   int32_t mode;        // DivMode
   int32_t pad;

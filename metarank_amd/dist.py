@@ -34,3 +34,21 @@ def all_gather_scores(local, sizes=None, group=None):
     parts = [torch.empty(pad, dtype=local.dtype, device=local.device) for _ in range(world)]
     dist.all_gather(parts, buf, group=group)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)])
+
+
+def padded_chunk(n: int, world: int, tile: int = 128) -> int:
+    """items per shard of an item-sharded run (== mrk_batch_shard_chunk): ceil(n / world) rounded up to
+    whole scorer tiles, so every shard starts on a tile boundary and all shards have the same length"""
+    per = -(-n // world)
+    return -(-per // tile) * tile
+
+
+def all_gather_padded(buf, chunk: int, group=None):
+    """In-place merge of an item-sharded run: `buf` (1-D, >= world * chunk elements) already holds this
+    rank's scores in buf[rank * chunk : (rank + 1) * chunk]; afterwards it holds every rank's slice."""
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = buf[rank * chunk:(rank + 1) * chunk].clone()  # no aliasing between the collective's input and output
+    dist.all_gather_into_tensor(buf[:world * chunk], mine, group=group)
+    return buf

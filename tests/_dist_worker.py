@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 from backends import OracleBackend  # noqa: E402
 from metarank_amd import ranklens, synth  # noqa: E402
-from metarank_amd.dist import all_gather_scores, shard_range  # noqa: E402
+from metarank_amd.dist import all_gather_padded, all_gather_scores, padded_chunk, shard_range  # noqa: E402
 
 
 def main():
@@ -37,6 +37,14 @@ def main():
     lo2, hi2 = shard_range(len(m), rank, world)
     part = b.forest.predict(m[lo2:hi2])
     merged2 = all_gather_scores(torch.from_numpy(part), [shard_range(len(m), r, world)[1] - shard_range(len(m), r, world)[0] for r in range(world)])
+    # (3) the same the way the library shards it (mrk_batch_run_shard): equal tile-aligned chunks, each rank
+    #     fills its slice of one padded buffer, one in-place all-gather
+    chunk = padded_chunk(len(m), world)
+    buf = torch.zeros(chunk * world, dtype=torch.float64)
+    lo3, hi3 = min(rank * chunk, len(m)), min((rank + 1) * chunk, len(m))
+    buf[lo3:hi3] = torch.from_numpy(b.forest.predict(m[lo3:hi3]))
+    all_gather_padded(buf, chunk)
+    assert chunk % 128 == 0 and np.array_equal(buf[:len(m)].numpy(), b.forest.predict(m))
     if rank == 0:
         full = np.concatenate([b.rerank(ev)[1] for ev in reqs])
         assert np.array_equal(merged.numpy(), full)
