@@ -20,7 +20,7 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
                            uint16_t *cells, bool f64);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64);
-size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap);
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads);
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 
@@ -176,7 +176,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.fused_threads = std::min(256, std::max(64, (hb.max_items + 63) / 64 * 64));
   const bool fused_enabled = [] { const char *e = getenv("MRK_RANK_FUSED"); return !e || atoi(e) != 0; }();
   b.fused_ok = fused_enabled && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
-               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals) <= 64 * 1024;
+               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads) <= 64 * 1024;
 }
 
 static void check_model_fits(mrk_model *model, const Program &prog) {

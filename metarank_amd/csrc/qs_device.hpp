@@ -19,38 +19,48 @@ struct QsDev {             // what a kernel needs to bin a value of any matrix c
   int32_t n_views;
 };
 
-// Bins one matrix value `x` of a column described by `ft` into every view of that column and hands
-// (view index, cell) to `emit`.  F64: LightGBM semantics, else XGBoost.  Returns false iff the value
-// is one XGBoost rejects (+-inf after the Double -> Float narrowing ltrlib performs).
-template <bool F64, typename Emit>
-__device__ __forceinline__ bool qs_bin_column(double x, const QsFeature ft, const QsView *__restrict__ views,
-                                              const double *__restrict__ thr, Emit emit) {
-  bool ok = true;
+typedef __attribute__((address_space(3))) double qs_lds_double;  // forces ds_read for tables staged in LDS
+constexpr uint32_t QS_LDS_THR = 256;  // thresholds of one column a wavefront stages in LDS (LightGBM: max_bin - 1 = 254)
+
+// The library's own preprocessing of a dense-row value.  ok = false iff XGBoost would reject it.
+template <bool F64>
+__device__ __forceinline__ double qs_prep(double x, bool &ok) {
+  ok = true;
   if constexpr (F64) {
     // LightGBM RowFunctionFromDenseMatric keeps a cell only if |x| > kZeroThreshold (1e-35f) or NaN
     const double kZero = (double)1e-35f;
-    x = (fabs(x) > kZero || x != x) ? x : 0.0;
+    return (fabs(x) > kZero || x != x) ? x : 0.0;
   } else {
     // ltrlib narrows Double -> Float before DMatrix; XGBoost rejects +-inf ("Input data contains `inf`")
     const float f = (float)x;
     ok = !__builtin_isinf(f);
-    x = (double)f;
+    return (double)f;
   }
-  const bool isn = x != x;
-  const bool isz = x == 0.0;
-  // bin = number of thresholds strictly below x (LightGBM: x <= t goes left) / not above x (XGBoost: x < t)
+}
+
+// bin = number of thresholds strictly below x (LightGBM: x <= t goes left) / not above x (XGBoost: x < t).
+// T: sorted, `len` entries, in global memory (const double *) or LDS (qs_lds_double *).
+template <bool F64, typename P>
+__device__ __forceinline__ uint32_t qs_bin_search(P T, uint32_t len, double x) {
   uint32_t pos = 0;
-  if (ft.thr_len) {
-    const double *T = thr + ft.thr_off;
-    for (uint32_t step = 1u << (31 - __builtin_clz(ft.thr_len)); step > 0; step >>= 1) {
+  if (len) {
+    for (uint32_t step = 1u << (31 - __builtin_clz(len)); step > 0; step >>= 1) {
       const uint32_t p = pos + step;
-      if (p <= ft.thr_len) {
+      if (p <= len) {
         const double t = T[p - 1];
         const bool below = F64 ? (t < x) : (t <= x);
         pos = below ? p : pos;
       }
     }
   }
+  return pos;
+}
+
+// every view of the column: (view index, cell) -> emit
+template <bool F64, typename Emit>
+__device__ __forceinline__ void qs_emit_views(double x, uint32_t pos, const QsFeature ft, const QsView *__restrict__ views, Emit emit) {
+  const bool isn = x != x;
+  const bool isz = x == 0.0;
   for (uint32_t v = ft.view_begin; v < ft.view_end; ++v) {
     const QsView vw = views[v];
     uint32_t cell;
@@ -76,6 +86,17 @@ __device__ __forceinline__ bool qs_bin_column(double x, const QsFeature ft, cons
     }
     emit(v, cell);
   }
+}
+
+// Bins one matrix value `x` of a column described by `ft` into every view of that column and hands
+// (view index, cell) to `emit`.  F64: LightGBM semantics, else XGBoost.  Returns false iff the value
+// is one XGBoost rejects (+-inf after the Double -> Float narrowing ltrlib performs).
+template <bool F64, typename Emit>
+__device__ __forceinline__ bool qs_bin_column(double x, const QsFeature ft, const QsView *__restrict__ views,
+                                              const double *__restrict__ thr, Emit emit) {
+  bool ok;
+  x = qs_prep<F64>(x, ok);
+  qs_emit_views<F64>(x, qs_bin_search<F64>(thr + ft.thr_off, ft.thr_len, x), ft, views, emit);
   return ok;
 }
 

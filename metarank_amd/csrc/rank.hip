@@ -312,10 +312,14 @@ __device__ __forceinline__ long long long_div(long long a, long long b) {
   return a / b;
 }
 
-// ---- sinks: where an assembled value goes
+// ---- sinks: where an assembled value goes.  A sink is driven by whole wavefronts: lanes without an item
+// (`active` false) run the same program on a missing record and write nothing.
 struct MatrixSink {   // row-major f64 matrix, ClickthroughQuery's layout
   double *row;
-  __device__ __forceinline__ void put(int col, double v) const { row[col] = v; }
+  bool active;
+  __device__ __forceinline__ void put(int col, double v) const {
+    if (active) row[col] = v;
+  }
 };
 
 template <bool F64>
@@ -323,13 +327,30 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
   QsDev q;
   uint16_t *dst;      // &cells[tile][0][row]
   int32_t *status;    // the request's status word
+  qs_lds_double *thr_lds;  // QS_LDS_THR doubles private to this wavefront
+  bool active;
+  // `col` is uniform across the wavefront.  The column's threshold table is staged in LDS by the whole
+  // wavefront (one coalesced load) and searched there: a per-lane binary search in global memory would
+  // be log2(T) scattered wave-loads per column, and scattered loads are what bounds the assembly kernel.
   __device__ __forceinline__ void put(int col, double v) const {
     if (col >= q.n_feats) return;
-    const QsFeature ft = q.feats[col];  // col is uniform across the wave: scalar loads
+    const QsFeature ft = q.feats[col];  // scalar loads
     if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
+    bool ok;
+    const double x = qs_prep<F64>(v, ok);
+    uint32_t pos;
+    if (ft.thr_len <= QS_LDS_THR) {
+      __builtin_amdgcn_wave_barrier();  // LDS ops of one wavefront complete in order: no s_barrier needed
+      for (uint32_t k = threadIdx.x & 63; k < ft.thr_len; k += 64) thr_lds[k] = q.thr[ft.thr_off + k];
+      __builtin_amdgcn_wave_barrier();
+      pos = qs_bin_search<F64>(thr_lds, ft.thr_len, x);
+    } else {
+      pos = qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
+    }
     uint16_t *d = dst;
-    const bool ok = qs_bin_column<F64>(v, ft, q.views, q.thr, [d](uint32_t view, uint32_t cell) { d[view * QS_TILE_ROWS] = (uint16_t)cell; });
-    if (!ok) atomicOr(status, 32);
+    const bool act = active;
+    qs_emit_views<F64>(x, pos, ft, q.views, [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; });
+    if (!ok && act) atomicOr(status, 32);
   }
 };
 
@@ -338,7 +359,7 @@ template <typename Sink>
 __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, int gi, int r,
                                               const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
                                               const PrepOut *pos, const Sink &sink) {
-  const int islot = b.item_slot[gi];
+  const int islot = sink.active ? b.item_slot[gi] : -1;  // lanes without an item: a missing record
   const uint8_t *irec = record(st, SC_ITEM, islot);
   const double NaN = d_nan();
 
@@ -358,11 +379,12 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
       }
       case OP_VECTOR: {
         const Cell c = load_cell(record(st, op.scope, scoped_slot(rq, op.scope, islot)), op.c0);
-        if (c.tag == TAG_DOUBLE_LIST) {
-          const uint32_t off = c.lo(), len = c.hi();
-          for (int k = 0; k < op.dim; ++k) sink.put(dst + k, (uint32_t)k < len ? st.f64_pool[off + k] : 0.0);
-        } else {
-          for (int k = 0; k < op.dim; ++k) sink.put(dst + k, NaN);
+        const bool has = c.tag == TAG_DOUBLE_LIST;
+        const uint32_t off = c.lo(), len = c.hi();
+        for (int k = 0; k < op.dim; ++k) {  // every put at a wavefront-uniform point (CellSink stages tables cooperatively)
+          double v = NaN;
+          if (has) v = (uint32_t)k < len ? st.f64_pool[off + k] : 0.0;
+          sink.put(dst + k, v);
         }
         break;
       }
@@ -445,7 +467,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
             } else {
               const long long tg = load_cell(grec, op.c2, k).i64(), bg = load_cell(grec, op.c3, k).i64();
               if (tg == 0) {
-                atomicOr(&b.status[r], ST_ARITHMETIC);
+                if (sink.active) atomicOr(&b.status[r], ST_ARITHMETIC);
                 thrown = true;
               } else {
                 const double ratio = (double)long_div(bg, tg);
@@ -506,7 +528,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
           const long long updated = java_round(c.f64() * 1000.0);
           long long diff = (long long)((unsigned long long)rq.ts_ms - (unsigned long long)updated);
           if (diff < 0) diff = (long long)(0ull - (unsigned long long)diff);
-          if (diff < 0 || diff > 9223372036854LL) atomicOr(&b.status[r], ST_ILLEGAL_ARG);  // FiniteDuration bound
+          if (diff < 0 || diff > 9223372036854LL) { if (sink.active) atomicOr(&b.status[r], ST_ILLEGAL_ARG); }  // FiniteDuration bound
           else v = (double)(diff / 1000);
         }
         sink.put(dst + 0, v);
@@ -529,7 +551,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
         double v = NaN;
         if (qn >= 0 && c.tag == TAG_DOUBLE_LIST) {
           if ((int)c.hi() < qn) {
-            atomicOr(&b.status[r], ST_DIM);
+            if (sink.active) atomicOr(&b.status[r], ST_DIM);
           } else {
             const double *item = st.f64_pool + c.lo();
             double top = 0.0, a = 0.0, bs = 0.0;
@@ -552,27 +574,34 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
 
 __global__ void __launch_bounds__(ASM_THREADS)
 assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
-  const int gi = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
-  if (gi >= b.item_hi) return;
+  const int gi0 = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
+  const bool active = gi0 < b.item_hi;
+  if (!__any(active)) return;                      // whole wavefront past the end
+  const int gi = active ? gi0 : b.item_hi - 1;     // lanes without an item ride along on a missing record
   const int r = (int)b.item_req[gi];
   const ReqDev rq = b.reqs[r];
-  MatrixSink sink{b.matrix + (size_t)gi * prog.dim};
+  MatrixSink sink{b.matrix + (size_t)gi * prog.dim, active};
   assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
 }
 
 template <bool F64>
 __global__ void __launch_bounds__(ASM_THREADS)
 assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_t *cells) {
-  const int gi = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
-  if (gi >= b.item_hi) return;
+  __shared__ double s_thr[ASM_THREADS / 64][QS_LDS_THR];
+  const int gi0 = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
+  const bool active = gi0 < b.item_hi;
+  if (!__any(active)) return;
+  const int gi = active ? gi0 : b.item_hi - 1;
   const int r = (int)b.item_req[gi];
   const ReqDev rq = b.reqs[r];
-  CellSink<F64> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r]};
+  CellSink<F64> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r],
+                     (qs_lds_double *)s_thr[threadIdx.x >> 6], active};
   assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
 }
 
 // Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
-// Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x n_prep][ints]
+// Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][16 ints]
+//              [threshold staging: QS_LDS_THR x 8 B per wavefront]
 template <typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                                                 int vals_cap, const SinkMaker &make_sink) {
@@ -581,6 +610,7 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Progra
   double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
   PrepOut *s_po = (PrepOut *)(smem + (size_t)tab_entries * 8 + (size_t)vals_cap * 8);
   int *s_int = (int *)(s_po + FUSED_MAX_PREP);
+  qs_lds_double *s_thr = (qs_lds_double *)(s_int + 16) + (size_t)(threadIdx.x >> 6) * QS_LDS_THR;
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
@@ -588,24 +618,27 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Progra
   __syncthreads();
   PrepScratch sc{s_vals, vals_cap, s_int, s_int + 4, s_int + 8};
   prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
-  for (int i = threadIdx.x; i < rq.n_items; i += blockDim.x) {
-    const int gi = rq.item_begin + i;
-    if (gi < b.item_lo || gi >= b.item_hi) continue;
-    assemble_item(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r));
+  for (int base = 0; base < rq.n_items; base += blockDim.x) {
+    const int i = base + (int)threadIdx.x;
+    const int gi0 = rq.item_begin + i;
+    const bool active = i < rq.n_items && gi0 >= b.item_lo && gi0 < b.item_hi;
+    if (!__any(active)) continue;  // wavefront-uniform
+    const int gi = active ? gi0 : rq.item_begin;
+    assemble_item(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr));
   }
 }
 
 __global__ void __launch_bounds__(256)
 rank_fused_matrix_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap) {
   rank_fused_body(st, prog, b, tab_entries, vals_cap,
-                  [&](int gi, int) { return MatrixSink{b.matrix + (size_t)gi * prog.dim}; });
+                  [&](int gi, int, bool active, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
 }
 
 template <bool F64>
 __global__ void __launch_bounds__(256)
 rank_fused_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, QsDev q, uint16_t *cells) {
-  rank_fused_body(st, prog, b, tab_entries, vals_cap, [&](int gi, int r) {
-    return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r]};
+  rank_fused_body(st, prog, b, tab_entries, vals_cap, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
+    return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
   });
 }
 
@@ -624,9 +657,12 @@ __global__ void override_cells_kernel(BatchDev b, QsDev q, uint16_t *cells) {
   if (i >= b.n_overrides) return;
   const Override o = b.overrides[i];
   if ((int)o.item < b.item_lo || (int)o.item >= b.item_hi) return;
-  CellSink<F64> sink{q, cells + (size_t)(o.item / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (o.item % QS_TILE_ROWS),
-                     &b.status[b.item_req[o.item]]};
-  sink.put((int)o.col, o.value);
+  // lanes of this kernel hold different columns: the per-lane search in global memory, not the staged one
+  if ((int)o.col >= q.n_feats) return;
+  const QsFeature ft = q.feats[o.col];
+  uint16_t *d = cells + (size_t)(o.item / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (o.item % QS_TILE_ROWS);
+  const bool ok = qs_bin_column<F64>(o.value, ft, q.views, q.thr, [d](uint32_t view, uint32_t cell) { d[view * QS_TILE_ROWS] = (uint16_t)cell; });
+  if (!ok) atomicOr(&b.status[b.item_req[o.item]], 32);
 }
 
 // ---------------------------------------------------------------- ordering
@@ -783,8 +819,9 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
   launch_override_cells(ctx, b, q, cells, f64);
 }
 
-size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap) {
-  return (size_t)tab_entries * 8 + (size_t)vals_cap * 8 + FUSED_MAX_PREP * sizeof(PrepOut) + 16 * sizeof(int);
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads) {
+  return (size_t)tab_entries * 8 + (size_t)vals_cap * 8 + FUSED_MAX_PREP * sizeof(PrepOut) + 16 * sizeof(int) +
+         (size_t)((threads + 63) / 64) * QS_LDS_THR * 8;  // threshold staging, one table per wavefront
 }
 int fused_max_prep() { return FUSED_MAX_PREP; }
 
@@ -793,7 +830,7 @@ int fused_max_prep() { return FUSED_MAX_PREP; }
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64) {
   if (b.n_req <= 0) return;
-  const size_t lds = fused_lds_bytes(tab_entries, vals_cap);
+  const size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads);
   {
     ScopedKernelTimer timer(ctx, "assemble");
     static thread_local bool configured = false;
