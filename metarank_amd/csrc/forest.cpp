@@ -547,7 +547,7 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
     // |x| <= kZeroThreshold to the default side; NaN sends NaN to the default side.
     if (fl & NF_MISS_ZERO) return dl ? QV_MISS_LEFT : QV_MISS_RIGHT;
     if (fl & NF_MISS_NAN) return dl ? QV_NAN_LEFT : QV_NAN_RIGHT;
-    return (0.0 <= t.thr[i]) ? QV_NAN_LEFT : QV_NAN_RIGHT;
+    return QV_NAN_ZERO;  // NaN is compared as 0.0
   };
   std::vector<std::vector<double>> tabs(nf);
   std::map<std::pair<int, int>, int> view_ids;  // (feature, kind) -> tile column; ordered => grouped by feature
@@ -561,7 +561,7 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
       }
       view_ids.emplace(std::make_pair(t.feat[i], node_kind(t, i)), 0);
     }
-  pf.feats.assign(nf, QsFeature{0, 0, 0, 0});
+  pf.feats.assign(nf, QsFeature{0, 0, 0, 0, 0});
   for (int ft = 0; ft < nf; ++ft) {
     auto &v = tabs[ft];
     std::sort(v.begin(), v.end());
@@ -569,6 +569,7 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
     if (v.size() > 32766) return fail("more than 32766 distinct thresholds on one column");
     pf.feats[ft].thr_off = (uint32_t)pf.thr.size();
     pf.feats[ft].thr_len = (uint32_t)v.size();
+    pf.feats[ft].zero_bin = (uint32_t)(std::lower_bound(v.begin(), v.end(), 0.0) - v.begin());  // #{t < 0.0}: LightGBM only
     pf.thr.insert(pf.thr.end(), v.begin(), v.end());
   }
   {
@@ -577,10 +578,10 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
       kv.second = id;
       pf.views.push_back(QsView{(uint16_t)kv.first.first, (uint8_t)kv.first.second, 0});
       if (kv.first.first != cur) {
-        pf.feats[kv.first.first].view_begin = (uint32_t)id;
+        pf.feats[kv.first.first].view_begin = (uint16_t)id;
         cur = kv.first.first;
       }
-      pf.feats[kv.first.first].view_end = (uint32_t)id + 1;
+      pf.feats[kv.first.first].view_end = (uint16_t)(id + 1);
       ++id;
     }
   }

@@ -120,6 +120,8 @@ PackedForest pack_forest(const Forest &f, uint32_t chunk_bytes);
 // its own rule, so the kernel has no special cases:
 //   QV_NAN_RIGHT   NaN -> 0x7FFF (greater than every k: right)   else bin
 //   QV_NAN_LEFT    NaN -> 0      (<= every k: left)              else bin
+//   QV_NAN_ZERO    NaN -> bin(0.0)  (LightGBM MissingType::None compares NaN as 0.0: one view serves the
+//                  nodes on both sides of zero)
 //   QV_MISS_RIGHT  NaN or 0.0 -> 0x7FFF   (LightGBM MissingType::Zero, default right)
 //   QV_MISS_LEFT   NaN or 0.0 -> 0        (LightGBM MissingType::Zero, default left)
 //   QV_CAT         the category id itself (one view per categorical column): 0..0x7FFC, 0x7FFD = a valid
@@ -140,7 +142,7 @@ constexpr int QS_LEAVES = 16;
 constexpr int QS_TREE_WORDS = QS_SLOTS * 2;
 constexpr int QS_MAX_VIEWS = 255;
 constexpr uint16_t QS_RIGHT = 0x7FFF;
-enum QsViewKind : uint8_t { QV_NAN_RIGHT = 0, QV_NAN_LEFT = 1, QV_MISS_RIGHT = 2, QV_MISS_LEFT = 3, QV_CAT = 4 };
+enum QsViewKind : uint8_t { QV_NAN_RIGHT = 0, QV_NAN_LEFT = 1, QV_MISS_RIGHT = 2, QV_MISS_LEFT = 3, QV_CAT = 4, QV_NAN_ZERO = 5 };
 
 constexpr uint16_t QS_CAT_BEYOND = 0x7FFD, QS_CAT_INVALID = 0x7FFE, QS_CAT_NAN = 0x7FFF;
 struct QsView {        // 4 B, one per column of the binned tile; grouped by feature
@@ -156,7 +158,8 @@ struct QsCatNode {     // 16 B
 };
 struct QsFeature {     // 16 B, one per matrix column
   uint32_t thr_off, thr_len;       // sorted distinct thresholds of this column in PackedForestQS::thr
-  uint32_t view_begin, view_end;   // its views
+  uint16_t view_begin, view_end;   // its views
+  uint32_t zero_bin;               // bin(0.0): the cell of a NaN in a QV_NAN_ZERO view
 };
 
 struct PackedForestQS {

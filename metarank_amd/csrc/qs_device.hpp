@@ -79,6 +79,8 @@ __device__ __forceinline__ void qs_emit_views(double x, uint32_t pos, const QsFe
           cell = iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv;
         }
       }
+    } else if (vw.kind == QV_NAN_ZERO) {
+      cell = isn ? ft.zero_bin : pos;  // MissingType::None: NaN is compared as 0.0
     } else {
       const bool miss = (vw.kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
       const uint32_t mval = (vw.kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
