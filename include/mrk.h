@@ -137,6 +137,21 @@ int mrk_store_put_counter(mrk_ctx *ctx, const char *key, int64_t v);            
 int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *values, int n); /* PeriodicCounterValue.values(i).value */
 int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *values, int n); /* BoundedListValue of SString */
 int mrk_store_delete(mrk_ctx *ctx, const char *key);
+
+/* Write path: instead of a refreshed FeatureValue the host may forward the raw Writes of
+ * FeatureValueFlow.commitWrite (M/flow/FeatureValueFlow.scala:44-62); the FeatureValue the read path needs is
+ * then derived by the library - always fresh, no `refresh` interval.
+ *   mrk_store_increment_periodic  Write.PeriodicIncrement(key, ts, inc): added to the key's bucket ring in HBM
+ *                                 (bucket = ts.toStartOfPeriod(bucket)); the window sums of
+ *                                 PeriodicCounterFeature.fromMap (M/model/Feature.scala:142-161) are recomputed on
+ *                                 the device at the next flush.  A key is fed either by these or by
+ *                                 mrk_store_put_periodic, not both (the ring wins).
+ *   mrk_store_increment           Write.Increment(key, ts, inc) -> CounterValue
+ *   mrk_store_append              Write.Append(key, SString(value), ts) -> BoundedListValue, bounded by the
+ *                                 feature's count / duration (M/fstore/memory/MemBoundedList.scala:18-37) */
+int mrk_store_increment_periodic(mrk_ctx *ctx, const char *key, int64_t ts_ms, int64_t inc);
+int mrk_store_increment(mrk_ctx *ctx, const char *key, int64_t inc);
+int mrk_store_append(mrk_ctx *ctx, const char *key, const char *value, int64_t ts_ms);
 int mrk_store_flush(mrk_ctx *ctx);
 
 /* ---------------------------------------------------------------- requests */

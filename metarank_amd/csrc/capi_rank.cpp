@@ -330,6 +330,9 @@ int mrk_store_put_counter(mrk_ctx *ctx, const char *key, int64_t v) { STORE_PUT(
 int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *v, int n) { STORE_PUT(put_periodic(key, v, n)); }
 int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *v, int n) { STORE_PUT(put_bounded_list(key, v, n)); }
 int mrk_store_delete(mrk_ctx *ctx, const char *key) { STORE_PUT(erase(key)); }
+int mrk_store_increment_periodic(mrk_ctx *ctx, const char *key, int64_t ts_ms, int64_t inc) { STORE_PUT(increment_periodic(key, ts_ms, inc)); }
+int mrk_store_increment(mrk_ctx *ctx, const char *key, int64_t inc) { STORE_PUT(increment(key, inc)); }
+int mrk_store_append(mrk_ctx *ctx, const char *key, const char *value, int64_t ts_ms) { STORE_PUT(append(key, value, ts_ms)); }
 
 int mrk_store_flush(mrk_ctx *ctx) {
   return guard([&] {

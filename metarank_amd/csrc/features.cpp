@@ -88,6 +88,34 @@ int vector_dim(const json::Value *reduce) {
   return d;
 }
 
+// util/DurationJson.scala:9-13: ([0-9]+)([smhd])
+static bool parse_duration_ms(const std::string &s, int64_t &out) {
+  if (s.size() < 2) return false;
+  int64_t n = 0;
+  for (size_t i = 0; i + 1 < s.size(); ++i) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    n = n * 10 + (s[i] - '0');
+  }
+  switch (s.back()) {
+    case 's': out = n * 1000; return true;
+    case 'm': out = n * 60 * 1000; return true;
+    case 'h': out = n * 3600 * 1000; return true;
+    case 'd': out = n * 86400 * 1000; return true;
+    default: return false;
+  }
+}
+
+// window_count / rate: `bucket` and `periods` (PeriodicCounterConfig(period = bucket, sumPeriodRanges = periods.map(PeriodRange(_, 0))),
+// feature/WindowInteractionCountFeature.scala:25-32, feature/RateFeature.scala:50-90)
+static void parse_window(const json::Value &o, FeatureDef &f) {
+  if (const json::Value *b = o.find("bucket"))
+    if (!b->is_null() && !parse_duration_ms(b->as_string(), f.bucket_ms))
+      throw StatusError(MRK_ERR_PARSE, "duration is in wrong format: " + b->as_string());
+  if (const json::Value *p = o.find("periods"))
+    if (!p->is_null())
+      for (auto &v : p->arr) f.periods.push_back((int32_t)v.as_int());
+}
+
 std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
   std::unique_ptr<FeatureDef> f(new FeatureDef());
   const std::string type = o.at("type").as_string();
@@ -137,6 +165,7 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
     f->type = FType::WindowCount;
     plain_scope();
     f->dim = (int)need(o, "periods", nm).arr.size();
+    parse_window(o, *f);
   } else if (type == "rate") {
     f->type = FType::Rate;
     const json::Value *sc = o.find("scope");
@@ -148,6 +177,7 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
     f->top = need(o, "top", nm).as_string();
     f->bottom = need(o, "bottom", nm).as_string();
     f->dim = (int)need(o, "periods", nm).arr.size();
+    parse_window(o, *f);
     const json::Value *norm = o.find("normalize");
     if (norm && !norm->is_null()) {
       f->normalize = true;
@@ -155,6 +185,9 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
     }
   } else if (type == "interacted_with") {
     f->type = FType::InteractedWith;
+    if (const json::Value *c = o.find("count")) if (!c->is_null()) f->list_count = c->as_int();  // InteractedWithFeature.scala:47-55
+    if (const json::Value *d = o.find("duration")) if (!d->is_null() && !parse_duration_ms(d->as_string(), f->list_duration_ms))
+      bad("duration is in wrong format: " + d->as_string());
     scope_required();
     if (f->scope != SC_SESSION && f->scope != SC_USER) bad("feature '" + nm + "': can only be scoped to user/session");
     const json::Value &fl = need(o, "field", nm);
@@ -275,7 +308,10 @@ void declare_columns(const FeatureDef &f, Store &st) {
       if (t != SC_COUNT) st.add_column(t, f.name, COL_COUNTER, 0);
       break;
     case FType::WindowCount:
-      if (t != SC_COUNT) st.add_column(t, f.name, COL_PERIODIC, f.dim);
+      if (t != SC_COUNT) {
+        st.add_column(t, f.name, COL_PERIODIC, f.dim);
+        st.set_periodic_config(t, f.name, f.bucket_ms, f.periods);
+      }
       break;
     case FType::Rate: {
       const std::string top = f.name + "_" + f.top, bot = f.name + "_" + f.bottom;
@@ -284,11 +320,16 @@ void declare_columns(const FeatureDef &f, Store &st) {
       st.add_column(target, bot, COL_PERIODIC, f.dim);
       st.add_column(SC_GLOBAL, top + "_norm", COL_PERIODIC, f.dim);
       st.add_column(SC_GLOBAL, bot + "_norm", COL_PERIODIC, f.dim);
+      st.set_periodic_config(target, top, f.bucket_ms, f.periods);
+      st.set_periodic_config(target, bot, f.bucket_ms, f.periods);
+      st.set_periodic_config(SC_GLOBAL, top + "_norm", f.bucket_ms, f.periods);
+      st.set_periodic_config(SC_GLOBAL, bot + "_norm", f.bucket_ms, f.periods);
       if (f.scope == SC_FIELD) st.add_column(SC_ITEM, f.name + "_field", COL_SCALAR, 0, f.scope_field);
       break;
     }
     case FType::InteractedWith:
       st.add_column(f.scope, f.name + "_interactions", COL_BOUNDED_LIST, 0);
+      st.set_list_config(f.scope, f.name + "_interactions", f.list_count, f.list_duration_ms);
       for (auto &fld : f.values) st.add_column(SC_ITEM, f.name + "_" + fld, COL_SCALAR, 0);
       break;
     case FType::Diversity: case FType::ItemAge: case FType::Biencoder:

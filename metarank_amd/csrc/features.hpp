@@ -36,6 +36,10 @@ struct FeatureDef {
   int norm = NORM_NOOP;                 // bi-encoder
   int qdim = 0;                         // bi-encoder embedding size
   std::string ext_field;                // request / item field carrying host-computed values
+  int64_t bucket_ms = 0;                // window_count / rate: bucket length
+  std::vector<int32_t> periods;         // window_count / rate: PeriodRange.startOffset per column
+  int64_t list_count = 100;             // interacted_with: BoundedListConfig.count
+  int64_t list_duration_ms = 24LL * 3600 * 1000;
 };
 
 // host-side description of what a request has to supply for one op

@@ -2,6 +2,7 @@
 #include "store.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace mrk {
@@ -45,6 +46,30 @@ void Store::freeze_layout() {
       off += 8u * (uint32_t)(t.cols[i].kind == COL_PERIODIC ? std::max(1, t.cols[i].periods) : 1);
     }
     t.stride = std::max(16u, (off + 15u) & ~15u);
+    // bucket rings of the periodic columns that have a write-path config
+    t.ring_col_of.assign(t.cols.size(), -1);
+    uint32_t roff = 0;
+    for (size_t i = 0; i < t.cols.size(); ++i) {
+      Column &c = t.cols[i];
+      if (c.kind != COL_PERIODIC || c.period_ms <= 0 || c.offsets.empty()) continue;
+      int maxo = 0;
+      for (int o : c.offsets) maxo = std::max(maxo, o);
+      if ((int)c.offsets.size() > RING_MAX_RANGES || maxo > 4095) continue;  // served by puts only
+      c.ring_w = maxo + 1;
+      c.ring_off = (int)roff;
+      RingColDev d{};
+      d.ring_off = roff;
+      d.w = (uint32_t)c.ring_w;
+      d.val_off = (uint32_t)c.val_off;
+      d.tag_index = (uint32_t)c.tag_index;
+      d.period_ms = c.period_ms;
+      d.n_ranges = (int32_t)c.offsets.size();
+      for (size_t k = 0; k < c.offsets.size(); ++k) d.offsets[k] = c.offsets[k];
+      t.ring_col_of[i] = (int)t.ring_cols.size();
+      t.ring_cols.push_back(d);
+      roff += (uint32_t)c.ring_w * 16u;
+    }
+    t.ring_stride = roff;
   }
   frozen = true;
   // the global scope has exactly one instance
@@ -262,8 +287,10 @@ static void flush_pool(Pool<T> &p, hipStream_t stream) {
 }
 
 void Store::flush(hipStream_t stream) {
+  uint32_t uploaded_lo[SC_COUNT], uploaded_hi[SC_COUNT];
   for (int s = 0; s < SC_COUNT; ++s) {
     Table &t = tables[s];
+    uploaded_lo[s] = uploaded_hi[s] = 0;
     if (t.n_slots > t.d_slots_cap) {
       uint32_t cap = std::max<uint32_t>(t.n_slots + t.n_slots / 2, 64);
       t.d_rows.release();
@@ -277,6 +304,8 @@ void Store::flush(hipStream_t stream) {
       MRK_HIP(hipMemcpyAsync((uint8_t *)t.d_rows.p + (size_t)t.dirty_lo * t.stride,
                              t.rows.data() + (size_t)t.dirty_lo * t.stride, (size_t)(hi - t.dirty_lo) * t.stride,
                              hipMemcpyHostToDevice, stream));
+      uploaded_lo[s] = t.dirty_lo;
+      uploaded_hi[s] = hi;
     }
     t.dirty_lo = UINT32_MAX;
     t.dirty_hi = 0;
@@ -284,8 +313,135 @@ void Store::flush(hipStream_t stream) {
   flush_pool(tok_pool, stream);
   flush_pool(f64_pool, stream);
   flush_pool(slot_pool, stream);
+  flush_writes(stream, uploaded_lo, uploaded_hi);
   // the host vectors may be reallocated by later puts: finish the copies before returning
   MRK_HIP(hipStreamSynchronize(stream));
+}
+
+// Write path: apply the staged PeriodicIncrements to the device bucket rings and recompute the window sums
+// of every touched (slot, column); rows that were just re-uploaded from the host mirror (which knows
+// nothing about ring-fed cells) get their ring-fed cells recomputed too.
+void Store::flush_writes(hipStream_t stream, const uint32_t *uploaded_lo, const uint32_t *uploaded_hi) {
+  std::sort(pending.begin(), pending.end(), [](const PendingInc &a, const PendingInc &b) {
+    if (a.table != b.table) return a.table < b.table;
+    if (a.slot != b.slot) return a.slot < b.slot;
+    if (a.ring_col != b.ring_col) return a.ring_col < b.ring_col;
+    return a.bucket < b.bucket;
+  });
+  size_t p = 0;
+  for (int s = 0; s < SC_COUNT; ++s) {
+    Table &t = tables[s];
+    if (!t.ring_used || t.ring_stride == 0) continue;
+    // grow the ring storage with the table (device-to-device copy keeps the buckets)
+    if (t.d_slots_cap > t.d_ring_slots) {
+      DevBuf nb;
+      nb.reserve((size_t)t.d_slots_cap * t.ring_stride);
+      MRK_HIP(hipMemsetAsync(nb.p, 0x80, (size_t)t.d_slots_cap * t.ring_stride, stream));
+      if (t.d_ring_slots)
+        MRK_HIP(hipMemcpyAsync(nb.p, t.d_ring.p, (size_t)t.d_ring_slots * t.ring_stride, hipMemcpyDeviceToDevice, stream));
+      MRK_HIP(hipStreamSynchronize(stream));
+      t.d_ring = std::move(nb);
+      t.d_ring_slots = t.d_slots_cap;
+      t.d_ring_cols.reserve(t.ring_cols.size() * sizeof(RingColDev));
+      MRK_HIP(hipMemcpyAsync(t.d_ring_cols.p, t.ring_cols.data(), t.ring_cols.size() * sizeof(RingColDev), hipMemcpyHostToDevice, stream));
+    }
+    if (uploaded_hi[s] > uploaded_lo[s])
+      launch_periodic_refresh(stream, (uint8_t *)t.d_rows.p, t.stride, (uint8_t *)t.d_ring.p, t.ring_stride,
+                              (const RingColDev *)t.d_ring_cols.p, (int)t.ring_cols.size(), uploaded_lo[s], uploaded_hi[s]);
+    std::vector<IncGroup> groups;
+    std::vector<IncUpdate> ups;
+    while (p < pending.size() && pending[p].table < s) ++p;
+    while (p < pending.size() && pending[p].table == s) {
+      IncGroup g{pending[p].slot, pending[p].ring_col, (uint32_t)ups.size(), 0};
+      while (p < pending.size() && pending[p].table == s && pending[p].slot == g.slot && pending[p].ring_col == g.col) {
+        if (!ups.empty() && ups.size() > g.begin && ups.back().bucket == pending[p].bucket) ups.back().inc += pending[p].inc;
+        else ups.push_back(IncUpdate{pending[p].bucket, pending[p].inc});
+        ++p;
+      }
+      g.end = (uint32_t)ups.size();
+      groups.push_back(g);
+    }
+    if (!groups.empty()) {
+      d_groups.reserve(groups.size() * sizeof(IncGroup));
+      d_updates.reserve(ups.size() * sizeof(IncUpdate));
+      MRK_HIP(hipMemcpyAsync(d_groups.p, groups.data(), groups.size() * sizeof(IncGroup), hipMemcpyHostToDevice, stream));
+      MRK_HIP(hipMemcpyAsync(d_updates.p, ups.data(), ups.size() * sizeof(IncUpdate), hipMemcpyHostToDevice, stream));
+      launch_periodic_apply(stream, (uint8_t *)t.d_rows.p, t.stride, (uint8_t *)t.d_ring.p, t.ring_stride,
+                            (const RingColDev *)t.d_ring_cols.p, groups.data() ? (const IncGroup *)d_groups.p : nullptr, (int)groups.size(),
+                            (const IncUpdate *)d_updates.p);
+      MRK_HIP(hipStreamSynchronize(stream));  // groups / ups are reused by the next table
+    }
+  }
+  pending.clear();
+}
+
+void Store::set_periodic_config(ScopeId scope, const std::string &name, int64_t period_ms, const std::vector<int32_t> &offsets) {
+  Table &t = tables[scope];
+  auto it = t.col_of.find(name);
+  if (it == t.col_of.end()) return;
+  t.cols[it->second].period_ms = period_ms;
+  t.cols[it->second].offsets = offsets;
+}
+
+void Store::set_list_config(ScopeId scope, const std::string &name, int64_t count, int64_t duration_ms) {
+  Table &t = tables[scope];
+  auto it = t.col_of.find(name);
+  if (it == t.col_of.end()) return;
+  t.cols[it->second].list_count = count;
+  t.cols[it->second].list_duration_ms = duration_ms;
+}
+
+bool Store::increment_periodic(const char *key, int64_t ts_ms, int64_t inc) {
+  Cell c;
+  if (!locate(key, c)) return false;
+  kind_check(c.c, COL_PERIODIC, key);
+  const int col = (int)(c.c - c.t->cols.data());
+  const int rc = c.t->ring_col_of.empty() ? -1 : c.t->ring_col_of[col];
+  if (rc < 0) throw StatusError(MRK_ERR_UNSUPPORTED, std::string("state '") + c.c->name + "' has no bucket / periods the device write path supports");
+  // Timestamp.toStartOfPeriod (model/Timestamp.scala:18-21): floor(ts.toDouble / period.toMillis).toLong * period.toMillis
+  const int64_t bucket = (int64_t)std::floor((double)ts_ms / (double)c.c->period_ms) * c.c->period_ms;
+  pending.push_back(PendingInc{(uint8_t)c.t->scope, c.slot, (uint32_t)rc, bucket, inc});
+  c.t->ring_used = true;
+  return true;
+}
+
+bool Store::increment(const char *key, int64_t inc) {
+  Cell c;
+  if (!locate(key, c)) return false;
+  kind_check(c.c, COL_COUNTER, key);
+  // MemCounter.put (fstore/memory/MemCounter.scala): existing + inc, else inc
+  int64_t cur = 0;
+  if (c.rec[c.c->tag_index] != TAG_MISSING) memcpy(&cur, c.rec + c.c->val_off, 8);
+  set_tag(c, TAG_PRESENT);
+  set_val(c, 0, (int64_t)((uint64_t)cur + (uint64_t)inc));
+  return true;
+}
+
+bool Store::append(const char *key, const char *value, int64_t ts_ms) {
+  {
+    Cell c;
+    if (!locate(key, c)) return false;
+    kind_check(c.c, COL_BOUNDED_LIST, key);
+    if (!value) throw StatusError(MRK_ERR_INVALID_ARG, "null list element");
+    // MemBoundedList.put (fstore/memory/MemBoundedList.scala:18-37): the first element is stored as is; later ones
+    // are prepended, then everything older than (this ts - duration) is dropped and `count` elements are kept
+    auto &lst = lists[key];
+    const int64_t count = c.c->list_count, dur = c.c->list_duration_ms;
+    if (lst.empty()) {
+      lst.emplace_back(ts_ms, value);
+    } else {
+      lst.insert(lst.begin(), std::make_pair(ts_ms, std::string(value)));
+      const int64_t cutoff = dur == INT64_MAX ? INT64_MIN : ts_ms - dur;
+      std::vector<std::pair<int64_t, std::string>> kept;
+      for (auto &e : lst)
+        if (e.first >= cutoff && (int64_t)kept.size() < count) kept.push_back(std::move(e));
+      lst.swap(kept);
+    }
+  }
+  auto &lst = lists[key];
+  std::vector<const char *> ptrs;
+  for (auto &e : lst) ptrs.push_back(e.second.c_str());
+  return put_bounded_list(key, ptrs.data(), (int)ptrs.size());
 }
 
 StoreDev Store::device_view() const {

@@ -13,6 +13,7 @@
 // slot reference.
 #pragma once
 #include <cstdint>
+#include <climits>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -46,7 +47,28 @@ struct Column {
   int tag_index = 0;         // byte index of the tag inside the record
   int val_off = 0;           // byte offset of the first value cell inside the record
   std::string link_field;    // SString scalar whose value is also a key into the FIELD table ("field=<link_field>:<value>")
+  // write path (raw state): PeriodicCounterConfig(period, sumPeriodRanges = periods.map(PeriodRange(_, 0))),
+  // model/Feature.scala:196-209; BoundedListConfig(count, duration), model/Feature.scala:100-108
+  int64_t period_ms = 0;            // COL_PERIODIC: bucket length; 0 = no write-path config (values arrive by put only)
+  std::vector<int32_t> offsets;     // COL_PERIODIC: PeriodRange.startOffset per cell
+  int ring_off = -1;                // byte offset of this column's bucket ring inside the table's ring record
+  int ring_w = 0;                   // ring entries = max(offsets) + 1
+  int64_t list_count = INT64_MAX;   // COL_BOUNDED_LIST
+  int64_t list_duration_ms = INT64_MAX;
 };
+
+// device descriptor of a periodic column that owns a bucket ring
+constexpr int RING_MAX_RANGES = 16;
+struct RingColDev {
+  uint32_t ring_off, w, val_off, tag_index;
+  int64_t period_ms;
+  int32_t n_ranges;
+  int32_t offsets[RING_MAX_RANGES];
+  int32_t pad;
+};
+struct IncGroup { uint32_t slot, col, begin, end; };   // updates [begin, end) of one (slot, ring column)
+struct IncUpdate { int64_t bucket, inc; };             // bucket = start of period (ms)
+constexpr unsigned long long RING_EMPTY = 0x8080808080808080ull;  // memset(0x80): "no bucket here"
 
 struct Table {
   ScopeId scope;
@@ -59,6 +81,13 @@ struct Table {
   // device side
   DevBuf d_rows;
   uint32_t d_slots_cap = 0;       // slots allocated on device
+  // write path: one ring record per slot = the bucket rings of every periodic column with a config; device only
+  uint32_t ring_stride = 0;
+  std::vector<RingColDev> ring_cols;      // host copy of the descriptors
+  std::vector<int> ring_col_of;           // column index -> index into ring_cols, -1
+  DevBuf d_ring, d_ring_cols;
+  uint32_t d_ring_slots = 0;
+  bool ring_used = false;
   uint32_t dirty_lo = UINT32_MAX, dirty_hi = 0;  // slot range to upload
   bool dirty_all = false;
   void mark(uint32_t slot) {
@@ -94,6 +123,10 @@ struct Store {
   Pool<double> f64_pool;
   Pool<uint32_t> slot_pool;  // item slots of bounded lists
   std::unordered_map<std::string, uint32_t> token_of;  // string -> token id (>= 1)
+  struct PendingInc { uint8_t table; uint32_t slot; uint32_t ring_col; int64_t bucket, inc; };
+  std::vector<PendingInc> pending;   // staged PeriodicIncrements
+  std::unordered_map<std::string, std::vector<std::pair<int64_t, std::string>>> lists;  // raw bounded lists, newest first
+  DevBuf d_groups, d_updates;        // scratch of the apply kernel
   bool frozen = false;       // layout frozen after the first slot is created
   uint64_t version = 0;      // bumped on every put
 
@@ -121,6 +154,15 @@ struct Store {
   bool put_bounded_list(const char *key, const char *const *v, int n);
   bool erase(const char *key);
 
+  // ---- write path (raw Writes of flow/FeatureValueFlow.scala:44-62; the FeatureValue is derived here) ----
+  void set_periodic_config(ScopeId scope, const std::string &name, int64_t period_ms, const std::vector<int32_t> &offsets);
+  void set_list_config(ScopeId scope, const std::string &name, int64_t count, int64_t duration_ms);
+  // Write.PeriodicIncrement: staged; applied to the device bucket rings (and the window sums recomputed
+  // there) at the next flush
+  bool increment_periodic(const char *key, int64_t ts_ms, int64_t inc);
+  bool increment(const char *key, int64_t inc);                          // Write.Increment
+  bool append(const char *key, const char *value, int64_t ts_ms);        // Write.Append(SString)
+
   // host-side readers (used to size per-request scratch; never to compute features)
   const uint8_t *record(ScopeId scope, uint32_t slot) const {
     return tables[scope].rows.data() + (size_t)slot * tables[scope].stride;
@@ -128,6 +170,7 @@ struct Store {
 
   // copies everything that changed since the last call to the device (async on stream)
   void flush(hipStream_t stream);
+  void flush_writes(hipStream_t stream, const uint32_t *uploaded_lo, const uint32_t *uploaded_hi);
   StoreDev device_view() const;
   size_t device_bytes() const;
 
@@ -137,5 +180,11 @@ struct Store {
   void set_tag(Cell &c, uint8_t tag) { c.rec[c.c->tag_index] = tag; }
   template <typename T> void set_val(Cell &c, int idx, T v) { memcpy(c.rec + c.c->val_off + idx * 8, &v, sizeof(T)); }
 };
+
+// writes.hip: bucket rings -> window sums (PeriodicCounterFeature.fromMap, model/Feature.scala:142-161)
+void launch_periodic_apply(hipStream_t stream, uint8_t *rows, uint32_t stride, uint8_t *ring, uint32_t ring_stride,
+                           const RingColDev *cols, const IncGroup *groups, int n_groups, const IncUpdate *updates);
+void launch_periodic_refresh(hipStream_t stream, uint8_t *rows, uint32_t stride, uint8_t *ring, uint32_t ring_stride,
+                             const RingColDev *cols, int n_cols, uint32_t slot_lo, uint32_t slot_hi);
 
 }  // namespace mrk

@@ -121,6 +121,16 @@ class HipRanker:
         arr, _keep = _strs(v)
         N.check(N.lib().mrk_store_put_bounded_list(self.ctx.handle, self._k(key), arr, len(v)))
 
+    # ---- write path: raw Writes (FeatureValueFlow.commitWrite); the FeatureValue is derived by the library
+    def increment_periodic(self, key, ts_ms, inc=1):
+        N.check(N.lib().mrk_store_increment_periodic(self.ctx.handle, self._k(key), int(ts_ms), int(inc)))
+
+    def increment(self, key, inc=1):
+        N.check(N.lib().mrk_store_increment(self.ctx.handle, self._k(key), int(inc)))
+
+    def append(self, key, value, ts_ms):
+        N.check(N.lib().mrk_store_append(self.ctx.handle, self._k(key), str(value).encode(), int(ts_ms)))
+
     def delete(self, key): N.check(N.lib().mrk_store_delete(self.ctx.handle, self._k(key)))
     def flush(self): N.check(N.lib().mrk_store_flush(self.ctx.handle))
 

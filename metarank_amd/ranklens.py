@@ -64,6 +64,34 @@ def c3_config() -> dict:
     return cfg
 
 
+def c5_config(dim: int = 384) -> dict:
+    """C5: the 24 Ranklens columns + one bi-encoder `field_match` column (cosine between the query embedding
+    the host supplies as the request field `__embedding:title_match` and the stored item embedding)."""
+    cfg = ranklens_config()
+    cfg["features"].append({"name": "title_match", "type": "field_match", "itemField": "item.title", "rankingField": "ranking.query",
+                            "method": {"type": "bi-encoder", "model": "metarank/all-MiniLM-L6-v2", "dim": dim}, "distance": "cosine"})
+    cfg["models"]["xgboost"]["features"] = cfg["models"]["xgboost"]["features"] + ["title_match"]
+    return cfg
+
+
+def c5_embeddings(n_items: int, dim: int = 384, seed: int = SEED + 7, missing_frac: float = 0.05):
+    """(kind, key, value) puts of the item embeddings: f32 values widened to f64 (Scalar.scala:24-32), one
+    all-zero vector (cosine -> NaN, no epsilon) and a few items without an embedding"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for i in range(n_items):
+        if rng.random() < missing_frac:
+            continue
+        v = rng.normal(size=dim).astype(np.float32).astype(np.float64)
+        if i == 7:
+            v[:] = 0.0
+        yield "double_list", f"item={i}/title_match", v
+
+
+def c5_query(dim: int = 384, seed: int = 1) -> list:
+    rng = np.random.Generator(np.random.PCG64(SEED + 1000 + seed))
+    return [float(x) for x in rng.normal(size=dim).astype(np.float32)]
+
+
 def _zipf_choice(rng, n, size, s=1.1):
     w = 1.0 / np.arange(1, n + 1) ** s
     return rng.choice(n, size=size, p=w / w.sum())

@@ -14,10 +14,18 @@ class OracleBackend:
     def __init__(self, config: dict, model: str):
         from oracle.assembly import OraclePlan, OracleStore
 
+        from oracle.writes import WriteState
+
         self.store = OracleStore()
         self.plan = OraclePlan(config, model)
         self.dim = self.plan.dim
         self.forest = None
+        self.writes = WriteState(config)
+
+    # raw Writes (FeatureValueFlow.commitWrite + makeValue): the oracle derives the FeatureValue and puts it
+    def increment_periodic(self, k, ts, inc=1): self.store.put_periodic(k, self.writes.increment_periodic(k, ts, inc))
+    def increment(self, k, inc=1): self.store.put_counter(k, self.writes.increment(k, inc))
+    def append(self, k, v, ts): self.store.put_bounded_list(k, self.writes.append(k, v, ts))
 
     # KVStore.put
     def put_double(self, k, v): self.store.put_double(k, v)
@@ -79,6 +87,9 @@ class HipBackend:
     def put_periodic(self, k, v): self.ranker.put_periodic(k, v)
     def put_bounded_list(self, k, v): self.ranker.put_bounded_list(k, v)
     def delete(self, k): self.ranker.delete(k)
+    def increment_periodic(self, k, ts, inc=1): self.ranker.increment_periodic(k, ts, inc)
+    def increment(self, k, inc=1): self.ranker.increment(k, inc)
+    def append(self, k, v, ts): self.ranker.append(k, v, ts)
 
     def load_model(self, blob: bytes, backend: int):
         self.booster = self.M.HipBooster(blob, backend, self.ctx)

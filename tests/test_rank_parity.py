@@ -263,3 +263,42 @@ def test_c4_100k_candidates_sharded_and_sorted(oracle_c2):
         batch.close()
     finally:
         hip.close()
+
+
+@pytest.mark.gpu
+def test_c5_biencoder_column():
+    """BASELINE config C5 minus the ONNX forward (the query embedding arrives as a request field): 24 Ranklens
+    columns + the bi-encoder cosine column (f32 query x f64 item, f64 accumulators, no epsilon,
+    FieldMatchBiencoderFeature.scala:80-109 / DistanceFunction.scala:14-26), 500-tree LambdaMART."""
+    cfg = ranklens.c5_config()
+    orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+    try:
+        for b in (orc, hip):
+            load(b)
+            ranklens.load_state(b, ranklens.c5_embeddings(N_ITEMS))
+        assert orc.dim == 25 and hip.dim == 25
+        reqs = ranklens.generate_requests(12, 100, N_ITEMS, N_SESS, seed=51)
+        for k, ev in enumerate(reqs):
+            if k % 4 != 3:  # every fourth request has no query: the column is NaN for all its items
+                ev["fields"] = [{"name": "__embedding:title_match", "value": ranklens.c5_query(seed=k)}]
+        reqs[0]["items"][0]["id"] = "7"  # the all-zero embedding: 0 / (x * 0) = NaN
+        mats = [orc.matrix(ev) for ev in reqs]
+        col = np.concatenate(mats)[:, 24]
+        assert np.isfinite(col).any() and np.isnan(col).any() and np.nanmax(np.abs(col)) <= 1.0 + 1e-12
+        blob = synth.synthetic_lgbm_model(n_trees=500, n_features=25, quantiles=ranklens.column_quantiles(np.concatenate(mats)),
+                                          cat_features=[7], cat_prob=0.01, missing="per_feature")
+        orc.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        batch = hip.ranker.prepare("xgboost", reqs)
+        batch.run(hip.booster)
+        scores, order, mat = batch.fetch(matrix=True)
+        assert (batch.status() == 0).all()
+        for r, ev in enumerate(reqs):
+            lo, hi = batch.offsets[r], batch.offsets[r + 1]
+            _, es, eo = orc.rerank(ev)
+            assert same(mat[lo:hi], mats[r]), r
+            assert same(scores[lo:hi], es), r
+            assert order[lo:hi].tolist() == eo.tolist(), r
+        batch.close()
+    finally:
+        hip.close()
