@@ -150,6 +150,8 @@ int mrk_store_delete(mrk_ctx *ctx, const char *key);
  *   mrk_store_append              Write.Append(key, SString(value), ts) -> BoundedListValue, bounded by the
  *                                 feature's count / duration (M/fstore/memory/MemBoundedList.scala:18-37) */
 int mrk_store_increment_periodic(mrk_ctx *ctx, const char *key, int64_t ts_ms, int64_t inc);
+/* n PeriodicIncrements in one call (one event usually produces several: item, field-scoped, global keys) */
+int mrk_store_increment_periodic_batch(mrk_ctx *ctx, const char *const *keys, const int64_t *ts_ms, const int64_t *inc, int n);
 int mrk_store_increment(mrk_ctx *ctx, const char *key, int64_t inc);
 int mrk_store_append(mrk_ctx *ctx, const char *key, const char *value, int64_t ts_ms);
 int mrk_store_flush(mrk_ctx *ctx);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "mrk_store_put_bounded_list": (_I, [_V, _S, C.POINTER(_S), _I]),
     "mrk_store_delete": (_I, [_V, _S]),
     "mrk_store_increment_periodic": (_I, [_V, _S, C.c_int64, C.c_int64]),
+    "mrk_store_increment_periodic_batch": (_I, [_V, C.POINTER(_S), _P, _P, _I]),
     "mrk_store_increment": (_I, [_V, _S, C.c_int64]),
     "mrk_store_append": (_I, [_V, _S, _S, C.c_int64]),
     "mrk_store_flush": (_I, [_V]),

@@ -331,6 +331,17 @@ int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *v, int 
 int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *v, int n) { STORE_PUT(put_bounded_list(key, v, n)); }
 int mrk_store_delete(mrk_ctx *ctx, const char *key) { STORE_PUT(erase(key)); }
 int mrk_store_increment_periodic(mrk_ctx *ctx, const char *key, int64_t ts_ms, int64_t inc) { STORE_PUT(increment_periodic(key, ts_ms, inc)); }
+int mrk_store_increment_periodic_batch(mrk_ctx *ctx, const char *const *keys, const int64_t *ts_ms, const int64_t *inc, int n) {
+  return guard([&] {
+    if (n < 0 || (n > 0 && (!keys || !ts_ms || !inc))) throw StatusError(MRK_ERR_INVALID_ARG, "bad increment batch");
+    Store &st = store_of(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < n; ++i) {
+      if (!keys[i]) throw StatusError(MRK_ERR_INVALID_ARG, "null key");
+      (void)st.increment_periodic(keys[i], ts_ms[i], inc[i]);
+    }
+  });
+}
 int mrk_store_increment(mrk_ctx *ctx, const char *key, int64_t inc) { STORE_PUT(increment(key, inc)); }
 int mrk_store_append(mrk_ctx *ctx, const char *key, const char *value, int64_t ts_ms) { STORE_PUT(append(key, value, ts_ms)); }
 
