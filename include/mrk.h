@@ -138,6 +138,13 @@ int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *values,
 int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *values, int n); /* BoundedListValue of SString */
 int mrk_store_delete(mrk_ctx *ctx, const char *key);
 
+/* Bulk load from the reference's binary wire format: `bytes` is any concatenation of
+ * FeatureValueCodec records (M/fstore/codec/impl/FeatureValueCodec.scala:40-168, tags 0-13) - what the
+ * Redis / RocksDB / MapDB `values` store holds per key.  Every record is applied like the matching
+ * mrk_store_put_* (NumStats / Map / Frequency values are parsed and ignored: /rank does not read them).
+ * out_records (nullable) receives the number of records decoded. */
+int mrk_store_put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int *out_records);
+
 /* Write path: instead of a refreshed FeatureValue the host may forward the raw Writes of
  * FeatureValueFlow.commitWrite (M/flow/FeatureValueFlow.scala:44-62); the FeatureValue the read path needs is
  * then derived by the library - always fresh, no `refresh` interval.

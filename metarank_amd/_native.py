@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
-SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "capi.cpp", "capi_rank.cpp", "score.hip", "score_qs.hip", "rank.hip", "writes.hip"]
+SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "capi.cpp", "capi_rank.cpp", "score.hip", "score_qs.hip", "rank.hip", "writes.hip"]
 HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
 
 MRK_OK = 0
@@ -91,6 +91,7 @@ SIGNATURES = {
     "mrk_store_put_bounded_list": (_I, [_V, _S, C.POINTER(_S), _I]),
     "mrk_store_delete": (_I, [_V, _S]),
     "mrk_store_increment_periodic": (_I, [_V, _S, C.c_int64, C.c_int64]),
+    "mrk_store_put_binary": (_I, [_V, _P, C.c_size_t, C.POINTER(C.c_int)]),
     "mrk_store_increment_periodic_batch": (_I, [_V, C.POINTER(_S), _P, _P, _I]),
     "mrk_store_increment": (_I, [_V, _S, C.c_int64]),
     "mrk_store_append": (_I, [_V, _S, _S, C.c_int64]),

@@ -23,6 +23,7 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads);
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
+int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
 
 void free_rank_state(mrk_ctx *ctx) {
   delete ctx->registry;
@@ -331,6 +332,17 @@ int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *v, int 
 int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *v, int n) { STORE_PUT(put_bounded_list(key, v, n)); }
 int mrk_store_delete(mrk_ctx *ctx, const char *key) { STORE_PUT(erase(key)); }
 int mrk_store_increment_periodic(mrk_ctx *ctx, const char *key, int64_t ts_ms, int64_t inc) { STORE_PUT(increment_periodic(key, ts_ms, inc)); }
+int mrk_store_put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int *out_records) {
+  return guard([&] {
+    if (out_records) *out_records = 0;
+    if (!bytes && len) throw StatusError(MRK_ERR_INVALID_ARG, "null blob");
+    Store &st = store_of(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int n = load_feature_values(st, bytes, len);
+    if (out_records) *out_records = n;
+  });
+}
+
 int mrk_store_increment_periodic_batch(mrk_ctx *ctx, const char *const *keys, const int64_t *ts_ms, const int64_t *inc, int n) {
   return guard([&] {
     if (n < 0 || (n > 0 && (!keys || !ts_ms || !inc))) throw StatusError(MRK_ERR_INVALID_ARG, "bad increment batch");

@@ -131,6 +131,12 @@ class HipRanker:
     def append(self, key, value, ts_ms):
         N.check(N.lib().mrk_store_append(self.ctx.handle, self._k(key), str(value).encode(), int(ts_ms)))
 
+    def put_binary(self, blob: bytes) -> int:
+        """bulk load: concatenated FeatureValueCodec records (the reference's binary wire format)"""
+        n = C.c_int(0)
+        N.check(N.lib().mrk_store_put_binary(self.ctx.handle, blob, len(blob), C.byref(n)))
+        return n.value
+
     def delete(self, key): N.check(N.lib().mrk_store_delete(self.ctx.handle, self._k(key)))
     def flush(self): N.check(N.lib().mrk_store_flush(self.ctx.handle))
 

@@ -1,0 +1,72 @@
+"""Bulk load from Metarank's binary FeatureValue wire format.  CPU: the test-side writer/reader
+restatement round-trips the reference's own test values and VarNum known answers; GPU: a store loaded from the
+binary blobs (mrk_store_put_binary) ranks exactly like the same store loaded through the typed puts."""
+import numpy as np
+import pytest
+
+from oracle import codec
+
+
+def test_varnum_known_answers():  # util/VarNum.java = unsigned LEB128 (hand-computed)
+    assert codec.var_long(0) == b"\x00" and codec.var_long(1) == b"\x01" and codec.var_long(127) == b"\x7f"
+    assert codec.var_long(128) == b"\x80\x01" and codec.var_long(300) == b"\xac\x02"
+    assert codec.var_long(1661345221008) == bytes([0x90, 0x93, 0x91, 0xff, 0xac, 0x30])
+    assert codec.var_long(-1) == b"\xff" * 9 + b"\x01"  # two's complement: ten bytes
+    assert codec.var_int(300) == b"\xac\x02" and codec.var_int(-1) == b"\xff\xff\xff\xff\x0f"
+    assert codec.utf("foo") == b"\x00\x03foo" and codec.utf("é€") == b"\x00\x05\xc3\xa9\xe2\x82\xac"
+    assert codec.utf("a\x00b") == b"\x00\x04a\xc0\x80b"  # modified UTF-8
+    assert codec.f64(1.0) == b"\x3f\xf0" + b"\x00" * 6
+
+
+def test_roundtrip_of_the_reference_test_values():  # T/fstore/redis/codec/impl/FeatureValueCodecTest.scala:27-53
+    k, ts = "user=u1/foo", 1661345221008
+    values = [("string", "foo"), ("counter", 1), ("numstats", (1.0, 2.0, {1: 1.0})), ("map", {"foo": ("string", "bar")}),
+              ("periodic", [1]), ("freq", {"foo": 1.0}), ("bounded_list", ["foo"])]
+    for compat in (False, True):
+        blob = b"".join(codec.feature_value(kind, k, v, ts, compat=compat) for kind, v in values)
+        back = codec.decode(blob)
+        assert [(b[0], b[1], b[2], b[3]) for b in back] == [(kind, k, v, ts) for kind, v in values]
+        assert all(b[4] == (None if compat else codec.DAYS_90_MS) for b in back)
+    # every scope of ScopeCodec
+    for key in ("item=i/x", "global/x", "session=s/x", "field=genre:drama/x", "irf=query:red socks:p1/x", "ranking=r1/x"):
+        assert codec.decode(codec.feature_value("double", key, 2.5))[0][1:3] == (key, 2.5)
+    assert codec.decode(codec.feature_value("double_list", "item=i/v", [1.5, -2.0]))[0][2] == [1.5, -2.0]
+    assert codec.decode(codec.feature_value("string_list", "item=i/v", ["a", "é"]))[0][2] == ["a", "é"]
+    assert codec.decode(codec.feature_value("counter", "item=i/c", -5))[0][2] == -5
+
+
+@pytest.mark.gpu
+def test_store_loaded_from_binary_ranks_like_typed_puts():
+    from backends import HipBackend
+    from metarank_amd import ranklens, synth
+
+    cfg = ranklens.c3_config()
+    a, b = HipBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+    try:
+        state = list(ranklens.generate_state(2000, 200, c3=True))
+        ranklens.load_state(a, iter(state))
+        blob = bytearray()
+        for i, (kind, key, value) in enumerate(state):
+            blob += codec.feature_value(kind, key, value, compat=(i % 7 == 0))
+            if i % 500 == 0:  # values /rank does not read must be skipped cleanly
+                blob += codec.feature_value("numstats", key, (0.0, 1.0, {50: 0.5}))
+                blob += codec.feature_value("map", key, {"k": ("double", 1.0)}) + codec.feature_value("freq", key, {"k": 0.5})
+        n = b.ranker.put_binary(bytes(blob))
+        assert n == len(state) + 3 * len(range(0, len(state), 500))
+        reqs = ranklens.generate_requests(8, 300, 2000, 200, seed=7)
+        ma = np.concatenate([a.matrix(ev) for ev in reqs])
+        mb = np.concatenate([b.matrix(ev) for ev in reqs])
+        assert ((ma == mb) | (np.isnan(ma) & np.isnan(mb))).all()
+        model = synth.synthetic_lgbm_model(n_trees=100, n_features=64, quantiles=ranklens.column_quantiles(ma))
+        a.load_model(model, 0)
+        b.load_model(model, 0)
+        for ev in reqs:
+            (_, sa, oa), (_, sb, ob) = a.rerank(ev), b.rerank(ev)
+            assert np.array_equal(sa, sb) and oa.tolist() == ob.tolist()
+        with pytest.raises(a.M.MrkError):
+            b.ranker.put_binary(bytes(blob[:-3]))  # truncated record
+        with pytest.raises(a.M.MrkError):
+            b.ranker.put_binary(b"\x63")           # "cannot decode fv index"
+    finally:
+        a.close()
+        b.close()
