@@ -25,13 +25,6 @@ int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
 
-void free_rank_state(mrk_ctx *ctx) {
-  delete ctx->registry;
-  delete ctx->store;
-  ctx->registry = nullptr;
-  ctx->store = nullptr;
-}
-
 template <typename F>
 static int guard(F &&f) {
   try {
@@ -73,7 +66,10 @@ struct mrk_batch {
   mrk_ctx *ctx = nullptr;
   const Program *prog = nullptr;
   int n_req = 0, total_items = 0;
-  DevBuf d_in, d_prep_out, d_arena, d_status, d_matrix, d_scores, d_order;
+  DevBuf d_in, d_prep_out, d_arena, d_matrix;
+  DevBuf d_out;              // [scores: (T + shard padding) f64][order: T i32][status: n_req i32], fetched with ONE copy
+  size_t out_order_off = 0, out_status_off = 0, out_bytes = 0;
+  PinBuf h_out;
   DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
   DevBuf d_sort_keys, d_sort_idx;       // scratch of the multi-workgroup sort
   std::vector<std::pair<int, int>> big; // (request, n_items) with n_items > SORT_MAX_ITEMS
@@ -91,6 +87,18 @@ struct mrk_batch {
 };
 
 namespace mrk {
+
+void free_rank_state(mrk_ctx *ctx) {
+  if (ctx->rank_scratch) {
+    (void)hipSetDevice(ctx->device);
+    delete (mrk_batch *)ctx->rank_scratch;
+    ctx->rank_scratch = nullptr;
+  }
+  delete ctx->registry;
+  delete ctx->store;
+  ctx->registry = nullptr;
+  ctx->store = nullptr;
+}
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -130,10 +138,13 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   put(o_prep, hb.prep_out.data(), hb.prep_out.size() * sizeof(PrepOut));
   MRK_HIP(hipMemcpyAsync(b.d_in.p, h, total_bytes, hipMemcpyHostToDevice, ctx->stream));
   b.d_arena.reserve(std::max<size_t>(hb.arena_entries, 1) * 8);
-  b.d_status.reserve(std::max<size_t>(n_req, 1) * 4);
+  // outputs in one allocation: one device-to-host copy per fetch (single-request latency)
+  const size_t score_slots = (size_t)T + 256 * QS_TILE_ROWS;  // room for the padded chunks of an item-sharded all-gather
+  b.out_order_off = align_up(score_slots * 8, 256);
+  b.out_status_off = align_up(b.out_order_off + std::max<size_t>(T, 1) * 4, 256);
+  b.out_bytes = b.out_status_off + std::max<size_t>(n_req, 1) * 4;
+  b.d_out.reserve(b.out_bytes);
   b.d_matrix.reserve(std::max<size_t>((size_t)T * prog.dim, 1) * 8);
-  b.d_scores.reserve(((size_t)T + 256 * QS_TILE_ROWS) * 8);  // room for the padded chunks of an item-sharded all-gather
-  b.d_order.reserve(std::max<size_t>(T, 1) * 4);
   uint8_t *d = b.d_in.as<uint8_t>();
   BatchDev &v = b.view;
   v.reqs = (const ReqDev *)(d + o_reqs);
@@ -149,10 +160,10 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   v.n_overrides = (int)hb.overrides.size();
   v.prep_out = (PrepOut *)(d + o_prep);
   v.arena = (unsigned long long *)b.d_arena.p;
-  v.status = (int32_t *)b.d_status.p;
+  v.status = (int32_t *)(b.d_out.as<uint8_t>() + b.out_status_off);
   v.matrix = (double *)b.d_matrix.p;
-  v.scores = (double *)b.d_scores.p;
-  v.order = (int32_t *)b.d_order.p;
+  v.scores = (double *)b.d_out.p;
+  v.order = (int32_t *)(b.d_out.as<uint8_t>() + b.out_order_off);
   b.h_status.assign(n_req, 0);
   b.ran = false;
   b.matrix_valid = false;
@@ -222,7 +233,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
   check_model_fits(model, *b.prog);
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
-  MRK_HIP(hipMemsetAsync(b.d_status.p, 0, std::max<size_t>(b.n_req, 1) * 4, ctx->stream));
+  MRK_HIP(hipMemsetAsync(b.view.status, 0, std::max<size_t>(b.n_req, 1) * 4, ctx->stream));
   b.view.item_lo = lo;
   b.view.item_hi = hi;
   const int rows = hi - lo;
@@ -276,11 +287,24 @@ static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *ma
     // the last run assembled straight into the scorer's tile: materialise the f64 matrix now
     assemble_matrix(b, ctx->store->device_view(), b.prog->device_view());
   }
-  if (scores && T) MRK_HIP(hipMemcpyAsync(scores, b.d_scores.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (order && T) MRK_HIP(hipMemcpyAsync(order, b.d_order.p, T * 4, hipMemcpyDeviceToHost, ctx->stream));
+  // scores + order + status: one copy into pinned memory (a copy into pageable caller memory is staged by the
+  // runtime anyway, and three small copies cost three round trips)
+  const size_t tight = (size_t)T * 8 <= 64 * 1024 ? b.out_bytes : 0;  // small batch: copy the whole blob; else the used ranges
+  b.h_out.reserve(b.out_bytes);
+  uint8_t *h = b.h_out.as<uint8_t>();
+  const uint8_t *d = b.d_out.as<uint8_t>();
+  if (tight) {
+    MRK_HIP(hipMemcpyAsync(h, d, b.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    if (scores && T) MRK_HIP(hipMemcpyAsync(h, d, T * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (order && T) MRK_HIP(hipMemcpyAsync(h + b.out_order_off, d + b.out_order_off, T * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (b.n_req) MRK_HIP(hipMemcpyAsync(h + b.out_status_off, d + b.out_status_off, (size_t)b.n_req * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   if (matrix && T && b.prog->dim) MRK_HIP(hipMemcpyAsync(matrix, b.d_matrix.p, T * b.prog->dim * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (b.n_req) MRK_HIP(hipMemcpyAsync(b.h_status.data(), b.d_status.p, (size_t)b.n_req * 4, hipMemcpyDeviceToHost, ctx->stream));
   MRK_HIP(hipStreamSynchronize(ctx->stream));
+  if (scores && T) memcpy(scores, h, T * 8);
+  if (order && T) memcpy(order, h + b.out_order_off, T * 4);
+  if (b.n_req) memcpy(b.h_status.data(), h + b.out_status_off, (size_t)b.n_req * 4);
   drain_profile_events(ctx);
 }
 
@@ -382,7 +406,9 @@ int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_r
     if (model && model->ctx != ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
     std::lock_guard<std::mutex> lk(ctx->mu);
     const Program &prog = program_of(ctx, model_name);
-    mrk_batch b;
+    // one grow-only scratch batch per context: no hipMalloc / hipFree on the single-request path
+    if (!ctx->rank_scratch) ctx->rank_scratch = new mrk_batch();
+    mrk_batch &b = *(mrk_batch *)ctx->rank_scratch;
     build_batch(ctx, prog, req, 1, b);
     b.want_matrix = out_matrix != nullptr;
     run_batch(b, model);

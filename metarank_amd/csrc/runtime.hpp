@@ -109,6 +109,7 @@ struct mrk_ctx {
   // feature side (created by mrk_config_load_json)
   mrk::Registry *registry = nullptr;  // owned; freed by mrk::free_rank_state
   mrk::Store *store = nullptr;
+  void *rank_scratch = nullptr;       // mrk_batch reused by mrk_rank (owned; freed by mrk::free_rank_state)
   mrk_ctx();
   ~mrk_ctx();
 };
