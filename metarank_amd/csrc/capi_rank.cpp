@@ -14,6 +14,7 @@ void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, co
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_sort(mrk_ctx *ctx, const BatchDev &b);
 void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx);
+size_t big_sort_padded(int n_items);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
@@ -172,13 +173,11 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   for (int r = 0; r < n_req; ++r)
     if (hb.reqs[r].n_items > SORT_MAX_ITEMS) {
       b.big.emplace_back(r, hb.reqs[r].n_items);
-      size_t p2 = SORT_MAX_ITEMS;
-      while (p2 < (size_t)hb.reqs[r].n_items) p2 <<= 1;
-      big_p2 = std::max(big_p2, p2);
+      big_p2 = std::max(big_p2, big_sort_padded(hb.reqs[r].n_items));
     }
-  if (big_p2) {
-    b.d_sort_keys.reserve(big_p2 * 8);
-    b.d_sort_idx.reserve(big_p2 * 4);
+  if (big_p2) {  // ping-pong buffers of the merge passes
+    b.d_sort_keys.reserve(2 * big_p2 * 8);
+    b.d_sort_idx.reserve(2 * big_p2 * 4);
   }
   // small requests: both phases in one workgroup, tables in LDS (<= 64 KB keeps two workgroups per CU)
   uint32_t vals = 1;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <utility>
 
 #include "qs_device.hpp"
 #include "rank.hpp"
@@ -711,40 +712,39 @@ sort_kernel(BatchDev b) {
   for (int i = tid; i < n; i += SORT_THREADS) b.order[rq.item_begin + i] = s_idx[i];
 }
 
-// ---- requests with more than SORT_MAX_ITEMS candidates (C4: 100 000): bitonic network over global memory.
-// Chunks of SORT_MAX_ITEMS elements are sorted / merged in LDS; only the compare distances >= one chunk
-// run as global steps.  (key, index) pairs are distinct, so the result is the stable order.
-__device__ __forceinline__ bool pair_gt(unsigned long long ka, int ia, unsigned long long kb, int ib) {
-  return ka > kb || (ka == kb && ia > ib);
+// ---- requests with more than SORT_MAX_ITEMS candidates (C4: 100 000): merge sort.  Chunks of SORT_MAX_ITEMS
+// (key, index) pairs are sorted in LDS (bitonic), then log2(chunks) merge passes; in a pass every workgroup
+// produces SORT_MAX_ITEMS consecutive outputs of one pair of runs: merge-path binary searches find its input
+// ranges, the inputs go to LDS, every lane merges 16 outputs.  (key, index) pairs are distinct, so the result
+// is the stable order.
+__device__ __forceinline__ bool pair_lt(unsigned long long ka, int ia, unsigned long long kb, int ib) {
+  return ka < kb || (ka == kb && ia < ib);
 }
 
-__global__ void __launch_bounds__(SORT_THREADS)
-bigsort_init_kernel(BatchDev b, int r, unsigned long long *keys, int *idx, int p2) {
-  const ReqDev rq = b.reqs[r];
-  const int i = blockIdx.x * SORT_THREADS + threadIdx.x;
-  if (i >= p2) return;
-  keys[i] = i < rq.n_items ? sort_key(b.scores[rq.item_begin + i]) : ~0ull;
-  idx[i] = i < rq.n_items ? i : 0x7fffffff;
-}
+constexpr int MS_PER_THREAD = SORT_MAX_ITEMS / SORT_THREADS;  // 16
 
-// one chunk per workgroup: every stage (k, j) with j < SORT_MAX_ITEMS of the sizes k in [k_lo, k_hi]
 __global__ void __launch_bounds__(SORT_THREADS)
-bigsort_local_kernel(unsigned long long *keys, int *idx, int k_lo, int k_hi) {
+msort_chunk_kernel(BatchDev b, int r, unsigned long long *keys, int *idx) {
   __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
   __shared__ int s_idx[SORT_MAX_ITEMS];
+  const ReqDev rq = b.reqs[r];
   const int base = blockIdx.x * SORT_MAX_ITEMS;
   const int tid = threadIdx.x;
-  for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) { s_key[i] = keys[base + i]; s_idx[i] = idx[base + i]; }
+  for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) {
+    const int g = base + i;
+    s_key[i] = g < rq.n_items ? sort_key(b.scores[rq.item_begin + g]) : ~0ull;  // padding sorts last
+    s_idx[i] = g < rq.n_items ? g : 0x7fffffff;
+  }
   __syncthreads();
-  for (int k = k_lo; k <= k_hi; k <<= 1) {
-    for (int j = min(k >> 1, SORT_MAX_ITEMS >> 1); j > 0; j >>= 1) {
+  for (int k = 2; k <= SORT_MAX_ITEMS; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const unsigned long long ka = s_key[i], kb = s_key[ixj];
           const int ia = s_idx[i], ib = s_idx[ixj];
-          const bool up = ((base + i) & k) == 0;
-          if (pair_gt(ka, ia, kb, ib) == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
+          const bool up = (i & k) == 0;
+          if (pair_lt(kb, ib, ka, ia) == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
         }
       }
       __syncthreads();
@@ -753,16 +753,72 @@ bigsort_local_kernel(unsigned long long *keys, int *idx, int k_lo, int k_hi) {
   for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) { keys[base + i] = s_key[i]; idx[base + i] = s_idx[i]; }
 }
 
+// number of elements taken from run A among the first `diag` outputs of merge(A, B); A, B sorted, pairs distinct
+template <typename KeyP, typename IdxP>
+__device__ __forceinline__ int merge_path(KeyP ka, IdxP ia, int na, KeyP kb, IdxP ib, int nb, int diag) {
+  int lo = max(0, diag - nb), hi = min(diag, na);
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;  // take mid from A, diag - mid from B
+    // A[mid] must come after B[diag - mid - 1] to stop taking from A
+    if (pair_lt(ka[mid], ia[mid], kb[diag - mid - 1], ib[diag - mid - 1])) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// the same split found by the whole workgroup: SORT_THREADS candidates per round instead of one, so a split
+// over runs of 100 000 elements in global memory takes 3 rounds of loads instead of 17 dependent ones
+__device__ __forceinline__ int merge_path_block(const unsigned long long *ka, const int *ia, int na, const unsigned long long *kb,
+                                                const int *ib, int nb, int diag) {
+  int lo = max(0, diag - nb), hi = min(diag, na);  // the answer is the first mid in [lo, hi] whose test is false (hi: false)
+  while (lo < hi) {
+    const int step = (hi - lo + SORT_THREADS - 1) / SORT_THREADS;
+    const int mid = lo + (int)threadIdx.x * step;
+    const bool p = mid < hi && pair_lt(ka[mid], ia[mid], kb[diag - mid - 1], ib[diag - mid - 1]);  // monotone: true ... true false ... false
+    const int cnt = __syncthreads_count(p);
+    if (cnt == 0) { hi = lo; break; }
+    const int last_true = lo + (cnt - 1) * step;
+    hi = min(hi, lo + cnt * step);
+    lo = last_true + 1;
+  }
+  return lo;
+}
+
 __global__ void __launch_bounds__(SORT_THREADS)
-bigsort_global_kernel(unsigned long long *keys, int *idx, int p2, int k, int j) {
-  const int t = blockIdx.x * SORT_THREADS + threadIdx.x;  // one compare-exchange per thread
-  if (t >= (p2 >> 1)) return;
-  const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // the lower index of the pair: bit j clear
-  const int ixj = i | j;
-  const unsigned long long ka = keys[i], kb = keys[ixj];
-  const int ia = idx[i], ib = idx[ixj];
-  const bool up = (i & k) == 0;
-  if (pair_gt(ka, ia, kb, ib) == up) { keys[i] = kb; keys[ixj] = ka; idx[i] = ib; idx[ixj] = ia; }
+msort_merge_kernel(const unsigned long long *__restrict__ src_k, const int *__restrict__ src_i, unsigned long long *__restrict__ dst_k,
+                   int *__restrict__ dst_i, int n_pad, int run) {
+  __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
+  __shared__ int s_idx[SORT_MAX_ITEMS];
+  const int tid = threadIdx.x;
+  const int out0 = blockIdx.x * SORT_MAX_ITEMS;
+  const int pair0 = (out0 / (2 * run)) * (2 * run);
+  const int na = min(run, n_pad - pair0);
+  const int nb = max(0, min(run, n_pad - pair0 - run));
+  const unsigned long long *ak = src_k + pair0, *bk = src_k + pair0 + run;
+  const int *ai = src_i + pair0, *bi = src_i + pair0 + run;
+  const int d0 = out0 - pair0;
+  const int a0 = merge_path_block(ak, ai, na, bk, bi, nb, d0);
+  const int a1 = merge_path_block(ak, ai, na, bk, bi, nb, min(d0 + SORT_MAX_ITEMS, na + nb));
+  const int b0 = d0 - a0, b1 = min(d0 + SORT_MAX_ITEMS, na + nb) - a1;
+  const int la = a1 - a0, lb = b1 - b0;  // la + lb outputs (SORT_MAX_ITEMS: n_pad is a multiple of it)
+  for (int i = tid; i < la; i += SORT_THREADS) { s_key[i] = ak[a0 + i]; s_idx[i] = ai[a0 + i]; }
+  for (int i = tid; i < lb; i += SORT_THREADS) { s_key[la + i] = bk[b0 + i]; s_idx[la + i] = bi[b0 + i]; }
+  __syncthreads();
+  const int d = tid * MS_PER_THREAD;  // la + lb == SORT_MAX_ITEMS
+  int x = merge_path(s_key, s_idx, la, s_key + la, s_idx + la, lb, d);
+  int y = d - x;
+#pragma unroll
+  for (int o = 0; o < MS_PER_THREAD; ++o) {
+    bool take_a;
+    if (x >= la) take_a = false;
+    else if (y >= lb) take_a = true;
+    else take_a = pair_lt(s_key[x], s_idx[x], s_key[la + y], s_idx[la + y]);
+    const int p = take_a ? x : la + y;
+    dst_k[out0 + d + o] = s_key[p];
+    dst_i[out0 + d + o] = s_idx[p];
+    x += take_a ? 1 : 0;
+    y += take_a ? 0 : 1;
+  }
 }
 
 __global__ void __launch_bounds__(SORT_THREADS)
@@ -863,21 +919,24 @@ void launch_sort(mrk_ctx *ctx, const BatchDev &b) {
   MRK_HIP(hipGetLastError());
 }
 
-// one request with n_items > SORT_MAX_ITEMS; keys / idx hold p2 = next power of two >= n_items elements
+// one request with n_items > SORT_MAX_ITEMS; keys / idx hold 2 x n_pad elements (ping-pong), n_pad = n_items rounded
+// up to whole chunks (big_sort_padded)
+size_t big_sort_padded(int n_items) { return ((size_t)n_items + SORT_MAX_ITEMS - 1) / SORT_MAX_ITEMS * SORT_MAX_ITEMS; }
+
 void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx) {
-  int p2 = SORT_MAX_ITEMS;
-  while (p2 < n_items) p2 <<= 1;
+  const int n_pad = (int)big_sort_padded(n_items);
+  const int chunks = n_pad / SORT_MAX_ITEMS;
   ScopedKernelTimer timer(ctx, "sort");
   const dim3 blk(SORT_THREADS);
-  hipLaunchKernelGGL(bigsort_init_kernel, dim3(p2 / SORT_THREADS), blk, 0, ctx->stream, b, r, keys, idx, p2);
-  const int chunks = p2 / SORT_MAX_ITEMS;
-  hipLaunchKernelGGL(bigsort_local_kernel, dim3(chunks), blk, 0, ctx->stream, keys, idx, 2, SORT_MAX_ITEMS);
-  for (int k = SORT_MAX_ITEMS << 1; k <= p2; k <<= 1) {
-    for (int j = k >> 1; j >= SORT_MAX_ITEMS; j >>= 1)
-      hipLaunchKernelGGL(bigsort_global_kernel, dim3((p2 / 2 + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->stream, keys, idx, p2, k, j);
-    hipLaunchKernelGGL(bigsort_local_kernel, dim3(chunks), blk, 0, ctx->stream, keys, idx, k, k);
+  unsigned long long *k0 = keys, *k1 = keys + n_pad;
+  int *i0 = idx, *i1 = idx + n_pad;
+  hipLaunchKernelGGL(msort_chunk_kernel, dim3(chunks), blk, 0, ctx->stream, b, r, k0, i0);
+  for (int run = SORT_MAX_ITEMS; run < n_pad; run <<= 1) {
+    hipLaunchKernelGGL(msort_merge_kernel, dim3(chunks), blk, 0, ctx->stream, k0, i0, k1, i1, n_pad, run);
+    std::swap(k0, k1);
+    std::swap(i0, i1);
   }
-  hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->stream, b, r, idx);
+  hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->stream, b, r, i0);
   MRK_HIP(hipGetLastError());
 }
 
