@@ -51,6 +51,10 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
     ap.add_argument("--requests", type=int, default=None, help="requests per step per GPU (c2: 3840, c3: 384, c4: 1)")
     ap.add_argument("--items", type=int, default=None, help="candidate items per request (c2: 100, c3: 1000, c4: 100000)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="batches in flight per GPU (each on its own HIP stream; steps alternate between them). "
+                         "Default 2 for c2 / c3 (the assembly kernels wait on memory while the scorer is VALU-bound: consecutive "
+                         "batches overlap), 1 for c4")
     ap.add_argument("--catalogue", type=int, default=100_000)
     ap.add_argument("--sessions", type=int, default=10_000)
     ap.add_argument("--trees", type=int, default=500)
@@ -63,6 +67,9 @@ def main():
     if args.items is None:
         args.items = {"c2": 100, "c3": 1000, "c4": 100_000}[wl]
     sharded = wl == "c4"
+    if args.streams is None:
+        args.streams = 1 if sharded else 2
+    n_streams = max(1, args.streams)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,9 +129,10 @@ def main():
     log(f"state: {n_puts} feature values for {args.catalogue} items / {args.sessions} sessions in {time.perf_counter() - t0:.1f}s")
 
     # ---- requests (per-rank seeds) and the model
-    # item-sharded: every rank holds the same request; else per-rank requests
-    events = ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
-                                        seed=ranklens.SEED + 1 + (0 if sharded else rank))
+    # item-sharded: every rank holds the same request; else per-rank (and per-stream) requests
+    all_events = [ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
+                                             seed=ranklens.SEED + 1 + (0 if sharded else rank) + 1000 * k) for k in range(n_streams)]
+    events = all_events[0]
     sample = ranker.prepare(model_name, ranklens.generate_requests(64, 100, args.catalogue, args.sessions, seed=ranklens.SEED + 99))
     sample.run(None)
     _, _, sm = sample.fetch(matrix=True)
@@ -135,35 +143,42 @@ def main():
     booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
     info = booster.info()
     t0 = time.perf_counter()
-    batch = ranker.prepare(model_name, events)
+    batches = [ranker.prepare(model_name, ev) for ev in all_events]
+    batch = batches[0]
     total_items = batch.total_items
     log(f"batch: {args.requests} requests x {args.items} items resolved + uploaded in {time.perf_counter() - t0:.2f}s; "
         f"model {info['n_trees']} trees, {info['n_nodes']} nodes, {info['device_bytes']} B on device")
 
     # ---- multi-GPU merge buffers (scores of every rank) ----
-    gather = None
+    gathers = [None] * n_streams
     chunk = batch.shard_chunk(n_gpus) if sharded else total_items
     if use_dist:
         from metarank_amd.dist import all_gather_padded
 
-        d_scores, _, _ = batch.device_outputs()
-        n_view = chunk * n_gpus if sharded else total_items  # the library's score buffer has room for the padded chunks
+        def make_gather(bt):
+            d_scores, _, _ = bt.device_outputs()
+            n_view = chunk * n_gpus if sharded else total_items  # the library's score buffer has room for the padded chunks
 
-        class _Arr:  # __cuda_array_interface__ view of the library-owned score buffer
-            __cuda_array_interface__ = {"shape": (n_view,), "typestr": "<f8", "data": (d_scores, False), "version": 3}
+            class _Arr:  # __cuda_array_interface__ view of the library-owned score buffer
+                __cuda_array_interface__ = {"shape": (n_view,), "typestr": "<f8", "data": (d_scores, False), "version": 3}
 
-        scores_t = torch.as_tensor(_Arr(), device=f"cuda:{local_rank}")
-        merged = None if sharded else torch.empty(n_gpus * total_items, dtype=torch.float64, device=f"cuda:{local_rank}")
-        ext = torch.cuda.ExternalStream(M._native.lib().mrk_stream(ctx.handle), device=f"cuda:{local_rank}")
+            scores_t = torch.as_tensor(_Arr(), device=f"cuda:{local_rank}")
+            merged = None if sharded else torch.empty(n_gpus * total_items, dtype=torch.float64, device=f"cuda:{local_rank}")
+            ext = torch.cuda.ExternalStream(bt.stream, device=f"cuda:{local_rank}")  # the collective follows the batch on its stream
 
-        def gather():
-            with torch.cuda.stream(ext):
-                if sharded:
-                    all_gather_padded(scores_t, chunk)  # in place: every rank ends up with every slice
-                else:
-                    dist.all_gather_into_tensor(merged, scores_t)
+            def gather():
+                with torch.cuda.stream(ext):
+                    if sharded:
+                        all_gather_padded(scores_t, chunk)  # in place: every rank ends up with every slice
+                    else:
+                        dist.all_gather_into_tensor(merged, scores_t)
+            return gather
+
+        gathers = [make_gather(bt) for bt in batches]
 
     def sync_all():
+        for bt in batches:
+            bt.sync()
         ctx.sync()
         if torch is not None:
             torch.cuda.synchronize()
@@ -172,25 +187,26 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def step():
+    def step(i):
+        bt, gather = batches[i % n_streams], gathers[i % n_streams]
         if sharded:  # this rank's slice -> merge -> order
-            batch.run_shard(booster, rank, n_gpus)
+            bt.run_shard(booster, rank, n_gpus)
             if gather is not None:
                 gather()
-            batch.sort()
+            bt.sort()
         else:
-            batch.run(booster)
+            bt.run(booster)
             if gather is not None:
                 gather()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     sync_all()
     barrier()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     sync_all()
     barrier()
     sync_all()
@@ -199,12 +215,14 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    st = batch.status()
-    assert (st == 0).all(), f"requests failed: {st[st != 0][:5]}"
+    for bt in batches:
+        st = bt.status()
+        assert (st == 0).all(), f"requests failed: {st[st != 0][:5]}"
     ms_per_step = elapsed / args.steps * 1e3
     value = total_items * (1 if sharded else n_gpus) * args.steps / elapsed
 
-    # ---- per-kernel HIP-event timing (outside the timed region: the events add a little overhead)
+    # ---- per-kernel HIP-event timing (outside the timed region, one batch at a time: the events add a little
+    #      overhead and overlapping batches would stretch each other's kernels)
     ctx.profile_enable(True)
     prof_steps = max(5, min(args.steps, 20))
     for _ in range(prof_steps):
@@ -213,7 +231,7 @@ def main():
             batch.sort()
         else:
             batch.run(booster)
-    ctx.sync()
+        batch.sync()
     kernels = {}
     for k in ("prepass", "assemble", "override", "bin", "score", "sort"):
         ms, n = ctx.profile_get(k)
@@ -316,7 +334,7 @@ def main():
             "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-lightgbm", "requests_per_step_per_gpu": args.requests,
                        "items_per_request": args.items, "items_per_step_per_gpu": total_items, "catalogue_items": args.catalogue,
                        "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16,
-                       "tile_columns": V,
+                       "tile_columns": V, "batches_in_flight": n_streams,
                        "parallelism": (f"item-sharded x{n_gpus}" if sharded else f"request-sharded x{n_gpus}") +
                                       (", RCCL all-gather of scores" if n_gpus > 1 else "")},
             "latency": latency,
@@ -325,7 +343,8 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    batch.close()
+    for bt in batches:
+        bt.close()
     booster.close()
     if dist is not None:
         dist.barrier()

@@ -221,6 +221,12 @@ int mrk_batch_run(mrk_batch *batch, mrk_model *model);
 int mrk_batch_shard_chunk(mrk_batch *batch, int shard_count);
 int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int shard_count);
 int mrk_batch_sort(mrk_batch *batch);
+/* A prepared batch owns a HIP stream: batches of one context may be in flight together (mrk_batch_run is
+ * asynchronous), which is how consecutive batches overlap on the device - the assembly kernels wait on memory,
+ * the scorer is VALU-bound.  mrk_batch_sync waits for this batch; mrk_batch_fetch / _status synchronise it too.
+ * mrk_store_flush (and every put that grows a table) waits for all batches before it rewrites device memory. */
+void *mrk_batch_stream(mrk_batch *batch);
+int mrk_batch_sync(mrk_batch *batch);
 /* device pointers of the batch outputs (valid until mrk_batch_free): scores f64[total_items],
  * order i32[total_items] (request-local indices), matrix f64[total_items*dim].
  * The f64 matrix (ClickthroughQuery's layout) is materialised on demand only: with a LightGBM /

@@ -103,6 +103,8 @@ SIGNATURES = {
     "mrk_batch_shard_chunk": (_I, [_V, _I]),
     "mrk_batch_run_shard": (_I, [_V, _V, _I, _I]),
     "mrk_batch_sort": (_I, [_V]),
+    "mrk_batch_stream": (_V, [_V]),
+    "mrk_batch_sync": (_I, [_V]),
     "mrk_batch_device_outputs": (_I, [_V, C.POINTER(_V), C.POINTER(_V), C.POINTER(_V)]),
     "mrk_batch_fetch": (_I, [_V, _P, _P, _P]),
     "mrk_batch_status": (_I, [_V, _P]),

@@ -16,11 +16,11 @@ ScopedKernelTimer::ScopedKernelTimer(mrk_ctx *c, const char *n) : ctx(c), name(n
     a = b = nullptr;
     return;
   }
-  (void)hipEventRecord(a, ctx->stream);
+  (void)hipEventRecord(a, ctx->launch);
 }
 ScopedKernelTimer::~ScopedKernelTimer() {
   if (!a || !b) return;
-  (void)hipEventRecord(b, ctx->stream);
+  (void)hipEventRecord(b, ctx->launch);
   ctx->pending_events.emplace_back(name, a, b);
 }
 void drain_profile_events(mrk_ctx *ctx) {
@@ -140,6 +140,7 @@ int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out) {
     ctx->n_cus = prop.multiProcessorCount;
     ctx->lds_per_block = prop.sharedMemPerBlock;
     MRK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->launch = ctx->stream;
     ctx->d_flag.reserve(256);
     ctx->h_flag.reserve(4096);
     MRK_HIP(hipMemset(ctx->d_flag.p, 0, 256));

@@ -68,6 +68,8 @@ struct mrk_batch {
   const Program *prog = nullptr;
   int n_req = 0, total_items = 0;
   DevBuf d_in, d_prep_out, d_arena, d_matrix;
+  hipStream_t stream = nullptr;   // batches made by mrk_batch_prepare own a stream: several can be in flight on one device
+  hipStream_t s() const { return stream ? stream : ctx->stream; }
   DevBuf d_out;              // [scores: (T + shard padding) f64][order: T i32][status: n_req i32], fetched with ONE copy
   size_t out_order_off = 0, out_status_off = 0, out_bytes = 0;
   PinBuf h_out;
@@ -137,7 +139,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   put(o_irf, hb.irf.data(), hb.irf.size() * 4);
   put(o_ov, hb.overrides.data(), hb.overrides.size() * sizeof(Override));
   put(o_prep, hb.prep_out.data(), hb.prep_out.size() * sizeof(PrepOut));
-  MRK_HIP(hipMemcpyAsync(b.d_in.p, h, total_bytes, hipMemcpyHostToDevice, ctx->stream));
+  MRK_HIP(hipMemcpyAsync(b.d_in.p, h, total_bytes, hipMemcpyHostToDevice, b.s()));
   b.d_arena.reserve(std::max<size_t>(hb.arena_entries, 1) * 8);
   // outputs in one allocation: one device-to-host copy per fetch (single-request latency)
   const size_t score_slots = (size_t)T + 256 * QS_TILE_ROWS;  // room for the padded chunks of an item-sharded all-gather
@@ -226,13 +228,20 @@ static void sort_batch(mrk_batch &b) {
 }
 
 // enqueue the pipeline on the context stream for batch items [lo, hi); ctx->mu must be held
+struct LaunchOn {  // routes kernel launches (and their timers) to a batch's stream while ctx->mu is held
+  mrk_ctx *ctx;
+  LaunchOn(mrk_ctx *c, hipStream_t s) : ctx(c) { ctx->launch = s; }
+  ~LaunchOn() { ctx->launch = ctx->stream; }
+};
+
 static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort) {
   mrk_ctx *ctx = b.ctx;
   MRK_HIP(hipSetDevice(ctx->device));
+  LaunchOn on(ctx, b.s());
   check_model_fits(model, *b.prog);
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
-  MRK_HIP(hipMemsetAsync(b.view.status, 0, std::max<size_t>(b.n_req, 1) * 4, ctx->stream));
+  MRK_HIP(hipMemsetAsync(b.view.status, 0, std::max<size_t>(b.n_req, 1) * 4, b.s()));
   b.view.item_lo = lo;
   b.view.item_hi = hi;
   const int rows = hi - lo;
@@ -249,7 +258,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
     const size_t n_tiles = ((size_t)b.total_items + QS_TILE_ROWS - 1) / QS_TILE_ROWS;
     b.d_cells.reserve(std::max<size_t>(n_tiles * tile_bytes, 16));
     if (hi % QS_TILE_ROWS && tile_bytes)  // rows past the last item of the last tile of this range
-      MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (size_t)(hi / QS_TILE_ROWS) * tile_bytes, 0, tile_bytes, ctx->stream));
+      MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (size_t)(hi / QS_TILE_ROWS) * tile_bytes, 0, tile_bytes, b.s()));
     const bool f64 = model->forest.backend == Backend::LightGBM;
     if (b.fused_ok) {
       launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64);
@@ -267,7 +276,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
       launch_score_batch(ctx, model, b.view.matrix + (size_t)lo * pd.dim, rows, pd.dim, b.view.scores + lo, b.view.status, b.view.item_req + lo);
     } else if (rows > 0) {
       // NoopModel (ml/rank/NoopRanker.scala:22-26): every score is 0.0
-      MRK_HIP(hipMemsetAsync(b.view.scores + lo, 0, (size_t)rows * 8, ctx->stream));
+      MRK_HIP(hipMemsetAsync(b.view.scores + lo, 0, (size_t)rows * 8, b.s()));
     }
   }
   b.view.item_lo = 0;
@@ -281,6 +290,7 @@ static void run_batch(mrk_batch &b, mrk_model *model) { run_batch(b, model, 0, b
 static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *matrix) {
   mrk_ctx *ctx = b.ctx;
   MRK_HIP(hipSetDevice(ctx->device));
+  LaunchOn on(ctx, b.s());
   const size_t T = (size_t)b.total_items;
   if (matrix && T && b.prog->dim && !b.matrix_valid) {
     // the last run assembled straight into the scorer's tile: materialise the f64 matrix now
@@ -293,14 +303,14 @@ static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *ma
   uint8_t *h = b.h_out.as<uint8_t>();
   const uint8_t *d = b.d_out.as<uint8_t>();
   if (tight) {
-    MRK_HIP(hipMemcpyAsync(h, d, b.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MRK_HIP(hipMemcpyAsync(h, d, b.out_bytes, hipMemcpyDeviceToHost, b.s()));
   } else {
-    if (scores && T) MRK_HIP(hipMemcpyAsync(h, d, T * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (order && T) MRK_HIP(hipMemcpyAsync(h + b.out_order_off, d + b.out_order_off, T * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (b.n_req) MRK_HIP(hipMemcpyAsync(h + b.out_status_off, d + b.out_status_off, (size_t)b.n_req * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores && T) MRK_HIP(hipMemcpyAsync(h, d, T * 8, hipMemcpyDeviceToHost, b.s()));
+    if (order && T) MRK_HIP(hipMemcpyAsync(h + b.out_order_off, d + b.out_order_off, T * 4, hipMemcpyDeviceToHost, b.s()));
+    if (b.n_req) MRK_HIP(hipMemcpyAsync(h + b.out_status_off, d + b.out_status_off, (size_t)b.n_req * 4, hipMemcpyDeviceToHost, b.s()));
   }
-  if (matrix && T && b.prog->dim) MRK_HIP(hipMemcpyAsync(matrix, b.d_matrix.p, T * b.prog->dim * 8, hipMemcpyDeviceToHost, ctx->stream));
-  MRK_HIP(hipStreamSynchronize(ctx->stream));
+  if (matrix && T && b.prog->dim) MRK_HIP(hipMemcpyAsync(matrix, b.d_matrix.p, T * b.prog->dim * 8, hipMemcpyDeviceToHost, b.s()));
+  MRK_HIP(hipStreamSynchronize(b.s()));
   if (scores && T) memcpy(scores, h, T * 8);
   if (order && T) memcpy(order, h + b.out_order_off, T * 4);
   if (b.n_req) memcpy(b.h_status.data(), h + b.out_status_off, (size_t)b.n_req * 4);
@@ -427,8 +437,10 @@ int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *r
     const Program &prog = program_of(ctx, model_name);
     if (ctx->closed) throw StatusError(MRK_ERR_INVALID_ARG, "context is shut down");
     std::unique_ptr<mrk_batch> b(new mrk_batch());
+    MRK_HIP(hipSetDevice(ctx->device));
+    MRK_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     build_batch(ctx, prog, reqs, n_req, *b);
-    MRK_HIP(hipStreamSynchronize(ctx->stream));
+    MRK_HIP(hipStreamSynchronize(b->s()));
     ctx_retain(ctx);
     *out = b.release();
   });
@@ -469,7 +481,20 @@ int mrk_batch_sort(mrk_batch *batch) {
     if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
     std::lock_guard<std::mutex> lk(batch->ctx->mu);
     MRK_HIP(hipSetDevice(batch->ctx->device));
+    LaunchOn on(batch->ctx, batch->s());
     sort_batch(*batch);
+  });
+}
+
+void *mrk_batch_stream(mrk_batch *batch) { return batch ? (void *)batch->s() : nullptr; }
+
+int mrk_batch_sync(mrk_batch *batch) {
+  return guard([&] {
+    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    MRK_HIP(hipSetDevice(batch->ctx->device));
+    MRK_HIP(hipStreamSynchronize(batch->s()));
+    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    drain_profile_events(batch->ctx);
   });
 }
 
@@ -513,7 +538,8 @@ void mrk_batch_free(mrk_batch *batch) {
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
       (void)hipSetDevice(ctx->device);
-      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipStreamSynchronize(batch->s());
+      if (batch->stream) (void)hipStreamDestroy(batch->stream);
       delete batch;
     }
     ctx_release(ctx);

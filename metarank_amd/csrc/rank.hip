@@ -833,7 +833,7 @@ bigsort_store_kernel(BatchDev b, int r, const int *idx) {
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b) {
   if (b.n_req <= 0 || prog.n_prep <= 0) return;
   ScopedKernelTimer timer(ctx, "prepass");
-  hipLaunchKernelGGL(prepass_kernel, dim3(b.n_req), dim3(PREP_THREADS), 0, ctx->stream, st, prog, b);
+  hipLaunchKernelGGL(prepass_kernel, dim3(b.n_req), dim3(PREP_THREADS), 0, ctx->launch, st, prog, b);
   MRK_HIP(hipGetLastError());
 }
 
@@ -842,12 +842,12 @@ void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
   {
     ScopedKernelTimer timer(ctx, "assemble");
     const int grid = (b.item_hi - b.item_lo + ASM_THREADS - 1) / ASM_THREADS;
-    hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(ASM_THREADS), 0, ctx->stream, st, prog, b);
+    hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(ASM_THREADS), 0, ctx->launch, st, prog, b);
     MRK_HIP(hipGetLastError());
   }
   if (b.n_overrides > 0) {
     ScopedKernelTimer timer(ctx, "override");
-    hipLaunchKernelGGL(override_kernel, dim3((b.n_overrides + 255) / 256), dim3(256), 0, ctx->stream, b, prog.dim);
+    hipLaunchKernelGGL(override_kernel, dim3((b.n_overrides + 255) / 256), dim3(256), 0, ctx->launch, b, prog.dim);
     MRK_HIP(hipGetLastError());
   }
 }
@@ -856,8 +856,8 @@ static void launch_override_cells(mrk_ctx *ctx, const BatchDev &b, const QsDev &
   if (b.n_overrides <= 0) return;
   ScopedKernelTimer timer(ctx, "override");
   const dim3 grid((b.n_overrides + 255) / 256);
-  if (f64) hipLaunchKernelGGL(override_cells_kernel<true>, grid, dim3(256), 0, ctx->stream, b, q, cells);
-  else hipLaunchKernelGGL(override_cells_kernel<false>, grid, dim3(256), 0, ctx->stream, b, q, cells);
+  if (f64) hipLaunchKernelGGL(override_cells_kernel<true>, grid, dim3(256), 0, ctx->launch, b, q, cells);
+  else hipLaunchKernelGGL(override_cells_kernel<false>, grid, dim3(256), 0, ctx->launch, b, q, cells);
   MRK_HIP(hipGetLastError());
 }
 
@@ -868,8 +868,8 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
   {
     ScopedKernelTimer timer(ctx, "assemble");
     const dim3 grid((b.item_hi - b.item_lo + ASM_THREADS - 1) / ASM_THREADS);
-    if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), 0, ctx->stream, st, prog, b, q, cells);
-    else hipLaunchKernelGGL(assemble_cells_kernel<false>, grid, dim3(ASM_THREADS), 0, ctx->stream, st, prog, b, q, cells);
+    if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), 0, ctx->launch, st, prog, b, q, cells);
+    else hipLaunchKernelGGL(assemble_cells_kernel<false>, grid, dim3(ASM_THREADS), 0, ctx->launch, st, prog, b, q, cells);
     MRK_HIP(hipGetLastError());
   }
   launch_override_cells(ctx, b, q, cells, f64);
@@ -896,15 +896,15 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
       MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       configured = true;
     }
-    if (!cells) hipLaunchKernelGGL(rank_fused_matrix_kernel, dim3(b.n_req), dim3(threads), lds, ctx->stream, st, prog, b, tab_entries, vals_cap);
-    else if (f64) hipLaunchKernelGGL(rank_fused_cells_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->stream, st, prog, b, tab_entries, vals_cap, *q, cells);
-    else hipLaunchKernelGGL(rank_fused_cells_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->stream, st, prog, b, tab_entries, vals_cap, *q, cells);
+    if (!cells) hipLaunchKernelGGL(rank_fused_matrix_kernel, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap);
+    else if (f64) hipLaunchKernelGGL(rank_fused_cells_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, *q, cells);
+    else hipLaunchKernelGGL(rank_fused_cells_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, *q, cells);
     MRK_HIP(hipGetLastError());
   }
   if (!cells) {
     if (b.n_overrides > 0) {
       ScopedKernelTimer timer(ctx, "override");
-      hipLaunchKernelGGL(override_kernel, dim3((b.n_overrides + 255) / 256), dim3(256), 0, ctx->stream, b, prog.dim);
+      hipLaunchKernelGGL(override_kernel, dim3((b.n_overrides + 255) / 256), dim3(256), 0, ctx->launch, b, prog.dim);
       MRK_HIP(hipGetLastError());
     }
   } else {
@@ -915,7 +915,7 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
 void launch_sort(mrk_ctx *ctx, const BatchDev &b) {
   if (b.n_req <= 0) return;
   ScopedKernelTimer timer(ctx, "sort");
-  hipLaunchKernelGGL(sort_kernel, dim3(b.n_req), dim3(SORT_THREADS), 0, ctx->stream, b);
+  hipLaunchKernelGGL(sort_kernel, dim3(b.n_req), dim3(SORT_THREADS), 0, ctx->launch, b);
   MRK_HIP(hipGetLastError());
 }
 
@@ -930,13 +930,13 @@ void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsign
   const dim3 blk(SORT_THREADS);
   unsigned long long *k0 = keys, *k1 = keys + n_pad;
   int *i0 = idx, *i1 = idx + n_pad;
-  hipLaunchKernelGGL(msort_chunk_kernel, dim3(chunks), blk, 0, ctx->stream, b, r, k0, i0);
+  hipLaunchKernelGGL(msort_chunk_kernel, dim3(chunks), blk, 0, ctx->launch, b, r, k0, i0);
   for (int run = SORT_MAX_ITEMS; run < n_pad; run <<= 1) {
-    hipLaunchKernelGGL(msort_merge_kernel, dim3(chunks), blk, 0, ctx->stream, k0, i0, k1, i1, n_pad, run);
+    hipLaunchKernelGGL(msort_merge_kernel, dim3(chunks), blk, 0, ctx->launch, k0, i0, k1, i1, n_pad, run);
     std::swap(k0, k1);
     std::swap(i0, i1);
   }
-  hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->stream, b, r, i0);
+  hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->launch, b, r, i0);
   MRK_HIP(hipGetLastError());
 }
 

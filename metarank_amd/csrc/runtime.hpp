@@ -95,6 +95,9 @@ struct mrk_ctx {
   bool closed = false;
   int device = 0;
   hipStream_t stream = nullptr;
+  // the stream kernel launches and their HIP-event timers go to: the context stream, or - while a batch with
+  // its own stream runs (ctx->mu held) - that batch's stream
+  hipStream_t launch = nullptr;
   int n_cus = 0;
   size_t lds_per_block = 0;
   std::mutex mu;  // serialises stream use + scratch buffers (one in-flight call per ctx)

@@ -262,7 +262,7 @@ void launch_t(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols,
     configured = (const void *)kern;
   }
   const int grid = (rows + TILE - 1) / TILE;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), smem, ctx->stream, m->d_image.as<uint8_t>(),
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), smem, ctx->launch, m->d_image.as<uint8_t>(),
                      m->d_trees.as<TreeRef>(), m->d_chunks.as<ChunkRef>(), (int)m->packed.chunks.size(),
                      m->d_cat.as<uint32_t>(), d_x, rows, cols, m->forest.base_score, d_out, d_flag, d_row_req,
                      chunk_cap, ref_cap);

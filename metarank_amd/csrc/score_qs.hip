@@ -341,7 +341,7 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
   // the allocation granularity makes a 12.25 KB request the largest that still fits 12 per CU.
   const size_t lds = (size_t)V * 256;
   ScopedKernelTimer timer(ctx, "score");
-  hipLaunchKernelGGL(wk, dim3((unsigned)n_tiles), dim3(64), lds, ctx->stream, m->d_qs_nodes.as<uint32_t>(),
+  hipLaunchKernelGGL(wk, dim3((unsigned)n_tiles), dim3(64), lds, ctx->launch, m->d_qs_nodes.as<uint32_t>(),
                      m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(), d_cells,
                      q.n_trees, V, rows, m->forest.base_score, d_out);
   MRK_HIP(hipGetLastError());
@@ -360,7 +360,7 @@ void launch_generic(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int row
   }
   ScopedKernelTimer timer(ctx, "score");
   const int grid = (int)((n_tiles + QS_WAVES - 1) / QS_WAVES);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(QS_WAVES * 64), smem, ctx->stream, m->d_qs_nodes.as<uint32_t>(),
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(QS_WAVES * 64), smem, ctx->launch, m->d_qs_nodes.as<uint32_t>(),
                      m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(), d_cells,
                      q.n_trees, V, rows, n_tiles, m->forest.base_score, d_out, chunk_trees);
   MRK_HIP(hipGetLastError());
@@ -374,7 +374,7 @@ void launch_bin(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int col
   ctx->d_cells.reserve((size_t)padded * m->qs.views.size() * 2);
   ScopedKernelTimer timer(ctx, "bin");
   const int grid = (int)((padded + 255) / 256);
-  hipLaunchKernelGGL(qs_bin_kernel<F64>, dim3(grid), dim3(256), 0, ctx->stream, d_x, rows, cols, qs_device_view(m),
+  hipLaunchKernelGGL(qs_bin_kernel<F64>, dim3(grid), dim3(256), 0, ctx->launch, d_x, rows, cols, qs_device_view(m),
                      ctx->d_cells.as<uint16_t>(), tile_rows, padded, d_flag, d_row_req);
   MRK_HIP(hipGetLastError());
 }

@@ -287,6 +287,13 @@ static void flush_pool(Pool<T> &p, hipStream_t stream) {
 }
 
 void Store::flush(hipStream_t stream) {
+  // batches run on their own streams: nothing may be reading the tables / pools while they are rewritten or
+  // reallocated.  Nothing dirty (the serving steady state between feedback events): no synchronisation at all.
+  bool dirty = !pending.empty() || tok_pool.host.size() > tok_pool.uploaded || f64_pool.host.size() > f64_pool.uploaded ||
+               slot_pool.host.size() > slot_pool.uploaded;
+  for (int s = 0; s < SC_COUNT && !dirty; ++s) dirty = tables[s].dirty_hi > tables[s].dirty_lo || tables[s].n_slots > tables[s].d_slots_cap;
+  if (!dirty) return;
+  MRK_HIP(hipDeviceSynchronize());
   uint32_t uploaded_lo[SC_COUNT], uploaded_hi[SC_COUNT];
   for (int s = 0; s < SC_COUNT; ++s) {
     Table &t = tables[s];

@@ -53,6 +53,13 @@ class Batch:
     def sort(self):
         N.check(N.lib().mrk_batch_sort(self._h))
 
+    def sync(self):
+        N.check(N.lib().mrk_batch_sync(self._h))
+
+    @property
+    def stream(self):
+        return N.lib().mrk_batch_stream(self._h)
+
     def device_outputs(self, matrix: bool = False):
         """device pointers (scores, order, matrix | None); asking for the matrix makes later runs write it"""
         s, o, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
