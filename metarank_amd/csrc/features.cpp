@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <set>
@@ -464,6 +465,9 @@ void build_program(Program &p, const std::vector<const FeatureDef *> &feats, con
 }
 
 void upload(Program &p) {
+  if (p.prep.size() > 32)  // FUSED_MAX_PREP (rank.hip): per-request reductions the pre-pass keeps scratch for
+    throw StatusError(MRK_ERR_UNSUPPORTED, "model '" + p.model + "' needs " + std::to_string(p.prep.size()) +
+                                               " per-request reductions (interacted_with fields + diversity features); 32 are supported");
   auto up = [](DevBuf &b, const void *src, size_t bytes) {
     b.reserve(bytes ? bytes : 16);
     if (bytes) MRK_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
@@ -667,11 +671,15 @@ double map_datetime(int mapper, const Civil &c) {
   }
 }
 
-// open-addressing capacity for a table that receives `tokens` insertions (distinct keys <= tokens): load
-// factor <= 0.75 in the worst case, usually far lower (tokens repeat); even => the 8-byte entries of
-// consecutive tables stay 16-byte aligned
+// open-addressing capacity for a table that receives `tokens` insertions (distinct keys <= tokens): load factor
+// <= 0.75 in the worst case, usually far lower (tokens repeat).  The tables of a request live in LDS and their
+// size sets how many requests a CU works on at once; measured on the Ranklens workload (MRK_TABLE_LOAD_PCT
+// sweep): 75 % -> 0.42 ms per 3840 requests, 50 % -> 0.45, 33 % -> 0.52, 25 % -> 0.60: shorter probe chains do
+// not pay for the lost occupancy.  Even => the 8-byte entries of consecutive tables stay 16-byte aligned.
 static uint32_t table_capacity(uint64_t tokens) {
-  uint64_t cap = tokens + tokens / 3 + 2;
+  const char *e = getenv("MRK_TABLE_LOAD_PCT");  // experiments: worst-case load factor in percent
+  const uint64_t pct = e ? (uint64_t)std::max(10, std::min(90, atoi(e))) : 75;
+  uint64_t cap = tokens * 100 / pct + 2;
   return (uint32_t)((cap + 1) & ~1ull);
 }
 

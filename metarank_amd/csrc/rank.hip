@@ -107,14 +107,18 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
 
 // ---------------------------------------------------------------- pre-pass
 constexpr int PREP_THREADS = 256;
-constexpr int FUSED_MAX_PREP = 32;  // pre-pass entries a fused workgroup keeps in LDS
+constexpr int FUSED_MAX_PREP = 32;  // pre-pass entries of one model (PrepOut copies + `first` slots kept in LDS)
+constexpr int PREP_GROUP = 4;       // entries handled by one merged pass (their loads are issued together)
+constexpr int PREP_INTS = 96;       // ints of LDS scratch: wave_tot[4][PREP_GROUP] | first[FUSED_MAX_PREP] | misc[4] | tokens[PREP_GROUP]
 
 struct PrepScratch {   // LDS scratch of one workgroup
   double *vals;        // vals_cap doubles: diversity median
   int vals_cap;
-  int *wave_tot;       // 4
-  int *first;          // 1
-  int *misc;           // 4
+  int *ints;           // PREP_INTS
+  __device__ __forceinline__ int *wave_tot() const { return ints; }                              // [4][PREP_GROUP]
+  __device__ __forceinline__ int *first() const { return ints + 4 * PREP_GROUP; }                // [FUSED_MAX_PREP]
+  __device__ __forceinline__ int *misc() const { return ints + 4 * PREP_GROUP + FUSED_MAX_PREP; }   // [4]
+  __device__ __forceinline__ int *tokens() const { return misc() + 4; }                          // [PREP_GROUP]
 };
 
 // exclusive prefix sum of a 0/1 flag over the workgroup + total (blockDim.x <= 256 = 4 waves of 64)
@@ -136,161 +140,308 @@ __device__ __forceinline__ int block_scan_flag(bool flag, int *s_wave_tot, int &
   return before + within;
 }
 
+// the same for PREP_GROUP flags at once (two barriers for the whole group)
+__device__ __forceinline__ void block_scan_flags(const bool (&flag)[PREP_GROUP], int n, int *s_wave_tot, int (&excl)[PREP_GROUP],
+                                                 int (&total)[PREP_GROUP]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_waves = (blockDim.x + 63) >> 6;
+  int within[PREP_GROUP];
+#pragma unroll
+  for (int u = 0; u < PREP_GROUP; ++u) {
+    const unsigned long long ball = __ballot(u < n && flag[u]);
+    within[u] = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_tot[wave * PREP_GROUP + u] = __popcll(ball);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PREP_GROUP; ++u) {
+    int before = 0, tot = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      const int t = s_wave_tot[w * PREP_GROUP + u];
+      if (w < wave) before += t;
+      tot += t;
+    }
+    excl[u] = before + within[u];
+    total[u] = tot;
+  }
+  __syncthreads();
+}
+
+// commons-math Percentile (LEGACY estimation, NaN removed) .evaluate(50) of s_vals[0, n_raw); whole workgroup
+__device__ double median_of(double *s_vals, int n_raw, int *s_misc) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (n_raw == 1) return s_vals[0];
+  // NaN -> +inf placeholder (sorts last), counted
+  for (int i = tid; i < n_raw; i += nthr) {
+    double v = s_vals[i];
+    if (v != v) { s_vals[i] = __longlong_as_double(0x7ff0000000000000LL); atomicAdd(&s_misc[1], 1); }
+  }
+  int p2 = 1;
+  while (p2 < n_raw) p2 <<= 1;
+  for (int i = n_raw + tid; i < p2; i += nthr) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
+  __syncthreads();
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < p2; i += nthr) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const double a = s_vals[i], c2 = s_vals[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c2) == up) { s_vals[i] = c2; s_vals[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int m = n_raw - s_misc[1];
+  if (m <= 0) return d_nan();
+  const double pos = 0.5 * (double)(m + 1);
+  const double fpos = floor(pos);
+  const int ipos = (int)fpos;
+  const double dif = pos - fpos;
+  if (pos < 1.0) return s_vals[0];
+  if (pos >= (double)m) return s_vals[m - 1];
+  const double lower = s_vals[ipos - 1], upper = s_vals[ipos];
+  return __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
+}
+
 // The pre-pass of request r, run by one whole workgroup.  Tables live at tab_base + (po.tab_off - tab_sub)
 // (HBM arena: tab_sub = 0; LDS: tab_sub = the request's first arena entry); mode / scalar go to po_out[e].
+// The entries are not processed one by one: every global load is a trip to the Infinity Cache, so the loads
+// of up to PREP_GROUP entries are issued together -
+//   * all tables of the request are zeroed in one sweep;
+//   * the interacted_with entries that read the same bounded list (one per field) share ONE pass over the
+//     interacted items: slot -> the field cells of all entries -> their tokens;
+//   * the diversity entries share the pass that finds each one's first candidate with state, the load that
+//     decides string vs number, and - for the string ones - the pass over the first `top` candidates
+//     (one multi-flag prefix scan keeps request order); numeric ones then take their median one by one.
 __device__ void prepass_request(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, int r, const ReqDev &rq,
                                 unsigned long long *tab_base, uint32_t tab_sub, PrepOut *po_out, const PrepScratch &sc) {
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
-  double *s_vals = sc.vals;
-  int *s_misc = sc.misc;
-  for (int e = 0; e < prog.n_prep; ++e) {
-    const PrepEntry pe = prog.prep[e];
-    PrepOut *po = &po_out[e];
-    unsigned long long *tab = tab_base + (po->tab_off - tab_sub);
-    const uint32_t mask = po->tab_cap;  // capacity
-    for (uint32_t i = tid; i < mask; i += nthr) tab[i] = 0ull;
-    if (tid == 0) { *sc.first = 0x7fffffff; s_misc[0] = 0; s_misc[1] = 0; s_misc[2] = 0; }
-    __syncthreads();
+  const int n_prep = prog.n_prep;
+  int *s_first = sc.first();
+  int *s_misc = sc.misc();
+  int *s_tokens = sc.tokens();
 
-    if (pe.kind == PREP_IW_FIELD) {
-      // InteractedWithFeature.scala:134-147: histogram of the field tokens of every interacted item
-      const int vslot = pe.list_scope == SC_SESSION ? rq.session_slot : rq.user_slot;
-      const Cell lc = load_cell(record(st, pe.list_scope, vslot), pe.list_col);
-      if (lc.tag != TAG_MISSING) {
-        const uint32_t off = lc.lo(), len = lc.hi();
-        for (uint32_t k = tid; k < len; k += nthr) {
-          const int islot = (int)st.slot_pool[off + k];
-          const Cell ic = load_cell(record(st, SC_ITEM, islot), pe.item_col);
-          if (ic.tag == TAG_STRING_LIST) {
-            const uint32_t toff = ic.lo(), tlen = ic.hi();
+  // ---- all tables of the request, one sweep (they are contiguous: host assigns them in entry order)
+  {
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (int e = 0; e < n_prep; ++e) {
+      const uint32_t o = po_out[e].tab_off - tab_sub;
+      lo = min(lo, o);
+      hi = max(hi, o + po_out[e].tab_cap);
+    }
+    for (uint32_t i = lo + tid; i < hi; i += nthr) tab_base[i] = 0ull;
+    for (int e = tid; e < n_prep; e += nthr) s_first[e] = 0x7fffffff;
+  }
+  __syncthreads();
+
+  // Per-group state lives in registers indexed at COMPILE time (every loop over the group is fully unrolled
+  // and predicated on u < n): a run-time index into a register array costs a select chain per access.
+
+  // ---- interacted_with (InteractedWithFeature.scala:134-147): histogram of the field tokens of every interacted item
+  for (int e0 = 0; e0 < n_prep;) {
+    const PrepEntry pe0 = prog.prep[e0];
+    if (pe0.kind != PREP_IW_FIELD) { ++e0; continue; }
+    int n = 1;  // consecutive entries on the same bounded list
+    while (n < PREP_GROUP && e0 + n < n_prep) {
+      const PrepEntry q = prog.prep[e0 + n];
+      if (q.kind != PREP_IW_FIELD || q.list_scope != pe0.list_scope || q.list_col.tag != pe0.list_col.tag || q.list_col.val != pe0.list_col.val) break;
+      ++n;
+    }
+    ColRef col[PREP_GROUP];
+    unsigned long long *tab[PREP_GROUP];
+    uint32_t cap[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      const int e = e0 + (u < n ? u : 0);
+      col[u] = prog.prep[e].item_col;
+      tab[u] = tab_base + (po_out[e].tab_off - tab_sub);
+      cap[u] = po_out[e].tab_cap;
+    }
+    const int vslot = pe0.list_scope == SC_SESSION ? rq.session_slot : rq.user_slot;
+    const Cell lc = load_cell(record(st, pe0.list_scope, vslot), pe0.list_col);
+    if (lc.tag != TAG_MISSING) {
+      const uint32_t off = lc.lo(), len = lc.hi();
+      for (uint32_t k = tid; k < len; k += nthr) {
+        const uint8_t *irec = record(st, SC_ITEM, (int)st.slot_pool[off + k]);
+        Cell ic[PREP_GROUP];
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {  // the field cells of all entries: independent loads
+          ic[u].tag = TAG_MISSING;
+          ic[u].bits = 0;
+          if (u < n) ic[u] = load_cell(irec, col[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          if (u < n && ic[u].tag == TAG_STRING_LIST) {
+            const uint32_t toff = ic[u].lo(), tlen = ic[u].hi();
             for (uint32_t j = 0; j < tlen; ++j)
-              if (!table_add(tab, mask, st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
+              if (!table_add(tab[u], cap[u], st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
           }
         }
       }
-      __syncthreads();
-      continue;
     }
+    e0 += n;
+  }
 
-    // ---- PREP_DIVERSITY (DiversityFeature.scala:72-103) ----
-    // (a) the first candidate that has a ScalarValue decides string vs number
+  // ---- diversity (DiversityFeature.scala:72-103), PREP_GROUP entries at a time
+  for (int e0 = 0; e0 < n_prep;) {
+    if (prog.prep[e0].kind != PREP_DIVERSITY) { ++e0; continue; }
+    int ent[PREP_GROUP];
+    int n = 0, e1 = e0;
+    for (; e1 < n_prep && n < PREP_GROUP; ++e1) {
+      if (prog.prep[e1].kind != PREP_DIVERSITY) continue;
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) if (u == n) ent[u] = e1;
+      ++n;
+    }
+    ColRef col[PREP_GROUP];
+    unsigned long long *tab[PREP_GROUP];
+    uint32_t cap[PREP_GROUP];
+    int top[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      if (u >= n) ent[u] = e0;
+      col[u] = prog.prep[ent[u]].item_col;
+      top[u] = prog.prep[ent[u]].top;
+      tab[u] = tab_base + (po_out[ent[u]].tab_off - tab_sub);
+      cap[u] = po_out[ent[u]].tab_cap;
+    }
+    // (a) the first candidate that has a ScalarValue decides string vs number - for every entry of the group
     for (int base = 0; base < rq.n_items; base += nthr) {
       const int i = base + tid;
       if (i < rq.n_items) {
-        const Cell c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), pe.item_col);
-        if (c.tag != TAG_MISSING) atomicMin(sc.first, i);
+        const uint8_t *irec = record(st, SC_ITEM, b.item_slot[rq.item_begin + i]);
+        Cell c[PREP_GROUP];
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          c[u].tag = TAG_MISSING;
+          if (u < n) c[u] = load_cell(irec, col[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u)
+          if (u < n && c[u].tag != TAG_MISSING) atomicMin(&s_first[ent[u]], i);
       }
       __syncthreads();
-      const int found = *sc.first;
+      bool all = true;
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) all = all && (u >= n || s_first[ent[u]] != 0x7fffffff);
       __syncthreads();  // nobody may start the next round's atomicMin before everyone has read
-      if (found != 0x7fffffff) break;
+      if (all) break;
     }
-    const int first = *sc.first;
-    int mode = DIV_EMPTY;
-    if (first != 0x7fffffff) {
-      const Cell h = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + first]), pe.item_col);
-      if (h.tag == TAG_STRING || h.tag == TAG_STRING_LIST) mode = DIV_STRING;
-      else if (h.tag == TAG_DOUBLE) mode = DIV_DOUBLE;
+    int mode[PREP_GROUP];
+    {
+      Cell h[PREP_GROUP];
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) {
+        h[u].tag = TAG_MISSING;
+        const int first = u < n ? s_first[ent[u]] : 0x7fffffff;
+        if (first != 0x7fffffff) h[u] = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + first]), col[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u)
+        mode[u] = (h[u].tag == TAG_STRING || h[u].tag == TAG_STRING_LIST) ? DIV_STRING : (h[u].tag == TAG_DOUBLE ? DIV_DOUBLE : DIV_EMPTY);
     }
-    double scalar = 0.0;
-    if (mode != DIV_EMPTY) {
-      // (b) the first `top` candidates of that type, in request order
+    // (b) string entries: the first `top` candidates of that type, in request order, all entries in one pass
+    bool any_string = false;
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) any_string = any_string || (u < n && mode[u] == DIV_STRING);
+    if (tid < PREP_GROUP) s_tokens[tid] = 0;
+    __syncthreads();
+    if (any_string) {
+      int running[PREP_GROUP];
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) running[u] = 0;
+      for (int base = 0; base < rq.n_items; base += nthr) {
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) more = more || (u < n && mode[u] == DIV_STRING && running[u] < top[u]);
+        if (!more) break;
+        const int i = base + tid;
+        Cell c[PREP_GROUP];
+        bool cand[PREP_GROUP];
+        const uint8_t *irec = i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr;
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          c[u].tag = TAG_MISSING;
+          c[u].bits = 0;
+          if (u < n && mode[u] == DIV_STRING) c[u] = load_cell(irec, col[u]);
+          cand[u] = c[u].tag == TAG_STRING || c[u].tag == TAG_STRING_LIST;
+        }
+        int excl[PREP_GROUP], total[PREP_GROUP];
+        block_scan_flags(cand, n, sc.wave_tot(), excl, total);
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          if (u < n && cand[u] && running[u] + excl[u] < top[u]) {
+            if (c[u].tag == TAG_STRING) {
+              if (!table_add(tab[u], cap[u], c[u].lo())) atomicOr(&b.status[r], ST_TABLE_FULL);
+              atomicAdd(&s_tokens[u], 1);
+            } else {
+              const uint32_t toff = c[u].lo(), tlen = c[u].hi();
+              for (uint32_t j = 0; j < tlen; ++j)
+                if (!table_add(tab[u], cap[u], st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
+              atomicAdd(&s_tokens[u], (int)tlen);
+            }
+          }
+          running[u] += total[u];
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u)
+        if (u < n && mode[u] != DIV_DOUBLE) {
+          po_out[ent[u]].mode = mode[u];
+          // stringCounts.values.foldLeft(0.0)(_ + _): integers, exact in f64
+          po_out[ent[u]].scalar = mode[u] == DIV_STRING ? (double)s_tokens[u] : 0.0;
+        }
+    }
+    // (c) numeric entries, one at a time: the first `top` present values in request order, then their median
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      if (u >= n || mode[u] != DIV_DOUBLE) continue;
+      if (tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
+      __syncthreads();
       int running = 0;
-      for (int base = 0; base < rq.n_items && running < pe.top; base += nthr) {
+      for (int base = 0; base < rq.n_items && running < top[u]; base += nthr) {
         const int i = base + tid;
         Cell c;
         c.tag = TAG_MISSING;
         c.bits = 0;
-        if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), pe.item_col);
-        const bool cand = mode == DIV_STRING ? (c.tag == TAG_STRING || c.tag == TAG_STRING_LIST) : (c.tag == TAG_DOUBLE);
+        if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), col[u]);
+        const bool cand = c.tag == TAG_DOUBLE;
         int total;
-        const int rank = running + block_scan_flag(cand, sc.wave_tot, total);
-        if (cand && rank < pe.top) {
-          if (mode == DIV_STRING) {
-            if (c.tag == TAG_STRING) {
-              if (!table_add(tab, mask, c.lo())) atomicOr(&b.status[r], ST_TABLE_FULL);
-              atomicAdd(&s_misc[0], 1);
-            } else {
-              const uint32_t toff = c.lo(), tlen = c.hi();
-              for (uint32_t j = 0; j < tlen; ++j)
-                if (!table_add(tab, mask, st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
-              atomicAdd(&s_misc[0], (int)tlen);
-            }
-          } else {
-            if (rank < sc.vals_cap) s_vals[rank] = c.f64();
-            else atomicOr(&b.status[r], ST_TOO_MANY);
-          }
+        const int rank = running + block_scan_flag(cand, sc.wave_tot(), total);
+        if (cand && rank < top[u]) {
+          if (rank < sc.vals_cap) sc.vals[rank] = c.f64();
+          else atomicOr(&b.status[r], ST_TOO_MANY);
         }
         running += total;
       }
       __syncthreads();
-      if (mode == DIV_STRING) {
-        scalar = (double)s_misc[0];  // stringCounts.values.foldLeft(0.0)(_ + _): integers, exact in f64
-      } else {
-        // commons-math Percentile (LEGACY, NaN removed) .evaluate(50)
-        int n_raw = min(min(running, pe.top), sc.vals_cap);
-        if (n_raw == 1) {
-          scalar = s_vals[0];
-        } else {
-          // NaN -> +inf placeholder (sorts last), counted
-          for (int i = tid; i < n_raw; i += nthr) {
-            double v = s_vals[i];
-            if (v != v) { s_vals[i] = __longlong_as_double(0x7ff0000000000000LL); atomicAdd(&s_misc[1], 1); }
-          }
-          int p2 = 1;
-          while (p2 < n_raw) p2 <<= 1;
-          for (int i = n_raw + tid; i < p2; i += nthr) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
-          __syncthreads();
-          for (int k = 2; k <= p2; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-              for (int i = tid; i < p2; i += nthr) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                  const double a = s_vals[i], c2 = s_vals[ixj];
-                  const bool up = (i & k) == 0;
-                  if ((a > c2) == up) { s_vals[i] = c2; s_vals[ixj] = a; }
-                }
-              }
-              __syncthreads();
-            }
-          }
-          const int m = n_raw - s_misc[1];
-          if (m <= 0) {
-            scalar = d_nan();
-          } else {
-            const double pos = 0.5 * (double)(m + 1);
-            const double fpos = floor(pos);
-            const int ipos = (int)fpos;
-            const double dif = pos - fpos;
-            if (pos < 1.0) scalar = s_vals[0];
-            else if (pos >= (double)m) scalar = s_vals[m - 1];
-            else {
-              const double lower = s_vals[ipos - 1], upper = s_vals[ipos];
-              scalar = __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
-            }
-          }
-        }
+      const double scalar = median_of(sc.vals, min(min(running, top[u]), sc.vals_cap), s_misc);
+      if (tid == 0) {
+        po_out[ent[u]].mode = DIV_DOUBLE;
+        po_out[ent[u]].scalar = scalar;
       }
+      __syncthreads();
     }
-    if (tid == 0) {
-      po->mode = mode;
-      po->scalar = scalar;
-    }
-    __syncthreads();
+    e0 = e1;
   }
+  __syncthreads();
 }
 
 __global__ void __launch_bounds__(PREP_THREADS)
 prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
   __shared__ double s_vals[PREP_MAX_VALUES];
-  __shared__ int s_wave_tot[PREP_THREADS / 64];
-  __shared__ int s_first;
-  __shared__ int s_misc[4];
+  __shared__ int s_ints[PREP_INTS];
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
-  PrepScratch sc{s_vals, PREP_MAX_VALUES, s_wave_tot, &s_first, s_misc};
+  PrepScratch sc{s_vals, PREP_MAX_VALUES, s_ints};
   prepass_request(st, prog, b, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sc);
 }
 
@@ -601,7 +752,7 @@ assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_
 }
 
 // Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
-// Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][16 ints]
+// Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][PREP_INTS ints]
 //              [threshold staging: QS_LDS_THR x 8 B per wavefront]
 template <typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
@@ -611,13 +762,13 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Progra
   double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
   PrepOut *s_po = (PrepOut *)(smem + (size_t)tab_entries * 8 + (size_t)vals_cap * 8);
   int *s_int = (int *)(s_po + FUSED_MAX_PREP);
-  qs_lds_double *s_thr = (qs_lds_double *)(s_int + 16) + (size_t)(threadIdx.x >> 6) * QS_LDS_THR;
+  qs_lds_double *s_thr = (qs_lds_double *)(s_int + PREP_INTS) + (size_t)(threadIdx.x >> 6) * QS_LDS_THR;
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
   for (int e = threadIdx.x; e < prog.n_prep; e += blockDim.x) s_po[e] = b.prep_out[(size_t)r * prog.n_prep + e];
   __syncthreads();
-  PrepScratch sc{s_vals, vals_cap, s_int, s_int + 4, s_int + 8};
+  PrepScratch sc{s_vals, vals_cap, s_int};
   prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
   for (int base = 0; base < rq.n_items; base += blockDim.x) {
     const int i = base + (int)threadIdx.x;
@@ -876,7 +1027,7 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
 }
 
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads) {
-  return (size_t)tab_entries * 8 + (size_t)vals_cap * 8 + FUSED_MAX_PREP * sizeof(PrepOut) + 16 * sizeof(int) +
+  return (size_t)tab_entries * 8 + (size_t)vals_cap * 8 + FUSED_MAX_PREP * sizeof(PrepOut) + PREP_INTS * sizeof(int) +
          (size_t)((threads + 63) / 64) * QS_LDS_THR * 8;  // threshold staging, one table per wavefront
 }
 int fused_max_prep() { return FUSED_MAX_PREP; }
