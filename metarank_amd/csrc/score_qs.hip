@@ -325,11 +325,128 @@ qs_score_wave_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restri
     if (row0 + j < rows) out[row0 + j] = F64 ? acc64[j] : (double)acc32[j];
 }
 
+// Few tiles (a single request, a 100 000-candidate request on 256 CUs): NW wavefronts share ONE tile and split
+// its trees, so the forest is walked NW times faster.  The scores stay bit-identical because only the exit
+// LEAF INDICES are computed in parallel: per chunk of 8 * NW trees every wavefront writes the indices of its
+// trees (tree w, w + NW, ...) to LDS, then the rows' owners add the chunk's leaf values in tree order - the same
+// additions as the one-wavefront kernel, in the same order.
+template <bool F64, int NW>
+__global__ void __launch_bounds__(NW * 64)
+qs_score_split_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restrict__ leaves,
+                      const QsCatNode *__restrict__ cat_nodes, const uint32_t *__restrict__ cat_bits,
+                      const uint16_t *__restrict__ cells, int n_trees, int V, int rows, double base,
+                      double *__restrict__ out) {
+  constexpr int LS = F64 ? 8 : 4;
+  constexpr int TREE_LEAF_BYTES = QS_LEAVES * LS;
+  constexpr int CH = 8 * NW;  // trees per chunk
+  extern __shared__ __align__(16) uint8_t smem[];
+  // [slab: V x 256 B][leaf values of the chunk: CH x 16 leaves][exit leaf index of (tree, row): CH x 128 B]
+  uint8_t *s_leaf = smem + (size_t)V * 256;
+  uint8_t *s_idx = s_leaf + CH * TREE_LEAF_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wavefront-uniform: node constants by scalar loads
+  const long long tile = blockIdx.x;
+  {
+    const uint4 *src = (const uint4 *)(cells + (size_t)tile * V * QS_TILE_ROWS);
+    uint4 *dst = (uint4 *)smem;
+    for (int i = tid; i < V * 16; i += NW * 64) dst[i] = src[i];
+  }
+  double acc64 = 0.0;
+  float acc32 = (float)base;
+  for (int c0 = 0; c0 < n_trees; c0 += CH) {
+    const int nt = min(CH, n_trees - c0);
+    __syncthreads();  // slab staged / previous chunk consumed
+    {
+      const uint4 *src = (const uint4 *)(leaves + (size_t)c0 * TREE_LEAF_BYTES);
+      uint4 *dst = (uint4 *)s_leaf;
+      for (int i = tid; i < nt * (TREE_LEAF_BYTES / 16); i += NW * 64) dst[i] = src[i];
+    }
+    for (int tt = wave; tt < nt; tt += NW) {  // this wavefront's trees of the chunk
+      const uint32_t *nd = nodes + (size_t)(c0 + tt) * QS_TREE_WORDS;
+      QsNodeRegs r;
+      qs_load_nodes(r, nd);
+      uint32_t c[QS_SLOTS - 1], mm[QS_SLOTS - 1];
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; ++s)
+        asm volatile("s_lshr_b32 m0, %2, 16\n\ts_pack_ll_b32_b16 %1, %2, %2\n\tds_read_addtid_b32 %0"
+                     : "=v"(c[s]), "=s"(mm[s]) : "s"(r.mv[s]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads above are invisible to the compiler
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; ++s)
+        c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, r.kk[s]) - __builtin_bit_cast(short2v, c[s]));
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; ++s)
+        c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, c[s]) >> 15);
+      uint32_t acc_a = 0, acc_b = 0;
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; s += 2) {
+        asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_a) : "v"(c[s]), "s"(mm[s]));
+        if (s + 1 < QS_SLOTS - 1) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_b) : "v"(c[s + 1]), "s"(mm[s + 1]));
+      }
+      uint32_t accn = acc_a | acc_b;
+      const uint32_t catw = r.kk[QS_SLOTS - 1];
+      if (catw >> 24) {
+        const QsCatNode *cn = cat_nodes + (catw & 0xffffffu);
+        for (uint32_t j = 0; j < (catw >> 24); ++j) {
+          const QsCatNode cnode = cn[j];
+          accn |= qs_cat_pair<F64>(cnode, *(const uint32_t *)(smem + ((cnode.view_dl & 0xffffu) << 8) + lane * 4), cat_bits);
+        }
+      }
+      const uint32_t inv = ~accn;
+      const uint32_t pair = (uint32_t)__builtin_ctz(inv) | ((uint32_t)__builtin_ctz(inv >> 16) << 8);
+      *(uint16_t *)(s_idx + tt * QS_TILE_ROWS + lane * 2) = (uint16_t)pair;  // rows 2 * lane, 2 * lane + 1
+    }
+    __syncthreads();
+    if (tid < QS_TILE_ROWS) {  // row `tid`: the chunk's leaves, in tree order
+      for (int tt = 0; tt < nt; ++tt) {
+        const uint32_t li = s_idx[tt * QS_TILE_ROWS + tid];
+        if constexpr (F64) acc64 += *(const double *)(s_leaf + tt * TREE_LEAF_BYTES + li * 8);
+        else acc32 += *(const float *)(s_leaf + tt * TREE_LEAF_BYTES + li * 4);
+      }
+    }
+  }
+  const long long row = tile * QS_TILE_ROWS + tid;
+  if (tid < QS_TILE_ROWS && row < rows) out[row] = F64 ? acc64 : (double)acc32;
+}
+
 template <bool F64>
 void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, double *d_out) {
   const PackedForestQS &q = m->qs;
   const int V = (int)q.views.size();
   const long long n_tiles = ((long long)rows + QS_TILE_ROWS - 1) / QS_TILE_ROWS;
+  // fewer tiles than the chip has SIMDs (4 per CU): let 2 / 4 / 8 wavefronts split the trees of every tile
+  const int split_env = [] { const char *e = getenv("MRK_QS_SPLIT"); return e ? atoi(e) : -1; }();
+  const long long simds = 4LL * std::max(ctx->n_cus, 1);
+  int nw = 1;
+  if (split_env >= 0) nw = split_env;
+  else if (n_tiles * 8 <= 2 * simds) nw = 8;
+  else if (n_tiles * 4 <= 2 * simds) nw = 4;
+  else if (n_tiles * 2 <= 2 * simds) nw = 2;
+  if (nw == 2 || nw == 4 || nw == 8) {
+    const size_t lds = (size_t)V * 256 + (size_t)8 * nw * (QS_LEAVES * (F64 ? 8 : 4) + QS_TILE_ROWS);
+    if (lds <= 160 * 1024) {
+      ScopedKernelTimer timer(ctx, "score");
+#define MRK_SPLIT(NW_)                                                                                                      \
+      {                                                                                                                       \
+        auto sk = qs_score_split_kernel<F64, NW_>;                                                                            \
+        static thread_local const void *sconf = nullptr;                                                                      \
+        if (sconf != (const void *)sk) {                                                                                      \
+          MRK_HIP(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
+          sconf = (const void *)sk;                                                                                           \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(sk, dim3((unsigned)n_tiles), dim3(NW_ * 64), lds, ctx->launch, m->d_qs_nodes.as<uint32_t>(),       \
+                           m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(), d_cells, \
+                           q.n_trees, V, rows, m->forest.base_score, d_out);                                                  \
+      }
+      if (nw == 8) MRK_SPLIT(8) else if (nw == 4) MRK_SPLIT(4) else MRK_SPLIT(2)
+#undef MRK_SPLIT
+      MRK_HIP(hipGetLastError());
+      return;
+    }
+  }
   auto wk = qs_score_wave_kernel<F64>;
   static thread_local const void *configured = nullptr;
   if (configured != (const void *)wk) {

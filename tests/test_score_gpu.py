@@ -157,7 +157,7 @@ def test_full_size_properties_100k(ctx):
 # per call by the library, so a test can pin a kernel.
 @pytest.fixture
 def scorer_env():
-    saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R")}
+    saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT")}
     yield
     for k, v in saved.items():
         if v is None:
@@ -170,7 +170,11 @@ def _all_kernels(b, X):
     out = {}
     os.environ.pop("MRK_SCORER", None)
     os.environ["MRK_QS_KERNEL"] = "1"
-    out["bitvector-wave"] = b.predict(X)
+    for nw in ("1", "2", "4", "8"):  # 1 = one wavefront per tile; 2/4/8 = wavefronts splitting the trees of a tile
+        os.environ["MRK_QS_SPLIT"] = nw
+        out[f"bitvector-wave-split{nw}"] = b.predict(X)
+    os.environ.pop("MRK_QS_SPLIT", None)
+    out["bitvector-wave-auto"] = b.predict(X)
     for r in ("2", "4", "8"):
         os.environ["MRK_QS_KERNEL"] = "0"
         os.environ["MRK_QS_R"] = r
