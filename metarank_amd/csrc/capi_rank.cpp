@@ -407,25 +407,110 @@ static const Program &program_of(mrk_ctx *ctx, const char *model_name) {
   return *p;
 }
 
+// ---- mrk_rank with a batching front.  The reference serves every request on its own thread
+// (cats-effect compute pool, one rerank per fiber); here concurrent callers of mrk_rank are combined: whoever
+// arrives while nobody is ranking becomes the leader, takes every compatible request queued so far (same model
+// handle, same model name, same wish for the explain matrix; up to MRK_RANK_COMBINE_MAX), runs them as ONE
+// device batch (one upload, three launches, one download) and hands every caller its slice.  A single caller
+// sees exactly the old behaviour (a batch of one).  MRK_RANK_COMBINE=0 turns the front off.
+namespace {
+struct RankTicket {
+  mrk_model *model;
+  std::string model_name;
+  const mrk_request *req;
+  double *scores;
+  int32_t *order;
+  double *matrix;
+  int status = MRK_OK;
+  std::string err;
+  bool done = false;
+};
+
+// ranks tickets [0, n) as one batch; fills status / err of each; ctx->mu is taken inside
+void rank_tickets(mrk_ctx *ctx, RankTicket **tk, int n) {
+  auto fail_all = [&](int code, const std::string &msg) {
+    for (int i = 0; i < n; ++i) { tk[i]->status = code; tk[i]->err = msg; }
+  };
+  try {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const Program &prog = program_of(ctx, tk[0]->model_name.c_str());
+    if (!ctx->rank_scratch) ctx->rank_scratch = new mrk_batch();  // grow-only: no hipMalloc / hipFree per request
+    mrk_batch &b = *(mrk_batch *)ctx->rank_scratch;
+    std::vector<mrk_request> reqs(n);
+    for (int i = 0; i < n; ++i) reqs[i] = *tk[i]->req;
+    build_batch(ctx, prog, reqs.data(), n, b);
+    b.want_matrix = tk[0]->matrix != nullptr;
+    run_batch(b, tk[0]->model);
+    if (n == 1) {
+      fetch_batch(b, tk[0]->scores, tk[0]->order, tk[0]->matrix);
+    } else {
+      std::vector<double> sc((size_t)b.total_items), mat;
+      std::vector<int32_t> od((size_t)b.total_items);
+      if (b.want_matrix) mat.resize((size_t)b.total_items * prog.dim);
+      fetch_batch(b, sc.data(), od.data(), b.want_matrix ? mat.data() : nullptr);
+      size_t off = 0;
+      for (int i = 0; i < n; ++i) {
+        const size_t m = (size_t)std::max(tk[i]->req->n_items, 0);
+        if (tk[i]->scores) memcpy(tk[i]->scores, sc.data() + off, m * 8);
+        if (tk[i]->order) memcpy(tk[i]->order, od.data() + off, m * 4);
+        if (tk[i]->matrix) memcpy(tk[i]->matrix, mat.data() + off * prog.dim, m * prog.dim * 8);
+        off += m;
+      }
+    }
+    for (int i = 0; i < n; ++i) tk[i]->status = status_to_code(b.h_status[i], tk[i]->err);
+  } catch (const StatusError &e) {
+    if (n == 1) fail_all(e.status, e.what());
+    else {  // a request the host rejects (bad arguments, dim mismatch) must not fail its neighbours: one by one
+      for (int i = 0; i < n; ++i) rank_tickets(ctx, tk + i, 1);
+    }
+  } catch (const std::bad_alloc &) {
+    fail_all(MRK_ERR_DEVICE, "out of host memory");
+  } catch (const std::exception &e) {
+    fail_all(MRK_ERR_PARSE, e.what());
+  }
+}
+}  // namespace
+
 int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
              int32_t *out_order, double *out_matrix) {
-  return guard([&] {
-    if (!req) throw StatusError(MRK_ERR_INVALID_ARG, "null request");
-    if (!ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
-    if (model && model->ctx != ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const Program &prog = program_of(ctx, model_name);
-    // one grow-only scratch batch per context: no hipMalloc / hipFree on the single-request path
-    if (!ctx->rank_scratch) ctx->rank_scratch = new mrk_batch();
-    mrk_batch &b = *(mrk_batch *)ctx->rank_scratch;
-    build_batch(ctx, prog, req, 1, b);
-    b.want_matrix = out_matrix != nullptr;
-    run_batch(b, model);
-    fetch_batch(b, out_scores, out_order, out_matrix);
-    std::string msg;
-    int code = status_to_code(b.h_status[0], msg);
-    if (code != MRK_OK) throw StatusError(code, msg);
-  });
+  if (!req || !ctx || !model_name) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
+  if (model && model->ctx != ctx) { set_last_error("model belongs to another context"); return MRK_ERR_INVALID_ARG; }
+  RankTicket t{model, model_name, req, out_scores, out_order, out_matrix};
+  static const bool combine = [] { const char *e = getenv("MRK_RANK_COMBINE"); return !e || atoi(e) != 0; }();
+  static const int combine_max = [] { const char *e = getenv("MRK_RANK_COMBINE_MAX"); return e ? std::max(1, atoi(e)) : 256; }();
+  if (!combine) {
+    RankTicket *one = &t;
+    rank_tickets(ctx, &one, 1);
+  } else {
+    std::unique_lock<std::mutex> lk(ctx->qmu);
+    ctx->rank_queue.push_back(&t);
+    if (!ctx->rank_leader) {
+      ctx->rank_leader = true;
+      while (!ctx->rank_queue.empty()) {
+        // everything queued that is compatible with the oldest ticket
+        std::vector<RankTicket *> take;
+        RankTicket *head = (RankTicket *)ctx->rank_queue.front();
+        std::vector<void *> rest;
+        for (void *p : ctx->rank_queue) {
+          RankTicket *q = (RankTicket *)p;
+          const bool ok = (int)take.size() < combine_max && q->model == head->model && q->model_name == head->model_name &&
+                          (q->matrix != nullptr) == (head->matrix != nullptr);
+          if (ok) take.push_back(q); else rest.push_back(p);
+        }
+        ctx->rank_queue.swap(rest);
+        lk.unlock();
+        rank_tickets(ctx, take.data(), (int)take.size());
+        lk.lock();
+        for (RankTicket *q : take) q->done = true;
+        ctx->qcv.notify_all();
+      }
+      ctx->rank_leader = false;
+    } else {
+      ctx->qcv.wait(lk, [&] { return t.done; });
+    }
+  }
+  if (t.status != MRK_OK) set_last_error(t.err);
+  return t.status;
 }
 
 int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req, mrk_batch **out) {

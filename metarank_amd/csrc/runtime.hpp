@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -113,6 +114,12 @@ struct mrk_ctx {
   mrk::Registry *registry = nullptr;  // owned; freed by mrk::free_rank_state
   mrk::Store *store = nullptr;
   void *rank_scratch = nullptr;       // mrk_batch reused by mrk_rank (owned; freed by mrk::free_rank_state)
+  // batching front of mrk_rank: concurrent callers are combined into one device batch by whichever caller
+  // finds no leader active (capi_rank.cpp)
+  std::mutex qmu;
+  std::condition_variable qcv;
+  std::vector<void *> rank_queue;     // RankTicket*
+  bool rank_leader = false;
   mrk_ctx();
   ~mrk_ctx();
 };

@@ -302,3 +302,51 @@ def test_c5_biencoder_column():
         batch.close()
     finally:
         hip.close()
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_are_combined_and_isolated(oracle_c2):
+    """The batching front of mrk_rank: 16 threads rank different requests at the same time (the reference's
+    threading model: one rerank per request thread); every caller gets exactly its own request's scores and
+    order, the explain matrix when it asked for it, and a request that throws fails alone."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        load(hip)
+        reqs = ranklens.generate_requests(96, 100, N_ITEMS, N_SESS, seed=61) + ranklens.generate_requests(8, 7, N_ITEMS, N_SESS, seed=62)
+        mats = [oracle_c2.matrix(ev) for ev in reqs]
+        blob = synth.synthetic_lgbm_model(n_trees=200, n_features=24, quantiles=ranklens.column_quantiles(np.concatenate(mats)),
+                                          cat_features=[7], cat_prob=0.02)
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        expected = [oracle_c2.rerank(ev) for ev in reqs]
+
+        def one(k):
+            explain = k % 5 == 0
+            m, s, o = hip.ranker.rerank("xgboost", reqs[k], hip.booster, explain=explain)
+            return k, m, s, o
+
+        for _ in range(3):
+            with ThreadPoolExecutor(16) as ex:
+                results = list(ex.map(one, range(len(reqs))))
+            for k, m, s, o in results:
+                em, es, eo = expected[k]
+                assert same(s, es) and o.tolist() == eo.tolist(), k
+                assert m is None or same(m, em), k
+        # a request that makes the reference throw (normalised rate, global clicks == 0) among healthy ones
+        for b in (hip,):
+            b.put_periodic("global/ctr_click_norm", [0, 5])
+
+        def guarded(k):
+            try:
+                hip.ranker.rerank("xgboost", reqs[k], hip.booster)
+                return None
+            except Exception as e:  # noqa: BLE001
+                return e
+
+        with ThreadPoolExecutor(8) as ex:
+            errs = list(ex.map(guarded, range(24)))
+        assert all(e is not None and getattr(e, "status", 0) == -5 for e in errs)  # every request reads the global counter
+    finally:
+        hip.close()
