@@ -204,6 +204,17 @@ typedef struct mrk_request {
 int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req,
              double *out_scores, int32_t *out_order, double *out_matrix);
 
+/* The same for a request in the reference's binary RankingEventFormat (M/util/RankingEventFormat.scala:12-62; the
+ * encoding of the warm-up requests inside the model container, and a cheaper wire form than JSON for a host that
+ * already holds the event).  `event` holds one record; out_n_items receives its item count; out_scores /
+ * out_order must have room for `capacity` items (MRK_ERR_INVALID_ARG with out_n_items set if it has more). */
+int mrk_rank_binary(mrk_ctx *ctx, mrk_model *model, const char *model_name, const uint8_t *event, size_t len,
+                    int *out_n_items, double *out_scores, int32_t *out_order, int capacity);
+/* Warm-up (Serve.maybeWarmup, M/main/command/Serve.scala:130-150): a model loaded with mrk_model_load_container keeps
+ * the container's warm-up requests; mrk_model_warmup ranks each of them once (results discarded) and returns the
+ * number replayed through out_replayed. */
+int mrk_model_warmup(mrk_ctx *ctx, mrk_model *model, const char *model_name, int *out_replayed);
+
 /* Batched form: resolve n_req requests once into a device-resident batch, then run it any number
  * of times (the benchmark's timed region is mrk_batch_run only). */
 int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req,

@@ -97,6 +97,8 @@ SIGNATURES = {
     "mrk_store_append": (_I, [_V, _S, _S, C.c_int64]),
     "mrk_store_flush": (_I, [_V]),
     "mrk_rank": (_I, [_V, _V, _S, C.POINTER(mrk_request), _P, _P, _P]),
+    "mrk_rank_binary": (_I, [_V, _V, _S, _P, C.c_size_t, C.POINTER(C.c_int), _P, _P, _I]),
+    "mrk_model_warmup": (_I, [_V, _V, _S, C.POINTER(C.c_int)]),
     "mrk_batch_prepare": (_I, [_V, _S, C.POINTER(mrk_request), _I, C.POINTER(_V)]),
     "mrk_batch_total_items": (_I, [_V]),
     "mrk_batch_run": (_I, [_V, _V]),

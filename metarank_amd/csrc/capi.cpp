@@ -186,6 +186,8 @@ int mrk_model_load_container(mrk_ctx *ctx, const uint8_t *blob, size_t len, cons
     }
     mrk_model *m = make_model(ctx, c.booster_tag, c.inner, c.inner_len);
     m->container_features = c.features;
+    m->n_warmup = c.n_warmup;
+    if (c.n_warmup > 0) m->warmup_bytes.assign(c.warmup, c.warmup + c.warmup_len);
     *out = m;
   });
 }

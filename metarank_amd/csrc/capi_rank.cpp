@@ -513,6 +513,39 @@ int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_r
   return t.status;
 }
 
+int mrk_rank_binary(mrk_ctx *ctx, mrk_model *model, const char *model_name, const uint8_t *event, size_t len,
+                    int *out_n_items, double *out_scores, int32_t *out_order, int capacity) {
+  DecodedRequest dr;
+  int rc = guard([&] {
+    if (out_n_items) *out_n_items = 0;
+    if (!event) throw StatusError(MRK_ERR_INVALID_ARG, "null event");
+    dr.decode(event, len);
+    if (out_n_items) *out_n_items = dr.req.n_items;
+    if (dr.req.n_items > capacity) throw StatusError(MRK_ERR_INVALID_ARG, "the event has more items than the output buffers hold");
+  });
+  if (rc != MRK_OK) return rc;
+  return mrk_rank(ctx, model, model_name, &dr.req, out_scores, out_order, nullptr);
+}
+
+int mrk_model_warmup(mrk_ctx *ctx, mrk_model *model, const char *model_name, int *out_replayed) {
+  if (out_replayed) *out_replayed = 0;
+  if (!ctx || !model || !model_name) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
+  size_t off = 0;
+  std::vector<double> sc;
+  std::vector<int32_t> od;
+  for (int i = 0; i < model->n_warmup; ++i) {
+    DecodedRequest dr;
+    int rc = guard([&] { off += dr.decode(model->warmup_bytes.data() + off, model->warmup_bytes.size() - off); });
+    if (rc != MRK_OK) return rc;
+    sc.resize((size_t)std::max(dr.req.n_items, 1));
+    od.resize(sc.size());
+    rc = mrk_rank(ctx, model, model_name, &dr.req, sc.data(), od.data(), nullptr);
+    if (rc != MRK_OK) return rc;  // Serve.maybeWarmup propagates a failing warm-up request
+    if (out_replayed) *out_replayed = i + 1;
+  }
+  return MRK_OK;
+}
+
 int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req, mrk_batch **out) {
   return guard([&] {
     if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");

@@ -5,6 +5,7 @@
 // (varint size + elements), util/VarNum.java (unsigned LEB128), java.io.DataOutput (big-endian, writeUTF =
 // u16 length + modified UTF-8).  Records are self-delimiting, so a blob is any concatenation of them.
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 
 #include "store.hpp"
@@ -177,6 +178,90 @@ int load_feature_values(Store &store, const uint8_t *bytes, size_t len) {
     ++n;
   }
   return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RankingEventFormat (util/RankingEventFormat.scala:12-62): the binary form of a `ranking` event the reference
+// uses for the warm-up requests stored in the model container (ml/rank/LambdaMARTRanker.scala:223,387):
+//   UTF id, i64 ts, [bool + UTF] user, [bool + UTF] session, i32 n + fields, i32 n + items {UTF id, i32 n + fields}
+//   field: u8 tag (0 string, 1 boolean, 2 number, 3 string list, 4 number list), UTF name, value
+// (DataOutputStream: big-endian, fixed-width ints - not the varints of the FeatureValue codec).
+namespace {
+struct Fixed {
+  In in;
+  int64_t i64() { in.need(8); uint64_t u = 0; for (int i = 0; i < 8; ++i) u = (u << 8) | in.p[i]; in.p += 8; return (int64_t)u; }
+  int32_t i32() { in.need(4); uint32_t u = 0; for (int i = 0; i < 4; ++i) u = (u << 8) | in.p[i]; in.p += 4; return (int32_t)u; }
+};
+}  // namespace
+
+static void read_field(Fixed &f, mrk_field &out, std::vector<std::unique_ptr<std::string>> &strs,
+                       std::vector<std::unique_ptr<std::vector<const char *>>> &lists, std::vector<std::unique_ptr<std::vector<double>>> &nums) {
+  auto keep = [&](std::string s) { strs.emplace_back(new std::string(std::move(s))); return strs.back()->c_str(); };
+  memset(&out, 0, sizeof(out));
+  const uint8_t tag = f.in.byte();
+  out.name = keep(f.in.utf());
+  switch (tag) {
+    case 0: out.type = MRK_FIELD_STRING; out.str = keep(f.in.utf()); break;
+    case 1: out.type = MRK_FIELD_BOOL; out.num = f.in.byte() ? 1.0 : 0.0; break;
+    case 2: out.type = MRK_FIELD_NUMBER; out.num = f.in.f64(); break;
+    case 3: {
+      const int n = f.i32();
+      if (n < 0) throw StatusError(MRK_ERR_PARSE, "ranking event: negative list size");
+      lists.emplace_back(new std::vector<const char *>());
+      for (int i = 0; i < n; ++i) lists.back()->push_back(keep(f.in.utf()));
+      out.type = MRK_FIELD_STRING_LIST;
+      out.n = n;
+      out.strs = lists.back()->data();
+      break;
+    }
+    case 4: {
+      const int n = f.i32();
+      if (n < 0) throw StatusError(MRK_ERR_PARSE, "ranking event: negative list size");
+      nums.emplace_back(new std::vector<double>());
+      for (int i = 0; i < n; ++i) nums.back()->push_back(f.in.f64());
+      out.type = MRK_FIELD_NUMBER_LIST;
+      out.n = n;
+      out.nums = nums.back()->data();
+      break;
+    }
+    default: throw StatusError(MRK_ERR_PARSE, "ranking event: unknown field tag");
+  }
+}
+
+size_t DecodedRequest::decode(const uint8_t *bytes, size_t len) {
+  Fixed f{In{bytes, bytes + len}};
+  auto keep = [&](std::string s) { strs.emplace_back(new std::string(std::move(s))); return strs.back()->c_str(); };
+  memset(&req, 0, sizeof(req));
+  req.id = keep(f.in.utf());
+  req.timestamp_ms = f.i64();
+  req.user = f.in.byte() ? keep(f.in.utf()) : nullptr;
+  req.session = f.in.byte() ? keep(f.in.utf()) : nullptr;
+  const int nf = f.i32();
+  if (nf < 0) throw StatusError(MRK_ERR_PARSE, "ranking event: negative field count");
+  fields.resize(nf);
+  for (int i = 0; i < nf; ++i) read_field(f, fields[i], strs, lists, nums);
+  const int ni = f.i32();
+  if (ni < 0) throw StatusError(MRK_ERR_PARSE, "ranking event: negative item count");
+  item_ids.clear();
+  item_offsets.assign(1, 0);
+  item_fields.clear();
+  for (int i = 0; i < ni; ++i) {
+    item_ids.push_back(keep(f.in.utf()));
+    const int k = f.i32();
+    if (k < 0) throw StatusError(MRK_ERR_PARSE, "ranking event: negative field count");
+    for (int j = 0; j < k; ++j) {
+      item_fields.emplace_back();
+      read_field(f, item_fields.back(), strs, lists, nums);
+    }
+    item_offsets.push_back((int32_t)item_fields.size());
+  }
+  req.fields = fields.data();
+  req.n_fields = nf;
+  req.n_items = ni;
+  req.item_ids = item_ids.data();
+  req.item_field_offsets = item_fields.empty() ? nullptr : item_offsets.data();
+  req.item_fields = item_fields.empty() ? nullptr : item_fields.data();
+  return (size_t)(f.in.p - bytes);
 }
 
 }  // namespace mrk

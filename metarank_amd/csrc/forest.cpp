@@ -424,8 +424,14 @@ Container parse_container(const uint8_t *blob, size_t len) {
   r.need((size_t)sz);
   c.inner = r.p;
   c.inner_len = (size_t)sz;
-  // v3 appends warm-up requests (RankingEventFormat); they are host-side replay material and are
-  // not needed to score.
+  r.p += sz;
+  // v3 appends warm-up requests: i32 count + RankingEventFormat records (LambdaMARTRanker.scala:219-224,384-388)
+  if (c.version >= 3 && r.p < r.end) {
+    c.n_warmup = r.i32();
+    if (c.n_warmup < 0) throw std::runtime_error("model container: bad warm-up count");
+    c.warmup = r.p;
+    c.warmup_len = (size_t)(r.end - r.p);
+  }
   return c;
 }
 

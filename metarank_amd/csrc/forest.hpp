@@ -52,6 +52,9 @@ struct Container {
   int booster_tag = 0;
   const uint8_t *inner = nullptr;
   size_t inner_len = 0;
+  int n_warmup = 0;                // v3: number of RankingEventFormat records that follow
+  const uint8_t *warmup = nullptr; // their bytes (to the end of the blob)
+  size_t warmup_len = 0;
 };
 // Metarank bitstream v2/v3 (reference: ml/rank/LambdaMARTRanker.scala:192-236,367-389)
 Container parse_container(const uint8_t *blob, size_t len);

@@ -130,6 +130,8 @@ struct mrk_model {
   mrk::Forest forest;
   mrk::PackedForest packed;
   std::vector<std::string> container_features;
+  int n_warmup = 0;                    // container v3: RankingEventFormat records kept for mrk_model_warmup
+  std::vector<uint8_t> warmup_bytes;
   mrk::DevBuf d_image, d_trees, d_chunks, d_cat;
   // bit-vector image (forests of <= 16-leaf trees); qs.ok == false => tree-walk kernel only
   mrk::PackedForestQS qs;

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <climits>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -179,6 +180,18 @@ struct Store {
   bool locate(const char *key, Cell &out);
   void set_tag(Cell &c, uint8_t tag) { c.rec[c.c->tag_index] = tag; }
   template <typename T> void set_val(Cell &c, int idx, T v) { memcpy(c.rec + c.c->val_off + idx * 8, &v, sizeof(T)); }
+};
+
+// codec.cpp: a `ranking` event decoded from the reference's binary RankingEventFormat; `req` points into this object
+struct DecodedRequest {
+  mrk_request req;
+  std::vector<std::unique_ptr<std::string>> strs;
+  std::vector<std::unique_ptr<std::vector<const char *>>> lists;
+  std::vector<std::unique_ptr<std::vector<double>>> nums;
+  std::vector<mrk_field> fields, item_fields;
+  std::vector<const char *> item_ids;
+  std::vector<int32_t> item_offsets;
+  size_t decode(const uint8_t *bytes, size_t len);  // returns the bytes consumed; throws StatusError(MRK_ERR_PARSE)
 };
 
 // writes.hip: bucket rings -> window sums (PeriodicCounterFeature.fromMap, model/Feature.scala:142-161)

@@ -170,6 +170,21 @@ class HipRanker:
                                  mat.ctypes.data_as(C.c_void_p) if explain else None))
         return mat, scores, order
 
+    def rerank_binary(self, model_name: str, event_bytes: bytes, booster: HipBooster | None, capacity: int = 4096):
+        """Ranker.rerank for a request in the reference's binary RankingEventFormat -> (scores, order)"""
+        scores = np.empty(capacity, dtype=np.float64)
+        order = np.empty(capacity, dtype=np.int32)
+        n = C.c_int(0)
+        N.check(N.lib().mrk_rank_binary(self.ctx.handle, booster.handle if booster is not None else None, model_name.encode(),
+                                        event_bytes, len(event_bytes), C.byref(n), scores.ctypes.data_as(C.c_void_p),
+                                        order.ctypes.data_as(C.c_void_p), capacity))
+        return scores[:n.value], order[:n.value]
+
+    def warmup(self, model_name: str, booster: HipBooster) -> int:
+        n = C.c_int(0)
+        N.check(N.lib().mrk_model_warmup(self.ctx.handle, booster.handle, model_name.encode(), C.byref(n)))
+        return n.value
+
     def prepare(self, model_name: str, events) -> Batch:
         return Batch(self, model_name, events)
 

@@ -139,6 +139,39 @@ def feature_value(kind: str, key: str, value, ts: int = 1661345221008, ttl_ms: i
     raise ValueError(kind)
 
 
+# ---------------------------------------------------------------------------- RankingEventFormat
+def _field(f: dict) -> bytes:
+    """RankingEventFormat.writeField (util/RankingEventFormat.scala:64-88): fixed-width big-endian ints, no varints"""
+    name, v = f["name"], f["value"]
+    if isinstance(v, bool):
+        return b"\x01" + utf(name) + (b"\x01" if v else b"\x00")
+    if isinstance(v, (int, float)):
+        return b"\x02" + utf(name) + f64(float(v))
+    if isinstance(v, str):
+        return b"\x00" + utf(name) + utf(v)
+    if len(v) > 0 and isinstance(v[0], str):
+        return b"\x03" + utf(name) + struct.pack(">i", len(v)) + b"".join(utf(s) for s in v)
+    return b"\x04" + utf(name) + struct.pack(">i", len(v)) + b"".join(f64(float(x)) for x in v)
+
+
+def ranking_event(ev: dict) -> bytes:
+    """RankingEventFormat.write (util/RankingEventFormat.scala:39-62) of the JSON-shaped `ranking` event the tests use;
+    an item's `relevancy` is not part of the binary form (RankItem(id, fields) only)"""
+    out = utf(str(ev.get("id", ""))) + struct.pack(">q", int(ev["timestamp"]))
+    for k in ("user", "session"):
+        v = ev.get(k)
+        out += (b"\x01" + utf(str(v))) if v is not None else b"\x00"
+    fields = ev.get("fields") or []
+    out += struct.pack(">i", len(fields)) + b"".join(_field(f) for f in fields)
+    items = ev["items"]
+    out += struct.pack(">i", len(items))
+    for it in items:
+        it = it if isinstance(it, dict) else {"id": it}
+        fl = it.get("fields") or []
+        out += utf(str(it["id"])) + struct.pack(">i", len(fl)) + b"".join(_field(f) for f in fl)
+    return out
+
+
 # ---------------------------------------------------------------------------- reader (roundtrip tests)
 class _In:
     def __init__(self, b: bytes):

@@ -70,3 +70,47 @@ def test_store_loaded_from_binary_ranks_like_typed_puts():
     finally:
         a.close()
         b.close()
+
+
+def test_ranking_event_format_rejects_garbage_without_a_gpu():
+    import ctypes as C
+
+    from metarank_amd import _native as N
+
+    L = N.lib()
+    n = C.c_int(0)
+    assert L.mrk_rank_binary(None, None, b"m", b"\x00\x05ab", 4, C.byref(n), None, None, 0) == N.ERR_PARSE  # truncated UTF
+    ev = codec.ranking_event({"id": "r", "timestamp": 5, "user": "u", "session": None, "fields": [], "items": ["a", "b"]})
+    assert ev == b"\x00\x01r" + b"\x00" * 7 + b"\x05" + b"\x01\x00\x01u" + b"\x00" + b"\x00\x00\x00\x00" + b"\x00\x00\x00\x02" + \
+        b"\x00\x01a\x00\x00\x00\x00" + b"\x00\x01b\x00\x00\x00\x00"
+    # decodes (n_items is reported) but there is no context to rank with
+    assert L.mrk_rank_binary(None, None, b"m", ev, len(ev), C.byref(n), None, None, 2) == N.ERR_INVALID_ARG and n.value == 2
+
+
+@pytest.mark.gpu
+def test_binary_requests_and_container_warmup():
+    from backends import HipBackend
+    from metarank_amd import ranklens, synth
+
+    cfg = ranklens.ranklens_config()
+    hip = HipBackend(cfg, "xgboost")
+    try:
+        ranklens.load_state(hip, ranklens.generate_state(2000, 200))
+        reqs = ranklens.generate_requests(6, 100, 2000, 200, seed=71)
+        reqs[0]["items"][0]["fields"] = [{"name": "popularity", "value": 5.5}, {"name": "genres", "value": ["drama"]}]
+        reqs[1]["fields"] = [{"name": "query", "value": "socks"}, {"name": "flags", "value": [1.0, 2.0]}, {"name": "b", "value": True}]
+        reqs[2]["user"] = None
+        sample = np.concatenate([hip.matrix(ev) for ev in reqs])
+        inner = synth.synthetic_lgbm_model(n_trees=120, n_features=24, quantiles=ranklens.column_quantiles(sample))
+        names = cfg["models"]["xgboost"]["features"]
+        blob = synth.write_container(names, 0, inner, warmup=[codec.ranking_event(ev) for ev in reqs[:3]])
+        booster = hip.M.HipBooster.from_container(blob, names, hip.ctx)
+        for ev in reqs:
+            _, s1, o1 = hip.ranker.rerank("xgboost", ev, booster)
+            s2, o2 = hip.ranker.rerank_binary("xgboost", codec.ranking_event(ev), booster)
+            assert np.array_equal(s1, s2) and o1.tolist() == o2.tolist()
+        assert hip.ranker.warmup("xgboost", booster) == 3
+        with pytest.raises(hip.M.MrkError):
+            hip.ranker.rerank_binary("xgboost", codec.ranking_event(reqs[0]), booster, capacity=10)  # more items than room
+    finally:
+        hip.close()
