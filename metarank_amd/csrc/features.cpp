@@ -683,11 +683,6 @@ static uint32_t table_capacity(uint64_t tokens) {
   return (uint32_t)((cap + 1) & ~1ull);
 }
 
-uint32_t pow2_at_least(uint64_t n) {
-  uint32_t c = 1;
-  while (c < n) c <<= 1;
-  return c;
-}
 
 struct HostCell { uint8_t tag; uint64_t bits; };
 HostCell host_cell(const Store &st, ScopeId scope, int32_t slot, ColRef c) {
