@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MRK_ABI_VERSION 2
+#define MRK_ABI_VERSION 3
 
 typedef enum mrk_status {
   MRK_OK = 0,
@@ -262,6 +262,61 @@ void *mrk_stream(mrk_ctx *ctx);        /* the hipStream_t all work is enqueued o
  * Enable with mrk_profile_enable(ctx, 1); returns accumulated ms and launch count since enable. */
 int mrk_profile_enable(mrk_ctx *ctx, int on);
 int mrk_profile_get(mrk_ctx *ctx, const char *kernel, double *total_ms, int64_t *launches);
+
+/* ---- text encoders (BASELINE config 5) ------------------------------------------------------------
+ * Replaces ml/onnx/sbert/OnnxSession.scala:29-57 (load), OnnxBiEncoder.scala:13-60 (embed + masked mean pool) and
+ * OnnxCrossEncoder.scala:22-51 (pair logits).  The tokenizer is host code and needs no device. */
+typedef struct mrk_tokenizer mrk_tokenizer;
+typedef struct mrk_encoder mrk_encoder;
+
+/* HuggingFaceTokenizer.newInstance(tokenizer.json, {padding: true, truncation: true}) -- OnnxSession.scala:42-43.
+ * BERT WordPiece pipelines only; other pipelines -> MRK_ERR_UNSUPPORTED. */
+int mrk_tokenizer_load(const char *tokenizer_json, size_t len, mrk_tokenizer **out);
+/* tokenizer.batchEncode(a) / batchEncode(PairList(a, b)): rows padded to the longest row of the batch.  `b` may be
+ * NULL.  ids/type_ids/mask are n x capacity row-major with row stride *seq_len on return; MRK_ERR_INVALID_ARG when
+ * capacity < longest row (then *seq_len holds the length needed). */
+int mrk_tokenizer_encode_batch(mrk_tokenizer *tok, const char *const *a, const char *const *b, int n, int32_t *ids,
+                               int32_t *type_ids, int32_t *mask, int capacity, int *seq_len);
+void mrk_tokenizer_free(mrk_tokenizer *tok);
+
+typedef struct mrk_encoder_info {
+  int32_t layers, hidden, heads, intermediate, vocab, max_positions, type_vocab;
+  int32_t has_classifier; /* pooler + 1-logit classifier present (cross-encoder) */
+  int32_t max_length;     /* tokenizer truncation length */
+  int64_t device_bytes;
+  double layer_norm_eps;
+} mrk_encoder_info;
+
+/* env.createSession(modelBytes) + the tokenizer -- OnnxSession.scala:42-56.  `weights` is the model file the reference
+ * reads (`pytorch_model.onnx`: the initializers of a BERT-family graph are extracted) or the same checkpoint as
+ * `model.safetensors`; detected by content.  `heads` = number of attention heads (0: read it from the graph's
+ * reshape constants / the safetensors metadata key "num_attention_heads").  Weights are kept in fp16 on the device,
+ * the residual stream, LayerNorm statistics, softmax and every accumulation are f32. */
+int mrk_encoder_load(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len,
+                     int heads, mrk_encoder **out);
+int mrk_encoder_get_info(mrk_encoder *enc, mrk_encoder_info *info);
+/* Host-only view of what mrk_encoder_load reads from a model file: writes a JSON object
+ * {"heads": h, "tensors": {name: {"shape": [...], "sum": s, "abs_sum": a}}} (BertModel state_dict names, Linear weights
+ * as [out, in]) into `out`; MRK_ERR_INVALID_ARG with *needed set when `cap` is too small. No device needed. */
+int mrk_checkpoint_describe(const uint8_t *weights, size_t len, char *out, size_t cap, size_t *needed);
+/* OnnxBiEncoder.embed: n texts -> n x hidden f32 (masked mean over tokens, f64 accumulation, no normalisation) */
+int mrk_encoder_embed(mrk_encoder *enc, const char *const *texts, int n, float *out);
+/* same from token ids (n x seq_len, as mrk_tokenizer_encode_batch returns them) */
+int mrk_encoder_embed_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *type_ids, const int32_t *mask, int n,
+                          int seq_len, float *out);
+/* last_hidden_state (output 0 of the graph) for parity checks: n x seq_len x hidden f32 */
+int mrk_encoder_hidden_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *type_ids, const int32_t *mask, int n,
+                           int seq_len, float *out);
+/* OnnxCrossEncoder.encode: n (a, b) pairs -> n logits; MRK_ERR_UNSUPPORTED without a classifier head */
+int mrk_encoder_score_pairs(mrk_encoder *enc, const char *const *a, const char *const *b, int n, float *out);
+int mrk_encoder_score_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *type_ids, const int32_t *mask, int n,
+                          int seq_len, float *out);
+void mrk_encoder_free(mrk_encoder *enc);
+/* FieldMatchBiencoderSchema.create / FieldMatchCrossEncoderSchema.create with `method.model` set
+ * (feature/FieldMatchBiencoderFeature.scala:118-124, FieldMatchCrossEncoderFeature.scala:131-135): from now on
+ * mrk_rank / mrk_batch_prepare encode the request's `rankingField` text with this encoder (queries are cached by
+ * text, as EmbeddingCache does) instead of expecting a host-computed embedding. */
+int mrk_config_bind_encoder(mrk_ctx *ctx, const char *feature, mrk_encoder *enc);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
-SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "capi.cpp", "capi_rank.cpp", "score.hip", "score_qs.hip", "rank.hip", "writes.hip"]
+SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "score.hip", "score_qs.hip", "rank.hip", "writes.hip", "encoder.hip"]
 HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
 
 MRK_OK = 0
@@ -51,6 +51,12 @@ class mrk_model_info(C.Structure):
     _fields_ = [("backend", C.c_int32), ("n_trees", C.c_int32), ("max_depth", C.c_int32), ("n_features", C.c_int32),
                 ("is_f64", C.c_int32), ("n_categorical", C.c_int32), ("n_nodes", C.c_int64), ("n_leaves", C.c_int64),
                 ("device_bytes", C.c_int64), ("base_score", C.c_double), ("bitvector", C.c_int32), ("tile_columns", C.c_int32)]
+
+
+class mrk_encoder_info(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("intermediate", C.c_int32),
+                ("vocab", C.c_int32), ("max_positions", C.c_int32), ("type_vocab", C.c_int32), ("has_classifier", C.c_int32),
+                ("max_length", C.c_int32), ("device_bytes", C.c_int64), ("layer_norm_eps", C.c_double)]
 
 
 class mrk_field(C.Structure):
@@ -115,6 +121,19 @@ SIGNATURES = {
     "mrk_stream": (_V, [_V]),
     "mrk_profile_enable": (_I, [_V, _I]),
     "mrk_profile_get": (_I, [_V, _S, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mrk_tokenizer_load": (_I, [_P, C.c_size_t, C.POINTER(_V)]),
+    "mrk_tokenizer_encode_batch": (_I, [_V, C.POINTER(_S), C.POINTER(_S), _I, _P, _P, _P, _I, C.POINTER(C.c_int)]),
+    "mrk_tokenizer_free": (None, [_V]),
+    "mrk_encoder_load": (_I, [_V, _P, C.c_size_t, _P, C.c_size_t, _I, C.POINTER(_V)]),
+    "mrk_checkpoint_describe": (_I, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mrk_encoder_get_info": (_I, [_V, C.POINTER(mrk_encoder_info)]),
+    "mrk_encoder_embed": (_I, [_V, C.POINTER(_S), _I, _P]),
+    "mrk_encoder_embed_ids": (_I, [_V, _P, _P, _P, _I, _I, _P]),
+    "mrk_encoder_hidden_ids": (_I, [_V, _P, _P, _P, _I, _I, _P]),
+    "mrk_encoder_score_pairs": (_I, [_V, C.POINTER(_S), C.POINTER(_S), _I, _P]),
+    "mrk_encoder_score_ids": (_I, [_V, _P, _P, _P, _I, _I, _P]),
+    "mrk_encoder_free": (None, [_V]),
+    "mrk_config_bind_encoder": (_I, [_V, _S, _V]),
 }
 
 _lib = None

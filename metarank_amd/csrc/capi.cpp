@@ -155,6 +155,7 @@ void mrk_shutdown(mrk_ctx *ctx) {
     if (ctx->closed) return;
     ctx->closed = true;
   }
+  unbind_encoders(ctx);  // bound encoders hold a context reference each
   ctx_release(ctx);  // freed once the last model / batch handle is gone
 }
 

@@ -1,0 +1,361 @@
+// C ABI of the text-encoder leg (include/mrk.h "text encoders"): tokenizer handles (host only) and encoder
+// handles (BERT-family graph on the device, encoder.hip).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "encoder.hpp"
+#include "runtime.hpp"
+#include "tokenizer.hpp"
+
+using namespace mrk;
+
+struct mrk_tokenizer {
+  Tokenizer tok;
+};
+
+namespace {
+template <typename F>
+int guard(F &&f) {
+  try {
+    f();
+    return MRK_OK;
+  } catch (const StatusError &e) {
+    set_last_error(e.what());
+    return e.status;
+  } catch (const std::bad_alloc &) {
+    set_last_error("out of host memory");
+    return MRK_ERR_DEVICE;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return MRK_ERR_PARSE;
+  }
+}
+
+void need(bool ok, const char *what) {
+  if (!ok) throw StatusError(MRK_ERR_INVALID_ARG, what);
+}
+
+void flatten(const std::vector<Encoding> &rows, int len, int32_t *ids, int32_t *types, int32_t *mask);
+
+enum { MODE_HIDDEN, MODE_POOL, MODE_LOGIT };
+
+uint16_t to_half(float f) {
+  const _Float16 h = (_Float16)f;  // round to nearest even, as a checkpoint saved in fp16 would be
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+
+// Validates the checkpoint against the BertModel layout, converts and uploads it (one device allocation).
+void build_encoder(mrk_encoder &e, const Checkpoint &ck) {
+  auto get = [&](const std::string &name) -> const HostTensor & {
+    auto it = ck.tensors.find(name);
+    if (it == ck.tensors.end()) throw StatusError(MRK_ERR_PARSE, "encoder weights: tensor " + name + " is missing (BERT-family graphs only)");
+    return it->second;
+  };
+  auto shape2 = [&](const HostTensor &t, int64_t a, int64_t b, const std::string &name) {
+    if (t.shape.size() != 2 || t.shape[0] != a || t.shape[1] != b)
+      throw StatusError(MRK_ERR_PARSE, "encoder weights: " + name + " has an unexpected shape");
+  };
+  EncoderShape sh;
+  const HostTensor &word = get("embeddings.word_embeddings.weight");
+  if (word.shape.size() != 2) throw StatusError(MRK_ERR_PARSE, "encoder weights: word embeddings are not a matrix");
+  sh.vocab = (int)word.shape[0];
+  sh.hidden = (int)word.shape[1];
+  sh.max_pos = (int)get("embeddings.position_embeddings.weight").shape.at(0);
+  sh.type_vocab = (int)get("embeddings.token_type_embeddings.weight").shape.at(0);
+  while (ck.tensors.count("encoder.layer." + std::to_string(sh.layers) + ".attention.self.query.weight")) ++sh.layers;
+  if (!sh.layers) throw StatusError(MRK_ERR_PARSE, "encoder weights: no encoder.layer.N tensors found (fused / non-BERT graph?)");
+  sh.inter = (int)get("encoder.layer.0.intermediate.dense.weight").shape.at(0);
+  sh.heads = ck.heads;
+  sh.classifier = ck.tensors.count("pooler.dense.weight") && ck.tensors.count("classifier.weight");
+  if (sh.classifier && get("classifier.weight").numel() != sh.hidden)
+    throw StatusError(MRK_ERR_UNSUPPORTED, "encoder weights: classifier heads with more than one logit are not supported");
+  if (sh.heads <= 0) throw StatusError(MRK_ERR_INVALID_ARG, "encoder: number of attention heads unknown - pass `heads`");
+  const int dh = sh.hidden % sh.heads == 0 ? sh.hidden / sh.heads : 0;
+  if ((dh != 32 && dh != 64) || sh.hidden % 64 || sh.inter % 64 || sh.hidden > 1024)
+    throw StatusError(MRK_ERR_UNSUPPORTED, "encoder: hidden " + std::to_string(sh.hidden) + " / heads " + std::to_string(sh.heads) + " / intermediate " +
+                      std::to_string(sh.inter) + " is outside the supported shapes (head size 32 or 64, widths multiple of 64, hidden <= 1024)");
+  const int H = sh.hidden, I = sh.inter;
+
+  // host image: fp16 block then f32 block, every tensor 256-byte aligned
+  std::vector<uint16_t> hs;
+  std::vector<float> fs;
+  auto put_h = [&](const HostTensor &t) { size_t off = hs.size(); for (float v : t.data) hs.push_back(to_half(v)); hs.resize((hs.size() + 127) / 128 * 128); return off; };
+  auto put_f = [&](const HostTensor &t) { size_t off = fs.size(); fs.insert(fs.end(), t.data.begin(), t.data.end()); fs.resize((fs.size() + 63) / 64 * 64); return off; };
+  struct LayerOff { size_t wqkv, wo, w1, w2, bqkv, bo, b1, b2, g1, be1, g2, be2; };
+  std::vector<LayerOff> lo(sh.layers);
+  const size_t o_word = put_h(word), o_pos = put_h(get("embeddings.position_embeddings.weight")), o_type = put_h(get("embeddings.token_type_embeddings.weight"));
+  const size_t o_eg = put_f(get("embeddings.LayerNorm.weight")), o_eb = put_f(get("embeddings.LayerNorm.bias"));
+  for (int l = 0; l < sh.layers; ++l) {
+    const std::string p = "encoder.layer." + std::to_string(l) + ".";
+    HostTensor wqkv, bqkv;
+    for (const char *nm : {"query", "key", "value"}) {
+      const HostTensor &w = get(p + "attention.self." + nm + ".weight"), &b = get(p + "attention.self." + nm + ".bias");
+      shape2(w, H, H, p + nm);
+      wqkv.data.insert(wqkv.data.end(), w.data.begin(), w.data.end());
+      bqkv.data.insert(bqkv.data.end(), b.data.begin(), b.data.end());
+    }
+    shape2(get(p + "attention.output.dense.weight"), H, H, p + "attention.output.dense.weight");
+    shape2(get(p + "intermediate.dense.weight"), I, H, p + "intermediate.dense.weight");
+    shape2(get(p + "output.dense.weight"), H, I, p + "output.dense.weight");
+    lo[l] = LayerOff{put_h(wqkv), put_h(get(p + "attention.output.dense.weight")), put_h(get(p + "intermediate.dense.weight")),
+                     put_h(get(p + "output.dense.weight")), put_f(bqkv), put_f(get(p + "attention.output.dense.bias")),
+                     put_f(get(p + "intermediate.dense.bias")), put_f(get(p + "output.dense.bias")),
+                     put_f(get(p + "attention.output.LayerNorm.weight")), put_f(get(p + "attention.output.LayerNorm.bias")),
+                     put_f(get(p + "output.LayerNorm.weight")), put_f(get(p + "output.LayerNorm.bias"))};
+  }
+  size_t o_pw = 0, o_pb = 0, o_cw = 0, o_cb = 0;
+  if (sh.classifier) {
+    shape2(get("pooler.dense.weight"), H, H, "pooler.dense.weight");
+    o_pw = put_h(get("pooler.dense.weight"));
+    o_pb = put_f(get("pooler.dense.bias"));
+    o_cw = put_f(get("classifier.weight"));
+    o_cb = put_f(get("classifier.bias"));
+  }
+  const size_t hbytes = hs.size() * 2, fbytes = fs.size() * 4;
+  e.weights.reserve(hbytes + fbytes);
+  MRK_HIP(hipMemcpy(e.weights.p, hs.data(), hbytes, hipMemcpyHostToDevice));
+  MRK_HIP(hipMemcpy((char *)e.weights.p + hbytes, fs.data(), fbytes, hipMemcpyHostToDevice));
+  e.device_bytes = (int64_t)(hbytes + fbytes);
+  const uint16_t *hb = e.weights.as<uint16_t>();
+  const float *fb = (const float *)((char *)e.weights.p + hbytes);
+  EncoderDev &d = e.dev;
+  d.shape = sh;
+  d.word = hb + o_word; d.pos = hb + o_pos; d.type = hb + o_type;
+  d.embg = fb + o_eg; d.embb = fb + o_eb;
+  for (auto &o : lo)
+    d.layers.push_back(LayerDev{hb + o.wqkv, hb + o.wo, hb + o.w1, hb + o.w2, fb + o.bqkv, fb + o.bo, fb + o.b1, fb + o.b2,
+                                fb + o.g1, fb + o.be1, fb + o.g2, fb + o.be2});
+  if (sh.classifier) { d.pool_w = hb + o_pw; d.pool_b = fb + o_pb; d.cls_w = fb + o_cw; d.cls_b = fb + o_cb; }
+}
+
+// one forward pass over a padded id batch; `out` is host memory sized by the mode
+void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const int32_t *mask, int n, int seq, int mode, float *out) {
+  if (n == 0) return;
+  const EncoderShape &sh = e.dev.shape;
+  if (seq > sh.max_pos) throw StatusError(MRK_ERR_INVALID_ARG, "encoder: sequence length " + std::to_string(seq) + " exceeds the model's " +
+                                          std::to_string(sh.max_pos) + " positions");
+  if (mode == MODE_LOGIT && !sh.classifier) throw StatusError(MRK_ERR_UNSUPPORTED, "encoder: the model has no pooler/classifier head (not a cross-encoder)");
+  MRK_HIP(hipSetDevice(e.ctx->device));
+  const size_t M = (size_t)n * seq;
+  e.h_ids.reserve(3 * M * 4);
+  int32_t *h = e.h_ids.as<int32_t>();
+  memcpy(h, ids, M * 4);
+  if (types) memcpy(h + M, types, M * 4); else memset(h + M, 0, M * 4);
+  memcpy(h + 2 * M, mask, M * 4);
+  e.scratch.ids.reserve(3 * M * 4);
+  MRK_HIP(hipMemcpyAsync(e.scratch.ids.p, h, 3 * M * 4, hipMemcpyHostToDevice, e.stream));
+  encoder_forward(e.dev, e.scratch, n, seq, e.stream);
+  const size_t out_n = mode == MODE_HIDDEN ? M * sh.hidden : mode == MODE_POOL ? (size_t)n * sh.hidden : (size_t)n;
+  const float *src;
+  if (mode == MODE_HIDDEN) src = e.scratch.x.as<float>();
+  else {
+    e.scratch.out.reserve(out_n * 4);
+    src = e.scratch.out.as<float>();
+    if (mode == MODE_POOL) encoder_meanpool(e.dev, e.scratch, n, seq, e.scratch.out.as<float>(), e.stream);
+    else encoder_classify(e.dev, e.scratch, n, seq, e.scratch.out.as<float>(), e.stream);
+  }
+  e.h_out.reserve(out_n * 4);
+  MRK_HIP(hipMemcpyAsync(e.h_out.p, src, out_n * 4, hipMemcpyDeviceToHost, e.stream));
+  MRK_HIP(hipStreamSynchronize(e.stream));
+  memcpy(out, e.h_out.p, out_n * 4);
+}
+
+void encode_texts(mrk_encoder &e, const char *const *a, const char *const *b, int n, int mode, float *out) {
+  std::vector<Encoding> rows;
+  const int len = e.tok.encode_batch(a, b, n, rows);
+  std::vector<int32_t> ids((size_t)n * len), types((size_t)n * len), mask((size_t)n * len);
+  flatten(rows, len, ids.data(), types.data(), mask.data());
+  run_encoder(e, ids.data(), types.data(), mask.data(), n, len, mode, out);
+}
+
+}  // namespace
+
+namespace mrk {
+
+void encoder_retain(mrk_encoder *e) { e->refs.fetch_add(1); }
+
+void encoder_embed_cached(mrk_encoder *e, const std::vector<std::string> &texts, std::vector<std::vector<float>> &out) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  const int H = e->dev.shape.hidden;
+  out.assign(texts.size(), std::vector<float>());
+  std::vector<size_t> miss;
+  for (size_t i = 0; i < texts.size(); ++i) {
+    auto it = e->cache.find(texts[i]);
+    if (it != e->cache.end()) out[i] = it->second; else miss.push_back(i);
+  }
+  constexpr size_t CHUNK = 256, CACHE_MAX = 1 << 16;
+  std::vector<float> buf;
+  for (size_t at = 0; at < miss.size(); at += CHUNK) {
+    const size_t n = std::min(CHUNK, miss.size() - at);
+    std::vector<const char *> ptrs(n);
+    for (size_t k = 0; k < n; ++k) ptrs[k] = texts[miss[at + k]].c_str();
+    buf.resize(n * H);
+    encode_texts(*e, ptrs.data(), nullptr, (int)n, MODE_POOL, buf.data());
+    if (e->cache.size() + n > CACHE_MAX) e->cache.clear();
+    for (size_t k = 0; k < n; ++k) {
+      out[miss[at + k]].assign(buf.begin() + k * H, buf.begin() + (k + 1) * H);
+      e->cache[texts[miss[at + k]]] = out[miss[at + k]];
+    }
+  }
+}
+
+void encoder_release(mrk_encoder *e) {
+  if (e->refs.fetch_sub(1) != 1) return;
+  mrk_ctx *ctx = e->ctx;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+  delete e;
+  if (ctx) ctx_release(ctx);
+}
+
+}  // namespace mrk
+
+namespace {
+
+// rows of a padded batch -> three n x len int32 arrays
+void flatten(const std::vector<Encoding> &rows, int len, int32_t *ids, int32_t *types, int32_t *mask) {
+  for (size_t i = 0; i < rows.size(); ++i) {
+    if (ids) memcpy(ids + i * len, rows[i].ids.data(), sizeof(int32_t) * len);
+    if (types) memcpy(types + i * len, rows[i].type_ids.data(), sizeof(int32_t) * len);
+    if (mask) memcpy(mask + i * len, rows[i].mask.data(), sizeof(int32_t) * len);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mrk_tokenizer_load(const char *tokenizer_json, size_t len, mrk_tokenizer **out) {
+  return guard([&] {
+    need(tokenizer_json && out, "mrk_tokenizer_load: null argument");
+    *out = new mrk_tokenizer{Tokenizer::from_json(tokenizer_json, len)};
+  });
+}
+
+int mrk_tokenizer_encode_batch(mrk_tokenizer *tok, const char *const *a, const char *const *b, int n, int32_t *ids,
+                               int32_t *type_ids, int32_t *mask, int capacity, int *seq_len) {
+  return guard([&] {
+    need(tok && (a || n == 0) && n >= 0 && seq_len, "mrk_tokenizer_encode_batch: null argument");
+    std::vector<Encoding> rows;
+    const int len = tok->tok.encode_batch(a, b, n, rows);
+    *seq_len = len;
+    if (len > capacity) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_tokenizer_encode_batch: capacity " + std::to_string(capacity) +
+                                          " < padded length " + std::to_string(len));
+    flatten(rows, len, ids, type_ids, mask);
+  });
+}
+
+void mrk_tokenizer_free(mrk_tokenizer *tok) { delete tok; }
+
+int mrk_encoder_load(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
+                     mrk_encoder **out) {
+  return guard([&] {
+    need(ctx && weights && tokenizer_json && out, "mrk_encoder_load: null argument");
+    std::unique_ptr<mrk_encoder> e(new mrk_encoder);
+    e->tok = Tokenizer::from_json(tokenizer_json, tok_len);
+    Checkpoint ck = read_checkpoint(weights, len);
+    if (heads > 0) ck.heads = heads;
+    MRK_HIP(hipSetDevice(ctx->device));
+    build_encoder(*e, ck);
+    MRK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->ctx = ctx;
+    ctx_retain(ctx);
+    *out = e.release();
+  });
+}
+
+int mrk_checkpoint_describe(const uint8_t *weights, size_t len, char *out, size_t cap, size_t *needed) {
+  return guard([&] {
+    need(weights && needed, "mrk_checkpoint_describe: null argument");
+    const Checkpoint ck = read_checkpoint(weights, len);
+    std::string js = "{\"heads\": " + std::to_string(ck.heads) + ", \"tensors\": {";
+    bool first = true;
+    char num[64];
+    for (auto &kv : ck.tensors) {
+      double s = 0.0, a = 0.0;
+      for (float v : kv.second.data) { s += (double)v; a += std::fabs((double)v); }
+      js += std::string(first ? "" : ", ") + "\"" + kv.first + "\": {\"shape\": [";
+      for (size_t i = 0; i < kv.second.shape.size(); ++i) js += (i ? ", " : "") + std::to_string(kv.second.shape[i]);
+      snprintf(num, sizeof num, "%.17g", s);
+      js += std::string("], \"sum\": ") + num;
+      snprintf(num, sizeof num, "%.17g", a);
+      js += std::string(", \"abs_sum\": ") + num + "}";
+      first = false;
+    }
+    js += "}}";
+    *needed = js.size() + 1;
+    if (!out || cap < js.size() + 1) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_checkpoint_describe: output buffer too small");
+    memcpy(out, js.c_str(), js.size() + 1);
+  });
+}
+
+int mrk_encoder_get_info(mrk_encoder *enc, mrk_encoder_info *info) {
+  return guard([&] {
+    need(enc && info, "mrk_encoder_get_info: null argument");
+    const EncoderShape &s = enc->dev.shape;
+    *info = mrk_encoder_info{s.layers, s.hidden, s.heads, s.inter, s.vocab, s.max_pos, s.type_vocab, s.classifier ? 1 : 0,
+                             enc->tok.max_length(), enc->device_bytes, (double)s.eps};
+  });
+}
+
+int mrk_encoder_hidden_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *type_ids, const int32_t *mask, int n, int seq_len,
+                           float *out) {
+  return guard([&] {
+    need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_hidden_ids: bad argument");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_HIDDEN, out);
+  });
+}
+
+int mrk_encoder_embed_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *type_ids, const int32_t *mask, int n, int seq_len,
+                          float *out) {
+  return guard([&] {
+    need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_embed_ids: bad argument");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_POOL, out);
+  });
+}
+
+int mrk_encoder_score_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *type_ids, const int32_t *mask, int n, int seq_len,
+                          float *out) {
+  return guard([&] {
+    need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_score_ids: bad argument");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_LOGIT, out);
+  });
+}
+
+int mrk_encoder_embed(mrk_encoder *enc, const char *const *texts, int n, float *out) {
+  return guard([&] {
+    need(enc && (texts || n == 0) && out && n >= 0, "mrk_encoder_embed: bad argument");
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lk(enc->mu);
+    encode_texts(*enc, texts, nullptr, n, MODE_POOL, out);
+  });
+}
+
+int mrk_encoder_score_pairs(mrk_encoder *enc, const char *const *a, const char *const *b, int n, float *out) {
+  return guard([&] {
+    need(enc && ((a && b) || n == 0) && out && n >= 0, "mrk_encoder_score_pairs: bad argument");
+    if (n == 0) return;  // OnnxCrossEncoder.scala:23-24: empty batch -> empty result
+    std::lock_guard<std::mutex> lk(enc->mu);
+    encode_texts(*enc, a, b, n, MODE_LOGIT, out);
+  });
+}
+
+void mrk_encoder_free(mrk_encoder *enc) {
+  if (enc) encoder_release(enc);
+}
+
+}  // extern "C"
+
+extern "C" int mrk_config_bind_encoder(mrk_ctx *ctx, const char *feature, mrk_encoder *enc) {
+  return guard([&] {
+    need(ctx && feature && enc, "mrk_config_bind_encoder: null argument");
+    bind_encoder(ctx, feature, enc);
+  });
+}

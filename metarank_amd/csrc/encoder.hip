@@ -1,0 +1,363 @@
+// BERT-family encoder forward pass for gfx950 (the only MFMA work on the /rank path).
+//
+// Replaces `session.run` of OnnxBiEncoder.embed / OnnxCrossEncoder.encode (ml/onnx/sbert/OnnxBiEncoder.scala:29,
+// OnnxCrossEncoder.scala:38) and the post-processing around it (avgpool :36-60; logits(j)(0) :40-45).
+//
+// Numerics: weights and the operands of every matrix product are fp16, products accumulate in f32 on the matrix
+// cores (v_mfma_f32_32x32x16_f16); the residual stream, LayerNorm statistics, softmax and GELU are f32; the mean
+// pool accumulates in f64 in token order exactly as avgpool does.
+//
+// Layouts: activations are token-major [n*seq, width]; Linear weights stay in the checkpoint's [out, in] order, which
+// is already the "B transposed" form an MFMA B-fragment wants (8 consecutive k per lane = one 16-byte load).
+// MFMA 32x32x16 fragments (guide §3): A lane l = row l&31, k = (l>>5)*8 + j; B lane l = col l&31, same k;
+// C/D lane l = col l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "encoder.hpp"
+
+namespace mrk {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int LN_MAX_PER_LANE = 16;  // hidden <= 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// LayerNorm of one row held as v[e] = row[e*64 + lane]; two-pass statistics in f32 (as the f32 graph computes them)
+__device__ __forceinline__ void layer_norm_row(float (&v)[LN_MAX_PER_LANE], int H, int lane, const float *g, const float *b, float eps,
+                                               float *x_out, _Float16 *xh_out) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < LN_MAX_PER_LANE; ++e) if (e * 64 + lane < H) s += v[e];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < LN_MAX_PER_LANE; ++e) if (e * 64 + lane < H) { const float d = v[e] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int e = 0; e < LN_MAX_PER_LANE; ++e) {
+    const int c = e * 64 + lane;
+    if (c < H) {
+      const float o = (v[e] - mean) * rstd * g[c] + b[c];
+      x_out[c] = o;
+      xh_out[c] = (_Float16)o;
+    }
+  }
+}
+
+// word + position + token-type embeddings, then LayerNorm: one wavefront per token
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *ids, const int32_t *types, int M, int seq, int H, int vocab, int type_vocab,
+                                                       const _Float16 *word, const _Float16 *pos, const _Float16 *type, const float *g, const float *b,
+                                                       float eps, float *x, _Float16 *xh) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= M) return;
+  int id = ids[t], ty = types[t];
+  id = id < 0 ? 0 : id >= vocab ? vocab - 1 : id;
+  ty = ty < 0 ? 0 : ty >= type_vocab ? type_vocab - 1 : ty;
+  const int p = t % seq;
+  float v[LN_MAX_PER_LANE];
+#pragma unroll
+  for (int e = 0; e < LN_MAX_PER_LANE; ++e) {
+    const int c = e * 64 + lane;
+    v[e] = c < H ? ((float)word[(size_t)id * H + c] + (float)pos[(size_t)p * H + c]) + (float)type[(size_t)ty * H + c] : 0.f;
+  }
+  layer_norm_row(v, H, lane, g, b, eps, x + (size_t)t * H, xh + (size_t)t * H);
+}
+
+__global__ __launch_bounds__(256) void ln_kernel(const float *y, int M, int H, const float *g, const float *b, float eps, float *x, _Float16 *xh) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= M) return;
+  float v[LN_MAX_PER_LANE];
+#pragma unroll
+  for (int e = 0; e < LN_MAX_PER_LANE; ++e) {
+    const int c = e * 64 + lane;
+    v[e] = c < H ? y[(size_t)t * H + c] : 0.f;
+  }
+  layer_norm_row(v, H, lane, g, b, eps, x + (size_t)t * H, xh + (size_t)t * H);
+}
+
+// ---- C[M,N] = A[M,K] * W[N,K]^T + bias, fused epilogue -------------------------------------------------
+enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_RES_F32 = 2 };
+constexpr int BK = 32, LDS_PAD = 8;
+
+template <int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, const float *__restrict__ bias,
+                                                   const float *__restrict__ res, void *__restrict__ out, int M, int N, int K) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  __shared__ _Float16 As[BM][BK + LDS_PAD];
+  __shared__ _Float16 Bs[BN][BK + LDS_PAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lr = tid >> 2, lc = (tid & 3) * 8;  // staging: row within a 64-row slab, 8-half chunk
+
+  half8 ra[WM], rb[WN];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      int m = m0 + i * 64 + lr;
+      m = m < M ? m : M - 1;
+      ra[i] = *(const half8 *)(A + (size_t)m * K + k0 + lc);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) rb[j] = *(const half8 *)(W + (size_t)(n0 + j * 64 + lr) * K + k0 + lc);
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) *(half8 *)&As[i * 64 + lr][lc] = ra[i];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) *(half8 *)&Bs[j * 64 + lr][lc] = rb[j];
+  };
+
+  floatx16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = K / BK;
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) load_tiles((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      half8 fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) fa[i] = *(const half8 *)&As[(wr * WM + i) * 32 + fr][kk + fk];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) fb[j] = *(const half8 *)&Bs[(wc * WN + j) * 32 + fr][kk + fk];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < KT) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + (wc * WN + j) * 32 + col;
+      const float bv = bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wr * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (m >= M) continue;
+        float v = acc[i][j][r] + bv;
+        if (EPI == EPI_GELU_F16) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        if (EPI == EPI_RES_F32) ((float *)out)[(size_t)m * N + n] = v + res[(size_t)m * N + n];
+        else ((_Float16 *)out)[(size_t)m * N + n] = (_Float16)v;
+      }
+    }
+}
+
+// ---- attention: one wavefront per (32 queries, head, sequence); scores are computed transposed (keys x queries)
+// so that every lane owns one query column: the row-wise softmax is then a per-lane reduction plus one exchange
+// with lane^32, and the probabilities already sit in B-fragment order for O^T = V^T P^T.
+template <int DH>
+__global__ __launch_bounds__(64) void attention_kernel(const _Float16 *__restrict__ qkv, const int32_t *__restrict__ mask, int seq, int H,
+                                                      float scale, _Float16 *__restrict__ ctx) {
+  constexpr int KC = DH / 16, DT = DH / 32;
+  const int lane = threadIdx.x, q = lane & 31, g = lane >> 5;
+  const int q0 = blockIdx.x * 32, head = blockIdx.y, b = blockIdx.z;
+  const size_t row = (size_t)3 * H;
+  const _Float16 *base = qkv + (size_t)b * seq * row + head * DH;
+  const int32_t *mrow = mask + (size_t)b * seq;
+
+  const int qi = q0 + q < seq ? q0 + q : seq - 1;
+  half8 qf[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) qf[c] = *(const half8 *)(base + (size_t)qi * row + c * 16 + g * 8);
+
+  floatx16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < seq; k0 += 32) {
+    const int kr = k0 + q < seq ? k0 + q : seq - 1;  // A operand: this lane's key row
+    floatx16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const half8 kf = *(const half8 *)(base + (size_t)kr * row + H + c * 16 + g * 8);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c], st, 0, 0, 0);
+    }
+    float p[16];
+    float bm = -FLT_MAX;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      const bool live = key < seq && mrow[key < seq ? key : seq - 1] != 0;
+      p[r] = live ? st[r] * scale : -FLT_MAX;
+      bm = fmaxf(bm, p[r]);
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float m_new = fmaxf(m_run, bm);
+    const float alpha = __expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = p[r] == -FLT_MAX && m_new != -FLT_MAX ? 0.f : __expf(p[r] - m_new);
+      ls += p[r];
+    }
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    // O^T += V^T P^T, 16 keys per MFMA; slot j of chunk c stands for key 16c + 8(j>>2) + 4g + (j&3) on BOTH operands
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      half8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (_Float16)p[8 * c + j];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        half8 vf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int key = k0 + 16 * c + 8 * (j >> 2) + 4 * g + (j & 3);
+          key = key < seq ? key : seq - 1;
+          vf[j] = base[(size_t)key * row + 2 * H + d * 32 + q];
+        }
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[d], 0, 0, 0);
+      }
+    }
+  }
+  if (q0 + q >= seq) return;
+  const float inv = 1.0f / l_run;
+  _Float16 *dst = ctx + ((size_t)b * seq + q0 + q) * H + head * DH;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      half4 h;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h[k] = (_Float16)(o[d][r4 * 4 + k] * inv);
+      *(half4 *)(dst + d * 32 + 8 * r4 + 4 * g) = h;
+    }
+}
+
+// OnnxBiEncoder.avgpool (OnnxBiEncoder.scala:36-60): f64 sum of the first sum(mask) tokens in token order
+__global__ void meanpool_kernel(const float *x, const int32_t *mask, int seq, int H, float *out) {
+  const int b = blockIdx.x;
+  int cnt = 0;
+  for (int j = 0; j < seq; ++j) cnt += mask[(size_t)b * seq + j];
+  for (int d = threadIdx.x; d < H; d += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < cnt && j < seq; ++j) acc += (double)x[((size_t)b * seq + j) * H + d];
+    out[(size_t)b * H + d] = (float)(acc / (double)cnt);
+  }
+}
+
+// BertPooler (dense + tanh on the [CLS] row) and the 1-logit classifier: one workgroup per sequence
+__global__ __launch_bounds__(256) void classify_kernel(const float *x, int seq, int H, const _Float16 *pw, const float *pb, const float *cw,
+                                                       const float *cb, float *out) {
+  extern __shared__ float sm[];  // H inputs | 4 partials
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *cls = x + (size_t)b * seq * H;
+  for (int c = tid; c < H; c += 256) sm[c] = cls[c];
+  __syncthreads();
+  float part = 0.f;
+  for (int o = tid; o < H; o += 256) {
+    float acc = 0.f;
+    const _Float16 *w = pw + (size_t)o * H;
+    for (int c = 0; c < H; ++c) acc += (float)w[c] * sm[c];
+    part += tanhf(acc + pb[o]) * cw[o];
+  }
+  part = wave_sum(part);
+  if ((tid & 63) == 0) sm[H + (tid >> 6)] = part;
+  __syncthreads();
+  if (tid == 0) out[b] = ((sm[H] + sm[H + 1]) + (sm[H + 2] + sm[H + 3])) + cb[0];
+}
+
+template <int EPI>
+void launch_gemm(const uint16_t *A, const uint16_t *W, const float *bias, const float *res, void *out, int M, int N, int K, hipStream_t s) {
+  // 128x128 tiles once the grid still covers the chip with them, 64x64 tiles otherwise
+  const bool big = N % 128 == 0 && (size_t)((M + 127) / 128) * (N / 128) >= 256;
+  if (big) {
+    dim3 grid(N / 128, (M + 127) / 128);
+    hipLaunchKernelGGL((gemm_kernel<2, 2, EPI>), grid, dim3(256), 0, s, (const _Float16 *)A, (const _Float16 *)W, bias, res, out, M, N, K);
+  } else {
+    dim3 grid(N / 64, (M + 63) / 64);
+    hipLaunchKernelGGL((gemm_kernel<1, 1, EPI>), grid, dim3(256), 0, s, (const _Float16 *)A, (const _Float16 *)W, bias, res, out, M, N, K);
+  }
+}
+
+}  // namespace
+
+void encoder_forward(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, hipStream_t s) {
+  const EncoderShape &sh = enc.shape;
+  const int M = n * seq, H = sh.hidden, I = sh.inter, DH = H / sh.heads;
+  if (M <= 0) return;
+  sc.x.reserve((size_t)M * H * 4);
+  sc.xh.reserve((size_t)M * H * 2);
+  sc.qkv.reserve((size_t)M * 3 * H * 2);
+  sc.ctx.reserve((size_t)M * H * 2);
+  sc.mid.reserve((size_t)M * I * 2);
+  sc.y.reserve((size_t)M * H * 4);
+  const int32_t *ids = sc.ids.as<int32_t>(), *types = ids + M, *mask = ids + 2 * (size_t)M;
+  float *x = sc.x.as<float>(), *y = sc.y.as<float>();
+  uint16_t *xh = sc.xh.as<uint16_t>(), *qkv = sc.qkv.as<uint16_t>(), *ctx = sc.ctx.as<uint16_t>(), *mid = sc.mid.as<uint16_t>();
+  const int row_blocks = (M + 3) / 4;
+  hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids, types, M, seq, H, sh.vocab, sh.type_vocab, (const _Float16 *)enc.word,
+                     (const _Float16 *)enc.pos, (const _Float16 *)enc.type, enc.embg, enc.embb, sh.eps, x, (_Float16 *)xh);
+  const float scale = 1.0f / sqrtf((float)DH);
+  for (const LayerDev &L : enc.layers) {
+    launch_gemm<EPI_F16>(xh, L.wqkv, L.bqkv, nullptr, qkv, M, 3 * H, H, s);
+    dim3 ag((seq + 31) / 32, sh.heads, n);
+    if (DH == 32) hipLaunchKernelGGL((attention_kernel<32>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, seq, H, scale, (_Float16 *)ctx);
+    else hipLaunchKernelGGL((attention_kernel<64>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, seq, H, scale, (_Float16 *)ctx);
+    launch_gemm<EPI_RES_F32>(ctx, L.wo, L.bo, x, y, M, H, H, s);
+    hipLaunchKernelGGL(ln_kernel, dim3(row_blocks), dim3(256), 0, s, (const float *)y, M, H, L.ln1g, L.ln1b, sh.eps, x, (_Float16 *)xh);
+    launch_gemm<EPI_GELU_F16>(xh, L.w1, L.b1, nullptr, mid, M, I, H, s);
+    launch_gemm<EPI_RES_F32>(mid, L.w2, L.b2, x, y, M, H, I, s);
+    hipLaunchKernelGGL(ln_kernel, dim3(row_blocks), dim3(256), 0, s, (const float *)y, M, H, L.ln2g, L.ln2b, sh.eps, x, (_Float16 *)xh);
+  }
+  MRK_HIP(hipGetLastError());
+}
+
+void encoder_meanpool(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, float *d_out, hipStream_t s) {
+  if (n <= 0) return;
+  const int32_t *mask = sc.ids.as<int32_t>() + 2 * (size_t)n * seq;
+  hipLaunchKernelGGL(meanpool_kernel, dim3(n), dim3(128), 0, s, (const float *)sc.x.as<float>(), mask, seq, enc.shape.hidden, d_out);
+  MRK_HIP(hipGetLastError());
+}
+
+void encoder_classify(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, float *d_out, hipStream_t s) {
+  if (n <= 0) return;
+  const int H = enc.shape.hidden;
+  hipLaunchKernelGGL(classify_kernel, dim3(n), dim3(256), (H + 4) * sizeof(float), s, (const float *)sc.x.as<float>(), seq, H,
+                     (const _Float16 *)enc.pool_w, enc.pool_b, enc.cls_w, enc.cls_b, d_out);
+  MRK_HIP(hipGetLastError());
+}
+
+}  // namespace mrk

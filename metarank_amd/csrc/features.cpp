@@ -8,6 +8,7 @@
 #include <limits>
 #include <set>
 
+#include "encoder.hpp"
 #include "json.hpp"
 
 namespace mrk {
@@ -247,6 +248,11 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
              o.at("method").at("type").as_string() == "bi-encoder") {
     f->type = FType::Biencoder;
     f->ext_field = "__embedding:" + nm;
+    if (const json::Value *rf = o.find("rankingField"))  // "ranking.<field>": the query text (FieldMatchBiencoderFeature.scala:89-92)
+      if (rf->is_string()) {
+        const std::string &s = rf->as_string();
+        f->field = s.compare(0, 8, "ranking.") == 0 ? s.substr(8) : s;
+      }
     const json::Value *d = o.at("method").find("dim");
     if (!d || d->is_null()) bad("feature '" + nm + "': method.dim (embedding size) is required");
     f->qdim = (int)d->as_int();
@@ -491,6 +497,36 @@ ProgramDev Program::device_view() const {
   return d;
 }
 
+Registry::~Registry() {
+  for (auto &f : features)
+    if (f->encoder) encoder_release(f->encoder);
+}
+
+void unbind_encoders(mrk_ctx *ctx) {
+  std::vector<mrk_encoder *> drop;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->registry)
+      for (auto &f : ctx->registry->features)
+        if (f->encoder) { drop.push_back(f->encoder); f->encoder = nullptr; }
+  }
+  for (mrk_encoder *e : drop) encoder_release(e);
+}
+
+void bind_encoder(mrk_ctx *ctx, const char *feature, mrk_encoder *enc) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_bind_encoder: load a config first");
+  for (auto &f : ctx->registry->features)
+    if (f->name == feature) {
+      if (f->type != FType::Biencoder) throw StatusError(MRK_ERR_UNSUPPORTED, std::string("feature ") + feature + " is not a bi-encoder field_match");
+      encoder_retain(enc);
+      if (f->encoder) encoder_release(f->encoder);
+      f->encoder = enc;
+      return;
+    }
+  throw StatusError(MRK_ERR_NOT_FOUND, std::string("feature ") + feature + " is not configured");
+}
+
 const Program *Registry::program(const std::string &model) const {
   auto it = programs.find(model);
   return it == programs.end() ? nullptr : it->second.get();
@@ -696,8 +732,41 @@ HostCell host_cell(const Store &st, ScopeId scope, int32_t slot, ColRef c) {
 
 }  // namespace
 
+// the request's rankingField as one string (StringField as is, StringListField joined by " ")
+static bool query_text(const mrk_request &rq, const FeatureDef &f, std::string &out) {
+  if (f.field.empty()) return false;
+  const mrk_field *fl = fields_map_get(rq, f.field);
+  if (!fl) return false;
+  if (fl->type == MRK_FIELD_STRING && fl->str) { out = fl->str; return true; }
+  if (fl->type == MRK_FIELD_STRING_LIST) {
+    out.clear();
+    for (int k = 0; k < fl->n; ++k) { if (k) out.push_back(' '); if (fl->strs && fl->strs[k]) out += fl->strs[k]; }
+    return true;
+  }
+  return false;
+}
+
 void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs, int n_req, HostBatch &hb) {
   hb = HostBatch();
+  // queries of encoder-backed bi-encoder columns: every distinct uncached text of the batch goes through the device
+  // encoder in one call, before the per-request loop reads them back
+  std::map<std::pair<mrk_encoder *, std::string>, std::vector<float>> queries;
+  for (const HostOp &ho : prog.host_ops) {
+    const FeatureDef &f = *ho.def;
+    if (f.type != FType::Biencoder || !f.encoder) continue;
+    std::vector<std::string> texts;
+    std::string text;
+    for (int r = 0; r < n_req; ++r) {
+      const mrk_field *fl = fields_map_get(reqs[r], f.ext_field);
+      if (fl && fl->type == MRK_FIELD_NUMBER_LIST) continue;
+      if (query_text(reqs[r], f, text) && queries.emplace(std::make_pair(f.encoder, text), std::vector<float>()).second) texts.push_back(text);
+    }
+    if (!texts.empty()) {
+      std::vector<std::vector<float>> out;
+      encoder_embed_cached(f.encoder, texts, out);
+      for (size_t i = 0; i < texts.size(); ++i) queries[std::make_pair(f.encoder, texts[i])] = std::move(out[i]);
+    }
+  }
   int total = 0;
   for (int r = 0; r < n_req; ++r) {
     if (reqs[r].n_items < 0 || (reqs[r].n_items > 0 && !reqs[r].item_ids)) throw StatusError(MRK_ERR_INVALID_ARG, "bad item list");
@@ -784,10 +853,18 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
         case FType::Biencoder: {
           const mrk_field *fl = fields_map_get(rq, f.ext_field);
           cs[ho.const_idx] = -1.0;
-          if (fl && fl->type == MRK_FIELD_NUMBER_LIST) {
+          if (fl && fl->type == MRK_FIELD_NUMBER_LIST) {  // host-side cache hit / host-computed embedding
             if (fl->n > f.qdim) throw StatusError(MRK_ERR_DIM_MISMATCH, "query embedding of " + f.name + " is longer than method.dim");
             cs[ho.const_idx] = (double)fl->n;
             for (int k = 0; k < fl->n; ++k) cs[ho.const_idx + 1 + k] = (double)(float)fl->nums[k];
+          } else if (f.encoder) {  // rankingCache miss -> encoder.embed(Array(queryString)), FieldMatchBiencoderFeature.scala:93-99
+            std::string text;
+            if (query_text(rq, f, text)) {
+              const std::vector<float> &q = queries.at(std::make_pair(f.encoder, text));
+              if ((int)q.size() > f.qdim) throw StatusError(MRK_ERR_DIM_MISMATCH, "encoder of " + f.name + " returns more than method.dim values");
+              cs[ho.const_idx] = (double)q.size();
+              for (size_t k = 0; k < q.size(); ++k) cs[ho.const_idx + 1 + k] = (double)q[k];
+            }
           }
           break;
         }

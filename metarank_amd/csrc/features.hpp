@@ -10,6 +10,8 @@
 
 #include "rank.hpp"
 
+struct mrk_encoder;
+
 namespace mrk {
 
 enum class FType {
@@ -40,6 +42,7 @@ struct FeatureDef {
   std::vector<int32_t> periods;         // window_count / rate: PeriodRange.startOffset per column
   int64_t list_count = 100;             // interacted_with: BoundedListConfig.count
   int64_t list_duration_ms = 24LL * 3600 * 1000;
+  mrk_encoder *encoder = nullptr;       // bi-encoder with `method.model`: bound by mrk_config_bind_encoder (one reference held)
 };
 
 // host-side description of what a request has to supply for one op
@@ -69,6 +72,7 @@ struct Registry {
   std::vector<std::unique_ptr<FeatureDef>> features;
   std::map<std::string, std::unique_ptr<Program>> programs;
   const Program *program(const std::string &model) const;
+  ~Registry();
 };
 
 // parses the config, declares every state column in `store`, freezes the layout, builds and

@@ -155,6 +155,8 @@ void ctx_release(mrk_ctx *ctx);
 
 // capi_rank.cpp: releases ctx->registry / ctx->store
 void free_rank_state(mrk_ctx *ctx);
+// features.cpp: drops the encoder references mrk_config_bind_encoder took
+void unbind_encoders(mrk_ctx *ctx);
 
 // score.hip
 void launch_score(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,

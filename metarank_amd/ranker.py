@@ -185,6 +185,10 @@ class HipRanker:
         N.check(N.lib().mrk_model_warmup(self.ctx.handle, booster.handle, model_name.encode(), C.byref(n)))
         return n.value
 
+    def bind_encoder(self, feature: str, encoder):
+        """mrk_config_bind_encoder: the bi-encoder `feature` embeds its rankingField text on the device from now on"""
+        N.check(N.lib().mrk_config_bind_encoder(self.ctx.handle, feature.encode(), encoder.handle))
+
     def prepare(self, model_name: str, events) -> Batch:
         return Batch(self, model_name, events)
 
