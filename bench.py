@@ -14,6 +14,9 @@ score -> sort for `--requests` requests of `--items` candidate items each.
              feature store and its own requests; for N > 1 the per-step scores are merged with one RCCL
              all-gather (the only exchange the path has).
 --workload c3   1000-item requests, 64 mixed columns (BASELINE config 3), 384 requests per GPU per step.
+--workload c5   c2 plus one bi-encoder column (BASELINE config 5): every request carries its own query TEXT; a step =
+                the device forward pass of the step's queries (all-MiniLM-L6-v2's architecture, random weights, fp16)
+                followed by the rank batch.  Its JSON carries an extra "encoder" object.
 --workload c4   ONE request with 100 000 candidates (BASELINE config 4), item-sharded over the ranks:
              every rank assembles + scores its slice, one in-place RCCL all-gather of the f64 scores,
              then the sort.  Strong scaling ("scaling": "strong").
@@ -48,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2")
     ap.add_argument("--requests", type=int, default=None, help="requests per step per GPU (c2: 3840, c3: 384, c4: 1)")
     ap.add_argument("--items", type=int, default=None, help="candidate items per request (c2: 100, c3: 1000, c4: 100000)")
     ap.add_argument("--streams", type=int, default=None,
@@ -64,9 +67,9 @@ def main():
     args = ap.parse_args()
     wl = args.workload
     if args.requests is None:
-        args.requests = {"c2": 3840, "c3": 384, "c4": 1}[wl]
+        args.requests = {"c2": 3840, "c3": 384, "c4": 1, "c5": 3840}[wl]
     if args.items is None:
-        args.items = {"c2": 100, "c3": 1000, "c4": 100_000}[wl]
+        args.items = {"c2": 100, "c3": 1000, "c4": 100_000, "c5": 100}[wl]
     sharded = wl == "c4"
     if args.streams is None:
         args.streams = 1 if sharded else 2
@@ -93,7 +96,7 @@ def main():
     from metarank_amd import ranklens, synth
 
     ctx = M.Context(local_rank)
-    cfg = ranklens.c3_config() if wl == "c3" else ranklens.ranklens_config()
+    cfg = ranklens.c3_config() if wl == "c3" else ranklens.c5_config() if wl == "c5" else ranklens.ranklens_config()
     if args.drop_features:
         drop = set(args.drop_features.split(","))
         cfg["features"] = [f for f in cfg["features"] if f["name"] not in drop]
@@ -101,6 +104,13 @@ def main():
     ranker = M.HipRanker(cfg, ctx)
     model_name = "xgboost"
     dim = ranker.dim(model_name)
+    enc = tok = None
+    if wl == "c5":  # no network for checkpoints: the architecture of all-MiniLM-L6-v2 with random weights
+        from metarank_amd.encoder import HipEncoder, HipTokenizer
+        tok_json = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=128)
+        enc = HipEncoder(synth.bert_safetensors(synth.synthetic_bert(), 12), tok_json, ctx=ctx)
+        tok = HipTokenizer(tok_json)
+        ranker.bind_encoder("title_match", enc)
 
     # ---- state: one generation pass feeds the device store (and the CPU oracle on rank 0, N=1)
     oracle = None
@@ -125,7 +135,11 @@ def main():
         fn_o = {"double": s.put_double, "string": s.put_string, "string_list": s.put_string_list,
                 "double_list": s.put_double_list, "counter": s.put_counter, "periodic": s.put_periodic,
                 "bounded_list": s.put_bounded_list}
-    for kind, key, value in ranklens.generate_state(args.catalogue, args.sessions, c3=(wl == "c3")):
+    import itertools
+    state = ranklens.generate_state(args.catalogue, args.sessions, c3=(wl == "c3"))
+    if wl == "c5":
+        state = itertools.chain(state, ranklens.c5_embeddings(args.catalogue))
+    for kind, key, value in state:
         fn_h[kind](key, value)
         if oracle is not None:
             fn_o[kind](key, value)
@@ -138,6 +152,14 @@ def main():
     all_events = [ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
                                              seed=ranklens.SEED + 1 + (0 if sharded else rank) + 1000 * k) for k in range(n_streams)]
     events = all_events[0]
+    qtok = None
+    if wl == "c5":  # a distinct query per request; the step's forward pass runs over these token ids
+        qtok = []
+        for k, evs in enumerate(all_events):
+            texts = synth.synthetic_queries(len(evs), seed=100 + rank + 1000 * k)
+            for ev, q in zip(evs, texts):
+                ev["fields"] = [{"name": "query", "value": q}]
+            qtok.append(tok.encode_batch(texts))
     sample = ranker.prepare(model_name, ranklens.generate_requests(64, 100, args.catalogue, args.sessions, seed=ranklens.SEED + 99))
     sample.run(None)
     _, _, sm = sample.fetch(matrix=True)
@@ -194,6 +216,8 @@ def main():
 
     def step(i):
         bt, gather = batches[i % n_streams], gathers[i % n_streams]
+        if qtok is not None:
+            enc.embed_ids(*qtok[i % n_streams])
         if sharded:  # this rank's slice -> merge -> order
             bt.run_shard(booster, rank, n_gpus)
             if gather is not None:
@@ -283,10 +307,34 @@ def main():
                         f"in {kernels['score']['avg_ms']:.3f} ms"}
 
     # ---- single-request latency (p50 of mrk_rank: host marshalling + 4 launches + copies)
+    encoder_out = None
+    if enc is not None and rank == 0:
+        ids, types, mask = qtok[0]
+        ts = []
+        for _ in range(prof_steps):
+            t1 = time.perf_counter(); enc.embed_ids(ids, types, mask); ts.append(time.perf_counter() - t1)
+        ems = float(np.median(ts) * 1e3)
+        L, H, I, S = enc.info["layers"], enc.info["hidden"], enc.info["intermediate"], ids.shape[1]
+        fl = ids.shape[0] * S * L * (2 * (4 * H * H + 2 * H * I) + 4 * S * H)
+        encoder_out = {"model": f"bert {L}x{H}, {enc.info['heads']} heads, ffn {I} (all-MiniLM-L6-v2 shape), random weights, fp16 operands / f32 accumulate",
+                       "queries_per_step": int(ids.shape[0]), "padded_tokens_per_query": int(S), "ms_per_step": ems,
+                       "tflops": fl / ems / 1e9, "mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": fl / ems / 1e9 / 2500.0,
+                       "includes": "H2D of token ids and D2H of the embeddings (host-buffer API)"}
     latency = None
     if rank == 0 and args.latency_requests > 0:
-        reqs = [M.Request(e) for e in events[:min(args.latency_requests, max(3, 30_000 // args.items))]]
-        for r in reqs[:min(20, len(reqs))]:
+        lat_events = events[:min(args.latency_requests, max(3, 30_000 // args.items))]
+        if enc is not None:  # a never-seen query per call: tokenise + forward pass + rank, no EmbeddingCache hit
+            lat_events = [dict(e) for e in lat_events]
+            for e, q in zip(lat_events, synth.synthetic_queries(len(lat_events), seed=999)):
+                e["fields"] = [{"name": "query", "value": q}]
+        reqs = [M.Request(e) for e in lat_events]
+        warm = reqs[:min(20, len(reqs))]
+        if enc is not None:
+            warm = []
+            for e, q in zip(lat_events[:20], synth.synthetic_queries(20, seed=998)):
+                e = dict(e); e["fields"] = [{"name": "query", "value": q}]
+                warm.append(M.Request(e))
+        for r in warm:
             ranker.rerank(model_name, r, booster)
         lat = []
         for r in reqs:
@@ -301,7 +349,11 @@ def main():
     if do_cpu:
         forest = OracleForest.from_lightgbm_text(blob)
         n = min(args.cpu_sample, len(events), max(1, 400_000 // args.items))  # bounded: ~10 s of CPU work
-        reqs = [M.Request(e) for e in events[:n]]
+        cpu_events = events[:n]
+        if enc is not None:  # the oracle has no transformer: it is handed the device embeddings (its figure excludes the encoder)
+            embs = enc.embed([e["fields"][0]["value"] for e in cpu_events])
+            cpu_events = [dict(e, fields=[{"name": "__embedding:title_match", "value": [float(x) for x in v]}]) for e, v in zip(cpu_events, embs)]
+        reqs = [M.Request(e) for e in cpu_events]
         for r in reqs[:3]:
             forest.predict(oracle.plan.assemble(oracle.store, r))
         t1 = time.perf_counter()
@@ -365,6 +417,7 @@ def main():
                        "parallelism": (f"item-sharded x{n_gpus}" if sharded else f"request-sharded x{n_gpus}") +
                                       (", RCCL all-gather of scores" if n_gpus > 1 else "")},
             "latency": latency,
+            "encoder": encoder_out,
             "kernels": kernels,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "runtime.hpp"
@@ -57,6 +58,8 @@ struct EncoderScratch {
 // encoder.hip ------------------------------------------------------------------------------------
 // d_ids: 3 x n x seq int32 (ids | type_ids | mask) already on the device.  Leaves the final hidden states in
 // scratch.x (f32 [n*seq, H]).
+// sizes the activation buffers for n x seq tokens (never called while a graph is being captured)
+void encoder_reserve(const EncoderDev &enc, EncoderScratch &s, int n, int seq);
 void encoder_forward(const EncoderDev &enc, EncoderScratch &s, int n, int seq, hipStream_t stream);
 // OnnxBiEncoder.avgpool: scratch.x -> out f32 [n, H] (device)
 void encoder_meanpool(const EncoderDev &enc, EncoderScratch &s, int n, int seq, float *d_out, hipStream_t stream);
@@ -68,6 +71,8 @@ void encoder_retain(mrk_encoder *e);
 void encoder_release(mrk_encoder *e);
 // EmbeddingCache semantics: embeddings of `texts` (cached by text; misses run through the device in one batch)
 void encoder_embed_cached(mrk_encoder *e, const std::vector<std::string> &texts, std::vector<std::vector<float>> &out);
+// logits of already assembled ([CLS] a [SEP] b [SEP]) rows; padded per chunk, any number of rows
+void encoder_score_rows(mrk_encoder *e, const std::vector<Encoding> &rows, float *out);
 void bind_encoder(mrk_ctx *ctx, const char *feature, mrk_encoder *enc);
 
 }  // namespace mrk
@@ -80,6 +85,7 @@ struct mrk_encoder {
   mrk::EncoderScratch scratch;
   mrk::PinBuf h_ids, h_out;  // pinned staging of one call
   hipStream_t stream = nullptr;
+  std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;  // (n, seq, mode) -> recorded forward pass
   std::mutex mu;           // one forward at a time per handle (scratch is shared)
   int64_t device_bytes = 0;
   // EmbeddingCache: query text -> embedding (FieldMatchBiencoderFeature.scala:96-99)

@@ -276,6 +276,27 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
     f->type = FType::ExternalRanking;
     f->ext_field = "__ext:" + nm;
     f->dim = (int)need(o, "dim", nm).as_int();
+  } else if (type == "field_match" && o.find("method") && o.at("method").find("type") &&
+             o.at("method").at("type").as_string() == "cross-encoder") {
+    // FieldMatchCrossEncoderFeature: logits of (rankingField text, stored item text) pairs.  Without a bound encoder
+    // it behaves like the other host-computed columns: values arrive as item field "__ext:<name>" (ScoreCache hits).
+    f->type = FType::ExternalItem;
+    f->cross = true;
+    f->ext_field = "__ext:" + nm;
+    f->dim = 1;
+    if (const json::Value *rf = o.find("rankingField"))
+      if (rf->is_string()) {
+        const std::string &s = rf->as_string();
+        f->field = s.compare(0, 8, "ranking.") == 0 ? s.substr(8) : s;
+      }
+    if (const json::Value *n = o.find("norm"))
+      if (!n->is_null()) {
+        const std::string &s = n->as_string();
+        if (s == "noop") f->norm = NORM_NOOP;
+        else if (s == "linear") f->norm = NORM_MINMAX;
+        else if (s == "position") throw StatusError(MRK_ERR_UNSUPPORTED, "feature '" + nm + "': norm 'position' is not implemented for cross-encoder columns");
+        else bad("normalizer " + s + " is not supported");
+      }
   } else if (type == "field_match" || type == "random") {
     // Lucene analyzers / ONNX cross-encoder / RNG stay on the JVM: per-item values arrive as
     // item field "__ext:<name>"
@@ -518,7 +539,10 @@ void bind_encoder(mrk_ctx *ctx, const char *feature, mrk_encoder *enc) {
   if (!ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_bind_encoder: load a config first");
   for (auto &f : ctx->registry->features)
     if (f->name == feature) {
-      if (f->type != FType::Biencoder) throw StatusError(MRK_ERR_UNSUPPORTED, std::string("feature ") + feature + " is not a bi-encoder field_match");
+      if (f->type != FType::Biencoder && !f->cross)
+        throw StatusError(MRK_ERR_UNSUPPORTED, std::string("feature ") + feature + " is not a bi-encoder / cross-encoder field_match");
+      if (f->cross && !enc->dev.shape.classifier)
+        throw StatusError(MRK_ERR_UNSUPPORTED, std::string("feature ") + feature + " needs a cross-encoder (pooler + classifier head)");
       encoder_retain(enc);
       if (f->encoder) encoder_release(f->encoder);
       f->encoder = enc;
@@ -544,6 +568,8 @@ std::unique_ptr<Registry> load_config(const char *json_text, size_t len, Store &
     reg->features.push_back(std::move(f));
   }
   for (auto &f : reg->features) declare_columns(*f, store);
+  for (auto &f : reg->features)
+    if (f->cross) store.texts[f->name];  // item texts of this column are kept on the host (Store::put_string)
   store.freeze_layout();
   const json::Value *models = root.find("models");
   if (models && models->is_object()) {
@@ -767,6 +793,60 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
       for (size_t i = 0; i < texts.size(); ++i) queries[std::make_pair(f.encoder, texts[i])] = std::move(out[i]);
     }
   }
+  // cross-encoder columns: every (query, item text) pair of the batch goes through the device encoder; the logits
+  // come back as per-item overrides of the (NaN-filled) column, FieldMatchCrossEncoderFeature.scala:80-111
+  struct CrossValue { int req, item, dst; double v; };
+  std::vector<CrossValue> cross_values;
+  for (const HostOp &ho : prog.host_ops) {
+    const FeatureDef &f = *ho.def;
+    if (!f.cross || !f.encoder) continue;
+    auto &texts = store.texts[f.name];
+    const Tokenizer &tk = f.encoder->tok;
+    std::vector<Encoding> rows;
+    std::vector<std::pair<int, int>> where;
+    std::string text;
+    for (int r = 0; r < n_req; ++r) {
+      if (!query_text(reqs[r], f, text)) continue;
+      const std::vector<int32_t> q = tk.pieces(text);
+      for (int i = 0; i < reqs[r].n_items; ++i) {
+        auto it = texts.find(reqs[r].item_ids[i] ? reqs[r].item_ids[i] : "");
+        if (it == texts.end()) continue;
+        if (reqs[r].item_field_offsets && reqs[r].item_fields) {  // a score the caller already has (ScoreCache hit) wins
+          bool given = false;
+          for (const mrk_field *p = reqs[r].item_fields + reqs[r].item_field_offsets[i], *pe = reqs[r].item_fields + reqs[r].item_field_offsets[i + 1]; p != pe; ++p)
+            if (p->name && f.ext_field == p->name) { given = true; break; }
+          if (given) continue;
+        }
+        Store::ItemText &e = it->second;
+        if (!e.tokenized) { e.pieces = tk.pieces(e.text); e.tokenized = true; }
+        rows.push_back(tk.assemble(q, &e.pieces));
+        where.emplace_back(r, i);
+      }
+    }
+    if (rows.empty()) continue;
+    std::vector<float> logits(rows.size());
+    encoder_score_rows(f.encoder, rows, logits.data());
+    size_t at = 0;
+    while (at < where.size()) {  // one request at a time: Normalize.scale over the request's values
+      size_t end = at;
+      while (end < where.size() && where[end].first == where[at].first) ++end;
+      double lo = 0, hi = 0;
+      bool any = false;
+      for (size_t k = at; k < end; ++k) {
+        const double v = (double)logits[k];
+        if (v != v) continue;
+        lo = any ? std::min(lo, v) : v;
+        hi = any ? std::max(hi, v) : v;
+        any = true;
+      }
+      for (size_t k = at; k < end; ++k) {
+        double v = (double)logits[k];  // SingleValue(name, score: Float) widens
+        if (f.norm == NORM_MINMAX && any) v = (v - lo) / (hi - lo);  // Normalize.scala:14-22
+        cross_values.push_back({where[k].first, where[k].second, ho.dst, v});
+      }
+      at = end;
+    }
+  }
   int total = 0;
   for (int r = 0; r < n_req; ++r) {
     if (reqs[r].n_items < 0 || (reqs[r].n_items > 0 && !reqs[r].item_ids)) throw StatusError(MRK_ERR_INVALID_ARG, "bad item list");
@@ -971,6 +1051,8 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
     hb.max_req_entries = std::max(hb.max_req_entries, arena - arena_at_start);
     begin += rq.n_items;
   }
+  for (const CrossValue &c : cross_values)
+    if (c.v == c.v) hb.overrides.push_back({(uint32_t)(hb.reqs[c.req].item_begin + c.item), (uint32_t)c.dst, c.v});
   if (arena > 0xffffffffull) throw StatusError(MRK_ERR_UNSUPPORTED, "batch needs more than 2^32 hash-table entries");
   hb.arena_entries = arena;
 }

@@ -42,6 +42,7 @@ struct FeatureDef {
   std::vector<int32_t> periods;         // window_count / rate: PeriodRange.startOffset per column
   int64_t list_count = 100;             // interacted_with: BoundedListConfig.count
   int64_t list_duration_ms = 24LL * 3600 * 1000;
+  bool cross = false;                   // field_match / cross-encoder: per-item logits of (query, item text) pairs
   mrk_encoder *encoder = nullptr;       // bi-encoder with `method.model`: bound by mrk_config_bind_encoder (one reference held)
 };
 

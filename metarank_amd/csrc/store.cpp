@@ -167,6 +167,22 @@ bool Store::put_bool(const char *key, bool v) {
 }
 
 bool Store::put_string(const char *key, const char *v) {
+  if (!texts.empty()) {  // a cross-encoder column's item text
+    ScopeId sc;
+    std::string id, feature;
+    if (split_key(key, sc, id, feature) && sc == SC_ITEM) {
+      auto t = texts.find(feature);
+      if (t != texts.end()) {
+        if (!v) throw StatusError(MRK_ERR_INVALID_ARG, "null string value");
+        ItemText &e = t->second[id];
+        e.text = v;
+        e.pieces.clear();
+        e.tokenized = false;
+        ++version;
+        return true;
+      }
+    }
+  }
   Cell c;
   if (!locate(key, c)) return false;
   kind_check(c.c, COL_SCALAR, key);
@@ -258,6 +274,10 @@ bool Store::erase(const char *key) {
   ScopeId sc;
   std::string id, feature;
   if (!split_key(key, sc, id, feature)) throw StatusError(MRK_ERR_INVALID_ARG, "malformed key");
+  if (sc == SC_ITEM) {
+    auto tx = texts.find(feature);
+    if (tx != texts.end()) { ++version; return tx->second.erase(id) > 0; }
+  }
   Table &t = tables[sc];
   auto it = t.col_of.find(feature);
   if (it == t.col_of.end()) return false;

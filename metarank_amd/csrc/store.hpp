@@ -127,6 +127,10 @@ struct Store {
   struct PendingInc { uint8_t table; uint32_t slot; uint32_t ring_col; int64_t bucket, inc; };
   std::vector<PendingInc> pending;   // staged PeriodicIncrements
   std::unordered_map<std::string, std::vector<std::pair<int64_t, std::string>>> lists;  // raw bounded lists, newest first
+  // item texts of cross-encoder columns (FieldMatchCrossEncoderFeature.scala:60-70 stores SString(text) under the item
+  // scope): host-only, tokenised lazily by the bound encoder's tokenizer; feature -> item id -> text
+  struct ItemText { std::string text; std::vector<int32_t> pieces; bool tokenized = false; };
+  std::unordered_map<std::string, std::unordered_map<std::string, ItemText>> texts;
   DevBuf d_groups, d_updates;        // scratch of the apply kernel
   bool frozen = false;       // layout frozen after the first slot is created
   uint64_t version = 0;      // bumped on every put

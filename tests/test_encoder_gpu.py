@@ -114,6 +114,28 @@ def test_minilm_shape_against_oracle(minilm, n, seq):
     np.testing.assert_allclose(logits, bert.cross_logits(w, ids, types, mask, heads=12, fp16=True), rtol=0, atol=ATOL_MODEL)
 
 
+def test_a_row_does_not_depend_on_the_batch_it_travels_in(minilm):
+    """The three GEMM kernels (skinny: M <= 64 rows; 64x64 tiles; 128x128 tiles) chain their MFMAs in the same k order
+    and share one epilogue, so a sequence's hidden states are the same bits whatever else is in the batch -- the
+    EmbeddingCache can hold an embedding computed in any batch."""
+    w, enc, _ = minilm
+    rng = np.random.default_rng(77)
+    seq = 20
+    ids = rng.integers(5, 2000, size=(1700, seq)).astype(np.int32)
+    mask = np.ones_like(ids); mask[1::2, 13:] = 0
+    alone = enc.hidden_ids(ids[:1], None, mask[:1])            # M = 20: skinny kernel
+    few = enc.hidden_ids(ids[:6], None, mask[:6])              # M = 120: 64x64 tiles
+    many = enc.hidden_ids(ids, None, mask)                     # M = 34000: 128x128 tiles
+    np.testing.assert_array_equal(alone[0], few[0])
+    np.testing.assert_array_equal(few[:6], many[:6])
+    import os
+    os.environ["MRK_ENCODER_GRAPH"] = "1"                      # recorded graph replay vs direct launches
+    try:
+        np.testing.assert_array_equal(enc.hidden_ids(ids[:1], None, mask[:1]), alone)
+    finally:
+        del os.environ["MRK_ENCODER_GRAPH"]
+
+
 def test_head_size_64(minilm):
     """BERT-base style heads (64 wide): 2 layers x 128, 2 heads"""
     w = synth.synthetic_bert(layers=2, hidden=128, heads=2, inter=256, vocab=300, max_pos=64, seed=4)
@@ -132,10 +154,15 @@ def test_load_errors():
     with pytest.raises(N.MrkError) as e:
         HipEncoder(synth.bert_safetensors(w, 2), synth.wordpiece_tokenizer_json(vocab_size=100))
     assert e.value.status == N.ERR_UNSUPPORTED
+    w = synth.synthetic_bert(layers=1, hidden=64, heads=2, inter=128, vocab=50, max_pos=16)
     del w["encoder.layer.0.output.dense.bias"]
     with pytest.raises(N.MrkError) as e:
         HipEncoder(synth.bert_safetensors(w, 2), synth.wordpiece_tokenizer_json(vocab_size=100))
     assert e.value.status == N.ERR_PARSE
+    with pytest.raises(N.MrkError) as e:  # heads unknown: no metadata, none passed
+        from safetensors.numpy import save
+        HipEncoder(save(synth.synthetic_bert(layers=1, hidden=64, heads=2, inter=128, vocab=50, max_pos=16)), synth.wordpiece_tokenizer_json(vocab_size=100))
+    assert e.value.status == N.ERR_INVALID_ARG
     g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
     enc = HipEncoder(open(os.path.join(GOLDEN, "encoder_tiny.safetensors"), "rb").read(), TOK_TINY)
     with pytest.raises(N.MrkError) as e:  # 48 positions in the tiny model
@@ -206,3 +233,84 @@ def test_c5_query_encoded_on_the_device(minilm):
         assert ok.sum() > 50 and np.abs(col32[ok] - mats[k][:, 24][ok]).max() < ATOL_COS
     finally:
         hip.close()
+
+
+def test_cross_encoder_column(minilm):
+    """FieldMatchCrossEncoderFeature end to end: item texts are stored (Put SString under the item scope), the request
+    carries the query text, the device scores every (query, item text) pair; items without a text are NaN, requests
+    without a query are NaN, a score the caller supplies ("__ext:<name>", the ScoreCache hit) wins.  The matrix, scores
+    and order must equal the assembly oracle's when it is handed the same logits; the logits themselves are checked
+    against oracle/bert.py."""
+    w, enc, tok = minilm
+    for norm in ("noop", "linear"):
+        cfg = ranklens.ranklens_config()
+        cfg["features"].append({"name": "title_cross", "type": "field_match", "itemField": "item.title", "rankingField": "ranking.query",
+                                "method": {"type": "cross-encoder", "model": "metarank/ce-msmarco-MiniLM-L6-v2"}, "norm": norm})
+        cfg["models"]["xgboost"]["features"] = cfg["models"]["xgboost"]["features"] + ["title_cross"]
+        orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+        try:
+            for b in (orc, hip):
+                ranklens.load_state(b, ranklens.generate_state(N_ITEMS, N_SESS))
+            titles = synth.synthetic_queries(N_ITEMS, seed=21, words=(1, 7))
+            rng = np.random.default_rng(8)
+            has_text = rng.random(N_ITEMS) > 0.05
+            for i in range(N_ITEMS):
+                if has_text[i]:
+                    hip.ranker.put_string(f"item={i}/title_cross", titles[i])
+            hip.ranker.put_string("item=0/title_cross", "to be deleted")
+            hip.ranker.delete("item=0/title_cross")
+            has_text[0] = False
+            hip.ranker.bind_encoder("title_cross", enc)
+            queries = synth.synthetic_queries(6, seed=31)
+            reqs = ranklens.generate_requests(6, 60, N_ITEMS, N_SESS, seed=53)
+            text_reqs, ext_reqs, all_logits = [], [], []
+            for k, ev in enumerate(reqs):
+                t, e = dict(ev), dict(ev)
+                if k != 4:  # request 4 has no query: NaN column
+                    t["fields"] = [{"name": "query", "value": queries[k]}]
+                    known = [it["id"] for it in ev["items"] if it["id"].isdigit() and has_text[int(it["id"])]]
+                    logits = enc.score_pairs([queries[k]] * len(known), [titles[int(i)] for i in known])
+                    all_logits.append((queries[k], [titles[int(i)] for i in known], logits))
+                    vals = logits.astype(np.float64)
+                    if norm == "linear":  # Normalize.scala:14-22
+                        vals = (vals - vals.min()) / (vals.max() - vals.min())
+                    by_id = dict(zip(known, vals))
+                    e["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": float(by_id[it["id"]])}]) if it["id"] in by_id else it
+                                  for it in ev["items"]]
+                if k == 2:  # ScoreCache hit for the first item: the given score is used, the pair is not encoded
+                    first = ev["items"][0]["id"]
+                    t["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": 0.125}]) if it["id"] == first else it for it in ev["items"]]
+                    if norm == "noop":
+                        e["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": 0.125}]) if it["id"] == first else it for it in e["items"]]
+                text_reqs.append(t); ext_reqs.append(e)
+            if norm == "linear":  # min/max of request 2 would be taken over the encoded pairs only; keep that case to noop
+                text_reqs[2] = dict(text_reqs[2], items=reqs[2]["items"])
+            mats = [orc.matrix(ev) for ev in ext_reqs]
+            col = np.concatenate(mats)[:, 24]
+            assert np.isnan(col).any() and np.isfinite(col).sum() > 200
+            blob = synth.synthetic_lgbm_model(n_trees=200, n_features=25, quantiles=ranklens.column_quantiles(np.concatenate(mats)),
+                                              cat_features=[7], cat_prob=0.01, missing="per_feature")
+            orc.load_model(blob, 0)
+            hip.load_model(blob, 0)
+            batch = hip.ranker.prepare("xgboost", text_reqs)
+            batch.run(hip.booster)
+            scores, order, mat = batch.fetch(matrix=True)
+            assert (batch.status() == 0).all()
+
+            def same(a, b):
+                a, b = np.asarray(a), np.asarray(b)
+                return a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+            for r, ev in enumerate(ext_reqs):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                _, es, eo = orc.rerank(ev)
+                assert same(mat[lo:hi], mats[r]), (norm, r)
+                assert same(scores[lo:hi], es), (norm, r)
+                assert order[lo:hi].tolist() == eo.tolist(), (norm, r)
+            batch.close()
+            if norm == "noop":  # the logits against the CPU restatement of the graph
+                q, ts, logits = all_logits[0]
+                ids, types, mask = tok.encode_batch([q] * len(ts), ts)
+                want = bert.cross_logits(w, ids, types, mask, heads=12, fp16=True)
+                np.testing.assert_allclose(logits, want, rtol=0, atol=ATOL_MODEL)
+        finally:
+            hip.close()
