@@ -76,33 +76,79 @@ __device__ __forceinline__ int scoped_slot(const ReqDev &rq, int scope, int item
 // multiply-high range reduction of a multiplicative hash.
 __device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t cap) { return __umulhi(tok * 2654435761u, cap); }
 
-__device__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok) {
+// Both primitives are written for the wavefront, not for the lane: the probe loop runs while ANY active lane is
+// still looking (one scalar branch per round), lanes that are done - or that never wanted anything (`want`
+// false) - ride along on selects.  A per-lane `while` costs ~25 scalar exec-mask instructions per probe.
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+__device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
+  // tab / cap may differ between lanes (item-parallel kernel: lanes of several requests in one wavefront)
   uint32_t idx = tok_home(tok, cap);
-  for (uint32_t probe = 0; probe < cap; ++probe) {
-    unsigned long long cur = tab[idx];
-    if (cur == 0ull) {
-      unsigned long long prev = atomicCAS(&tab[idx], 0ull, (unsigned long long)tok | (1ull << 32));
-      if (prev == 0ull) return true;
-      cur = prev;
-    }
-    if ((uint32_t)cur == tok) {
-      atomicAdd(&tab[idx], 1ull << 32);
-      return true;
-    }
+  bool open = want, full = false;
+  const unsigned long long fresh = (unsigned long long)tok | (1ull << 32);
+  for (uint32_t probe = 1; wave_any(open); ++probe) {
+    unsigned long long prev = ~0ull;  // riding lanes: a foreign key
+    if (open) prev = atomicCAS(&tab[idx], 0ull, fresh);  // empty -> {tok, 1}
+    const bool same = open && (uint32_t)prev == tok;
+    if (same) atomicAdd(&tab[idx], 1ull << 32);
+    open = open && prev != 0ull && !same;
+    full = full || (open && probe >= cap);  // every entry holds another key
+    open = open && probe < cap;
     idx = idx + 1 == cap ? 0 : idx + 1;
   }
-  return false;
+  return !full;
 }
 
-__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok) {
+__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   uint32_t idx = tok_home(tok, cap);
-  for (uint32_t probe = 0; probe < cap; ++probe) {
-    unsigned long long cur = tab[idx];
-    if (cur == 0ull) return 0;
-    if ((uint32_t)cur == tok) return (uint32_t)(cur >> 32);
+  uint32_t res = 0;
+  bool open = want;
+  for (uint32_t probe = 1; wave_any(open); ++probe) {
+    const unsigned long long cur = tab[idx];  // every lane reads: idx stays inside its table
+    const uint32_t key = (uint32_t)cur;
+    res = open && key == tok ? (uint32_t)(cur >> 32) : res;
+    open = open && key != tok && key != 0u && probe < cap;  // keys are token ids >= 1: key 0 = empty entry
     idx = idx + 1 == cap ? 0 : idx + 1;
   }
-  return 0;
+  return res;
+}
+
+// The tokens of a list are fetched TOK_BATCH at a time (independent loads in flight together) before the
+// probes start: one trip to memory per batch instead of one per token.
+constexpr int TOK_BATCH = 8;
+
+// every token of tok_pool[off, off + len) -> table (pre-pass); len = 0 for lanes without a list.  Returns the
+// number of tokens this lane could not insert (table full).
+__device__ __forceinline__ uint32_t table_add_list(const StoreDev &st, unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len) {
+  uint32_t failed = 0;
+  for (uint32_t j0 = 0; wave_any(j0 < len); j0 += TOK_BATCH) {
+    uint32_t tk[TOK_BATCH];
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? st.tok_pool[off + j0 + t] : 0u;
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) {
+      if (!wave_any(j0 + t < len)) break;
+      failed += table_add(tab, cap, tk[t], j0 + t < len) ? 0u : 1u;
+    }
+  }
+  return failed;
+}
+
+// sum over the tokens of tok_pool[off, off + len) of their table counts, added as doubles in list order
+// (InteractedWithFeature.scala:150-160 / DiversityFeature.scala:112-122: integers, exact)
+__device__ __forceinline__ double table_sum_list(const StoreDev &st, const unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len) {
+  double cnt = 0.0;
+  for (uint32_t j0 = 0; wave_any(j0 < len); j0 += TOK_BATCH) {
+    uint32_t tk[TOK_BATCH];
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? st.tok_pool[off + j0 + t] : 0u;
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) {
+      if (!wave_any(j0 + t < len)) break;
+      cnt = cnt + (double)table_get(tab, cap, tk[t], j0 + t < len);  // riding lanes add 0.0
+    }
+  }
+  return cnt;
 }
 
 // ---------------------------------------------------------------- pre-pass
@@ -215,7 +261,7 @@ __device__ double median_of(double *s_vals, int n_raw, int *s_misc) {
 //   * the diversity entries share the pass that finds each one's first candidate with state, the load that
 //     decides string vs number, and - for the string ones - the pass over the first `top` candidates
 //     (one multi-flag prefix scan keeps request order); numeric ones then take their median one by one.
-__device__ void prepass_request(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, int r, const ReqDev &rq,
+__device__ __forceinline__ void prepass_request(const StoreDev &st, const ProgramDev &prog, const BatchDev &b, int r, const ReqDev &rq,
                                 unsigned long long *tab_base, uint32_t tab_sub, PrepOut *po_out, const PrepScratch &sc) {
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
@@ -275,10 +321,9 @@ __device__ void prepass_request(const StoreDev &st, const ProgramDev &prog, cons
         }
 #pragma unroll
         for (int u = 0; u < PREP_GROUP; ++u) {
-          if (u < n && ic[u].tag == TAG_STRING_LIST) {
-            const uint32_t toff = ic[u].lo(), tlen = ic[u].hi();
-            for (uint32_t j = 0; j < tlen; ++j)
-              if (!table_add(tab[u], cap[u], st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
+          if (u < n) {  // uniform
+            const bool list = ic[u].tag == TAG_STRING_LIST;
+            if (table_add_list(st, tab[u], cap[u], ic[u].lo(), list ? ic[u].hi() : 0u)) atomicOr(&b.status[r], ST_TABLE_FULL);
           }
         }
       }
@@ -374,16 +419,14 @@ __device__ void prepass_request(const StoreDev &st, const ProgramDev &prog, cons
         block_scan_flags(cand, n, sc.wave_tot(), excl, total);
 #pragma unroll
         for (int u = 0; u < PREP_GROUP; ++u) {
-          if (u < n && cand[u] && running[u] + excl[u] < top[u]) {
-            if (c[u].tag == TAG_STRING) {
-              if (!table_add(tab[u], cap[u], c[u].lo())) atomicOr(&b.status[r], ST_TABLE_FULL);
-              atomicAdd(&s_tokens[u], 1);
-            } else {
-              const uint32_t toff = c[u].lo(), tlen = c[u].hi();
-              for (uint32_t j = 0; j < tlen; ++j)
-                if (!table_add(tab[u], cap[u], st.tok_pool[toff + j])) atomicOr(&b.status[r], ST_TABLE_FULL);
-              atomicAdd(&s_tokens[u], (int)tlen);
-            }
+          if (u < n && mode[u] == DIV_STRING) {  // uniform
+            const bool take = cand[u] && running[u] + excl[u] < top[u];
+            const bool one = take && c[u].tag == TAG_STRING;
+            const uint32_t tlen = take && !one ? c[u].hi() : 0u;
+            uint32_t failed = table_add(tab[u], cap[u], c[u].lo(), one) ? 0u : 1u;
+            failed += table_add_list(st, tab[u], cap[u], c[u].lo(), tlen);
+            if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
+            if (take) atomicAdd(&s_tokens[u], one ? 1 : (int)tlen);
           }
           running[u] += total[u];
         }
@@ -642,12 +685,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
           const PrepOut po = pos[op.i1 + f];
           const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
           const Cell c = load_cell(irec, col);
-          double cnt = 0.0;
-          if (c.tag == TAG_STRING_LIST) {
-            const uint32_t off = c.lo(), len = c.hi();
-            for (uint32_t j = 0; j < len; ++j) cnt = cnt + (double)table_get(tab, po.tab_cap, st.tok_pool[off + j]);
-          }
-          sink.put(dst + f, cnt);
+          sink.put(dst + f, table_sum_list(st, tab, po.tab_cap, c.lo(), c.tag == TAG_STRING_LIST ? c.hi() : 0u));
         }
         break;
       }
@@ -661,14 +699,10 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const ProgramD
           if (c.tag == TAG_DOUBLE) v = c.f64() - po.scalar;
         } else {
           const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
-          if (c.tag == TAG_STRING) {
-            v = (0.0 + (double)table_get(tab, po.tab_cap, c.lo())) / po.scalar;
-          } else if (c.tag == TAG_STRING_LIST) {
-            const uint32_t off = c.lo(), len = c.hi();
-            double w = 0.0;
-            for (uint32_t j = 0; j < len; ++j) w = w + (double)table_get(tab, po.tab_cap, st.tok_pool[off + j]);
-            v = w / po.scalar;
-          }
+          const bool one = c.tag == TAG_STRING, list = c.tag == TAG_STRING_LIST;
+          const double w1 = 0.0 + (double)table_get(tab, po.tab_cap, c.lo(), one);
+          const double wl = table_sum_list(st, tab, po.tab_cap, c.lo(), list ? c.hi() : 0u);
+          if (one || list) v = (one ? w1 : wl) / po.scalar;
         }
         sink.put(dst + 0, v);
         break;
