@@ -119,6 +119,11 @@ int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len);
 
 /* number of matrix columns (DatasetDescriptor.dim) for a configured model, <0 on error */
 int mrk_model_dim(mrk_ctx *ctx, const char *model_name);
+/* Host-only (no device, no context): what the library builds the first time a model of this config is ranked - the
+ * assembly kernel specialised for the model's feature list (the reference fixes that list per model when the config is
+ * loaded, M/FeatureMapping.scala:56-99; here it becomes compile-time constants of the kernel).  what = 0: the HIP source
+ * handed to hiprtc; what = 1: the gfx950 code object.  MRK_ERR_INVALID_ARG with *needed set when `cap` is too small. */
+int mrk_config_specialize(const char *json, size_t len, const char *model_name, int what, uint8_t *out, size_t cap, size_t *needed);
 
 /* ------------------------- feature store (KVStore[Key, FeatureValue] mirror) */
 

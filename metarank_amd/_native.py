@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
-SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "score.hip", "score_qs.hip", "rank.hip", "writes.hip", "encoder.hip"]
+SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "jit.cpp", "score.hip", "score_qs.hip", "rank.hip", "writes.hip", "encoder.hip"]
 HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
 
 MRK_OK = 0
@@ -30,8 +30,33 @@ def sources():
     return [os.path.join(CSRC, f) for f in SOURCES + extra]
 
 
+# device headers that make up the translation unit of the run-time specialised assembly kernel (csrc/jit.cpp), in
+# include order
+JIT_HEADERS = ["device_types.hpp", "rank.hpp", "qs_device.hpp", "rank_device.hpp"]
+
+
+def embed_jit_sources() -> str:
+    """csrc/jit_embed.inc: the JIT_HEADERS without their #include / #pragma once lines as C++ raw string literals (the
+    text hiprtc compiles, followed at run time by the model's program as constants).  Generated, not committed."""
+    parts = []
+    for h in JIT_HEADERS:
+        lines = [ln for ln in open(os.path.join(CSRC, h)).read().split("\n")
+                 if not ln.startswith("#include") and not ln.startswith("#pragma once")]
+        parts.append(f"// ---- {h}\n" + "\n".join(lines))
+    text = "\n".join(parts)
+    assert ')MRKJIT"' not in text
+    # one literal per header: compilers cap the length of a single string literal, adjacent literals concatenate
+    out = "\n".join('R"MRKJIT(' + p + '\n)MRKJIT"' for p in parts) + "\n"
+    path = os.path.join(CSRC, "jit_embed.inc")
+    if not os.path.exists(path) or open(path).read() != out:
+        with open(path, "w") as f:
+            f.write(out)
+    return path
+
+
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every source into metarank_amd/libmrk_hip.so (in-tree)."""
+    embed_jit_sources()
     srcs = sources()
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [
         os.path.join(REPO, "include", "mrk.h")]
@@ -42,7 +67,8 @@ def build(force: bool = False) -> str:
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
            "-ffp-contract=off",  # the JVM never fuses a*b+c; parity with the reference is bit-exact
-           "-o", LIB_PATH] + [f"-D{d}" for d in os.environ.get("MRK_DEFINES", "").split()] + srcs
+           "-o", LIB_PATH] + [f"-D{d}" for d in os.environ.get("MRK_DEFINES", "").split()] + srcs + [
+               "-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"]  # hiprtc: csrc/jit.cpp
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -87,6 +113,7 @@ SIGNATURES = {
     "mrk_model_free": (None, [_V]),
     "mrk_config_load_json": (_I, [_V, _S, C.c_size_t]),
     "mrk_model_dim": (_I, [_V, _S]),
+    "mrk_config_specialize": (_I, [_S, C.c_size_t, _S, _I, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mrk_store_put_double": (_I, [_V, _S, C.c_double]),
     "mrk_store_put_bool": (_I, [_V, _S, _I]),
     "mrk_store_put_string": (_I, [_V, _S, _S]),

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "features.hpp"
+#include "jit.hpp"
 #include "qs_device.hpp"
 #include "rank.hpp"
 #include "runtime.hpp"
@@ -20,7 +21,7 @@ void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows,
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
                            uint16_t *cells, bool f64);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
-                       int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64);
+                       int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads);
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
@@ -207,7 +208,7 @@ static void check_model_fits(mrk_model *model, const Program &prog) {
 static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &pd) {
   mrk_ctx *ctx = b.ctx;
   if (b.fused_ok) {
-    launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, nullptr, nullptr, true);
+    launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, nullptr, nullptr, true, nullptr);
   } else {
     launch_prepass(ctx, st, pd, b.view);
     launch_assemble(ctx, st, pd, b.view);
@@ -261,7 +262,8 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
       MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (size_t)(hi / QS_TILE_ROWS) * tile_bytes, 0, tile_bytes, b.s()));
     const bool f64 = model->forest.backend == Backend::LightGBM;
     if (b.fused_ok) {
-      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64);
+      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64,
+                        jit_rank_function(*b.prog, f64));
     } else {
       launch_prepass(ctx, st, pd, b.view);
       launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64);
@@ -331,6 +333,27 @@ int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len) {
     std::unique_ptr<Registry> reg = load_config(json, len, *st);
     ctx->store = st.release();
     ctx->registry = reg.release();
+  });
+}
+
+int mrk_config_specialize(const char *json, size_t len, const char *model_name, int what, uint8_t *out, size_t cap, size_t *needed) {
+  return guard([&] {
+    if (!json || !model_name || !needed || (what != 0 && what != 1)) throw StatusError(MRK_ERR_INVALID_ARG, "null argument / unknown `what`");
+    Store st;
+    std::unique_ptr<Registry> reg = load_config(json, len, st, /*upload=*/false);
+    const Program *p = reg->program(model_name);
+    if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
+    const std::string src = jit_source(*p);
+    std::vector<char> code;
+    if (what == 1) {
+      std::string log;
+      code = jit_compile(src, log);
+    }
+    const char *data = what == 0 ? src.data() : code.data();
+    const size_t n = what == 0 ? src.size() : code.size();
+    *needed = n;
+    if (cap < n || (n && !out)) throw StatusError(MRK_ERR_INVALID_ARG, "output buffer too small (see *needed)");
+    memcpy(out, data, n);
   });
 }
 

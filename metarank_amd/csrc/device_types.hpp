@@ -1,0 +1,78 @@
+// Plain types shared by host code and device code: the record tags / scopes of the feature store (store.hpp),
+// what kernels see of the store, and the structs of the bit-vector forest format (forest.hpp).  This header, rank.hpp,
+// qs_device.hpp and rank_device.hpp are also the translation unit of the run-time specialised assembly kernel
+// (jit.cpp: hiprtc), so they use nothing but fixed-width integers.
+#pragma once
+#ifdef __HIPCC_RTC__
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#else
+#include <cstddef>
+#include <cstdint>
+#endif
+
+namespace mrk {
+
+// ---- feature store (layout: store.hpp)
+enum ScopeId : int {
+  SC_GLOBAL = 0, SC_ITEM = 1, SC_USER = 2, SC_SESSION = 3, SC_RANKING = 4, SC_FIELD = 5, SC_IRF = 6, SC_COUNT = 7
+};
+
+// tag byte of a record cell
+enum Tag : uint8_t {
+  TAG_MISSING = 0,
+  TAG_DOUBLE = 1,       // ScalarValue(SDouble): cell = f64
+  TAG_BOOL = 2,         // ScalarValue(SBoolean): cell = f64 0/1
+  TAG_STRING = 3,       // ScalarValue(SString): cell = {u32 token, u32 linked field slot + 1 (0 = none)}
+  TAG_STRING_LIST = 4,  // ScalarValue(SStringList): cell = {u32 offset into token pool, u32 length}
+  TAG_DOUBLE_LIST = 5,  // ScalarValue(SDoubleList): cell = {u32 offset into f64 pool, u32 length}
+  TAG_PRESENT = 1,      // counter / bounded list present; periodic: tag = 1 + min(len, 250)
+};
+
+struct TableDev {          // what kernels see
+  const uint8_t *rows;
+  uint32_t stride;
+  uint32_t n_slots;
+};
+
+struct StoreDev {
+  TableDev tab[SC_COUNT];
+  const uint32_t *tok_pool;
+  const double *f64_pool;
+  const uint32_t *slot_pool;
+};
+
+// ---- bit-vector forest format (described in forest.hpp)
+constexpr int QS_SLOTS = 16;
+constexpr int QS_LEAVES = 16;
+constexpr int QS_TREE_WORDS = QS_SLOTS * 2;
+constexpr int QS_MAX_VIEWS = 255;
+constexpr uint16_t QS_RIGHT = 0x7FFF;
+enum QsViewKind : uint8_t { QV_NAN_RIGHT = 0, QV_NAN_LEFT = 1, QV_MISS_RIGHT = 2, QV_MISS_LEFT = 3, QV_CAT = 4, QV_NAN_ZERO = 5 };
+
+constexpr uint16_t QS_CAT_BEYOND = 0x7FFD, QS_CAT_INVALID = 0x7FFE, QS_CAT_NAN = 0x7FFF;
+struct QsView {        // 4 B, one per column of the binned tile; grouped by feature
+  uint16_t feature;
+  uint8_t kind;        // QsViewKind
+  uint8_t pad;
+};
+struct QsCatNode {     // 16 B
+  uint32_t view_dl;    // view index | default_left << 16 (XGBoost: where NaN goes)
+  uint32_t mm;         // m | m << 16
+  uint32_t bits_begin; // first word of the bitset in PackedForestQS::cat_bits
+  uint32_t bits_words;
+};
+struct QsFeature {     // 16 B, one per matrix column
+  uint32_t thr_off, thr_len;       // sorted distinct thresholds of this column in PackedForestQS::thr
+  uint16_t view_begin, view_end;   // its views
+  uint32_t zero_bin;               // bin(0.0): the cell of a NaN in a QV_NAN_ZERO view
+};
+
+}  // namespace mrk

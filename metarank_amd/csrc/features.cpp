@@ -9,6 +9,7 @@
 #include <set>
 
 #include "encoder.hpp"
+#include "jit.hpp"
 #include "json.hpp"
 
 namespace mrk {
@@ -506,6 +507,8 @@ void upload(Program &p) {
 
 }  // namespace
 
+Program::~Program() { jit_release(*this); }
+
 ProgramDev Program::device_view() const {
   ProgramDev d{};
   d.ops = (const Op *)d_ops.p;
@@ -556,7 +559,7 @@ const Program *Registry::program(const std::string &model) const {
   return it == programs.end() ? nullptr : it->second.get();
 }
 
-std::unique_ptr<Registry> load_config(const char *json_text, size_t len, Store &store) {
+std::unique_ptr<Registry> load_config(const char *json_text, size_t len, Store &store, bool do_upload) {
   json::Value root = json::parse(json_text, len);
   std::unique_ptr<Registry> reg(new Registry());
   const json::Value *feats = root.find("features");
@@ -586,7 +589,7 @@ std::unique_ptr<Registry> load_config(const char *json_text, size_t len, Store &
           if (f->name == fn.as_string()) { ordered.push_back(f.get()); break; }
       }
       build_program(*p, ordered, store);
-      upload(*p);
+      if (do_upload) upload(*p);
       reg->programs[kv.first] = std::move(p);
     }
   }

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "rank.hpp"
+#include "store.hpp"
 
 struct mrk_encoder;
 
@@ -66,7 +67,10 @@ struct Program {
   int n_consts = 0;
   int n_irf = 0;
   DevBuf d_ops, d_prep, d_aux;
+  mutable void *jit = nullptr;      // JitKernels* (jit.cpp): the kernel specialised for this program, built on first use
+  mutable bool jit_failed = false;
   ProgramDev device_view() const;
+  ~Program();
 };
 
 struct Registry {
@@ -78,7 +82,8 @@ struct Registry {
 
 // parses the config, declares every state column in `store`, freezes the layout, builds and
 // uploads the programs
-std::unique_ptr<Registry> load_config(const char *json, size_t len, Store &store);
+// (`upload` false: host-side only, for mrk_config_specialize)
+std::unique_ptr<Registry> load_config(const char *json, size_t len, Store &store, bool upload = true);
 
 // ---- host half of a batch -------------------------------------------------------------------
 struct HostBatch {

@@ -4,6 +4,8 @@
 #include <string>
 #include <vector>
 
+#include "device_types.hpp"
+
 namespace mrk {
 
 enum class Backend : int { LightGBM = 0, XGBoost = 1 };
@@ -140,30 +142,7 @@ PackedForest pack_forest(const Forest &f, uint32_t chunk_bytes);
 // words} and are tested against their bitset one by one.  One all-zero tree is appended so that the
 // scorer's prefetch of "the next tree" never leaves the array.
 // Leaves are stored in left-to-right position order, QS_LEAVES per tree.
-constexpr int QS_SLOTS = 16;
-constexpr int QS_LEAVES = 16;
-constexpr int QS_TREE_WORDS = QS_SLOTS * 2;
-constexpr int QS_MAX_VIEWS = 255;
-constexpr uint16_t QS_RIGHT = 0x7FFF;
-enum QsViewKind : uint8_t { QV_NAN_RIGHT = 0, QV_NAN_LEFT = 1, QV_MISS_RIGHT = 2, QV_MISS_LEFT = 3, QV_CAT = 4, QV_NAN_ZERO = 5 };
-
-constexpr uint16_t QS_CAT_BEYOND = 0x7FFD, QS_CAT_INVALID = 0x7FFE, QS_CAT_NAN = 0x7FFF;
-struct QsView {        // 4 B, one per column of the binned tile; grouped by feature
-  uint16_t feature;
-  uint8_t kind;        // QsViewKind
-  uint8_t pad;
-};
-struct QsCatNode {     // 16 B
-  uint32_t view_dl;    // view index | default_left << 16 (XGBoost: where NaN goes)
-  uint32_t mm;         // m | m << 16
-  uint32_t bits_begin; // first word of the bitset in PackedForestQS::cat_bits
-  uint32_t bits_words;
-};
-struct QsFeature {     // 16 B, one per matrix column
-  uint32_t thr_off, thr_len;       // sorted distinct thresholds of this column in PackedForestQS::thr
-  uint16_t view_begin, view_end;   // its views
-  uint32_t zero_bin;               // bin(0.0): the cell of a NaN in a QV_NAN_ZERO view
-};
+// (constants and device structs of this format: device_types.hpp)
 
 struct PackedForestQS {
   bool ok = false;   // false: the forest does not fit this format; the tree-walk kernel is used

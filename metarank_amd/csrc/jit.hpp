@@ -1,0 +1,19 @@
+// Run-time specialised assembly kernel (jit.cpp).
+#pragma once
+#include <string>
+#include <vector>
+
+namespace mrk {
+
+struct Program;
+
+// the translation unit hiprtc compiles for this model's program: the shared device code + the program as constants
+std::string jit_source(const Program &prog);
+// gfx950 code object of `source`; throws StatusError(MRK_ERR_DEVICE) with the compiler log.  No device needed.
+std::vector<char> jit_compile(const std::string &source, std::string &log);
+// hipFunction_t of the specialised fused kernel for (program, scorer precision), built on first use; nullptr when
+// specialisation is switched off (MRK_RANK_JIT=0) or hiprtc failed (warning on stderr; MRK_RANK_JIT=require throws)
+void *jit_rank_function(const Program &prog, bool f64);
+void jit_release(Program &prog);
+
+}  // namespace mrk

@@ -3,9 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <cstdint>
-
-#include "forest.hpp"
+#include "device_types.hpp"
 
 namespace mrk {
 
@@ -42,16 +40,18 @@ __device__ __forceinline__ double qs_prep(double x, bool &ok) {
 // T: sorted, `len` entries, in global memory (const double *) or LDS (qs_lds_double *).
 template <bool F64, typename P>
 __device__ __forceinline__ uint32_t qs_bin_search(P T, uint32_t len, double x) {
+  // branch-free lower bound: `n` (hence the trip count) is the same in every lane, every read is inside the table
   uint32_t pos = 0;
   if (len) {
-    for (uint32_t step = 1u << (31 - __builtin_clz(len)); step > 0; step >>= 1) {
-      const uint32_t p = pos + step;
-      if (p <= len) {
-        const double t = T[p - 1];
-        const bool below = F64 ? (t < x) : (t <= x);
-        pos = below ? p : pos;
-      }
+    for (uint32_t n = len; n > 1;) {
+      const uint32_t half = n >> 1;
+      const double t = T[pos + half - 1];
+      const bool below = F64 ? (t < x) : (t <= x);
+      pos = below ? pos + half : pos;
+      n -= half;
     }
+    const double t = T[pos];
+    pos += (F64 ? (t < x) : (t <= x)) ? 1u : 0u;
   }
   return pos;
 }

@@ -1,8 +1,6 @@
 // Shared host/device structures of the rank pipeline (pre-pass -> assemble -> score -> sort).
 #pragma once
-#include <cstdint>
-
-#include "store.hpp"
+#include "device_types.hpp"
 
 namespace mrk {
 

@@ -1,0 +1,829 @@
+// Device code of the feature assembly (pre-pass + per-item program), shared by the kernels of rank.hip - which run
+// ANY model program from device memory (ProgramDev) - and by the run-time specialised kernel jit.cpp builds for one
+// model with hiprtc: there `Prog` is a type whose ops / prep / aux are compile-time constants, the op loop unrolls,
+// every switch folds and the record loads of all ops are issued together.
+// Reference: ml/Ranker.scala:27-83,97-106; feature/*.scala (cited per op in rank.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "qs_device.hpp"
+#include "rank.hpp"
+
+namespace mrk {
+
+namespace {
+
+__device__ __forceinline__ double d_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+struct Cell {
+  uint32_t tag;
+  uint64_t bits;
+  __device__ __forceinline__ double f64() const { return __longlong_as_double((long long)bits); }
+  __device__ __forceinline__ long long i64() const { return (long long)bits; }
+  __device__ __forceinline__ uint32_t lo() const { return (uint32_t)bits; }
+  __device__ __forceinline__ uint32_t hi() const { return (uint32_t)(bits >> 32); }
+};
+
+__device__ __forceinline__ const uint8_t *record(const StoreDev &st, int scope, int slot) {
+  if (slot < 0) return nullptr;
+  return st.tab[scope].rows + (size_t)slot * st.tab[scope].stride;
+}
+
+__device__ __forceinline__ Cell load_cell(const uint8_t *rec, ColRef c, int idx = 0) {
+  Cell out;
+  if (rec == nullptr || c.tag < 0) {
+    out.tag = TAG_MISSING;
+    out.bits = 0;
+    return out;
+  }
+  out.tag = rec[c.tag];
+  out.bits = *(const uint64_t *)(rec + c.val + idx * 8);
+  return out;
+}
+
+__device__ __forceinline__ int scoped_slot(const ReqDev &rq, int scope, int item_slot) {
+  switch (scope) {
+    case SC_GLOBAL: return 0;
+    case SC_ITEM: return item_slot;
+    case SC_USER: return rq.user_slot;
+    case SC_SESSION: return rq.session_slot;
+    case SC_RANKING: return rq.ranking_slot;
+    default: return -1;
+  }
+}
+
+// ---------------------------------------------------------------- token -> count hash tables
+// entry = key (token id, >= 1) in the low 32 bits, count in the high 32 bits; 0 = empty.  Open addressing
+// with linear probing; the capacity is any number > the number of tokens inserted (not a power of two:
+// the tables of a request live in LDS and their size sets the occupancy), the home slot is the
+// multiply-high range reduction of a multiplicative hash.
+__device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t cap) { return __umulhi(tok * 2654435761u, cap); }
+
+// Both primitives are written for the wavefront, not for the lane: the probe loop runs while ANY active lane is
+// still looking (one scalar branch per round), lanes that are done - or that never wanted anything (`want`
+// false) - ride along on selects.  A per-lane `while` costs ~25 scalar exec-mask instructions per probe.
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+__device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
+  // tab / cap may differ between lanes (item-parallel kernel: lanes of several requests in one wavefront)
+  uint32_t idx = tok_home(tok, cap);
+  bool open = want, full = false;
+  const unsigned long long fresh = (unsigned long long)tok | (1ull << 32);
+  for (uint32_t probe = 1; wave_any(open); ++probe) {
+    unsigned long long prev = ~0ull;  // riding lanes: a foreign key
+    if (open) prev = atomicCAS(&tab[idx], 0ull, fresh);  // empty -> {tok, 1}
+    const bool same = open && (uint32_t)prev == tok;
+    if (same) atomicAdd(&tab[idx], 1ull << 32);
+    open = open && prev != 0ull && !same;
+    full = full || (open && probe >= cap);  // every entry holds another key
+    open = open && probe < cap;
+    idx = idx + 1 == cap ? 0 : idx + 1;
+  }
+  return !full;
+}
+
+__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
+  uint32_t idx = tok_home(tok, cap);
+  uint32_t res = 0;
+  bool open = want;
+  for (uint32_t probe = 1; wave_any(open); ++probe) {
+    const unsigned long long cur = tab[idx];  // every lane reads: idx stays inside its table
+    const uint32_t key = (uint32_t)cur;
+    res = open && key == tok ? (uint32_t)(cur >> 32) : res;
+    open = open && key != tok && key != 0u && probe < cap;  // keys are token ids >= 1: key 0 = empty entry
+    idx = idx + 1 == cap ? 0 : idx + 1;
+  }
+  return res;
+}
+
+// The tokens of a list are fetched TOK_BATCH at a time (independent loads in flight together) before the
+// probes start: one trip to memory per batch instead of one per token.
+constexpr int TOK_BATCH = 8;
+
+// every token of tok_pool[off, off + len) -> table (pre-pass); len = 0 for lanes without a list.  Returns the
+// number of tokens this lane could not insert (table full).
+__device__ __forceinline__ uint32_t table_add_list(const StoreDev &st, unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len) {
+  uint32_t failed = 0;
+  for (uint32_t j0 = 0; wave_any(j0 < len); j0 += TOK_BATCH) {
+    uint32_t tk[TOK_BATCH];
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? st.tok_pool[off + j0 + t] : 0u;
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) {
+      if (!wave_any(j0 + t < len)) break;
+      failed += table_add(tab, cap, tk[t], j0 + t < len) ? 0u : 1u;
+    }
+  }
+  return failed;
+}
+
+// sum over the tokens of tok_pool[off, off + len) of their table counts, added as doubles in list order
+// (InteractedWithFeature.scala:150-160 / DiversityFeature.scala:112-122: integers, exact)
+__device__ __forceinline__ double table_sum_list(const StoreDev &st, const unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len) {
+  double cnt = 0.0;
+  for (uint32_t j0 = 0; wave_any(j0 < len); j0 += TOK_BATCH) {
+    uint32_t tk[TOK_BATCH];
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? st.tok_pool[off + j0 + t] : 0u;
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; ++t) {
+      if (!wave_any(j0 + t < len)) break;
+      cnt = cnt + (double)table_get(tab, cap, tk[t], j0 + t < len);  // riding lanes add 0.0
+    }
+  }
+  return cnt;
+}
+
+// ---------------------------------------------------------------- pre-pass
+constexpr int PREP_THREADS = 256;
+constexpr int FUSED_MAX_PREP = 32;  // pre-pass entries of one model (PrepOut copies + `first` slots kept in LDS)
+constexpr int PREP_GROUP = 4;       // entries handled by one merged pass (their loads are issued together)
+constexpr int PREP_INTS = 96;       // ints of LDS scratch: wave_tot[4][PREP_GROUP] | first[FUSED_MAX_PREP] | misc[4] | tokens[PREP_GROUP]
+
+struct PrepScratch {   // LDS scratch of one workgroup
+  double *vals;        // vals_cap doubles: diversity median
+  int vals_cap;
+  int *ints;           // PREP_INTS
+  __device__ __forceinline__ int *wave_tot() const { return ints; }                              // [4][PREP_GROUP]
+  __device__ __forceinline__ int *first() const { return ints + 4 * PREP_GROUP; }                // [FUSED_MAX_PREP]
+  __device__ __forceinline__ int *misc() const { return ints + 4 * PREP_GROUP + FUSED_MAX_PREP; }   // [4]
+  __device__ __forceinline__ int *tokens() const { return misc() + 4; }                          // [PREP_GROUP]
+};
+
+// exclusive prefix sum of a 0/1 flag over the workgroup + total (blockDim.x <= 256 = 4 waves of 64)
+__device__ __forceinline__ int block_scan_flag(bool flag, int *s_wave_tot, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_waves = (blockDim.x + 63) >> 6;
+  const unsigned long long ball = __ballot(flag);
+  const int within = __popcll(ball & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave_tot[wave] = __popcll(ball);
+  __syncthreads();
+  int before = 0;
+  total = 0;
+  for (int w = 0; w < n_waves; ++w) {
+    int t = s_wave_tot[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  __syncthreads();
+  return before + within;
+}
+
+// the same for PREP_GROUP flags at once (two barriers for the whole group)
+__device__ __forceinline__ void block_scan_flags(const bool (&flag)[PREP_GROUP], int n, int *s_wave_tot, int (&excl)[PREP_GROUP],
+                                                 int (&total)[PREP_GROUP]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_waves = (blockDim.x + 63) >> 6;
+  int within[PREP_GROUP];
+#pragma unroll
+  for (int u = 0; u < PREP_GROUP; ++u) {
+    const unsigned long long ball = __ballot(u < n && flag[u]);
+    within[u] = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_tot[wave * PREP_GROUP + u] = __popcll(ball);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PREP_GROUP; ++u) {
+    int before = 0, tot = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      const int t = s_wave_tot[w * PREP_GROUP + u];
+      if (w < wave) before += t;
+      tot += t;
+    }
+    excl[u] = before + within[u];
+    total[u] = tot;
+  }
+  __syncthreads();
+}
+
+// commons-math Percentile (LEGACY estimation, NaN removed) .evaluate(50) of s_vals[0, n_raw); whole workgroup
+__device__ double median_of(double *s_vals, int n_raw, int *s_misc) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (n_raw == 1) return s_vals[0];
+  // NaN -> +inf placeholder (sorts last), counted
+  for (int i = tid; i < n_raw; i += nthr) {
+    double v = s_vals[i];
+    if (v != v) { s_vals[i] = __longlong_as_double(0x7ff0000000000000LL); atomicAdd(&s_misc[1], 1); }
+  }
+  int p2 = 1;
+  while (p2 < n_raw) p2 <<= 1;
+  for (int i = n_raw + tid; i < p2; i += nthr) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
+  __syncthreads();
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < p2; i += nthr) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const double a = s_vals[i], c2 = s_vals[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c2) == up) { s_vals[i] = c2; s_vals[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int m = n_raw - s_misc[1];
+  if (m <= 0) return d_nan();
+  const double pos = 0.5 * (double)(m + 1);
+  const double fpos = floor(pos);
+  const int ipos = (int)fpos;
+  const double dif = pos - fpos;
+  if (pos < 1.0) return s_vals[0];
+  if (pos >= (double)m) return s_vals[m - 1];
+  const double lower = s_vals[ipos - 1], upper = s_vals[ipos];
+  return __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
+}
+
+// The pre-pass of request r, run by one whole workgroup.  Tables live at tab_base + (po.tab_off - tab_sub)
+// (HBM arena: tab_sub = 0; LDS: tab_sub = the request's first arena entry); mode / scalar go to po_out[e].
+// The entries are not processed one by one: every global load is a trip to the Infinity Cache, so the loads
+// of up to PREP_GROUP entries are issued together -
+//   * all tables of the request are zeroed in one sweep;
+//   * the interacted_with entries that read the same bounded list (one per field) share ONE pass over the
+//     interacted items: slot -> the field cells of all entries -> their tokens;
+//   * the diversity entries share the pass that finds each one's first candidate with state, the load that
+//     decides string vs number, and - for the string ones - the pass over the first `top` candidates
+//     (one multi-flag prefix scan keeps request order); numeric ones then take their median one by one.
+template <typename Prog>
+__device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &prog, const BatchDev &b, int r, const ReqDev &rq,
+                                unsigned long long *tab_base, uint32_t tab_sub, PrepOut *po_out, const PrepScratch &sc) {
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int n_prep = prog.n_prep;
+  int *s_first = sc.first();
+  int *s_misc = sc.misc();
+  int *s_tokens = sc.tokens();
+
+  // ---- all tables of the request, one sweep (they are contiguous: host assigns them in entry order)
+  {
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (int e = 0; e < n_prep; ++e) {
+      const uint32_t o = po_out[e].tab_off - tab_sub;
+      lo = min(lo, o);
+      hi = max(hi, o + po_out[e].tab_cap);
+    }
+    for (uint32_t i = lo + tid; i < hi; i += nthr) tab_base[i] = 0ull;
+    for (int e = tid; e < n_prep; e += nthr) s_first[e] = 0x7fffffff;
+  }
+  __syncthreads();
+
+  // Per-group state lives in registers indexed at COMPILE time (every loop over the group is fully unrolled
+  // and predicated on u < n): a run-time index into a register array costs a select chain per access.
+
+  // ---- interacted_with (InteractedWithFeature.scala:134-147): histogram of the field tokens of every interacted item
+  for (int e0 = 0; e0 < n_prep;) {
+    const PrepEntry pe0 = prog.prep[e0];
+    if (pe0.kind != PREP_IW_FIELD) { ++e0; continue; }
+    int n = 1;  // consecutive entries on the same bounded list
+    while (n < PREP_GROUP && e0 + n < n_prep) {
+      const PrepEntry q = prog.prep[e0 + n];
+      if (q.kind != PREP_IW_FIELD || q.list_scope != pe0.list_scope || q.list_col.tag != pe0.list_col.tag || q.list_col.val != pe0.list_col.val) break;
+      ++n;
+    }
+    ColRef col[PREP_GROUP];
+    unsigned long long *tab[PREP_GROUP];
+    uint32_t cap[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      const int e = e0 + (u < n ? u : 0);
+      col[u] = prog.prep[e].item_col;
+      tab[u] = tab_base + (po_out[e].tab_off - tab_sub);
+      cap[u] = po_out[e].tab_cap;
+    }
+    const int vslot = pe0.list_scope == SC_SESSION ? rq.session_slot : rq.user_slot;
+    const Cell lc = load_cell(record(st, pe0.list_scope, vslot), pe0.list_col);
+    if (lc.tag != TAG_MISSING) {
+      const uint32_t off = lc.lo(), len = lc.hi();
+      for (uint32_t k = tid; k < len; k += nthr) {
+        const uint8_t *irec = record(st, SC_ITEM, (int)st.slot_pool[off + k]);
+        Cell ic[PREP_GROUP];
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {  // the field cells of all entries: independent loads
+          ic[u].tag = TAG_MISSING;
+          ic[u].bits = 0;
+          if (u < n) ic[u] = load_cell(irec, col[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          if (u < n) {  // uniform
+            const bool list = ic[u].tag == TAG_STRING_LIST;
+            if (table_add_list(st, tab[u], cap[u], ic[u].lo(), list ? ic[u].hi() : 0u)) atomicOr(&b.status[r], ST_TABLE_FULL);
+          }
+        }
+      }
+    }
+    e0 += n;
+  }
+
+  // ---- diversity (DiversityFeature.scala:72-103), PREP_GROUP entries at a time
+  for (int e0 = 0; e0 < n_prep;) {
+    if (prog.prep[e0].kind != PREP_DIVERSITY) { ++e0; continue; }
+    int ent[PREP_GROUP];
+    int n = 0, e1 = e0;
+    for (; e1 < n_prep && n < PREP_GROUP; ++e1) {
+      if (prog.prep[e1].kind != PREP_DIVERSITY) continue;
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) if (u == n) ent[u] = e1;
+      ++n;
+    }
+    ColRef col[PREP_GROUP];
+    unsigned long long *tab[PREP_GROUP];
+    uint32_t cap[PREP_GROUP];
+    int top[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      if (u >= n) ent[u] = e0;
+      col[u] = prog.prep[ent[u]].item_col;
+      top[u] = prog.prep[ent[u]].top;
+      tab[u] = tab_base + (po_out[ent[u]].tab_off - tab_sub);
+      cap[u] = po_out[ent[u]].tab_cap;
+    }
+    // (a) the first candidate that has a ScalarValue decides string vs number - for every entry of the group
+    for (int base = 0; base < rq.n_items; base += nthr) {
+      const int i = base + tid;
+      if (i < rq.n_items) {
+        const uint8_t *irec = record(st, SC_ITEM, b.item_slot[rq.item_begin + i]);
+        Cell c[PREP_GROUP];
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          c[u].tag = TAG_MISSING;
+          if (u < n) c[u] = load_cell(irec, col[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u)
+          if (u < n && c[u].tag != TAG_MISSING) atomicMin(&s_first[ent[u]], i);
+      }
+      __syncthreads();
+      bool all = true;
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) all = all && (u >= n || s_first[ent[u]] != 0x7fffffff);
+      __syncthreads();  // nobody may start the next round's atomicMin before everyone has read
+      if (all) break;
+    }
+    int mode[PREP_GROUP];
+    {
+      Cell h[PREP_GROUP];
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) {
+        h[u].tag = TAG_MISSING;
+        const int first = u < n ? s_first[ent[u]] : 0x7fffffff;
+        if (first != 0x7fffffff) h[u] = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + first]), col[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u)
+        mode[u] = (h[u].tag == TAG_STRING || h[u].tag == TAG_STRING_LIST) ? DIV_STRING : (h[u].tag == TAG_DOUBLE ? DIV_DOUBLE : DIV_EMPTY);
+    }
+    // (b) string entries: the first `top` candidates of that type, in request order, all entries in one pass
+    bool any_string = false;
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) any_string = any_string || (u < n && mode[u] == DIV_STRING);
+    if (tid < PREP_GROUP) s_tokens[tid] = 0;
+    __syncthreads();
+    if (any_string) {
+      int running[PREP_GROUP];
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) running[u] = 0;
+      for (int base = 0; base < rq.n_items; base += nthr) {
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) more = more || (u < n && mode[u] == DIV_STRING && running[u] < top[u]);
+        if (!more) break;
+        const int i = base + tid;
+        Cell c[PREP_GROUP];
+        bool cand[PREP_GROUP];
+        const uint8_t *irec = i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr;
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          c[u].tag = TAG_MISSING;
+          c[u].bits = 0;
+          if (u < n && mode[u] == DIV_STRING) c[u] = load_cell(irec, col[u]);
+          cand[u] = c[u].tag == TAG_STRING || c[u].tag == TAG_STRING_LIST;
+        }
+        int excl[PREP_GROUP], total[PREP_GROUP];
+        block_scan_flags(cand, n, sc.wave_tot(), excl, total);
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          if (u < n && mode[u] == DIV_STRING) {  // uniform
+            const bool take = cand[u] && running[u] + excl[u] < top[u];
+            const bool one = take && c[u].tag == TAG_STRING;
+            const uint32_t tlen = take && !one ? c[u].hi() : 0u;
+            uint32_t failed = table_add(tab[u], cap[u], c[u].lo(), one) ? 0u : 1u;
+            failed += table_add_list(st, tab[u], cap[u], c[u].lo(), tlen);
+            if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
+            if (take) atomicAdd(&s_tokens[u], one ? 1 : (int)tlen);
+          }
+          running[u] += total[u];
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u)
+        if (u < n && mode[u] != DIV_DOUBLE) {
+          po_out[ent[u]].mode = mode[u];
+          // stringCounts.values.foldLeft(0.0)(_ + _): integers, exact in f64
+          po_out[ent[u]].scalar = mode[u] == DIV_STRING ? (double)s_tokens[u] : 0.0;
+        }
+    }
+    // (c) numeric entries, one at a time: the first `top` present values in request order, then their median
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      if (u >= n || mode[u] != DIV_DOUBLE) continue;
+      if (tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
+      __syncthreads();
+      int running = 0;
+      for (int base = 0; base < rq.n_items && running < top[u]; base += nthr) {
+        const int i = base + tid;
+        Cell c;
+        c.tag = TAG_MISSING;
+        c.bits = 0;
+        if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), col[u]);
+        const bool cand = c.tag == TAG_DOUBLE;
+        int total;
+        const int rank = running + block_scan_flag(cand, sc.wave_tot(), total);
+        if (cand && rank < top[u]) {
+          if (rank < sc.vals_cap) sc.vals[rank] = c.f64();
+          else atomicOr(&b.status[r], ST_TOO_MANY);
+        }
+        running += total;
+      }
+      __syncthreads();
+      const double scalar = median_of(sc.vals, min(min(running, top[u]), sc.vals_cap), s_misc);
+      if (tid == 0) {
+        po_out[ent[u]].mode = DIV_DOUBLE;
+        po_out[ent[u]].scalar = scalar;
+      }
+      __syncthreads();
+    }
+    e0 = e1;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------- assemble
+constexpr int ASM_THREADS = 256;
+
+// java.lang.Math.round(double)
+__device__ __forceinline__ long long java_round(double a) {
+  if (a != a) return 0;
+  if (a >= 9223372036854775807.0) return 0x7fffffffffffffffLL;
+  if (a <= -9223372036854775808.0) return (long long)0x8000000000000000ULL;
+  if (fabs(a) >= 4503599627370496.0) return (long long)a;
+  const double fl = floor(a);
+  return (long long)fl + ((a - fl) >= 0.5 ? 1 : 0);
+}
+
+// Scala Long / Long (truncating; Long.MinValue / -1 wraps); the zero divisor is reported by the caller
+__device__ __forceinline__ long long long_div(long long a, long long b) {
+  if (b == -1) return (long long)(0ull - (unsigned long long)a);
+  return a / b;
+}
+
+// ---- sinks: where an assembled value goes.  A sink is driven by whole wavefronts: lanes without an item
+// (`active` false) run the same program on a missing record and write nothing.
+struct MatrixSink {   // row-major f64 matrix, ClickthroughQuery's layout
+  double *row;
+  bool active;
+  __device__ __forceinline__ void put(int col, double v) const {
+    if (active) row[col] = v;
+  }
+};
+
+template <bool F64>
+struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row] u16
+  QsDev q;
+  uint16_t *dst;      // &cells[tile][0][row]
+  int32_t *status;    // the request's status word
+  qs_lds_double *thr_lds;  // QS_LDS_THR doubles private to this wavefront
+  bool active;
+  // `col` is uniform across the wavefront.  The column's threshold table is staged in LDS by the whole
+  // wavefront (one coalesced load) and searched there: a per-lane binary search in global memory would
+  // be log2(T) scattered wave-loads per column, and scattered loads are what bounds the assembly kernel.
+  __device__ __forceinline__ void put(int col, double v) const {
+    if (col >= q.n_feats) return;
+    const QsFeature ft = q.feats[col];  // scalar loads
+    if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
+    bool ok;
+    const double x = qs_prep<F64>(v, ok);
+    uint32_t pos;
+    if (ft.thr_len <= QS_LDS_THR) {
+      __builtin_amdgcn_wave_barrier();  // LDS ops of one wavefront complete in order: no s_barrier needed
+      for (uint32_t k = threadIdx.x & 63; k < ft.thr_len; k += 64) thr_lds[k] = q.thr[ft.thr_off + k];
+      __builtin_amdgcn_wave_barrier();
+      pos = qs_bin_search<F64>(thr_lds, ft.thr_len, x);
+    } else {
+      pos = qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
+    }
+    uint16_t *d = dst;
+    const bool act = active;
+    qs_emit_views<F64>(x, pos, ft, q.views, [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; });
+    if (!ok && act) atomicOr(status, 32);
+  }
+};
+
+// a program whose ops / prep / aux are compile-time constants (the run-time specialised kernel, jit.cpp) says so
+template <typename P> __device__ __forceinline__ constexpr auto prog_is_static(int) -> decltype(P::is_static) { return P::is_static; }
+template <typename P> __device__ __forceinline__ constexpr bool prog_is_static(...) { return false; }
+
+// f(IntC<I>{}) for I in [I0, I1): a loop whose index is a constant expression in the body
+template <int I> struct IntC { static constexpr int value = I; };
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I0 < I1) {
+    f(IntC<I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+
+// ops whose first load is the cell of their primary column op.c0
+__device__ __forceinline__ constexpr bool op_has_primary(int kind) {
+  return kind == OP_SCALAR_DOUBLE || kind == OP_SCALAR_BOOL || kind == OP_VECTOR || kind == OP_STRING_INDEX || kind == OP_STRING_ONEHOT ||
+         kind == OP_COUNTER || kind == OP_WINDOW || kind == OP_DIVERSITY || kind == OP_ITEM_AGE || kind == OP_BIENCODER;
+}
+
+// Evaluates the model program for batch item gi of request r.  Hash tables: tab_base + (po.tab_off - tab_sub).
+template <typename Prog, typename Sink>
+__device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &prog, const BatchDev &b, int gi, int r,
+                                              const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
+                                              const PrepOut *pos, const Sink &sink) {
+  const int islot = sink.active ? b.item_slot[gi] : -1;  // lanes without an item: a missing record
+  const uint8_t *irec = record(st, SC_ITEM, islot);
+  const double NaN = d_nan();
+
+  // the record an op's primary column (op.c0) lives in
+  auto primary_record = [&](const Op &op) -> const uint8_t * {
+    if (op.kind == OP_DIVERSITY || op.kind == OP_BIENCODER) return irec;
+    if (op.kind == OP_ITEM_AGE) return op.scope == SC_ITEM ? irec : nullptr;
+    return record(st, op.scope, scoped_slot(rq, op.scope, islot));
+  };
+  // one op, given its primary cell `pc` (missing for the kinds without one: op_has_primary)
+  auto run_op = [&](const Op &op, const Cell &pc) __attribute__((always_inline)) {
+    const int dst = op.dst;
+    switch (op.kind) {
+      case OP_SCALAR_DOUBLE: {
+        const Cell c = pc;
+        sink.put(dst + 0, c.tag == TAG_DOUBLE ? c.f64() : NaN);
+        break;
+      }
+      case OP_SCALAR_BOOL: {
+        const Cell c = pc;
+        sink.put(dst + 0, c.tag == TAG_BOOL ? c.f64() : NaN);
+        break;
+      }
+      case OP_VECTOR: {
+        const Cell c = pc;
+        const bool has = c.tag == TAG_DOUBLE_LIST;
+        const uint32_t off = c.lo(), len = c.hi();
+        for (int k = 0; k < op.dim; ++k) {  // every put at a wavefront-uniform point (CellSink stages tables cooperatively)
+          double v = NaN;
+          if (has) v = (uint32_t)k < len ? st.f64_pool[off + k] : 0.0;
+          sink.put(dst + k, v);
+        }
+        break;
+      }
+      case OP_STRING_INDEX: {
+        const Cell c = pc;
+        double idx = 0.0;
+        if (c.tag == TAG_STRING_LIST && c.hi() > 0) {
+          const uint32_t first = st.tok_pool[c.lo()];
+          for (int k = 0; k < op.i1; ++k)
+            if (prog.aux[op.i0 + k] == first) idx = (double)(k + 1);  // zipWithIndex.toMap: last duplicate wins
+        }
+        sink.put(dst + 0, idx);
+        break;
+      }
+      case OP_STRING_ONEHOT: {
+        // OneHotEncoder.fromValues: every token sets the FIRST position whose value equals it (indexOf)
+        const Cell c = pc;
+        const bool has = c.tag == TAG_STRING_LIST;
+        const uint32_t off = c.lo(), len = has ? c.hi() : 0u;
+        for (int k = 0; k < op.dim; ++k) {
+          double v = 0.0;
+          if (k < op.i1) {
+            const uint32_t want = prog.aux[op.i0 + k];
+            bool first = true;  // a duplicate possible value is never reached by indexOf
+            for (int k2 = 0; k2 < k; ++k2) first = first && prog.aux[op.i0 + k2] != want;
+            if (first)
+              for (uint32_t j = 0; j < len; ++j)
+                if (st.tok_pool[off + j] == want) { v = 1.0; break; }
+          }
+          sink.put(dst + k, v);
+        }
+        break;
+      }
+      case OP_COUNTER: {
+        const Cell c = pc;
+        sink.put(dst + 0, c.tag != TAG_MISSING ? (double)c.i64() : 0.0);
+        break;
+      }
+      case OP_WINDOW: {
+        const uint8_t *rec = primary_record(op);
+        const Cell c = pc;
+        const bool ok = c.tag != TAG_MISSING && (int)c.tag - 1 == op.dim;
+        for (int k = 0; k < op.dim; ++k) sink.put(dst + k, ok ? (double)load_cell(rec, op.c0, k).i64() : NaN);
+        break;
+      }
+      case OP_RATE: {
+        const uint8_t *trec = nullptr;  // record holding the target-scope counters
+        ColRef top = op.c0, bot = op.c1;
+        if (op.i0 == RATE_ITEM) {
+          trec = irec;
+        } else if (op.i0 == RATE_ITEM_FIELD) {
+          const Cell link = load_cell(irec, op.c0);  // item=<id>/<name>_field : SString -> field slot
+          if (link.tag == TAG_STRING && link.hi() != 0) trec = record(st, SC_FIELD, (int)link.hi() - 1);
+          top = op.c4;
+          bot = op.c5;
+        } else {
+          const int s = b.irf[(size_t)op.i2 * b.total_items + gi];
+          trec = record(st, SC_IRF, s);
+          top = op.c4;
+          bot = op.c5;
+        }
+        // every value present with exactly `dim` periods, else NaN x dim (RateFeature.scala:318-350)
+        bool valid = trec != nullptr;
+        if (valid) {
+          const Cell t0 = load_cell(trec, top), b0 = load_cell(trec, bot);
+          valid = t0.tag != TAG_MISSING && b0.tag != TAG_MISSING && (int)t0.tag - 1 == op.dim && (int)b0.tag - 1 == op.dim;
+        }
+        const uint8_t *grec = nullptr;
+        if (valid && op.i3 != 0) {
+          grec = record(st, SC_GLOBAL, 0);
+          const Cell gt = load_cell(grec, op.c2), gb = load_cell(grec, op.c3);
+          valid = gt.tag != TAG_MISSING && gb.tag != TAG_MISSING && (int)gt.tag - 1 == op.dim && (int)gb.tag - 1 == op.dim;
+        }
+        bool thrown = false;  // java.lang.ArithmeticException: / by zero aborts the request
+        for (int k = 0; k < op.dim; ++k) {
+          double v = NaN;
+          if (valid && !thrown) {
+            if (op.i3 == 0) {
+              v = (double)load_cell(trec, top, k).i64() / (double)load_cell(trec, bot, k).i64();
+            } else {
+              const long long tg = load_cell(grec, op.c2, k).i64(), bg = load_cell(grec, op.c3, k).i64();
+              if (tg == 0) {
+                if (sink.active) atomicOr(&b.status[r], ST_ARITHMETIC);
+                thrown = true;
+              } else {
+                const double ratio = (double)long_div(bg, tg);
+                const double num = __dadd_rn(op.d0, (double)load_cell(trec, top, k).i64());
+                const double den = __dadd_rn(__dmul_rn(op.d0, ratio), (double)load_cell(trec, bot, k).i64());
+                v = num / den;
+              }
+            }
+          }
+          sink.put(dst + k, v);
+        }
+        break;
+      }
+      case OP_INTERACTED: {
+        // per field: sum over the candidate's tokens of the session histogram
+        for (int f = 0; f < op.dim; ++f) {
+          ColRef col;
+          col.tag = (int32_t)prog.aux[op.i0 + 2 * f];
+          col.val = (int32_t)prog.aux[op.i0 + 2 * f + 1];
+          const PrepOut po = pos[op.i1 + f];
+          const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
+          const Cell c = load_cell(irec, col);
+          sink.put(dst + f, table_sum_list(st, tab, po.tab_cap, c.lo(), c.tag == TAG_STRING_LIST ? c.hi() : 0u));
+        }
+        break;
+      }
+      case OP_DIVERSITY: {
+        const PrepOut po = pos[op.i1];
+        const Cell c = pc;
+        double v = NaN;
+        if (po.mode == DIV_EMPTY) {
+          v = 0.0;
+        } else if (po.mode == DIV_DOUBLE) {
+          if (c.tag == TAG_DOUBLE) v = c.f64() - po.scalar;
+        } else {
+          const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
+          const bool one = c.tag == TAG_STRING, list = c.tag == TAG_STRING_LIST;
+          const double w1 = 0.0 + (double)table_get(tab, po.tab_cap, c.lo(), one);
+          const double wl = table_sum_list(st, tab, po.tab_cap, c.lo(), list ? c.hi() : 0u);
+          if (one || list) v = (one ? w1 : wl) / po.scalar;
+        }
+        sink.put(dst + 0, v);
+        break;
+      }
+      case OP_ITEM_AGE: {
+        const Cell c = pc;
+        double v = NaN;
+        if (c.tag == TAG_DOUBLE) {
+          const long long updated = java_round(c.f64() * 1000.0);
+          long long diff = (long long)((unsigned long long)rq.ts_ms - (unsigned long long)updated);
+          if (diff < 0) diff = (long long)(0ull - (unsigned long long)diff);
+          if (diff < 0 || diff > 9223372036854LL) { if (sink.active) atomicOr(&b.status[r], ST_ILLEGAL_ARG); }  // FiniteDuration bound
+          else v = (double)(diff / 1000);
+        }
+        sink.put(dst + 0, v);
+        break;
+      }
+      case OP_CONST: {
+        const double *cs = b.consts + (size_t)r * prog.n_consts + op.i0;
+        for (int k = 0; k < op.dim; ++k) sink.put(dst + k, cs[k]);
+        break;
+      }
+      case OP_FILL_NAN: {
+        for (int k = 0; k < op.dim; ++k) sink.put(dst + k, NaN);
+        break;
+      }
+      case OP_BIENCODER: {
+        // consts: [0] = query length (or -1: no query), [1..] = query embedding (f32 values widened)
+        const double *cs = b.consts + (size_t)r * prog.n_consts + op.i0;
+        const int qn = (int)cs[0];
+        const Cell c = pc;
+        double v = NaN;
+        if (qn >= 0 && c.tag == TAG_DOUBLE_LIST) {
+          if ((int)c.hi() < qn) {
+            if (sink.active) atomicOr(&b.status[r], ST_DIM);
+          } else {
+            const double *item = st.f64_pool + c.lo();
+            double top = 0.0, a = 0.0, bs = 0.0;
+            for (int k = 0; k < qn; ++k) {
+              const float q = (float)cs[1 + k];
+              top = __dadd_rn(top, __dmul_rn((double)q, item[k]));
+              a = __dadd_rn(a, (double)__fmul_rn(q, q));  // Float * Float is a Float product
+              bs = __dadd_rn(bs, __dmul_rn(item[k], item[k]));
+            }
+            v = top / (sqrt(a) * sqrt(bs));
+          }
+        }
+        sink.put(dst + 0, v);
+        break;
+      }
+      default: break;
+    }
+  };
+
+  if constexpr (prog_is_static<Prog>(0)) {
+    // compile-time program: the loops unroll, every `op` is a constant, and the primary cells of ALL ops are requested
+    // before the first op runs - one trip to memory instead of one per op
+    Cell pc[Prog::n_ops > 0 ? Prog::n_ops : 1];
+    static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int oi = decltype(ic)::value;
+      constexpr Op op = Prog{}.ops[oi];
+      pc[oi].tag = TAG_MISSING;
+      pc[oi].bits = 0;
+      if constexpr (op_has_primary(op.kind)) pc[oi] = load_cell(primary_record(op), op.c0);
+    });
+    static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int oi = decltype(ic)::value;
+      constexpr Op op = Prog{}.ops[oi];
+      run_op(op, pc[oi]);
+    });
+  } else {
+    for (int oi = 0; oi < prog.n_ops; ++oi) {
+      const Op op = prog.ops[oi];
+      Cell pc;
+      pc.tag = TAG_MISSING;
+      pc.bits = 0;
+      if (op_has_primary(op.kind)) pc = load_cell(primary_record(op), op.c0);
+      run_op(op, pc);
+    }
+  }
+}
+
+
+// Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
+// Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][PREP_INTS ints]
+//              [threshold staging: QS_LDS_THR x 8 B per wavefront]
+template <typename Prog, typename SinkMaker>
+__device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
+                                                int vals_cap, const SinkMaker &make_sink) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  unsigned long long *s_tab = (unsigned long long *)smem;
+  double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
+  PrepOut *s_po = (PrepOut *)(smem + (size_t)tab_entries * 8 + (size_t)vals_cap * 8);
+  int *s_int = (int *)(s_po + FUSED_MAX_PREP);
+  qs_lds_double *s_thr = (qs_lds_double *)(s_int + PREP_INTS) + (size_t)(threadIdx.x >> 6) * QS_LDS_THR;
+  const int r = blockIdx.x;
+  const ReqDev rq = b.reqs[r];
+  if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
+  for (int e = threadIdx.x; e < prog.n_prep; e += blockDim.x) s_po[e] = b.prep_out[(size_t)r * prog.n_prep + e];
+  __syncthreads();
+  PrepScratch sc{s_vals, vals_cap, s_int};
+  prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
+  for (int base = 0; base < rq.n_items; base += blockDim.x) {
+    const int i = base + (int)threadIdx.x;
+    const int gi0 = rq.item_begin + i;
+    const bool active = i < rq.n_items && gi0 >= b.item_lo && gi0 < b.item_hi;
+    if (!__any(active)) continue;  // wavefront-uniform
+    const int gi = active ? gi0 : rq.item_begin;
+    assemble_item(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr));
+  }
+}
+
+
+// the hot-path instance of rank_fused_body: straight into the scorer's binned tile
+template <bool F64, typename Prog>
+__device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
+                                                      int vals_cap, const QsDev &q, uint16_t *cells) {
+  rank_fused_body(st, prog, b, tab_entries, vals_cap, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
+    return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
+  });
+}
+
+}  // namespace
+
+}  // namespace mrk

@@ -20,26 +20,14 @@
 #include <unordered_map>
 #include <vector>
 
+#include "device_types.hpp"
 #include "runtime.hpp"
 
 namespace mrk {
 
-enum ScopeId : int {
-  SC_GLOBAL = 0, SC_ITEM = 1, SC_USER = 2, SC_SESSION = 3, SC_RANKING = 4, SC_FIELD = 5, SC_IRF = 6, SC_COUNT = 7
-};
 
 enum ColKind : uint8_t { COL_SCALAR = 0, COL_COUNTER = 1, COL_PERIODIC = 2, COL_BOUNDED_LIST = 3 };
 
-// tag byte of a record cell
-enum Tag : uint8_t {
-  TAG_MISSING = 0,
-  TAG_DOUBLE = 1,       // ScalarValue(SDouble): cell = f64
-  TAG_BOOL = 2,         // ScalarValue(SBoolean): cell = f64 0/1
-  TAG_STRING = 3,       // ScalarValue(SString): cell = {u32 token, u32 linked field slot + 1 (0 = none)}
-  TAG_STRING_LIST = 4,  // ScalarValue(SStringList): cell = {u32 offset into token pool, u32 length}
-  TAG_DOUBLE_LIST = 5,  // ScalarValue(SDoubleList): cell = {u32 offset into f64 pool, u32 length}
-  TAG_PRESENT = 1,      // counter / bounded list present; periodic: tag = 1 + min(len, 250)
-};
 
 struct Column {
   std::string name;
@@ -105,18 +93,6 @@ struct Pool {
   size_t dev_cap = 0;    // elements allocated on device
 };
 
-struct TableDev {          // what kernels see
-  const uint8_t *rows;
-  uint32_t stride;
-  uint32_t n_slots;
-};
-
-struct StoreDev {
-  TableDev tab[SC_COUNT];
-  const uint32_t *tok_pool;
-  const double *f64_pool;
-  const uint32_t *slot_pool;
-};
 
 struct Store {
   Table tables[SC_COUNT];

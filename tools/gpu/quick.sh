@@ -10,5 +10,6 @@ print("$tag".ljust(10), round(d['value']/1e6,1),'M items/s', round(d['ms_per_ste
 PY
 }
 run s1 --streams 1
+MRK_RANK_JIT=0 run s1_nojit --streams 1
 run s2
 for w in ${EXTRA_WORKLOADS:-}; do run $w --workload $w; done
