@@ -84,7 +84,11 @@ static void upload_model(mrk_ctx *ctx, mrk_model *m) {
   if (m->qs.ok) {
     up(m->d_qs_nodes, m->qs.nodes.data(), m->qs.nodes.size() * 4);
     up(m->d_qs_leaves, m->qs.leaves.data(), m->qs.leaves.size());
-    up(m->d_qs_thr, m->qs.thr.data(), m->qs.thr.size() * 8);
+    {  // the assembly kernel stages tables with 1 KiB wave-loads that may run past a table's end: slack after the last one
+      std::vector<double> padded(m->qs.thr);
+      padded.resize(padded.size() + 2 * QS_STAGE_CHUNK, 0.0);
+      up(m->d_qs_thr, padded.data(), padded.size() * 8);
+    }
     up(m->d_qs_feats, m->qs.feats.data(), m->qs.feats.size() * sizeof(QsFeature));
     up(m->d_qs_views, m->qs.views.data(), m->qs.views.size() * sizeof(QsView));
     up(m->d_qs_catnodes, m->qs.cat_nodes.data(), m->qs.cat_nodes.size() * sizeof(QsCatNode));

@@ -22,7 +22,7 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
                            uint16_t *cells, bool f64);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
-size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads);
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap);
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
@@ -190,7 +190,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.fused_threads = std::min(256, std::max(64, (hb.max_items + 63) / 64 * 64));
   const bool fused_enabled = [] { const char *e = getenv("MRK_RANK_FUSED"); return !e || atoi(e) != 0; }();
   b.fused_ok = fused_enabled && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
-               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads) <= 64 * 1024;
+               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR) <= 64 * 1024;
 }
 
 static void check_model_fits(mrk_model *model, const Program &prog) {
@@ -356,6 +356,17 @@ int mrk_config_specialize(const char *json, size_t len, const char *model_name, 
     memcpy(out, data, n);
   });
 }
+
+#ifdef MRK_PHASE_CLOCKS
+extern "C" int mrk_debug_phase_clocks(const mrk::Program *prog, unsigned long long *out64);
+// measurement builds only (not part of include/mrk.h): read-and-reset the per-phase cycle sums of the specialised kernel
+int mrk_debug_phase(mrk_ctx *ctx, const char *model_name, unsigned long long *out64) {
+  if (!ctx || !ctx->registry) return -1;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  (void)hipDeviceSynchronize();
+  return mrk_debug_phase_clocks(ctx->registry->program(model_name), out64);
+}
+#endif
 
 int mrk_model_dim(mrk_ctx *ctx, const char *model_name) {
   int dim = -1;

@@ -55,6 +55,7 @@ constexpr int QS_LEAVES = 16;
 constexpr int QS_TREE_WORDS = QS_SLOTS * 2;
 constexpr int QS_MAX_VIEWS = 255;
 constexpr uint16_t QS_RIGHT = 0x7FFF;
+constexpr uint32_t QS_STAGE_CHUNK = 128;  // doubles one global_load_lds_dwordx4 of a wavefront moves (64 lanes x 16 B)
 enum QsViewKind : uint8_t { QV_NAN_RIGHT = 0, QV_NAN_LEFT = 1, QV_MISS_RIGHT = 2, QV_MISS_LEFT = 3, QV_CAT = 4, QV_NAN_ZERO = 5 };
 
 constexpr uint16_t QS_CAT_BEYOND = 0x7FFD, QS_CAT_INVALID = 0x7FFE, QS_CAT_NAN = 0x7FFF;
@@ -69,10 +70,13 @@ struct QsCatNode {     // 16 B
   uint32_t bits_begin; // first word of the bitset in PackedForestQS::cat_bits
   uint32_t bits_words;
 };
-struct QsFeature {     // 16 B, one per matrix column
-  uint32_t thr_off, thr_len;       // sorted distinct thresholds of this column in PackedForestQS::thr
-  uint16_t view_begin, view_end;   // its views
-  uint32_t zero_bin;               // bin(0.0): the cell of a NaN in a QV_NAN_ZERO view
+struct QsFeature {     // 16 B, one per matrix column (one s_load_dwordx4)
+  uint32_t thr_off;                // its sorted distinct thresholds in PackedForestQS::thr ...
+  uint16_t thr_len;                // ... <= 32766 of them
+  uint16_t zero_bin;               // bin(0.0): the cell of a NaN in a QV_NAN_ZERO view
+  uint8_t view_begin, view_end;    // its views (tile columns)
+  uint16_t pad;
+  uint32_t view_kinds;             // QsViewKind of view_begin + i in bits [4 i, 4 i + 4): at most 6 views per column
 };
 
 }  // namespace mrk

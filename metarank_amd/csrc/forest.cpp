@@ -567,15 +567,15 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
       }
       view_ids.emplace(std::make_pair(t.feat[i], node_kind(t, i)), 0);
     }
-  pf.feats.assign(nf, QsFeature{0, 0, 0, 0, 0});
+  pf.feats.assign(nf, QsFeature{0, 0, 0, 0, 0, 0, 0});
   for (int ft = 0; ft < nf; ++ft) {
     auto &v = tabs[ft];
     std::sort(v.begin(), v.end());
     v.erase(std::unique(v.begin(), v.end()), v.end());  // -0.0 == +0.0: one entry, compared numerically on the device too
     if (v.size() > 32766) return fail("more than 32766 distinct thresholds on one column");
     pf.feats[ft].thr_off = (uint32_t)pf.thr.size();
-    pf.feats[ft].thr_len = (uint32_t)v.size();
-    pf.feats[ft].zero_bin = (uint32_t)(std::lower_bound(v.begin(), v.end(), 0.0) - v.begin());  // #{t < 0.0}: LightGBM only
+    pf.feats[ft].thr_len = (uint16_t)v.size();
+    pf.feats[ft].zero_bin = (uint16_t)(std::lower_bound(v.begin(), v.end(), 0.0) - v.begin());  // #{t < 0.0}: LightGBM only
     pf.thr.insert(pf.thr.end(), v.begin(), v.end());
   }
   {
@@ -584,10 +584,13 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
       kv.second = id;
       pf.views.push_back(QsView{(uint16_t)kv.first.first, (uint8_t)kv.first.second, 0});
       if (kv.first.first != cur) {
-        pf.feats[kv.first.first].view_begin = (uint16_t)id;
+        pf.feats[kv.first.first].view_begin = (uint8_t)id;
         cur = kv.first.first;
       }
-      pf.feats[kv.first.first].view_end = (uint16_t)(id + 1);
+      if (id >= QS_MAX_VIEWS) return fail("more than 255 tile columns");
+      QsFeature &qf = pf.feats[kv.first.first];
+      qf.view_end = (uint8_t)(id + 1);
+      qf.view_kinds |= (uint32_t)kv.first.second << (4 * (id - qf.view_begin));  // <= 6 kinds per column
       ++id;
     }
   }

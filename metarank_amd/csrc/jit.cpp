@@ -92,8 +92,12 @@ std::vector<char> jit_compile(const std::string &source, std::string &log) {
   hiprtcProgram p = nullptr;
   if (hiprtcCreateProgram(&p, source.c_str(), "mrk_rank_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     throw StatusError(MRK_ERR_DEVICE, "hiprtcCreateProgram failed");
+#ifdef MRK_PHASE_CLOCKS
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DMRK_PHASE_CLOCKS"};
+#else
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-  const hiprtcResult rc = hiprtcCompileProgram(p, 4, opts);
+#endif
+  const hiprtcResult rc = hiprtcCompileProgram(p, (int)(sizeof opts / sizeof opts[0]), opts);
   size_t n = 0;
   if (hiprtcGetProgramLogSize(p, &n) == HIPRTC_SUCCESS && n > 1) {
     log.resize(n);
@@ -147,6 +151,19 @@ void *jit_rank_function(const Program &prog, bool f64) {
   }
   return (void *)((JitKernels *)prog.jit)->fn[f64 ? 1 : 0];
 }
+
+#ifdef MRK_PHASE_CLOCKS
+// measurement builds: read-and-reset the phase clocks of the specialised kernel of `prog`
+extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *out64) {
+  if (!prog || !prog->jit) return -1;
+  hipDeviceptr_t p = nullptr;
+  size_t bytes = 0;
+  if (hipModuleGetGlobal(&p, &bytes, ((JitKernels *)prog->jit)->mod, "mrk_phase_clocks") != hipSuccess || bytes < 64 * 8) return -2;
+  if (hipMemcpy(out64, (void *)p, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  (void)hipMemset((void *)p, 0, 64 * 8);
+  return 0;
+}
+#endif
 
 void jit_release(Program &prog) {
   if (!prog.jit) return;

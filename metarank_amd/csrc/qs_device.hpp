@@ -15,10 +15,13 @@ struct QsDev {             // what a kernel needs to bin a value of any matrix c
   const double *thr;
   int32_t n_feats;
   int32_t n_views;
+  uint32_t thr_cap;        // doubles per LDS staging buffer: the longest staged table rounded up to QS_STAGE_CHUNK
 };
 
 typedef __attribute__((address_space(3))) double qs_lds_double;  // forces ds_read for tables staged in LDS
 constexpr uint32_t QS_LDS_THR = 256;  // thresholds of one column a wavefront stages in LDS (LightGBM: max_bin - 1 = 254)
+// descriptors are read through the constant address space: uniform loads from it are always scalar loads
+typedef const __attribute__((address_space(4))) QsFeature *QsFeatureK;
 
 // The library's own preprocessing of a dense-row value.  ok = false iff XGBoost would reject it.
 template <bool F64>
@@ -43,6 +46,7 @@ __device__ __forceinline__ uint32_t qs_bin_search(P T, uint32_t len, double x) {
   // branch-free lower bound: `n` (hence the trip count) is the same in every lane, every read is inside the table
   uint32_t pos = 0;
   if (len) {
+#pragma unroll 1
     for (uint32_t n = len; n > 1;) {
       const uint32_t half = n >> 1;
       const double t = T[pos + half - 1];
@@ -61,10 +65,11 @@ template <bool F64, typename Emit>
 __device__ __forceinline__ void qs_emit_views(double x, uint32_t pos, const QsFeature ft, const QsView *__restrict__ views, Emit emit) {
   const bool isn = x != x;
   const bool isz = x == 0.0;
-  for (uint32_t v = ft.view_begin; v < ft.view_end; ++v) {
-    const QsView vw = views[v];
+#pragma unroll 1
+  for (uint32_t v = ft.view_begin; v < ft.view_end; ++v) {  // 1 - 2 views per column: unrolling only grows the code
+    const uint32_t kind = (ft.view_kinds >> (4u * (v - ft.view_begin))) & 15u;  // no load: the descriptor carries the kinds
     uint32_t cell;
-    if (vw.kind == QV_CAT) {
+    if (kind == QV_CAT) {
       // the category id; the node's bitset is consulted by the scorer
       if (isn) cell = QS_CAT_NAN;
       else if constexpr (F64) {
@@ -79,11 +84,11 @@ __device__ __forceinline__ void qs_emit_views(double x, uint32_t pos, const QsFe
           cell = iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv;
         }
       }
-    } else if (vw.kind == QV_NAN_ZERO) {
+    } else if (kind == QV_NAN_ZERO) {
       cell = isn ? ft.zero_bin : pos;  // MissingType::None: NaN is compared as 0.0
     } else {
-      const bool miss = (vw.kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
-      const uint32_t mval = (vw.kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
+      const bool miss = (kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
+      const uint32_t mval = (kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
       cell = miss ? mval : pos;
     }
     emit(v, cell);

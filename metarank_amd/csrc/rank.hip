@@ -36,7 +36,7 @@ prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
-  PrepScratch sc{s_vals, PREP_MAX_VALUES, s_ints};
+  PrepScratch sc{s_vals, PREP_MAX_VALUES, s_ints, 0ull, {0, 0, 0, 0, 0, 0}};
   prepass_request(st, prog, b, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sc);
 }
 
@@ -55,7 +55,7 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
 template <bool F64>
 __global__ void __launch_bounds__(ASM_THREADS)
 assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_t *cells) {
-  __shared__ double s_thr[ASM_THREADS / 64][QS_LDS_THR];
+  __shared__ __align__(16) double s_thr[ASM_THREADS / 64][2 * QS_LDS_THR];
   const int gi0 = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
   const bool active = gi0 < b.item_hi;
   if (!__any(active)) return;
@@ -69,7 +69,7 @@ assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_
 
 __global__ void __launch_bounds__(256)
 rank_fused_matrix_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap) {
-  rank_fused_body(st, prog, b, tab_entries, vals_cap,
+  rank_fused_body(st, prog, b, tab_entries, vals_cap, 0u,
                   [&](int gi, int, bool active, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
 }
 
@@ -311,9 +311,10 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
   launch_override_cells(ctx, b, q, cells, f64);
 }
 
-size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads) {
+// thr_cap: doubles per threshold staging buffer (QsDev::thr_cap; QS_LDS_THR = the largest any model needs)
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap) {
   return (size_t)tab_entries * 8 + (size_t)vals_cap * 8 + FUSED_MAX_PREP * sizeof(PrepOut) + PREP_INTS * sizeof(int) +
-         (size_t)((threads + 63) / 64) * QS_LDS_THR * 8;  // threshold staging, one table per wavefront
+         16 + (size_t)((threads + 63) / 64) * 2 * thr_cap * 8;  // threshold staging (16-B aligned), two buffers per wavefront
 }
 int fused_max_prep() { return FUSED_MAX_PREP; }
 
@@ -323,7 +324,7 @@ int fused_max_prep() { return FUSED_MAX_PREP; }
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn) {
   if (b.n_req <= 0) return;
-  const size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads);
+  const size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u);
   {
     ScopedKernelTimer timer(ctx, "assemble");
     static thread_local bool configured = false;

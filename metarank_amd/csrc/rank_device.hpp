@@ -9,6 +9,23 @@
 #include "qs_device.hpp"
 #include "rank.hpp"
 
+#ifdef MRK_PHASE_CLOCKS
+// measurement builds only (MRK_DEFINES=MRK_PHASE_CLOCKS): core-clock cycles thread 0 of every workgroup spends per phase
+// of the fused kernel, summed over workgroups: [0] table sweep, [1] interacted_with histograms, [2] diversity find-first +
+// type, [3] diversity strings, [4] diversity medians, [5] per-item assembly, [6] workgroups; [16 + op] per op (lane 0)
+__device__ unsigned long long mrk_phase_clocks[64];
+// (kept in registers and flushed with atomics once, at the end: an atomic per boundary would sit in front of
+// every later load in the in-order memory pipeline)
+#define MRK_PHASE(prev, acc)                                                   \
+  do {                                                                         \
+    const unsigned long long t_ = clock64();                                   \
+    (acc) += t_ - (prev);                                                      \
+    (prev) = t_;                                                               \
+  } while (0)
+#else
+#define MRK_PHASE(prev, acc) do { } while (0)
+#endif
+
 namespace mrk {
 
 namespace {
@@ -144,6 +161,8 @@ struct PrepScratch {   // LDS scratch of one workgroup
   double *vals;        // vals_cap doubles: diversity median
   int vals_cap;
   int *ints;           // PREP_INTS
+  mutable unsigned long long clk;  // MRK_PHASE_CLOCKS builds: time of the previous phase boundary
+  mutable unsigned long long acc[6];
   __device__ __forceinline__ int *wave_tot() const { return ints; }                              // [4][PREP_GROUP]
   __device__ __forceinline__ int *first() const { return ints + 4 * PREP_GROUP; }                // [FUSED_MAX_PREP]
   __device__ __forceinline__ int *misc() const { return ints + 4 * PREP_GROUP + FUSED_MAX_PREP; }   // [4]
@@ -266,6 +285,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
     for (int e = tid; e < n_prep; e += nthr) s_first[e] = 0x7fffffff;
   }
   __syncthreads();
+  MRK_PHASE(sc.clk, sc.acc[0]);
 
   // Per-group state lives in registers indexed at COMPILE time (every loop over the group is fully unrolled
   // and predicated on u < n): a run-time index into a register array costs a select chain per access.
@@ -315,6 +335,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
     e0 += n;
   }
 
+  MRK_PHASE(sc.clk, sc.acc[1]);
   // ---- diversity (DiversityFeature.scala:72-103), PREP_GROUP entries at a time
   for (int e0 = 0; e0 < n_prep;) {
     if (prog.prep[e0].kind != PREP_DIVERSITY) { ++e0; continue; }
@@ -373,6 +394,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
       for (int u = 0; u < PREP_GROUP; ++u)
         mode[u] = (h[u].tag == TAG_STRING || h[u].tag == TAG_STRING_LIST) ? DIV_STRING : (h[u].tag == TAG_DOUBLE ? DIV_DOUBLE : DIV_EMPTY);
     }
+    MRK_PHASE(sc.clk, sc.acc[2]);
     // (b) string entries: the first `top` candidates of that type, in request order, all entries in one pass
     bool any_string = false;
 #pragma unroll
@@ -426,6 +448,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
           po_out[ent[u]].scalar = mode[u] == DIV_STRING ? (double)s_tokens[u] : 0.0;
         }
     }
+    MRK_PHASE(sc.clk, sc.acc[3]);
     // (c) numeric entries, one at a time: the first `top` present values in request order, then their median
 #pragma unroll
     for (int u = 0; u < PREP_GROUP; ++u) {
@@ -456,6 +479,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
       }
       __syncthreads();
     }
+    MRK_PHASE(sc.clk, sc.acc[4]);
     e0 = e1;
   }
   __syncthreads();
@@ -485,6 +509,7 @@ __device__ __forceinline__ long long long_div(long long a, long long b) {
 struct MatrixSink {   // row-major f64 matrix, ClickthroughQuery's layout
   double *row;
   bool active;
+  __device__ __forceinline__ void begin() const {}
   __device__ __forceinline__ void put(int col, double v) const {
     if (active) row[col] = v;
   }
@@ -495,26 +520,65 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
   QsDev q;
   uint16_t *dst;      // &cells[tile][0][row]
   int32_t *status;    // the request's status word
-  qs_lds_double *thr_lds;  // QS_LDS_THR doubles private to this wavefront
+  qs_lds_double *thr_lds;  // two staging buffers of q.thr_cap doubles, private to this wavefront
   bool active;
-  // `col` is uniform across the wavefront.  The column's threshold table is staged in LDS by the whole
-  // wavefront (one coalesced load) and searched there: a per-lane binary search in global memory would
-  // be log2(T) scattered wave-loads per column, and scattered loads are what bounds the assembly kernel.
+  // A column's threshold table is searched in LDS (a per-lane binary search in global memory would be log2(T)
+  // scattered wave-loads per column).  Asking for the descriptor, then for the table, then searching costs two trips
+  // to memory per column - measured: 70 % of the assembly phase - so the tables travel one column ahead of the search:
+  // columns arrive in increasing order; while column c is searched in buffer c & 1, the table of c + 1 is on its way
+  // into the other buffer (global_load_lds: no registers, no ds_write) and the descriptor of c + 2 into scalar
+  // registers (constant address space: s_load).
+  mutable QsFeature ft_cur = {}, ft_next = {};   // feats[next_col], feats[next_col + 1]
+  mutable int next_col = -1;                     // the column whose table has been requested
+
+  __device__ __forceinline__ bool staged(const QsFeature &ft) const { return ft.thr_len <= q.thr_cap && ft.view_begin != ft.view_end; }
+  __device__ __forceinline__ QsFeature feature(int col) const {
+    QsFeature ft = {};
+    if (col < q.n_feats) {
+      const QsFeatureK f = (QsFeatureK)(unsigned long long)q.feats + col;
+      ft.thr_off = f->thr_off;
+      ft.thr_len = f->thr_len;
+      ft.zero_bin = f->zero_bin;
+      ft.view_begin = f->view_begin;
+      ft.view_end = f->view_end;
+      ft.view_kinds = f->view_kinds;
+    }
+    return ft;
+  }
+  __device__ __forceinline__ void request(const QsFeature &ft, int col) const {  // table of `col` -> buffer col & 1
+    if (!staged(ft)) return;
+    const double *src = q.thr + ft.thr_off + 2 * (threadIdx.x & 63);  // lane l: entries 2 l, 2 l + 1 of the chunk (runs past the
+    qs_lds_double *buf = thr_lds + (size_t)(col & 1) * q.thr_cap;     // table's end into the next one / the slack after the last)
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < ft.thr_len; k0 += QS_STAGE_CHUNK)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k0),
+                                       (__attribute__((address_space(3))) void *)(buf + k0), 16, 0, 0);
+  }
+  // before the first put of an item
+  __device__ __forceinline__ void begin() const { restart(0); }
+  __device__ __forceinline__ void restart(int col) const {
+    ft_cur = feature(col);
+    ft_next = feature(col + 1);
+    next_col = col;
+    request(ft_cur, col);
+  }
+
+  // `col` is uniform across the wavefront; every lane of the wavefront takes part (lanes without an item write nothing)
   __device__ __forceinline__ void put(int col, double v) const {
     if (col >= q.n_feats) return;
-    const QsFeature ft = q.feats[col];  // scalar loads
+    if (col != next_col) restart(col);  // a column out of order
+    const QsFeature ft = ft_cur;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the table of `col` has landed (the compiler does not track LDS-DMA)
+    __builtin_amdgcn_wave_barrier();
+    ft_cur = ft_next;
+    request(ft_cur, col + 1);
+    ft_next = feature(col + 2);
+    next_col = col + 1;
     if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
     bool ok;
     const double x = qs_prep<F64>(v, ok);
-    uint32_t pos;
-    if (ft.thr_len <= QS_LDS_THR) {
-      __builtin_amdgcn_wave_barrier();  // LDS ops of one wavefront complete in order: no s_barrier needed
-      for (uint32_t k = threadIdx.x & 63; k < ft.thr_len; k += 64) thr_lds[k] = q.thr[ft.thr_off + k];
-      __builtin_amdgcn_wave_barrier();
-      pos = qs_bin_search<F64>(thr_lds, ft.thr_len, x);
-    } else {
-      pos = qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
-    }
+    const uint32_t pos = staged(ft) ? qs_bin_search<F64>(thr_lds + (size_t)(col & 1) * q.thr_cap, ft.thr_len, x)
+                                    : qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
     uint16_t *d = dst;
     const bool act = active;
     qs_emit_views<F64>(x, pos, ft, q.views, [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; });
@@ -756,10 +820,14 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
     }
   };
 
+  sink.begin();
   if constexpr (prog_is_static<Prog>(0)) {
     // compile-time program: the loops unroll, every `op` is a constant, and the primary cells of ALL ops are requested
     // before the first op runs - one trip to memory instead of one per op
     Cell pc[Prog::n_ops > 0 ? Prog::n_ops : 1];
+#ifdef MRK_PHASE_CLOCKS
+    unsigned long long t_op = clock64(), op_acc[Prog::n_ops > 0 ? Prog::n_ops : 1] = {};
+#endif
     static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
       constexpr int oi = decltype(ic)::value;
       constexpr Op op = Prog{}.ops[oi];
@@ -771,7 +839,12 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
       constexpr int oi = decltype(ic)::value;
       constexpr Op op = Prog{}.ops[oi];
       run_op(op, pc[oi]);
+      MRK_PHASE(t_op, op_acc[oi]);
     });
+#ifdef MRK_PHASE_CLOCKS
+    if (threadIdx.x == 0)
+      for (int i = 0; i < Prog::n_ops && i < 48; ++i) atomicAdd(&mrk_phase_clocks[16 + i], op_acc[i]);
+#endif
   } else {
     for (int oi = 0; oi < prog.n_ops; ++oi) {
       const Op op = prog.ops[oi];
@@ -787,22 +860,26 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 
 // Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
 // Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][PREP_INTS ints]
-//              [threshold staging: QS_LDS_THR x 8 B per wavefront]
+//              [threshold staging: 2 buffers x thr_cap x 8 B per wavefront]
 template <typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
-                                                int vals_cap, const SinkMaker &make_sink) {
+                                                int vals_cap, uint32_t thr_cap, const SinkMaker &make_sink) {
   extern __shared__ __align__(16) uint8_t smem[];
   unsigned long long *s_tab = (unsigned long long *)smem;
   double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
   PrepOut *s_po = (PrepOut *)(smem + (size_t)tab_entries * 8 + (size_t)vals_cap * 8);
   int *s_int = (int *)(s_po + FUSED_MAX_PREP);
-  qs_lds_double *s_thr = (qs_lds_double *)(s_int + PREP_INTS) + (size_t)(threadIdx.x >> 6) * QS_LDS_THR;
+  const size_t thr_at = ((size_t)((uint8_t *)(s_int + PREP_INTS) - smem) + 15) & ~(size_t)15;  // LDS-DMA writes 16 B per lane
+  qs_lds_double *s_thr = (qs_lds_double *)(smem + thr_at) + (size_t)(threadIdx.x >> 6) * 2 * thr_cap;
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
   for (int e = threadIdx.x; e < prog.n_prep; e += blockDim.x) s_po[e] = b.prep_out[(size_t)r * prog.n_prep + e];
   __syncthreads();
-  PrepScratch sc{s_vals, vals_cap, s_int};
+  PrepScratch sc{s_vals, vals_cap, s_int, 0ull, {0, 0, 0, 0, 0, 0}};
+#ifdef MRK_PHASE_CLOCKS
+  sc.clk = clock64();
+#endif
   prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
   for (int base = 0; base < rq.n_items; base += blockDim.x) {
     const int i = base + (int)threadIdx.x;
@@ -812,6 +889,13 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
     const int gi = active ? gi0 : rq.item_begin;
     assemble_item(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr));
   }
+  MRK_PHASE(sc.clk, sc.acc[5]);
+#ifdef MRK_PHASE_CLOCKS
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&mrk_phase_clocks[i], sc.acc[i]);
+    atomicAdd(&mrk_phase_clocks[6], 1ull);
+  }
+#endif
 }
 
 
@@ -819,7 +903,7 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
 template <bool F64, typename Prog>
 __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
                                                       int vals_cap, const QsDev &q, uint16_t *cells) {
-  rank_fused_body(st, prog, b, tab_entries, vals_cap, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
+  rank_fused_body(st, prog, b, tab_entries, vals_cap, q.thr_cap, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
     return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
   });
 }
