@@ -113,7 +113,7 @@ SIGNATURES = {
     "mrk_model_free": (None, [_V]),
     "mrk_config_load_json": (_I, [_V, _S, C.c_size_t]),
     "mrk_model_dim": (_I, [_V, _S]),
-    "mrk_config_specialize": (_I, [_S, C.c_size_t, _S, _I, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mrk_config_specialize": (_I, [_S, C.c_size_t, _S, _I, _I, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mrk_store_put_double": (_I, [_V, _S, C.c_double]),
     "mrk_store_put_bool": (_I, [_V, _S, _I]),
     "mrk_store_put_string": (_I, [_V, _S, _S]),

@@ -336,23 +336,23 @@ int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len) {
   });
 }
 
-int mrk_config_specialize(const char *json, size_t len, const char *model_name, int what, uint8_t *out, size_t cap, size_t *needed) {
+int mrk_config_specialize(const char *json, size_t len, const char *model_name, int f64, int what, uint8_t *out, size_t cap, size_t *needed) {
   return guard([&] {
     if (!json || !model_name || !needed || (what != 0 && what != 1)) throw StatusError(MRK_ERR_INVALID_ARG, "null argument / unknown `what`");
     Store st;
     std::unique_ptr<Registry> reg = load_config(json, len, st, /*upload=*/false);
     const Program *p = reg->program(model_name);
     if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
-    const std::string src = jit_source(*p);
+    const std::string src = jit_source(*p, f64 != 0);
     std::vector<char> code;
-    if (what == 1) {
+    if (what == 1 && out) {  // sizing calls (out == NULL) do not compile
       std::string log;
       code = jit_compile(src, log);
     }
     const char *data = what == 0 ? src.data() : code.data();
     const size_t n = what == 0 ? src.size() : code.size();
-    *needed = n;
-    if (cap < n || (n && !out)) throw StatusError(MRK_ERR_INVALID_ARG, "output buffer too small (see *needed)");
+    *needed = what == 1 && !out ? (size_t)1 << 22 : n;  // code objects: an upper bound for the sizing call
+    if (cap < n || !out) throw StatusError(MRK_ERR_INVALID_ARG, "output buffer too small (see *needed)");
     memcpy(out, data, n);
   });
 }

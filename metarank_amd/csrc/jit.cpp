@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 #include "features.hpp"
@@ -50,7 +52,7 @@ uint64_t fnv1a(const std::string &s) {
 
 }  // namespace
 
-std::string jit_source(const Program &prog) {
+std::string jit_source(const Program &prog, bool f64) {
   std::string s;
   s.reserve(strlen(k_device_source) + 8192);
   s += k_device_source;
@@ -80,11 +82,13 @@ std::string jit_source(const Program &prog) {
   s += "  static constexpr int32_t n_ops = " + std::to_string(prog.ops.size()) + ", n_prep = " + std::to_string(prog.prep.size()) +
        ", dim = " + std::to_string(prog.dim) + ", n_consts = " + std::to_string(prog.n_consts) + ";\n";
   s += "  JitOps ops;\n  JitPrep prep;\n  JitAux aux;\n};\n}  // namespace\n}  // namespace mrk\n\n";
-  for (int f64 = 0; f64 < 2; ++f64) {
-    s += std::string("extern \"C\" __global__ void __launch_bounds__(256)\n") + (f64 ? "mrk_jit_rank_cells_f64" : "mrk_jit_rank_cells_f32") +
-         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells) {\n"
-         "  mrk::rank_fused_cells_body<" + (f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
-  }
+  // experiments: MRK_JIT_WAVES=n asks the compiler for n wavefronts per SIMD (register cap 512 / n)
+  std::string attr;
+  if (const char *w = getenv("MRK_JIT_WAVES"))
+    if (atoi(w) >= 1 && atoi(w) <= 8) attr = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(atoi(w)) + ", " + std::to_string(atoi(w)) + ")))";
+  s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
+       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells) {\n"
+       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
   return s;
 }
 
@@ -114,9 +118,9 @@ std::vector<char> jit_compile(const std::string &source, std::string &log) {
 }
 
 struct JitKernels {
-  hipModule_t mod = nullptr;
-  hipFunction_t fn[2] = {nullptr, nullptr};  // [f64]
-  uint64_t hash = 0;
+  hipModule_t mod[2] = {nullptr, nullptr};   // [f64]: one module per scorer precision, built when first needed
+  hipFunction_t fn[2] = {nullptr, nullptr};
+  bool failed[2] = {false, false};
 };
 
 int jit_mode() {  // 0 off, 1 on (fall back to the generic kernel with a warning if hiprtc fails), 2 required
@@ -126,39 +130,89 @@ int jit_mode() {  // 0 off, 1 on (fall back to the generic kernel with a warning
   return atoi(e) != 0 ? 1 : 0;
 }
 
+namespace {
+
+// code objects are kept on disk between processes: $MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else
+// ~/.cache/mrk_jit; the key covers the whole translation unit and the compiler's version
+std::string cache_path(const std::string &src) {
+  const char *dir = getenv("MRK_JIT_CACHE_DIR");
+  std::string d;
+  if (dir) d = dir;
+  else if (const char *x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/mrk_jit";
+  else if (const char *h = getenv("HOME")) d = std::string(h) + "/.cache/mrk_jit";
+  if (d.empty() || d == "off") return "";
+  int major = 0, minor = 0;
+  (void)hiprtcVersion(&major, &minor);
+  char name[96];
+  snprintf(name, sizeof name, "/%016llx-%zu-rtc%d.%d-gfx950.co", (unsigned long long)fnv1a(src), src.size(), major, minor);
+  return d + name;
+}
+
+std::vector<char> read_file(const std::string &path) {
+  std::vector<char> out;
+  if (path.empty()) return out;
+  if (FILE *f = fopen(path.c_str(), "rb")) {
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+    fclose(f);
+  }
+  return out;
+}
+
+void write_file(const std::string &path, const std::vector<char> &data) {
+  if (path.empty()) return;
+  const std::string dir = path.substr(0, path.rfind('/'));
+  for (size_t i = 1; i <= dir.size(); ++i)
+    if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  if (FILE *f = fopen(tmp.c_str(), "wb")) {
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+  }
+}
+
+}  // namespace
+
 // ctx->mu must be held (the program's cache slot is not otherwise protected)
 void *jit_rank_function(const Program &prog, bool f64) {
   const int mode = jit_mode();
   if (mode == 0) return nullptr;
-  if (prog.jit_failed && mode != 2) return nullptr;
-  if (!prog.jit) {
-    try {
-      const std::string src = jit_source(prog);
+  if (!prog.jit) prog.jit = new JitKernels();
+  JitKernels *k = (JitKernels *)prog.jit;
+  const int v = f64 ? 1 : 0;
+  if (k->fn[v]) return (void *)k->fn[v];
+  if (k->failed[v] && mode != 2) return nullptr;
+  try {
+    const std::string src = jit_source(prog, f64);
+    const std::string path = cache_path(src);
+    std::vector<char> code = read_file(path);
+    if (code.empty()) {
       std::string log;
-      const std::vector<char> code = jit_compile(src, log);
-      auto k = std::make_unique<JitKernels>();
-      k->hash = fnv1a(src);
-      MRK_HIP(hipModuleLoadData(&k->mod, code.data()));
-      MRK_HIP(hipModuleGetFunction(&k->fn[1], k->mod, "mrk_jit_rank_cells_f64"));
-      MRK_HIP(hipModuleGetFunction(&k->fn[0], k->mod, "mrk_jit_rank_cells_f32"));
-      prog.jit = k.release();
-    } catch (const std::exception &e) {
-      prog.jit_failed = true;
-      if (mode == 2) throw;
-      fprintf(stderr, "[mrk] specialised assembly kernel for model '%s' unavailable, using the generic kernel: %s\n", prog.model.c_str(), e.what());
-      return nullptr;
+      code = jit_compile(src, log);
+      write_file(path, code);
     }
+    MRK_HIP(hipModuleLoadData(&k->mod[v], code.data()));
+    MRK_HIP(hipModuleGetFunction(&k->fn[v], k->mod[v], "mrk_jit_rank_cells"));
+  } catch (const std::exception &e) {
+    k->failed[v] = true;
+    if (mode == 2) throw;
+    fprintf(stderr, "[mrk] specialised assembly kernel for model '%s' unavailable, using the generic kernel: %s\n", prog.model.c_str(), e.what());
+    return nullptr;
   }
-  return (void *)((JitKernels *)prog.jit)->fn[f64 ? 1 : 0];
+  return (void *)k->fn[v];
 }
 
 #ifdef MRK_PHASE_CLOCKS
 // measurement builds: read-and-reset the phase clocks of the specialised kernel of `prog`
 extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *out64) {
   if (!prog || !prog->jit) return -1;
+  JitKernels *k = (JitKernels *)prog->jit;
+  hipModule_t mod = k->mod[1] ? k->mod[1] : k->mod[0];
   hipDeviceptr_t p = nullptr;
   size_t bytes = 0;
-  if (hipModuleGetGlobal(&p, &bytes, ((JitKernels *)prog->jit)->mod, "mrk_phase_clocks") != hipSuccess || bytes < 64 * 8) return -2;
+  if (!mod || hipModuleGetGlobal(&p, &bytes, mod, "mrk_phase_clocks") != hipSuccess || bytes < 64 * 8) return -2;
   if (hipMemcpy(out64, (void *)p, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -3;
   (void)hipMemset((void *)p, 0, 64 * 8);
   return 0;
@@ -168,7 +222,8 @@ extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *o
 void jit_release(Program &prog) {
   if (!prog.jit) return;
   JitKernels *k = (JitKernels *)prog.jit;
-  if (k->mod) (void)hipModuleUnload(k->mod);
+  for (hipModule_t m : k->mod)
+    if (m) (void)hipModuleUnload(m);
   delete k;
   prog.jit = nullptr;
 }

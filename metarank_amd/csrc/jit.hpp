@@ -8,7 +8,7 @@ namespace mrk {
 struct Program;
 
 // the translation unit hiprtc compiles for this model's program: the shared device code + the program as constants
-std::string jit_source(const Program &prog);
+std::string jit_source(const Program &prog, bool f64);
 // gfx950 code object of `source`; throws StatusError(MRK_ERR_DEVICE) with the compiler log.  No device needed.
 std::vector<char> jit_compile(const std::string &source, std::string &log);
 // hipFunction_t of the specialised fused kernel for (program, scorer precision), built on first use; nullptr when

@@ -136,8 +136,8 @@ __device__ __forceinline__ uint32_t table_add_list(const StoreDev &st, unsigned 
 
 // sum over the tokens of tok_pool[off, off + len) of their table counts, added as doubles in list order
 // (InteractedWithFeature.scala:150-160 / DiversityFeature.scala:112-122: integers, exact)
-__device__ __forceinline__ double table_sum_list(const StoreDev &st, const unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len) {
-  double cnt = 0.0;
+__device__ __forceinline__ double table_sum_list(const StoreDev &st, const unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len,
+                                                 double cnt = 0.0) {
   for (uint32_t j0 = 0; wave_any(j0 < len); j0 += TOK_BATCH) {
     uint32_t tk[TOK_BATCH];
 #pragma unroll
@@ -601,7 +601,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 // ops whose first load is the cell of their primary column op.c0
-__device__ __forceinline__ constexpr bool op_has_primary(int kind) {
+__device__ __forceinline__ constexpr bool op_has_primary(const Op &op) {
+  const int kind = op.kind;
+  if (kind == OP_RATE) return op.i0 == RATE_ITEM_FIELD;  // the link cell
   return kind == OP_SCALAR_DOUBLE || kind == OP_SCALAR_BOOL || kind == OP_VECTOR || kind == OP_STRING_INDEX || kind == OP_STRING_ONEHOT ||
          kind == OP_COUNTER || kind == OP_WINDOW || kind == OP_DIVERSITY || kind == OP_ITEM_AGE || kind == OP_BIENCODER;
 }
@@ -617,7 +619,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 
   // the record an op's primary column (op.c0) lives in
   auto primary_record = [&](const Op &op) -> const uint8_t * {
-    if (op.kind == OP_DIVERSITY || op.kind == OP_BIENCODER) return irec;
+    if (op.kind == OP_DIVERSITY || op.kind == OP_BIENCODER || op.kind == OP_RATE) return irec;
     if (op.kind == OP_ITEM_AGE) return op.scope == SC_ITEM ? irec : nullptr;
     return record(st, op.scope, scoped_slot(rq, op.scope, islot));
   };
@@ -694,7 +696,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
         if (op.i0 == RATE_ITEM) {
           trec = irec;
         } else if (op.i0 == RATE_ITEM_FIELD) {
-          const Cell link = load_cell(irec, op.c0);  // item=<id>/<name>_field : SString -> field slot
+          const Cell link = pc;  // item=<id>/<name>_field : SString -> field slot (the op's primary cell)
           if (link.tag == TAG_STRING && link.hi() != 0) trec = record(st, SC_FIELD, (int)link.hi() - 1);
           top = op.c4;
           bot = op.c5;
@@ -704,51 +706,96 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
           top = op.c4;
           bot = op.c5;
         }
-        // every value present with exactly `dim` periods, else NaN x dim (RateFeature.scala:318-350)
-        bool valid = trec != nullptr;
-        if (valid) {
-          const Cell t0 = load_cell(trec, top), b0 = load_cell(trec, bot);
-          valid = t0.tag != TAG_MISSING && b0.tag != TAG_MISSING && (int)t0.tag - 1 == op.dim && (int)b0.tag - 1 == op.dim;
-        }
-        const uint8_t *grec = nullptr;
-        if (valid && op.i3 != 0) {
-          grec = record(st, SC_GLOBAL, 0);
-          const Cell gt = load_cell(grec, op.c2), gb = load_cell(grec, op.c3);
-          valid = gt.tag != TAG_MISSING && gb.tag != TAG_MISSING && (int)gt.tag - 1 == op.dim && (int)gb.tag - 1 == op.dim;
-        }
+        // every value present with exactly `dim` periods, else NaN x dim (RateFeature.scala:318-350).  All cells of
+        // the op are requested before the first one is looked at (one trip to memory, not one per cell); the value
+        // cells of a column exist whatever its tag says.
+        const bool norm = op.i3 != 0;
+        const bool has = trec != nullptr && top.tag >= 0 && bot.tag >= 0;
+        const uint8_t *grec = norm ? record(st, SC_GLOBAL, 0) : nullptr;
+        const bool ghas = grec != nullptr && op.c2.tag >= 0 && op.c3.tag >= 0;
+        uint32_t ttag = TAG_MISSING, btag = TAG_MISSING, gttag = TAG_MISSING, gbtag = TAG_MISSING;
+        if (has) { ttag = trec[top.tag]; btag = trec[bot.tag]; }
+        if (ghas) { gttag = grec[op.c2.tag]; gbtag = grec[op.c3.tag]; }
+        constexpr int RATE_BATCH = 4;  // periods fetched together
         bool thrown = false;  // java.lang.ArithmeticException: / by zero aborts the request
-        for (int k = 0; k < op.dim; ++k) {
-          double v = NaN;
-          if (valid && !thrown) {
-            if (op.i3 == 0) {
-              v = (double)load_cell(trec, top, k).i64() / (double)load_cell(trec, bot, k).i64();
-            } else {
-              const long long tg = load_cell(grec, op.c2, k).i64(), bg = load_cell(grec, op.c3, k).i64();
-              if (tg == 0) {
+        for (int k0 = 0; k0 < op.dim; k0 += RATE_BATCH) {
+          long long tv[RATE_BATCH], bv[RATE_BATCH], gtv[RATE_BATCH], gbv[RATE_BATCH];
+#pragma unroll
+          for (int u = 0; u < RATE_BATCH; ++u) {
+            tv[u] = bv[u] = gtv[u] = gbv[u] = 0;
+            if (k0 + u < op.dim && has) {
+              tv[u] = *(const long long *)(trec + top.val + (k0 + u) * 8);
+              bv[u] = *(const long long *)(trec + bot.val + (k0 + u) * 8);
+            }
+            if (k0 + u < op.dim && ghas) {
+              gtv[u] = *(const long long *)(grec + op.c2.val + (k0 + u) * 8);
+              gbv[u] = *(const long long *)(grec + op.c3.val + (k0 + u) * 8);
+            }
+          }
+          bool valid = ttag != TAG_MISSING && btag != TAG_MISSING && (int)ttag - 1 == op.dim && (int)btag - 1 == op.dim;
+          if (norm) valid = valid && gttag != TAG_MISSING && gbtag != TAG_MISSING && (int)gttag - 1 == op.dim && (int)gbtag - 1 == op.dim;
+#pragma unroll
+          for (int u = 0; u < RATE_BATCH; ++u) {
+            if (k0 + u >= op.dim) break;
+            double v = NaN;
+            if (valid && !thrown) {
+              if (!norm) {
+                v = (double)tv[u] / (double)bv[u];
+              } else if (gtv[u] == 0) {
                 if (sink.active) atomicOr(&b.status[r], ST_ARITHMETIC);
                 thrown = true;
               } else {
-                const double ratio = (double)long_div(bg, tg);
-                const double num = __dadd_rn(op.d0, (double)load_cell(trec, top, k).i64());
-                const double den = __dadd_rn(__dmul_rn(op.d0, ratio), (double)load_cell(trec, bot, k).i64());
+                const double ratio = (double)long_div(gbv[u], gtv[u]);
+                const double num = __dadd_rn(op.d0, (double)tv[u]);
+                const double den = __dadd_rn(__dmul_rn(op.d0, ratio), (double)bv[u]);
                 v = num / den;
               }
             }
+            sink.put(dst + k0 + u, v);
           }
-          sink.put(dst + k, v);
         }
         break;
       }
       case OP_INTERACTED: {
-        // per field: sum over the candidate's tokens of the session histogram
-        for (int f = 0; f < op.dim; ++f) {
-          ColRef col;
-          col.tag = (int32_t)prog.aux[op.i0 + 2 * f];
-          col.val = (int32_t)prog.aux[op.i0 + 2 * f + 1];
-          const PrepOut po = pos[op.i1 + f];
-          const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
-          const Cell c = load_cell(irec, col);
-          sink.put(dst + f, table_sum_list(st, tab, po.tab_cap, c.lo(), c.tag == TAG_STRING_LIST ? c.hi() : 0u));
+        // per field: sum over the candidate's tokens of the session histogram.  IW_BATCH fields at a time: their
+        // cells are requested together, then the first tokens of all their lists, then the tables are probed.
+        constexpr int IW_BATCH = 4, IW_TOK = 4;
+        for (int f0 = 0; f0 < op.dim; f0 += IW_BATCH) {
+          Cell fc[IW_BATCH];
+#pragma unroll
+          for (int u = 0; u < IW_BATCH; ++u) {
+            fc[u].tag = TAG_MISSING;
+            fc[u].bits = 0;
+            if (f0 + u < op.dim) {
+              ColRef col;
+              col.tag = (int32_t)prog.aux[op.i0 + 2 * (f0 + u)];
+              col.val = (int32_t)prog.aux[op.i0 + 2 * (f0 + u) + 1];
+              fc[u] = load_cell(irec, col);
+            }
+          }
+          uint32_t tk[IW_BATCH][IW_TOK];
+#pragma unroll
+          for (int u = 0; u < IW_BATCH; ++u) {
+            const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
+#pragma unroll
+            for (int t = 0; t < IW_TOK; ++t) tk[u][t] = (uint32_t)t < len ? st.tok_pool[fc[u].lo() + t] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < IW_BATCH; ++u) {
+            if (f0 + u >= op.dim) break;
+            const PrepOut po = pos[op.i1 + f0 + u];
+            const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
+            const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
+            double cnt = 0.0;
+#pragma unroll
+            for (int t = 0; t < IW_TOK; ++t) {
+              if (!wave_any((uint32_t)t < len)) break;
+              cnt = cnt + (double)table_get(tab, po.tab_cap, tk[u][t], (uint32_t)t < len);
+            }
+            if (wave_any(len > (uint32_t)IW_TOK))  // the rest of longer lists, in list order
+              cnt = table_sum_list(st, tab, po.tab_cap, fc[u].lo() + IW_TOK, len > (uint32_t)IW_TOK ? len - IW_TOK : 0u, cnt);
+            sink.put(dst + f0 + u, cnt);
+          }
         }
         break;
       }
@@ -833,7 +880,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
       constexpr Op op = Prog{}.ops[oi];
       pc[oi].tag = TAG_MISSING;
       pc[oi].bits = 0;
-      if constexpr (op_has_primary(op.kind)) pc[oi] = load_cell(primary_record(op), op.c0);
+      if constexpr (op_has_primary(op)) pc[oi] = load_cell(primary_record(op), op.c0);
     });
     static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
       constexpr int oi = decltype(ic)::value;
@@ -851,7 +898,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
       Cell pc;
       pc.tag = TAG_MISSING;
       pc.bits = 0;
-      if (op_has_primary(op.kind)) pc = load_cell(primary_record(op), op.c0);
+      if (op_has_primary(op)) pc = load_cell(primary_record(op), op.c0);
       run_op(op, pc);
     }
   }

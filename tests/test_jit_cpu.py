@@ -1,0 +1,53 @@
+"""CPU: the run-time specialised assembly kernel (metarank_amd/csrc/jit.cpp) can be generated and compiled for gfx950
+without a device: mrk_config_specialize returns the translation unit hiprtc gets (the shared device code + the model's
+program as constants) and its code object.  Whether that kernel computes the right thing is a GPU test
+(tests/test_rank_parity.py::test_assembly_paths_agree runs it against the generic kernel and the oracle)."""
+import ctypes as C
+import json
+
+import pytest
+
+from metarank_amd import _native, ranklens
+
+
+def specialize(cfg, what, f64=1, model=b"xgboost"):
+    lib = _native.lib()
+    js = json.dumps(cfg).encode()
+    need = C.c_size_t(0)
+    rc = lib.mrk_config_specialize(js, len(js), model, f64, what, None, 0, C.byref(need))
+    if rc == _native.ERR_INVALID_ARG and need.value:
+        buf = (C.c_uint8 * need.value)()
+        rc = lib.mrk_config_specialize(js, len(js), model, f64, what, buf, need.value, C.byref(need))
+        return rc, bytes(buf[:need.value])
+    return rc, b""
+
+
+def test_source_carries_the_program_as_constants():
+    cfg = ranklens.ranklens_config()
+    rc, src = specialize(cfg, 0)
+    assert rc == 0
+    text = src.decode()
+    # 18 features of the stock Ranklens model -> 18 ops, 24 matrix columns, 4 interacted_with fields + 5 diversity reductions
+    assert "n_ops = 18, n_prep = 9, dim = 24" in text
+    assert "struct JitOps" in text and "rank_fused_cells_body<true>" in text and "#include" not in text
+    rc, src32 = specialize(cfg, 0, f64=0)
+    assert rc == 0 and b"rank_fused_cells_body<false>" in src32
+    # the normalised rate's weight travels as an exact hexadecimal literal (10.0)
+    assert "0x1.4p+3" in text
+
+
+def test_unknown_model_and_bad_arguments():
+    lib = _native.lib()
+    rc, _ = specialize(ranklens.ranklens_config(), 0, model=b"nope")
+    assert rc == _native.ERR_NOT_FOUND
+    assert lib.mrk_config_specialize(None, 0, b"x", 1, 0, None, 0, None) == _native.ERR_INVALID_ARG
+    need = C.c_size_t(0)
+    assert lib.mrk_config_specialize(b"{", 1, b"x", 1, 0, None, 0, C.byref(need)) == _native.ERR_PARSE
+
+
+@pytest.mark.parametrize("which,f64", [("c2", 1), ("c3", 0)])
+def test_hiprtc_compiles_the_specialised_kernel_for_gfx950(which, f64):
+    cfg = ranklens.c3_config() if which == "c3" else ranklens.ranklens_config()
+    rc, code = specialize(cfg, 1, f64=f64)
+    assert rc == 0, _native.lib().mrk_last_error()
+    assert code[:4] == b"\x7fELF" and b"mrk_jit_rank_cells" in code and b"gfx950" in code

@@ -166,7 +166,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
     import os
 
     hip = HipBackend(ranklens.ranklens_config(), "xgboost")
-    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS")}
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT")}
     try:
         load(hip)
         reqs = ranklens.generate_requests(30, 100, N_ITEMS, N_SESS, seed=21)
@@ -186,17 +186,19 @@ def test_assembly_paths_agree(oracle_c2, kind):
         hip.load_model(blob, be)
         assert hip.booster.info()["bitvector"] == 1
         expected = [oracle_c2.rerank(ev) for ev in reqs]
-        for fused in ("1", "0"):
-            for cells in ("1", "0"):
-                os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"] = fused, cells
+        # (fused, cells, jit): the hot path runs the kernel specialised for this model's feature list at run time
+        # ("require": a hiprtc failure is an error, not a fall-back); "0" = the generic kernel that interprets the program
+        for fused, cells, jit in (("1", "1", "require"), ("1", "1", "0"), ("1", "0", "0"), ("0", "1", "0"), ("0", "0", "0")):
+            if True:
+                os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = fused, cells, jit
                 batch = hip.ranker.prepare("xgboost", reqs)
                 batch.run(hip.booster)
                 scores, order, _ = batch.fetch()
                 assert (batch.status() == 0).all()
                 for r, (_, es, eo) in enumerate(expected):
                     lo, hi = batch.offsets[r], batch.offsets[r + 1]
-                    assert same(scores[lo:hi], es), (fused, cells, r)
-                    assert order[lo:hi].tolist() == eo.tolist(), (fused, cells, r)
+                    assert same(scores[lo:hi], es), (fused, cells, jit, r)
+                    assert order[lo:hi].tolist() == eo.tolist(), (fused, cells, jit, r)
                 # the matrix is materialised on demand and is the oracle's
                 _, _, mat = batch.fetch(matrix=True)
                 for r in range(len(reqs)):
@@ -207,7 +209,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
                 assert same(s2, scores) and (o2 == order).all()
                 batch.close()
         # single requests: mrk_rank without / with the explain matrix
-        os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"] = "1", "1"
+        os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = "1", "1", "require"
         for ev, (_, es, eo), m in list(zip(reqs, expected, mats))[:8]:
             _, hs, ho = hip.ranker.rerank("xgboost", ev, hip.booster, explain=False)
             assert same(hs, es) and ho.tolist() == eo.tolist()
