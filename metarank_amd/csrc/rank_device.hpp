@@ -219,26 +219,44 @@ __device__ __forceinline__ void block_scan_flags(const bool (&flag)[PREP_GROUP],
 __device__ double median_of(double *s_vals, int n_raw, int *s_misc) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   if (n_raw == 1) return s_vals[0];
-  // NaN -> +inf placeholder (sorts last), counted
-  for (int i = tid; i < n_raw; i += nthr) {
-    double v = s_vals[i];
-    if (v != v) { s_vals[i] = __longlong_as_double(0x7ff0000000000000LL); atomicAdd(&s_misc[1], 1); }
-  }
-  int p2 = 1;
-  while (p2 < n_raw) p2 <<= 1;
-  for (int i = n_raw + tid; i < p2; i += nthr) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
-  __syncthreads();
-  for (int k = 2; k <= p2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < p2; i += nthr) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const double a = s_vals[i], c2 = s_vals[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > c2) == up) { s_vals[i] = c2; s_vals[ixj] = a; }
-        }
+  if (n_raw <= nthr) {
+    // one value per thread: its rank among the others is its place in the sorted array (two barriers instead of a
+    // compare-exchange network's log^2 n); NaNs are counted and left out (NaNStrategy.REMOVED)
+    const bool mine = tid < n_raw;
+    const double v = mine ? s_vals[tid] : 0.0;
+    const bool isn = v != v;
+    if (mine && isn) atomicAdd(&s_misc[1], 1);
+    int rank = 0;
+    if (mine && !isn)
+      for (int j = 0; j < n_raw; ++j) {
+        const double w = s_vals[j];  // the same address in every lane: a broadcast read
+        rank += (w < v || (w == v && j < tid)) ? 1 : 0;
       }
-      __syncthreads();
+    __syncthreads();
+    if (mine && !isn) s_vals[rank] = v;
+    __syncthreads();
+  } else {
+    // NaN -> +inf placeholder (sorts last), counted
+    for (int i = tid; i < n_raw; i += nthr) {
+      double v = s_vals[i];
+      if (v != v) { s_vals[i] = __longlong_as_double(0x7ff0000000000000LL); atomicAdd(&s_misc[1], 1); }
+    }
+    int p2 = 1;
+    while (p2 < n_raw) p2 <<= 1;
+    for (int i = n_raw + tid; i < p2; i += nthr) s_vals[i] = __longlong_as_double(0x7ff0000000000000LL);
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < p2; i += nthr) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const double a = s_vals[i], c2 = s_vals[ixj];
+            const bool up = (i & k) == 0;
+            if ((a > c2) == up) { s_vals[i] = c2; s_vals[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
     }
   }
   const int m = n_raw - s_misc[1];
@@ -359,7 +377,13 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
       tab[u] = tab_base + (po_out[ent[u]].tab_off - tab_sub);
       cap[u] = po_out[ent[u]].tab_cap;
     }
-    // (a) the first candidate that has a ScalarValue decides string vs number - for every entry of the group
+    // (a) the first candidate that has a ScalarValue decides string vs number - for every entry of the group:
+    // atomicMin over (index << 8 | tag) finds the first one AND what it holds.  A request that fits one round of the
+    // workgroup (the usual case) keeps its cells in registers for passes (b) and (c).
+    const bool single = rq.n_items <= nthr;
+    Cell keep[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) { keep[u].tag = TAG_MISSING; keep[u].bits = 0; }
     for (int base = 0; base < rq.n_items; base += nthr) {
       const int i = base + tid;
       if (i < rq.n_items) {
@@ -368,11 +392,14 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
 #pragma unroll
         for (int u = 0; u < PREP_GROUP; ++u) {
           c[u].tag = TAG_MISSING;
+          c[u].bits = 0;
           if (u < n) c[u] = load_cell(irec, col[u]);
         }
 #pragma unroll
-        for (int u = 0; u < PREP_GROUP; ++u)
-          if (u < n && c[u].tag != TAG_MISSING) atomicMin(&s_first[ent[u]], i);
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          if (u < n && c[u].tag != TAG_MISSING) atomicMin(&s_first[ent[u]], (i << 8) | (int)c[u].tag);
+          if (single) keep[u] = c[u];
+        }
       }
       __syncthreads();
       bool all = true;
@@ -382,17 +409,11 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
       if (all) break;
     }
     int mode[PREP_GROUP];
-    {
-      Cell h[PREP_GROUP];
 #pragma unroll
-      for (int u = 0; u < PREP_GROUP; ++u) {
-        h[u].tag = TAG_MISSING;
-        const int first = u < n ? s_first[ent[u]] : 0x7fffffff;
-        if (first != 0x7fffffff) h[u] = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + first]), col[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < PREP_GROUP; ++u)
-        mode[u] = (h[u].tag == TAG_STRING || h[u].tag == TAG_STRING_LIST) ? DIV_STRING : (h[u].tag == TAG_DOUBLE ? DIV_DOUBLE : DIV_EMPTY);
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      const int first = u < n ? s_first[ent[u]] : 0x7fffffff;
+      const int htag = first != 0x7fffffff ? (first & 255) : (int)TAG_MISSING;
+      mode[u] = (htag == TAG_STRING || htag == TAG_STRING_LIST) ? DIV_STRING : (htag == TAG_DOUBLE ? DIV_DOUBLE : DIV_EMPTY);
     }
     MRK_PHASE(sc.clk, sc.acc[2]);
     // (b) string entries: the first `top` candidates of that type, in request order, all entries in one pass
@@ -413,12 +434,12 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
         const int i = base + tid;
         Cell c[PREP_GROUP];
         bool cand[PREP_GROUP];
-        const uint8_t *irec = i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr;
+        const uint8_t *irec = !single && i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr;
 #pragma unroll
         for (int u = 0; u < PREP_GROUP; ++u) {
           c[u].tag = TAG_MISSING;
           c[u].bits = 0;
-          if (u < n && mode[u] == DIV_STRING) c[u] = load_cell(irec, col[u]);
+          if (u < n && mode[u] == DIV_STRING) c[u] = single ? keep[u] : load_cell(irec, col[u]);
           cand[u] = c[u].tag == TAG_STRING || c[u].tag == TAG_STRING_LIST;
         }
         int excl[PREP_GROUP], total[PREP_GROUP];
@@ -461,7 +482,8 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
         Cell c;
         c.tag = TAG_MISSING;
         c.bits = 0;
-        if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), col[u]);
+        if (single) c = keep[u];
+        else if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), col[u]);
         const bool cand = c.tag == TAG_DOUBLE;
         int total;
         const int rank = running + block_scan_flag(cand, sc.wave_tot(), total);
