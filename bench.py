@@ -286,7 +286,9 @@ def main():
     # the bytes of wide coalesced reads (the scorer's slab copy: x2); narrow scattered loads (assembly) are
     # reported uncorrected.  Only filled when the profiled launch had this run's item count.
     traffic = None
-    pmc_kernel = {"score": "qs_score_wave_kernel", "assemble": "rank_fused_cells_kernel"}.get(dominant)
+    # the assembly kernel of the hot path is the one specialised for the model at run time (csrc/jit.cpp)
+    jit_on = os.environ.get("MRK_RANK_JIT", "1") not in ("0",)
+    pmc_kernel = {"score": "qs_score_wave_kernel", "assemble": "mrk_jit_rank_cells" if jit_on else "rank_fused_cells_kernel"}.get(dominant)
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")), reverse=True):
