@@ -552,6 +552,7 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
   // registers (constant address space: s_load).
   mutable QsFeature ft_cur = {}, ft_next = {};   // feats[next_col], feats[next_col + 1]
   mutable int next_col = -1;                     // the column whose table has been requested
+  mutable bool landed = false;                   // ... and is known to be in its buffer
 
   __device__ __forceinline__ bool staged(const QsFeature &ft) const { return ft.thr_len <= q.thr_cap && ft.view_begin != ft.view_end; }
   __device__ __forceinline__ QsFeature feature(int col) const {
@@ -582,7 +583,12 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     ft_cur = feature(col);
     ft_next = feature(col + 1);
     next_col = col;
+    landed = false;
     request(ft_cur, col);
+  }
+  __device__ __forceinline__ void wait_landed() const {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the compiler does not track LDS-DMA
+    __builtin_amdgcn_wave_barrier();
   }
 
   // `col` is uniform across the wavefront; every lane of the wavefront takes part (lanes without an item write nothing)
@@ -590,17 +596,22 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     if (col >= q.n_feats) return;
     if (col != next_col) restart(col);  // a column out of order
     const QsFeature ft = ft_cur;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the table of `col` has landed (the compiler does not track LDS-DMA)
-    __builtin_amdgcn_wave_barrier();
+    if (!landed) wait_landed();  // the item's first column only: later tables are waited for at the end of the previous put
     ft_cur = ft_next;
     request(ft_cur, col + 1);
     ft_next = feature(col + 2);
     next_col = col + 1;
+    landed = false;
     if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
     bool ok;
     const double x = qs_prep<F64>(v, ok);
     const uint32_t pos = staged(ft) ? qs_bin_search<F64>(thr_lds + (size_t)(col & 1) * q.thr_cap, ft.thr_len, x)
                                     : qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
+    // vmcnt counts loads and stores alike, in order: waiting for the next table AFTER this column's cell stores would
+    // wait for the stores' round trip at every column (measured: 3 k cycles).  Here the table requested a whole search
+    // ago has landed long since, and the only stores in flight are the previous column's.
+    wait_landed();
+    landed = true;
     uint16_t *d = dst;
     const bool act = active;
     qs_emit_views<F64>(x, pos, ft, q.views, [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; });
