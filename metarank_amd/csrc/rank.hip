@@ -151,13 +151,13 @@ sort_kernel(BatchDev b) {
 // ---- requests with more than SORT_MAX_ITEMS candidates (C4: 100 000): merge sort.  Chunks of SORT_MAX_ITEMS
 // (key, index) pairs are sorted in LDS (bitonic), then log2(chunks) merge passes; in a pass every workgroup
 // produces SORT_MAX_ITEMS consecutive outputs of one pair of runs: merge-path binary searches find its input
-// ranges, the inputs go to LDS, every lane merges 16 outputs.  (key, index) pairs are distinct, so the result
+// ranges, the inputs go to LDS, every lane merges MERGE_TILE / 256 outputs.  (key, index) pairs are distinct, so the result
 // is the stable order.
 __device__ __forceinline__ bool pair_lt(unsigned long long ka, int ia, unsigned long long kb, int ib) {
   return ka < kb || (ka == kb && ia < ib);
 }
 
-constexpr int MS_PER_THREAD = SORT_MAX_ITEMS / SORT_THREADS;  // 16
+constexpr int MERGE_TILE = 1024;  // outputs of one workgroup of a merge pass
 
 __global__ void __launch_bounds__(SORT_THREADS)
 msort_chunk_kernel(BatchDev b, int r, unsigned long long *keys, int *idx) {
@@ -220,13 +220,17 @@ __device__ __forceinline__ int merge_path_block(const unsigned long long *ka, co
   return lo;
 }
 
+// TILE outputs per workgroup: a pass over 100 000 candidates is 25 workgroups at TILE = 4096 (a tenth of the chip),
+// 98 at 1024
+template <int TILE>
 __global__ void __launch_bounds__(SORT_THREADS)
 msort_merge_kernel(const unsigned long long *__restrict__ src_k, const int *__restrict__ src_i, unsigned long long *__restrict__ dst_k,
                    int *__restrict__ dst_i, int n_pad, int run) {
-  __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
-  __shared__ int s_idx[SORT_MAX_ITEMS];
+  constexpr int PER_THREAD = TILE / SORT_THREADS;
+  __shared__ unsigned long long s_key[TILE];
+  __shared__ int s_idx[TILE];
   const int tid = threadIdx.x;
-  const int out0 = blockIdx.x * SORT_MAX_ITEMS;
+  const int out0 = blockIdx.x * TILE;
   const int pair0 = (out0 / (2 * run)) * (2 * run);
   const int na = min(run, n_pad - pair0);
   const int nb = max(0, min(run, n_pad - pair0 - run));
@@ -234,17 +238,17 @@ msort_merge_kernel(const unsigned long long *__restrict__ src_k, const int *__re
   const int *ai = src_i + pair0, *bi = src_i + pair0 + run;
   const int d0 = out0 - pair0;
   const int a0 = merge_path_block(ak, ai, na, bk, bi, nb, d0);
-  const int a1 = merge_path_block(ak, ai, na, bk, bi, nb, min(d0 + SORT_MAX_ITEMS, na + nb));
-  const int b0 = d0 - a0, b1 = min(d0 + SORT_MAX_ITEMS, na + nb) - a1;
-  const int la = a1 - a0, lb = b1 - b0;  // la + lb outputs (SORT_MAX_ITEMS: n_pad is a multiple of it)
+  const int a1 = merge_path_block(ak, ai, na, bk, bi, nb, min(d0 + TILE, na + nb));
+  const int b0 = d0 - a0, b1 = min(d0 + TILE, na + nb) - a1;
+  const int la = a1 - a0, lb = b1 - b0;  // la + lb outputs (TILE: run and n_pad are multiples of it)
   for (int i = tid; i < la; i += SORT_THREADS) { s_key[i] = ak[a0 + i]; s_idx[i] = ai[a0 + i]; }
   for (int i = tid; i < lb; i += SORT_THREADS) { s_key[la + i] = bk[b0 + i]; s_idx[la + i] = bi[b0 + i]; }
   __syncthreads();
-  const int d = tid * MS_PER_THREAD;  // la + lb == SORT_MAX_ITEMS
+  const int d = tid * PER_THREAD;  // la + lb == TILE
   int x = merge_path(s_key, s_idx, la, s_key + la, s_idx + la, lb, d);
   int y = d - x;
 #pragma unroll
-  for (int o = 0; o < MS_PER_THREAD; ++o) {
+  for (int o = 0; o < PER_THREAD; ++o) {
     bool take_a;
     if (x >= la) take_a = false;
     else if (y >= lb) take_a = true;
@@ -377,7 +381,7 @@ void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsign
   int *i0 = idx, *i1 = idx + n_pad;
   hipLaunchKernelGGL(msort_chunk_kernel, dim3(chunks), blk, 0, ctx->launch, b, r, k0, i0);
   for (int run = SORT_MAX_ITEMS; run < n_pad; run <<= 1) {
-    hipLaunchKernelGGL(msort_merge_kernel, dim3(chunks), blk, 0, ctx->launch, k0, i0, k1, i1, n_pad, run);
+    hipLaunchKernelGGL(msort_merge_kernel<MERGE_TILE>, dim3(n_pad / MERGE_TILE), blk, 0, ctx->launch, k0, i0, k1, i1, n_pad, run);
     std::swap(k0, k1);
     std::swap(i0, i1);
   }
