@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r01_h}
+TAG=${TAG:-r01_i}
 mkdir -p gpurun_out/$TAG
 for w in c2 c3 c4 c5; do
 timeout 900 python bench.py --workload $w > gpurun_out/$TAG/bench_$w.json 2> gpurun_out/$TAG/bench_$w.log || tail -5 gpurun_out/$TAG/bench_$w.log
