@@ -6,7 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <exception>
 #include <set>
+#include <thread>
 
 #include "encoder.hpp"
 #include "jit.hpp"
@@ -741,11 +743,41 @@ double map_datetime(int mapper, const Civil &c) {
 // size sets how many requests a CU works on at once; measured on the Ranklens workload (MRK_TABLE_LOAD_PCT
 // sweep): 75 % -> 0.42 ms per 3840 requests, 50 % -> 0.45, 33 % -> 0.52, 25 % -> 0.60: shorter probe chains do
 // not pay for the lost occupancy.  Even => the 8-byte entries of consecutive tables stay 16-byte aligned.
-static uint32_t table_capacity(uint64_t tokens) {
+static uint64_t table_load_pct() {
   const char *e = getenv("MRK_TABLE_LOAD_PCT");  // experiments: worst-case load factor in percent
-  const uint64_t pct = e ? (uint64_t)std::max(10, std::min(90, atoi(e))) : 75;
+  return e ? (uint64_t)std::max(10, std::min(90, atoi(e))) : 75;
+}
+static uint32_t table_capacity(uint64_t tokens, uint64_t pct) {
   uint64_t cap = tokens * 100 / pct + 2;
   return (uint32_t)((cap + 1) & ~1ull);
+}
+
+// Host threads of one resolve_requests call: MRK_HOST_THREADS, else min(8, hardware threads).  The per-request work
+// (id -> slot lookups, request constants, table sizing) only READS the store, so requests are independent.
+static int host_threads() {
+  if (const char *e = getenv("MRK_HOST_THREADS")) return std::max(1, std::min(256, atoi(e)));
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+}
+
+// fn(lo, hi, worker) over [0, n) in contiguous ranges, worker w taking the w-th range; the first exception in range
+// order is rethrown (what a serial loop would have thrown first)
+template <typename Fn>
+static void parallel_ranges(int64_t n, int workers, const Fn &fn) {
+  if (workers <= 1 || n <= 1) { fn((int64_t)0, n, 0); return; }
+  workers = (int)std::min<int64_t>(workers, n);
+  std::vector<std::exception_ptr> errs((size_t)workers);
+  std::vector<std::thread> th;
+  th.reserve((size_t)workers - 1);
+  auto run = [&](int w) {
+    const int64_t lo = n * w / workers, hi = n * (w + 1) / workers;
+    try { fn(lo, hi, w); } catch (...) { errs[(size_t)w] = std::current_exception(); }
+  };
+  for (int w = 1; w < workers; ++w) th.emplace_back(run, w);
+  run(0);
+  for (auto &t : th) t.join();
+  for (auto &e : errs)
+    if (e) std::rethrow_exception(e);
 }
 
 
@@ -863,31 +895,75 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
   hb.consts.assign((size_t)n_req * prog.n_consts, kNaN);
   hb.irf.assign((size_t)prog.n_irf * total, -1);
   hb.prep_out.assign((size_t)n_req * prog.prep.size(), PrepOut{0, 0, 0.0, 0, 0});
-  uint64_t arena = 0;
-  int begin = 0;
-  std::vector<double> enc;
-  for (int r = 0; r < n_req; ++r) {
+  {
+    int at = 0;
+    for (int r = 0; r < n_req; ++r) { hb.reqs[r].item_begin = at; at += reqs[r].n_items; }
+  }
+  const uint64_t load_pct = table_load_pct();
+  const int n_workers = total >= 16384 ? host_threads() : 1;  // small batches (one request of mrk_rank): not worth a thread
+  struct Worker { std::vector<Override> overrides; int max_items = 0, max_doubles = 0; std::vector<double> enc; };
+  std::vector<Worker> workers((size_t)std::max(1, n_workers));
+  std::vector<uint64_t> req_entries((size_t)n_req, 0);  // hash-table entries of every request (its tables are contiguous)
+  // one request: everything but the position of its tables in the arena
+  auto resolve_one = [&](int r, Worker &wk, int item_workers) {
     const mrk_request &rq = reqs[r];
     ReqDev &rd = hb.reqs[r];
-    rd.item_begin = begin;
+    const int begin = rd.item_begin;
+    std::vector<double> &enc = wk.enc;
+    uint64_t arena = 0;  // relative to the request's first table
     rd.n_items = rq.n_items;
     auto slot_or = [&](ScopeId sc, const char *id) -> int32_t {
       if (!id) return -1;
-      uint32_t s = store.slot(sc, id, false);
+      uint32_t s = store.slot(sc, id, strlen(id), false);
       return s == Store::NO_SLOT ? -1 : (int32_t)s;
     };
     rd.user_slot = slot_or(SC_USER, rq.user);
     rd.session_slot = slot_or(SC_SESSION, rq.session);
     rd.ranking_slot = slot_or(SC_RANKING, rq.id ? rq.id : "");
-    rd.arena_begin = (uint32_t)arena;
-    const uint64_t arena_at_start = arena;
-    hb.max_items = std::max(hb.max_items, rq.n_items);
+    wk.max_items = std::max(wk.max_items, rq.n_items);
     rd.ts_ms = rq.timestamp_ms;
-    for (int i = 0; i < rq.n_items; ++i) {
-      hb.item_slot[begin + i] = slot_or(SC_ITEM, rq.item_ids[i] ? rq.item_ids[i] : "");
-      hb.item_req[begin + i] = (uint32_t)r;
-    }
+    // (one request with very many candidates - C4 - spreads its id lookups over the threads instead)
+    parallel_ranges(rq.n_items, rq.n_items >= 16384 ? item_workers : 1, [&](int64_t lo, int64_t hi, int) {
+      // id -> slot, a block at a time: hash every id and ask for its home entry, then probe (the misses overlap)
+      const SlotMap &map = store.tables[SC_ITEM].slot_of;
+      constexpr int BLOCK = 64;
+      uint64_t hs[BLOCK];
+      uint32_t lens[BLOCK];
+      for (int64_t i0 = lo; i0 < hi; i0 += BLOCK) {
+        const int nb = (int)std::min<int64_t>(BLOCK, hi - i0);
+        for (int k = 0; k < nb; ++k) {
+          const char *id = rq.item_ids[i0 + k] ? rq.item_ids[i0 + k] : "";
+          lens[k] = (uint32_t)strlen(id);
+          hs[k] = SlotMap::hash(id, lens[k]);
+          map.prefetch(hs[k]);
+        }
+        for (int k = 0; k < nb; ++k) {
+          const char *id = rq.item_ids[i0 + k] ? rq.item_ids[i0 + k] : "";
+          const uint32_t s = map.find_hashed(hs[k], id, lens[k]);
+          hb.item_slot[begin + i0 + k] = s == SlotMap::NONE ? -1 : (int32_t)s;
+          hb.item_req[begin + i0 + k] = (uint32_t)r;
+        }
+      }
+    });
     double *cs = prog.n_consts ? &hb.consts[(size_t)r * prog.n_consts] : nullptr;
+    // the table-sizing walks below read the host mirror of a few dozen item records (the head of the candidate list for
+    // diversity, the session's interacted items for interacted_with): ask for their lines now, all at once
+    auto prefetch_record = [&](int32_t slot) {
+      if (slot < 0) return;
+      const Table &t = store.tables[SC_ITEM];
+      const uint8_t *rec = t.rows.data() + (size_t)slot * t.stride;
+      for (uint32_t o = 0; o < t.stride; o += 64) __builtin_prefetch(rec + o);
+    };
+    if (!prog.prep.empty()) {
+      for (int i = 0; i < std::min(rq.n_items, 48); ++i) prefetch_record(hb.item_slot[begin + i]);
+      for (const HostOp &ho : prog.host_ops) {
+        if (ho.def->type != FType::InteractedWith) continue;
+        const HostCell lc = host_cell(store, ho.def->scope, ho.def->scope == SC_SESSION ? rd.session_slot : rd.user_slot, prog.prep[ho.prep_base].list_col);
+        if (lc.tag == TAG_MISSING) continue;
+        const uint32_t off = (uint32_t)lc.bits, len = (uint32_t)(lc.bits >> 32);
+        for (uint32_t k = 0; k < len; ++k) prefetch_record((int32_t)store.slot_pool.host[off + k]);
+      }
+    }
     for (const HostOp &ho : prog.host_ops) {
       const FeatureDef &f = *ho.def;
       switch (f.type) {
@@ -981,7 +1057,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
             }
           }
           PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base + fi];
-          const uint32_t cap = table_capacity(count);
+          const uint32_t cap = table_capacity(count, load_pct);
           po.tab_off = (uint32_t)arena;
           po.tab_cap = cap;
           arena += cap;
@@ -1000,11 +1076,11 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
           else if (mode == 1 && c.tag == TAG_STRING_LIST) { tokens += (uint32_t)(c.bits >> 32); ++taken; }
           else if (mode == 2 && c.tag == TAG_DOUBLE) { ++doubles; ++taken; }
         }
-        hb.max_doubles = std::max(hb.max_doubles, doubles);
+        wk.max_doubles = std::max(wk.max_doubles, doubles);
         if (doubles > PREP_MAX_VALUES)
           throw StatusError(MRK_ERR_UNSUPPORTED, "diversity feature '" + f.name + "' over more than " + std::to_string(PREP_MAX_VALUES) + " values: set `top`");
         PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base];
-        const uint32_t cap = table_capacity(tokens);
+        const uint32_t cap = table_capacity(tokens, load_pct);
         po.tab_off = (uint32_t)arena;
         po.tab_cap = cap;
         arena += cap;
@@ -1020,7 +1096,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
           const uint32_t gi = (uint32_t)(begin + i);
           if (f.type == FType::Number && f.scope != SC_RANKING) {  // NumberFeature.scala:86-92
             for (const mrk_field *p = fb; p != fe; ++p)
-              if (p->type == MRK_FIELD_NUMBER && p->name && f.field == p->name) { hb.overrides.push_back({gi, (uint32_t)ho.dst, p->num}); break; }
+              if (p->type == MRK_FIELD_NUMBER && p->name && f.field == p->name) { wk.overrides.push_back({gi, (uint32_t)ho.dst, p->num}); break; }
           } else if (f.type == FType::String && !f.field_is_ranking) {  // StringFeature.scala:96-99
             for (const mrk_field *p = fb; p != fe; ++p) {
               if (!p->name || f.field != p->name) continue;
@@ -1028,22 +1104,22 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
               enc.assign(f.dim, 0.0);
               if (p->type == MRK_FIELD_STRING) { const char *one[1] = {p->str ? p->str : ""}; encode_string(f, one, 1, enc.data()); }
               else encode_string(f, p->strs, p->n, enc.data());
-              for (int k = 0; k < f.dim; ++k) hb.overrides.push_back({gi, (uint32_t)(ho.dst + k), enc[k]});
+              for (int k = 0; k < f.dim; ++k) wk.overrides.push_back({gi, (uint32_t)(ho.dst + k), enc[k]});
               break;
             }
           } else if (f.type == FType::Relevancy) {  // RelevancyFeature.scala:41-48: the first field called "relevancy" decides
             for (const mrk_field *p = fb; p != fe; ++p)
               if (p->name && !strcmp(p->name, "relevancy")) {
-                if (p->type == MRK_FIELD_NUMBER) hb.overrides.push_back({gi, (uint32_t)ho.dst, p->num});
+                if (p->type == MRK_FIELD_NUMBER) wk.overrides.push_back({gi, (uint32_t)ho.dst, p->num});
                 break;
               }
           } else if (f.type == FType::ExternalItem) {
             for (const mrk_field *p = fb; p != fe; ++p)
               if (p->name && f.ext_field == p->name) {
-                if (p->type == MRK_FIELD_NUMBER && f.dim == 1) hb.overrides.push_back({gi, (uint32_t)ho.dst, p->num});
+                if (p->type == MRK_FIELD_NUMBER && f.dim == 1) wk.overrides.push_back({gi, (uint32_t)ho.dst, p->num});
                 else if (p->type == MRK_FIELD_NUMBER_LIST) {
                   if (p->n != f.dim) throw StatusError(MRK_ERR_DIM_MISMATCH, "for " + f.name + " dim mismatch: " + std::to_string(f.dim) + " != " + std::to_string(p->n));
-                  for (int k = 0; k < f.dim; ++k) hb.overrides.push_back({gi, (uint32_t)(ho.dst + k), p->nums[k]});
+                  for (int k = 0; k < f.dim; ++k) wk.overrides.push_back({gi, (uint32_t)(ho.dst + k), p->nums[k]});
                 }
                 break;
               }
@@ -1051,12 +1127,31 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
         }
       }
     }
-    hb.max_req_entries = std::max(hb.max_req_entries, arena - arena_at_start);
-    begin += rq.n_items;
+    req_entries[(size_t)r] = arena;
+  };
+  if (n_req == 1) {
+    resolve_one(0, workers[0], n_workers);
+  } else {
+    parallel_ranges(n_req, n_workers, [&](int64_t lo, int64_t hi, int w) {
+      for (int64_t r = lo; r < hi; ++r) resolve_one((int)r, workers[(size_t)w], 1);
+    });
+  }
+  // the arena: request after request (serial: a running sum), then every table offset becomes absolute
+  uint64_t arena = 0;
+  for (int r = 0; r < n_req; ++r) {
+    if (arena + req_entries[(size_t)r] > 0xffffffffull) throw StatusError(MRK_ERR_UNSUPPORTED, "batch needs more than 2^32 hash-table entries");
+    hb.reqs[r].arena_begin = (uint32_t)arena;
+    for (size_t e = 0; e < prog.prep.size(); ++e) hb.prep_out[(size_t)r * prog.prep.size() + e].tab_off += (uint32_t)arena;
+    hb.max_req_entries = std::max(hb.max_req_entries, req_entries[(size_t)r]);
+    arena += req_entries[(size_t)r];
+  }
+  for (Worker &wk : workers) {  // workers own increasing request ranges: concatenation keeps request order
+    hb.overrides.insert(hb.overrides.end(), wk.overrides.begin(), wk.overrides.end());
+    hb.max_items = std::max(hb.max_items, wk.max_items);
+    hb.max_doubles = std::max(hb.max_doubles, wk.max_doubles);
   }
   for (const CrossValue &c : cross_values)
     if (c.v == c.v) hb.overrides.push_back({(uint32_t)(hb.reqs[c.req].item_begin + c.item), (uint32_t)c.dst, c.v});
-  if (arena > 0xffffffffull) throw StatusError(MRK_ERR_UNSUPPORTED, "batch needs more than 2^32 hash-table entries");
   hb.arena_entries = arena;
 }
 

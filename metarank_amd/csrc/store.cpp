@@ -89,14 +89,14 @@ uint32_t Store::find_token(const std::string &s) const {
   return it == token_of.end() ? 0 : it->second;
 }
 
-uint32_t Store::slot(ScopeId scope, const std::string &id, bool create) {
+uint32_t Store::slot(ScopeId scope, const char *id, size_t len, bool create) {
   Table &t = tables[scope];
-  auto it = t.slot_of.find(id);
-  if (it != t.slot_of.end()) return it->second;
+  const uint32_t found = t.slot_of.find(id, len);
+  if (found != SlotMap::NONE) return found;
   if (!create) return NO_SLOT;
   if (!frozen) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called before the store is used");
   uint32_t s = t.n_slots++;
-  t.slot_of.emplace(id, s);
+  t.slot_of.insert(id, len, s);
   t.rows.resize((size_t)t.n_slots * t.stride, 0);
   t.mark(s);
   return s;
