@@ -14,8 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
@@ -121,12 +123,20 @@ struct JitKernels {
   hipModule_t mod[2] = {nullptr, nullptr};   // [f64]: one module per scorer precision, built when first needed
   hipFunction_t fn[2] = {nullptr, nullptr};
   bool failed[2] = {false, false};
+  // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
+  std::thread worker[2];
+  std::atomic<int> state[2] = {{0}, {0}};    // 0 idle, 1 compiling, 2 code ready, 3 failed
+  std::vector<char> code[2];
+  std::string error[2];
 };
 
-int jit_mode() {  // 0 off, 1 on (fall back to the generic kernel with a warning if hiprtc fails), 2 required
+// 0 off; 1 on: the first rank of a model waits for the compile (a failure falls back to the generic kernel with a warning);
+// 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready
+int jit_mode() {
   const char *e = getenv("MRK_RANK_JIT");
   if (!e) return 1;
   if (!strcmp(e, "require")) return 2;
+  if (!strcmp(e, "async")) return 3;
   return atoi(e) != 0 ? 1 : 0;
 }
 
@@ -184,7 +194,7 @@ void *jit_rank_function(const Program &prog, bool f64) {
   const int v = f64 ? 1 : 0;
   if (k->fn[v]) return (void *)k->fn[v];
   if (k->failed[v] && mode != 2) return nullptr;
-  try {
+  auto produce = [&prog, f64]() {  // host only: no device call (safe on any thread)
     const std::string src = jit_source(prog, f64);
     const std::string path = cache_path(src);
     std::vector<char> code = read_file(path);
@@ -192,6 +202,36 @@ void *jit_rank_function(const Program &prog, bool f64) {
       std::string log;
       code = jit_compile(src, log);
       write_file(path, code);
+    }
+    return code;
+  };
+  try {
+    std::vector<char> code;
+    if (mode == 3 || k->state[v].load() != 0) {
+      int st = k->state[v].load();
+      if (st == 0) {  // first sight of this (program, precision): start the compile, keep ranking with the generic kernel
+        k->state[v].store(1);
+        k->worker[v] = std::thread([k, v, produce]() {
+          try {
+            k->code[v] = produce();
+            k->state[v].store(2);
+          } catch (const std::exception &e) {
+            k->error[v] = e.what();
+            k->state[v].store(3);
+          }
+        });
+        return nullptr;
+      }
+      if (st == 1) {
+        if (mode != 2 && mode != 1) return nullptr;  // still compiling
+        k->worker[v].join();                         // a synchronous mode took over: wait for it
+        st = k->state[v].load();
+      }
+      if (k->worker[v].joinable()) k->worker[v].join();
+      if (st == 3) throw StatusError(MRK_ERR_DEVICE, k->error[v]);
+      code.swap(k->code[v]);
+    } else {
+      code = produce();
     }
     MRK_HIP(hipModuleLoadData(&k->mod[v], code.data()));
     MRK_HIP(hipModuleGetFunction(&k->fn[v], k->mod[v], "mrk_jit_rank_cells"));
@@ -222,6 +262,8 @@ extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *o
 void jit_release(Program &prog) {
   if (!prog.jit) return;
   JitKernels *k = (JitKernels *)prog.jit;
+  for (std::thread &t : k->worker)
+    if (t.joinable()) t.join();  // the worker reads `prog`
   for (hipModule_t m : k->mod)
     if (m) (void)hipModuleUnload(m);
   delete k;

@@ -352,3 +352,164 @@ def test_concurrent_callers_are_combined_and_isolated(oracle_c2):
         assert all(e is not None and getattr(e, "status", 0) == -5 for e in errs)  # every request reads the global counter
     finally:
         hip.close()
+
+
+def _stress_config():
+    """Shapes the Ranklens workloads do not reach: rates over 6 periods (more than one batch of the rate op), an
+    interacted_with over 6 fields (more than one batch of fields), token lists of up to 14 tokens (beyond the batches the
+    kernels prefetch), diversity over 40 numeric values."""
+    periods = [1, 2, 3, 7, 14, 30]
+    fields = [f"f{k}" for k in range(6)]
+    features = [
+        {"name": "pop", "type": "number", "scope": "item", "source": "metadata.pop"},
+        {"name": "price", "type": "number", "scope": "item", "source": "metadata.price"},
+        {"name": "ctr6", "type": "rate", "top": "click", "bottom": "impression", "bucket": "24h", "periods": periods, "normalize": {"weight": 3}},
+        {"name": "ctr_tag6", "type": "rate", "top": "click", "bottom": "impression", "bucket": "24h", "periods": periods, "scope": "item.tag"},
+        {"name": "profile6", "type": "interacted_with", "interaction": "click", "field": [f"item.{f}" for f in fields], "field_order": fields,
+         "scope": "session", "count": 100, "duration": "24h"},
+        {"name": "div_words", "type": "diversity", "source": "item.words", "top": 30},
+        {"name": "div_price", "type": "diversity", "source": "item.price", "top": 40},
+        {"name": "clicks", "type": "window_count", "interaction": "click", "scope": "item", "bucket": "24h", "periods": periods},
+    ]
+    names = [f["name"] for f in features]
+    return {"features": features, "models": {"m": {"type": "lambdamart", "backend": {"type": "lightgbm", "iterations": 10}, "features": names}}}, periods, fields
+
+
+def _stress_state(periods, fields, n_items=600, n_sessions=40, seed=5):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P = len(periods)
+    tag_tot = {}
+    g = [np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)]
+    for i in range(n_items):
+        k = f"item={i}/"
+        if rng.random() < 0.9:
+            yield "double", k + "pop", float(rng.integers(0, 100000))
+            yield "double", k + "price", float(np.round(rng.normal() * 50, 2))
+            yield "double", k + "div_price", float(np.round(rng.normal() * 50, 2)) if rng.random() < 0.95 else float("nan")
+            for f in fields:
+                yield "string_list", k + f"profile6_{f}", [f"{f}t{t}" for t in rng.integers(0, 60, int(rng.integers(0, 15)))]
+            yield "string_list", k + "div_words", [f"w{t}" for t in rng.integers(0, 200, int(rng.integers(1, 13)))]
+        if rng.random() < 0.85:
+            imp = np.sort(rng.integers(1, 5000, P))
+            clk = (imp * rng.random(P) * 0.3).astype(np.int64)
+            yield "periodic", k + "ctr6_click", [int(x) for x in clk]
+            yield "periodic", k + "ctr6_impression", [int(x) for x in imp]
+            yield "periodic", k + "clicks", [int(x) for x in clk]
+            g[0] += clk
+            g[1] += imp
+            if rng.random() < 0.7:
+                tag = f"tag{int(rng.integers(0, 25))}"
+                yield "string", k + "ctr_tag6_field", tag
+                e = tag_tot.setdefault(tag, [np.zeros(P, dtype=np.int64), np.zeros(P, dtype=np.int64)])
+                e[0] += clk
+                e[1] += imp
+    yield "periodic", "global/ctr6_click_norm", [int(x) for x in g[0]]
+    yield "periodic", "global/ctr6_impression_norm", [int(x) for x in g[1]]
+    for tag, (c, m) in tag_tot.items():
+        yield "periodic", f"field=tag:{tag}/ctr_tag6_click", [int(x) for x in c]
+        yield "periodic", f"field=tag:{tag}/ctr_tag6_impression", [int(x) for x in m]
+    for s in range(n_sessions):
+        ln = int(rng.integers(0, 101))
+        if ln:
+            yield "bounded_list", f"session=s{s}/profile6_interactions", [str(x) for x in rng.integers(0, n_items, ln)]
+
+
+@pytest.mark.gpu
+def test_shapes_beyond_the_kernels_batches_and_long_threshold_tables():
+    """Rates over 6 periods, interacted_with over 6 fields, token lists beyond the prefetched batches, a 40-value numeric
+    diversity - and a forest whose columns carry up to > 256 distinct thresholds, so the assembly sink stages tables in one
+    LDS-DMA chunk, in two, and falls back to searching in global memory.  Specialised and generic kernels vs the oracle."""
+    import os
+
+    cfg, periods, fields = _stress_config()
+    orc, hip = OracleBackend(cfg, "m"), HipBackend(cfg, "m")
+    saved = os.environ.get("MRK_RANK_JIT")
+    try:
+        for be in (orc, hip):
+            ranklens.load_state(be, _stress_state(periods, fields))
+        reqs = ranklens.generate_requests(24, 100, 600, 40, seed=31) + ranklens.generate_requests(3, 300, 600, 40, seed=32)
+        mats = [orc.matrix(ev) for ev in reqs]
+        allm = np.concatenate(mats)
+        dim = allm.shape[1]
+        assert dim == 2 + 6 + 6 + 6 + 1 + 1 + 6
+        # split candidates per column: 40 / 200 / 400 quantiles -> tables of < 128, 129..256 and > 256 thresholds
+        q = []
+        for j in range(dim):
+            col = allm[:, j]
+            col = col[np.isfinite(col)]
+            n = (40, 200, 400)[j % 3]
+            q.append(np.unique(np.quantile(col, np.linspace(0.01, 0.99, n))) if len(col) else np.array([0.0, 0.5]))
+        blob = synth.synthetic_lgbm_model(n_trees=3000, n_features=dim, quantiles=q, missing="per_feature")
+        orc.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        assert hip.booster.info()["bitvector"] == 1
+        expected = [orc.rerank(ev) for ev in reqs]
+        for jit in ("require", "0"):
+            os.environ["MRK_RANK_JIT"] = jit
+            batch = hip.ranker.prepare("m", reqs)
+            batch.run(hip.booster)
+            scores, order, _ = batch.fetch()
+            assert (batch.status() == 0).all()
+            for r, (_, es, eo) in enumerate(expected):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                assert same(scores[lo:hi], es), (jit, r)
+                assert order[lo:hi].tolist() == eo.tolist(), (jit, r)
+            _, _, mat = batch.fetch(matrix=True)
+            for r in range(len(reqs)):
+                assert same(mat[batch.offsets[r]:batch.offsets[r + 1]], mats[r]), (jit, r)
+            batch.close()
+    finally:
+        if saved is None:
+            os.environ.pop("MRK_RANK_JIT", None)
+        else:
+            os.environ["MRK_RANK_JIT"] = saved
+        hip.close()
+
+
+@pytest.mark.gpu
+def test_background_specialisation_swaps_in_without_changing_results(oracle_c2, tmp_path):
+    """MRK_RANK_JIT=async: the first rank of a model starts the hiprtc compile on a background thread and is served by the
+    generic kernel; once the code object exists (it appears in the cache directory) the specialised kernel takes over.
+    Every answer on the way is the oracle's."""
+    import glob
+    import os
+    import time
+
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_JIT", "MRK_JIT_CACHE_DIR")}
+    os.environ["MRK_RANK_JIT"], os.environ["MRK_JIT_CACHE_DIR"] = "async", str(tmp_path)
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        load(hip)
+        reqs = ranklens.generate_requests(12, 100, N_ITEMS, N_SESS, seed=41)
+        q = ranklens.column_quantiles(np.concatenate([oracle_c2.matrix(ev) for ev in reqs]))
+        blob = synth.synthetic_lgbm_model(n_trees=100, n_features=24, quantiles=q)
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        expected = [oracle_c2.rerank(ev) for ev in reqs]
+
+        def check():
+            batch = hip.ranker.prepare("xgboost", reqs)
+            batch.run(hip.booster)
+            scores, order, _ = batch.fetch()
+            for r, (_, es, eo) in enumerate(expected):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), r
+            batch.close()
+
+        t0 = time.time()
+        check()  # generic kernel; the compile starts
+        assert time.time() - t0 < 5.0, "the first rank waited for the compiler"
+        deadline = time.time() + 120
+        while not glob.glob(str(tmp_path / "*.co")) and time.time() < deadline:
+            check()
+            time.sleep(0.25)
+        assert glob.glob(str(tmp_path / "*.co")), "no code object was produced"
+        for _ in range(3):  # the specialised kernel is loaded by the next run and used from then on
+            check()
+    finally:
+        hip.close()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
