@@ -188,6 +188,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.fused_entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
   b.fused_vals = (int)vals;
   b.fused_threads = std::min(256, std::max(64, (hb.max_items + 63) / 64 * 64));
+  if (const char *e = getenv("MRK_FUSED_THREADS")) b.fused_threads = std::min(256, std::max(64, atoi(e) / 64 * 64));  // experiments
   const bool fused_enabled = [] { const char *e = getenv("MRK_RANK_FUSED"); return !e || atoi(e) != 0; }();
   b.fused_ok = fused_enabled && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
                hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR) <= 64 * 1024;

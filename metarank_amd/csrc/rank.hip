@@ -12,9 +12,11 @@
 //              *sink*: the row-major f64 matrix (ClickthroughQuery's layout: explain / parity / models
 //              without a bit-vector image) or, for the hot path, straight into the scorer's binned
 //              u16 tile (qs_device.hpp) - the f64 matrix is then never written or read
-// Small requests run both phases in ONE workgroup with the tables in LDS (rank_fused_kernel); large
+// Small requests run both phases in ONE workgroup with the tables in LDS (rank_fused_*_kernel); large
 // requests (more candidates than one workgroup should loop over, or tables that do not fit LDS) use
 // prepass_kernel -> tables in HBM -> assemble_kernel across many workgroups.
+// The device code of both phases lives in rank_device.hpp: the kernels here interpret any model program from
+// device memory; jit.cpp compiles the same code once more per model with the program as constants (the hot path).
 //   sort_kernel      one workgroup per request: stable descending order, java.lang.Double.compare
 // Compiled with -ffp-contract=off: the JVM never fuses a*b+c, and parity is bit-exact.
 #include <hip/hip_runtime.h>
