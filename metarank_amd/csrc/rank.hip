@@ -161,22 +161,23 @@ __device__ __forceinline__ bool pair_lt(unsigned long long ka, int ia, unsigned 
 
 constexpr int MERGE_TILE = 1024;  // outputs of one workgroup of a merge pass
 
+template <int CHUNK>
 __global__ void __launch_bounds__(SORT_THREADS)
 msort_chunk_kernel(BatchDev b, int r, unsigned long long *keys, int *idx) {
-  __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
-  __shared__ int s_idx[SORT_MAX_ITEMS];
+  __shared__ unsigned long long s_key[CHUNK];
+  __shared__ int s_idx[CHUNK];
   const ReqDev rq = b.reqs[r];
-  const int base = blockIdx.x * SORT_MAX_ITEMS;
+  const int base = blockIdx.x * CHUNK;
   const int tid = threadIdx.x;
-  for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) {
+  for (int i = tid; i < CHUNK; i += SORT_THREADS) {
     const int g = base + i;
     s_key[i] = g < rq.n_items ? sort_key(b.scores[rq.item_begin + g]) : ~0ull;  // padding sorts last
     s_idx[i] = g < rq.n_items ? g : 0x7fffffff;
   }
   __syncthreads();
-  for (int k = 2; k <= SORT_MAX_ITEMS; k <<= 1) {
+  for (int k = 2; k <= CHUNK; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) {
+      for (int i = tid; i < CHUNK; i += SORT_THREADS) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const unsigned long long ka = s_key[i], kb = s_key[ixj];
@@ -188,7 +189,7 @@ msort_chunk_kernel(BatchDev b, int r, unsigned long long *keys, int *idx) {
       __syncthreads();
     }
   }
-  for (int i = tid; i < SORT_MAX_ITEMS; i += SORT_THREADS) { keys[base + i] = s_key[i]; idx[base + i] = s_idx[i]; }
+  for (int i = tid; i < CHUNK; i += SORT_THREADS) { keys[base + i] = s_key[i]; idx[base + i] = s_idx[i]; }
 }
 
 // number of elements taken from run A among the first `diag` outputs of merge(A, B); A, B sorted, pairs distinct
@@ -227,7 +228,8 @@ __device__ __forceinline__ int merge_path_block(const unsigned long long *ka, co
 template <int TILE>
 __global__ void __launch_bounds__(SORT_THREADS)
 msort_merge_kernel(const unsigned long long *__restrict__ src_k, const int *__restrict__ src_i, unsigned long long *__restrict__ dst_k,
-                   int *__restrict__ dst_i, int n_pad, int run) {
+                   int *__restrict__ dst_i, int n_pad, int run, int *__restrict__ order, const ReqDev *__restrict__ rq, int n_items) {
+  int *order_out = order ? order + rq->item_begin : nullptr;  // last pass: the request's slice of the batch order
   constexpr int PER_THREAD = TILE / SORT_THREADS;
   __shared__ unsigned long long s_key[TILE];
   __shared__ int s_idx[TILE];
@@ -256,8 +258,12 @@ msort_merge_kernel(const unsigned long long *__restrict__ src_k, const int *__re
     else if (y >= lb) take_a = true;
     else take_a = pair_lt(s_key[x], s_idx[x], s_key[la + y], s_idx[la + y]);
     const int p = take_a ? x : la + y;
-    dst_k[out0 + d + o] = s_key[p];
-    dst_i[out0 + d + o] = s_idx[p];
+    if (order_out) {  // the last pass writes the request's order itself (padding sorts last: the first n_items are real)
+      if (out0 + d + o < n_items) order_out[out0 + d + o] = s_idx[p];
+    } else {
+      dst_k[out0 + d + o] = s_key[p];
+      dst_i[out0 + d + o] = s_idx[p];
+    }
     x += take_a ? 1 : 0;
     y += take_a ? 0 : 1;
   }
@@ -376,18 +382,26 @@ size_t big_sort_padded(int n_items) { return ((size_t)n_items + SORT_MAX_ITEMS -
 
 void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx) {
   const int n_pad = (int)big_sort_padded(n_items);
-  const int chunks = n_pad / SORT_MAX_ITEMS;
+  // chunks sorted in LDS: smaller chunks = more workgroups in the first launch and shallower compare-exchange networks,
+  // but more merge passes.  Measured on 100 000 candidates (MRK_SORT_CHUNK): see DESIGN.md
+  static const int chunk = [] { const char *e = getenv("MRK_SORT_CHUNK"); const int c = e ? atoi(e) : 1024; return c == 2048 || c == 4096 ? c : 1024; }();
   ScopedKernelTimer timer(ctx, "sort");
   const dim3 blk(SORT_THREADS);
   unsigned long long *k0 = keys, *k1 = keys + n_pad;
   int *i0 = idx, *i1 = idx + n_pad;
-  hipLaunchKernelGGL(msort_chunk_kernel, dim3(chunks), blk, 0, ctx->launch, b, r, k0, i0);
-  for (int run = SORT_MAX_ITEMS; run < n_pad; run <<= 1) {
-    hipLaunchKernelGGL(msort_merge_kernel<MERGE_TILE>, dim3(n_pad / MERGE_TILE), blk, 0, ctx->launch, k0, i0, k1, i1, n_pad, run);
+  if (chunk == 4096) hipLaunchKernelGGL(msort_chunk_kernel<4096>, dim3(n_pad / 4096), blk, 0, ctx->launch, b, r, k0, i0);
+  else if (chunk == 2048) hipLaunchKernelGGL(msort_chunk_kernel<2048>, dim3(n_pad / 2048), blk, 0, ctx->launch, b, r, k0, i0);
+  else hipLaunchKernelGGL(msort_chunk_kernel<1024>, dim3(n_pad / 1024), blk, 0, ctx->launch, b, r, k0, i0);
+  bool stored = false;
+  for (int run = chunk; run < n_pad; run <<= 1) {
+    const bool last = run * 2 >= n_pad;
+    hipLaunchKernelGGL(msort_merge_kernel<MERGE_TILE>, dim3(n_pad / MERGE_TILE), blk, 0, ctx->launch, k0, i0, k1, i1, n_pad, run,
+                       last ? b.order : (int *)nullptr, b.reqs + r, n_items);
+    stored = last;
     std::swap(k0, k1);
     std::swap(i0, i1);
   }
-  hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->launch, b, r, i0);
+  if (!stored) hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->launch, b, r, i0);
   MRK_HIP(hipGetLastError());
 }
 
