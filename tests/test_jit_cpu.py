@@ -51,3 +51,30 @@ def test_hiprtc_compiles_the_specialised_kernel_for_gfx950(which, f64):
     rc, code = specialize(cfg, 1, f64=f64)
     assert rc == 0, _native.lib().mrk_last_error()
     assert code[:4] == b"\x7fELF" and b"mrk_jit_rank_cells" in code and b"gfx950" in code
+
+
+def test_compiles_when_torch_brought_its_own_rocm_libraries(tmp_path):
+    """bench.py --gpus N > 1 imports torch (the RCCL binding) before the library; the PyTorch wheel bundles its own
+    libhiprtc / libamd_comgr / libamdhip64 under the same sonames, so those are what libmrk_hip.so then runs on.  The
+    specialised kernel must compile there too (own process: the import order is the point)."""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import torch, ctypes as C, json, os, sys
+sys.path.insert(0, %r)
+from metarank_amd import _native, ranklens
+lib = _native.lib()
+js = json.dumps(ranklens.ranklens_config()).encode()
+need = C.c_size_t(0)
+lib.mrk_config_specialize(js, len(js), b"xgboost", 1, 1, None, 0, C.byref(need))
+buf = (C.c_uint8 * need.value)()
+rc = lib.mrk_config_specialize(js, len(js), b"xgboost", 1, 1, buf, need.value, C.byref(need))
+maps = open("/proc/%%d/maps" %% os.getpid()).read()
+print("RC", rc, bytes(buf[:4]) == b"\x7fELF", "torch/lib/libhiprtc" in maps)
+""" % repo
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MRK_JIT_CACHE_DIR=str(tmp_path)))
+    assert "RC 0 True" in out.stdout, out.stdout + out.stderr
