@@ -1,0 +1,16 @@
+"""CPU: SlotMap (csrc/store.hpp), the id -> slot map of the device feature store's host side, against std::unordered_map:
+present ids resolve to their slot, absent ones (near misses included) never resolve.  Native test, compiled here."""
+import os
+import subprocess
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slotmap_matches_a_reference_map(tmp_path):
+    exe = str(tmp_path / "slotmap_test")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950",
+                           os.path.join(REPO, "tests", "native", "slotmap_test.cpp"), "-o", exe,
+                           "-I" + os.path.join(REPO, "metarank_amd", "csrc")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " bad 0 " in out.stdout
