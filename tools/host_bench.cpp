@@ -36,6 +36,7 @@ int main(int argc, char **argv) {
   struct Ev { std::string id, user, session; long long ts; std::vector<std::string> items; std::vector<const char *> ptrs; };
   std::vector<Ev> evs;
   size_t puts = 0;
+  double put_s = 0;
   while (std::getline(in, line)) {
     if (line.size() < 2) continue;
     if (line[0] == 'C') {
@@ -45,6 +46,7 @@ int main(int argc, char **argv) {
       const std::string &kind = f[0];
       const char *key = f[1].c_str();
       ++puts;
+      const auto load_s = std::chrono::steady_clock::now();
       if (kind == "double") store.put_double(key, atof(f[2].c_str()));
       else if (kind == "string") store.put_string(key, f[2].c_str());
       else if (kind == "counter") store.put_counter(key, atoll(f[2].c_str()));
@@ -62,6 +64,7 @@ int main(int argc, char **argv) {
         for (size_t i = 2; i < f.size(); ++i) v.push_back(atoll(f[i].c_str()));
         store.put_periodic(key, v.data(), (int)v.size());
       }
+      put_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - load_s).count();
     } else if (line[0] == 'R' && (int)evs.size() < n_req) {
       std::vector<std::string> f = split_tabs(line, 2);
       Ev e;
@@ -83,7 +86,7 @@ int main(int argc, char **argv) {
     total += e.ptrs.size();
   }
   const Program *prog = reg->program("xgboost");
-  fprintf(stderr, "%zu puts, %zu requests, %zu items\n", puts, reqs.size(), total);
+  fprintf(stderr, "%zu puts in %.2f s (%.2f M puts/s incl. argument conversion), %zu requests, %zu items\n", puts, put_s, puts / put_s / 1e6, reqs.size(), total);
   HostBatch hb;
   resolve_requests(*prog, store, reqs.data(), (int)reqs.size(), hb);  // warm
   const int reps = 5;
