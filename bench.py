@@ -3,9 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic Ranklens-shaped requests that is
-already resident in HBM: assembly (pre-pass + gather, straight into the scorer's binned tile) ->
-score -> sort for `--requests` requests of `--items` candidate items each.
+A "step" is one pass of the hot path over `--batches-per-step` device batches of synthetic Ranklens-shaped requests
+that are already resident in HBM (resolved, uploaded): per device batch, assembly (pre-pass + gather, straight into the
+scorer's binned tile) -> score -> sort for `--requests` requests of `--items` candidate items each.  The default
+(c2: 96 device batches = 368 640 requests = 36.9 M candidates per step) makes the driver's 20-step run a ~1 s timed
+region instead of 11 ms; the resident requests are `--streams` distinct device batches visited in turn, each on its own
+HIP stream.  `value` is that device-resident throughput (the contract: inputs in HBM when the clock starts).
+
+The JSON line also carries "e2e": the serving loop with FRESH requests every device batch - mrk_batch_load (host part
+of the request + upload of the id bytes; item ids are resolved to store slots by a kernel) -> run -> download of
+scores / order / status into pinned memory, `--e2e-batches` batches in flight, one host thread, >= 1 s of timed work.
 
 --workload c2 (default)  the configuration BASELINE.json's metric is quoted on: 100-item requests, the
              24 Ranklens columns (stock Ranklens model), 500-tree LightGBM-format LambdaMART;
@@ -58,6 +65,11 @@ def main():
                     help="batches in flight per GPU (each on its own HIP stream; steps alternate between them). "
                          "Default 2 for c2 / c3 (the assembly kernels wait on memory while the scorer is VALU-bound: consecutive "
                          "batches overlap), 1 for c4")
+    ap.add_argument("--batches-per-step", type=int, default=None,
+                    help="device batches one step runs (default: c2 / c3 96, c4 128, c5 8: a step is about 50 ms of device work)")
+    ap.add_argument("--e2e-seconds", type=float, default=1.5, help="timed length of the end-to-end serving loop (0 = skip)")
+    ap.add_argument("--e2e-batches", type=int, default=3, help="batches in flight in the end-to-end loop")
+    ap.add_argument("--e2e-sets", type=int, default=6, help="distinct request sets the end-to-end loop cycles through")
     ap.add_argument("--drop-features", default="", help="experiments only: comma-separated features removed from the model")
     ap.add_argument("--catalogue", type=int, default=100_000)
     ap.add_argument("--sessions", type=int, default=10_000)
@@ -74,6 +86,9 @@ def main():
     if args.streams is None:
         args.streams = 1 if sharded else 2
     n_streams = max(1, args.streams)
+    if args.batches_per_step is None:
+        args.batches_per_step = {"c2": 96, "c3": 96, "c4": 128, "c5": 8}[wl]
+    bps = max(1, args.batches_per_step)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -93,7 +108,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import metarank_amd as M
-    from metarank_amd import ranklens, synth
+    from workloads import ranklens, synth
 
     ctx = M.Context(local_rank)
     cfg = ranklens.c3_config() if wl == "c3" else ranklens.c5_config() if wl == "c5" else ranklens.ranklens_config()
@@ -214,7 +229,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def step(i):
+    def run_one(i):
         bt, gather = batches[i % n_streams], gathers[i % n_streams]
         if qtok is not None:
             enc.embed_ids(*qtok[i % n_streams])
@@ -227,6 +242,10 @@ def main():
             bt.run(booster)
             if gather is not None:
                 gather()
+
+    def step(i):
+        for j in range(bps):
+            run_one(i * bps + j)
 
     for i in range(args.warmup):
         step(i)
@@ -248,7 +267,8 @@ def main():
         st = bt.status()
         assert (st == 0).all(), f"requests failed: {st[st != 0][:5]}"
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_items * (1 if sharded else n_gpus) * args.steps / elapsed
+    value = total_items * bps * (1 if sharded else n_gpus) * args.steps / elapsed
+    ms_per_batch = ms_per_step / bps
 
     # ---- per-kernel HIP-event timing (outside the timed region, one batch at a time: the events add a little
     #      overhead and overlapping batches would stretch each other's kernels)
@@ -267,20 +287,23 @@ def main():
         if n:
             kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / prof_steps}
     ctx.profile_enable(False)
-    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
-    # algorithmic bytes per launch of the dominant kernel (DESIGN.md "Roofline accounting")
-    store_bytes_item = 8 * dim + 48           # one record worth of cells + ~12 list tokens
+    for k in kernels:
+        kernels[k]["launches_per_batch"] = kernels[k].pop("launches_per_step")
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_batch"])
+    # Algorithmic bytes per launch of the dominant kernel = SURVEY.md 8(d)'s per-item figure x the items one launch
+    # processes (+ the model, read once per launch).  B_item for the configuration as built (f64 columns, LightGBM):
+    #   store read  8 B x D matrix columns + ~48 B of list tokens (12 tokens x 4 B)
+    #   ids / slot in 4 B, score out 8 B
+    #   c5: + the item's stored embedding, 384 x 8 B (kept f64, as stored)
+    # No intermediate tile, no pre-pass tokens: what the fused path would move at best.
     V = info["tile_columns"]                  # u16 cells per item in the scorer's tile
     my_items = min(chunk, total_items) if sharded else total_items
-    prepass_bytes = args.requests * (100 * 12 * 4 + 20 * 11 * 4)  # session profile tokens + diversity head
-    alg = {
-        "score": my_items * (2 * V + 8) + info["n_trees"] * 256,   # cells in, score out, node constants + leaves
-        "bin": my_items * (8 * dim + 2 * V),
-        "assemble": my_items * (store_bytes_item + 8 + 2 * V) + prepass_bytes,  # record + tokens + slot in, cells out
-        "prepass": prepass_bytes,
-        "sort": total_items * (8 + 4),
-        "override": 0,
-    }
+    b_item = 8 * dim + 48 + 4 + 8 + (384 * 8 if wl == "c5" else 0)
+    model_bytes = info["n_trees"] * (15 * 16 + 16 * 8)
+    alg_path = my_items * b_item + model_bytes      # the whole fused path (8d)
+    alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass")}
+    alg["sort"] = total_items * (8 + 4)
+    alg["override"] = 0
     # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE, KB per
     # launch, collected in separate runs: tools/gpu/pmc_bench.sh).  MI355X_MICROARCH.md: FETCH_SIZE counts half of
     # the bytes of wide coalesced reads (the scorer's slab copy: x2); narrow scattered loads (assembly) are
@@ -303,10 +326,71 @@ def main():
     achieved = alg[dominant] / dur_s / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dominant],
+                "bytes_per_item": b_item, "items_per_launch": my_items, "model_bytes_per_launch": model_bytes,
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
+                "whole_path": {"achieved": alg_path / (ms_per_batch * 1e-3) / 1e9, "frac": alg_path / (ms_per_batch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "ms_per_batch": ms_per_batch},
                 "note": "the forest scorer is VALU-issue bound, not HBM bound (SURVEY.md 8d): "
                         f"{my_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G item-trees/s "
                         f"in {kernels['score']['avg_ms']:.3f} ms"}
+
+    # ---- end to end: FRESH requests every device batch (host part + upload of the id bytes + device-side id resolution
+    #      + run + download into pinned memory), several batches in flight, one host thread
+    e2e = None
+    if rank == 0 and n_gpus == 1 and args.e2e_seconds > 0 and not sharded and wl != "c5":
+        n_sets = max(2, args.e2e_sets)
+        sets = [M.RequestSet(ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
+                                                        seed=ranklens.SEED + 5000 + k)) for k in range(n_sets)]
+        nb = max(1, args.e2e_batches)
+        eb = [ranker.new_batch() for _ in range(nb)]
+        results = [None] * n_sets
+
+        def serve(i, keep=False):
+            b = eb[i % nb]
+            if i >= nb:
+                sc, od, st = b.host_outputs()           # waits for the batch's previous round
+                assert (st == 0).all()
+                if keep:
+                    results[(i - nb) % n_sets] = (sc.copy(), od.copy())
+            b.load(model_name, sets[i % n_sets])
+            b.run(booster)
+            b.enqueue_fetch()
+
+        for i in range(2 * nb + n_sets):
+            serve(i, keep=True)
+        for b in eb:
+            b.sync()
+        t1 = time.perf_counter()
+        n_done = 0
+        while True:
+            for _ in range(16):
+                serve(n_done)
+                n_done += 1
+            if time.perf_counter() - t1 >= args.e2e_seconds:
+                break
+        for b in eb:
+            b.host_outputs()
+        e2e_s = time.perf_counter() - t1
+        e2e_items = n_done * sets[0].total_items
+        # what the loop returned equals the device-resident path on the same requests (bit for bit)
+        chk = ranker.prepare(model_name, sets[0].requests_with_ids())
+        chk.run(booster)
+        cs, co, _ = chk.fetch()
+        chk.close()
+        assert results[0] is not None and np.array_equal(results[0][0], cs) and np.array_equal(results[0][1], co), "e2e results differ from the resident path"
+        e2e = {"value": e2e_items / e2e_s, "unit": "items/s", "seconds": e2e_s, "device_batches": n_done,
+               "ms_per_batch": e2e_s / n_done * 1e3, "frac_of_value": (e2e_items / e2e_s) / value,
+               "batches_in_flight": nb, "host_threads": 1, "distinct_request_sets": n_sets,
+               "h2d_bytes_per_batch": int(sets[0].id_bytes_total + 4 * (sets[0].total_items + 1)),
+               "d2h_bytes_per_batch": int(12 * sets[0].total_items + 4 * sets[0].n_req),
+               "includes": "per device batch: mrk_batch_load (user/session slots, request constants, table sizing on one host thread; "
+                           "upload of the raw id bytes; id -> slot resolution by a kernel) + mrk_batch_run (assembly, scoring, sort) + "
+                           "download of scores / order / status into pinned memory",
+               "excludes": "JSON decoding of the events (the host's HTTP layer) - the requests are pre-marshalled mrk_request structs + flat id bytes"}
+        for b in eb:
+            b.close()
+        for rs_ in sets:
+            rs_.close()
 
     # ---- single-request latency (p50 of mrk_rank: host marshalling + 4 launches + copies)
     encoder_out = None
@@ -410,14 +494,17 @@ def main():
         out = {
             "metric": f"ranked items/sec (feature assembly + {args.trees}-tree LambdaMART + ordering), Ranklens-shaped {args.items}-item requests",
             "value": value, "unit": "items/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_device_batch": ms_per_batch, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-lightgbm", "requests_per_step_per_gpu": args.requests,
-                       "items_per_request": args.items, "items_per_step_per_gpu": total_items, "catalogue_items": args.catalogue,
+                       "items_per_request": args.items, "device_batches_per_step": bps, "items_per_device_batch": total_items, "items_per_step_per_gpu": total_items * bps, "catalogue_items": args.catalogue,
                        "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16,
                        "tile_columns": V, "batches_in_flight": n_streams,
                        "parallelism": (f"item-sharded x{n_gpus}" if sharded else f"request-sharded x{n_gpus}") +
                                       (", RCCL all-gather of scores" if n_gpus > 1 else "")},
+            "value_is": "device-resident throughput: the requests of a step are resolved and in HBM before the clock starts (bench contract); "
+                        "the end-to-end serving rate with fresh requests per batch is `e2e`",
+            "e2e": e2e,
             "latency": latency,
             "encoder": encoder_out,
             "kernels": kernels,

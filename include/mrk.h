@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MRK_ABI_VERSION 4
+#define MRK_ABI_VERSION 5
 
 typedef enum mrk_status {
   MRK_OK = 0,
@@ -224,9 +224,45 @@ int mrk_rank_binary(mrk_ctx *ctx, mrk_model *model, const char *model_name, cons
 int mrk_model_warmup(mrk_ctx *ctx, mrk_model *model, const char *model_name, int *out_replayed);
 
 /* Batched form: resolve n_req requests once into a device-resident batch, then run it any number
- * of times (the benchmark's timed region is mrk_batch_run only). */
+ * of times (the benchmark's device-only timed region is mrk_batch_run only). */
 int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req,
                       mrk_batch **out);
+
+/* ---- the serving loop: reusable batches, flat item ids, results in pinned memory ----------------------------------
+ * What a host that decodes `ranking` events off the wire has in its hands is the UTF-8 bytes of the item ids, not an
+ * array of C strings - and the first hop of the read path (FeatureValueLoader.fromStateBackend building one
+ * Key(ItemScope(id), feature) per candidate, M/fstore/FeatureValueLoader.scala:11-25, M/model/Key.scala:7-10) is an id
+ * lookup per candidate.  With flat ids that hop runs on the device: the id bytes are uploaded as they are and a kernel
+ * hashes, probes the device mirror of the store's id table and compares (csrc/resolve.hip); the host does O(requests)
+ * work, nothing per item.
+ *
+ *   mrk_batch_create   an empty batch that owns a HIP stream and grow-only buffers;
+ *   mrk_batch_load     (re)fills it: waits for the batch's previous work, resolves the request-level part on the host
+ *                      (user / session / ranking slots, request constants, table sizing from bounds), uploads, and - with
+ *                      `ids` - enqueues the id resolution.  ids == NULL: reqs[r].item_ids are used (host lookups, exact
+ *                      table sizes), exactly like mrk_batch_prepare.  With ids, reqs[r].item_ids is ignored: the ids of
+ *                      request 0's items, then request 1's, ... lie back to back in ids->bytes, item i of the batch
+ *                      being bytes[offsets[i], offsets[i + 1]).  Buffers obtained from mrk_host_alloc are read by the
+ *                      copy engine directly; any other memory is staged through the batch's pinned buffer.
+ *   mrk_batch_run      as before (asynchronous);
+ *   mrk_batch_enqueue_fetch  enqueues the download of scores / order / status into the batch's pinned result buffer
+ *                      behind the run (asynchronous);
+ *   mrk_batch_host_outputs   waits for the batch and returns pointers INTO that pinned buffer (valid until the next
+ *                      mrk_batch_load / mrk_batch_run of this batch): scores[total_items] (request order), order
+ *                      [total_items] (request-local indices in response order), status[n_req] (mrk_status per request).
+ * Several batches of a context may be loaded, run and fetched from different host threads at the same time; store puts
+ * are serialised against them (a put never changes what a batch already in flight reads). */
+typedef struct mrk_item_ids {
+  const uint8_t *bytes;     /* concatenated UTF-8 ids, no terminators                  */
+  const uint32_t *offsets;  /* total_items + 1 byte offsets into `bytes`, ascending    */
+} mrk_item_ids;
+int mrk_batch_create(mrk_ctx *ctx, mrk_batch **out);
+int mrk_batch_load(mrk_batch *batch, const char *model_name, const mrk_request *reqs, int n_req, const mrk_item_ids *ids);
+int mrk_batch_enqueue_fetch(mrk_batch *batch);
+int mrk_batch_host_outputs(mrk_batch *batch, const double **scores, const int32_t **order, const int32_t **status);
+/* pinned (page-locked) host memory the device can read / write without a staging copy; NULL on failure */
+void *mrk_host_alloc(size_t bytes);
+void mrk_host_free(void *p);
 int mrk_batch_total_items(mrk_batch *batch);
 /* asynchronous on the context stream */
 int mrk_batch_run(mrk_batch *batch, mrk_model *model);

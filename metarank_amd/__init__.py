@@ -3,7 +3,7 @@
 The product is libmrk_hip.so (metarank_amd/csrc, C ABI in include/mrk.h); this package is the
 thin host-side mirror of the reference's interfaces used by tests and benchmarks.
 """
-from ._native import MrkError, build, lib  # noqa: F401
+from ._native import MrkError, build, lib, reload_switches  # noqa: F401
 from .booster import LIGHTGBM, XGBOOST, Context, HipBooster, default_context  # noqa: F401
 from .ranker import Batch, HipRanker  # noqa: F401,E402
-from .request import Request  # noqa: F401,E402
+from .request import Request, RequestSet  # noqa: F401,E402

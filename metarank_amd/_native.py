@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
-SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "jit.cpp", "score.hip", "score_qs.hip", "rank.hip", "writes.hip", "encoder.hip"]
+SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "jit.cpp", "score.hip", "score_qs.hip", "rank.hip", "resolve.hip", "writes.hip", "encoder.hip"]
 HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
 
 MRK_OK = 0
@@ -55,21 +55,41 @@ def embed_jit_sources() -> str:
 
 
 def build(force: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 every source into metarank_amd/libmrk_hip.so (in-tree)."""
+    """hipcc --offload-arch=gfx950 every source into metarank_amd/libmrk_hip.so (in-tree).  One object per source under
+    metarank_amd/build/ (compiled in parallel, rebuilt when the source or any header is newer), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     embed_jit_sources()
     srcs = sources()
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [
-        os.path.join(REPO, "include", "mrk.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + [os.path.join(REPO, "include", "mrk.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-ffp-contract=off",  # the JVM never fuses a*b+c; parity with the reference is bit-exact
-           "-o", LIB_PATH] + [f"-D{d}" for d in os.environ.get("MRK_DEFINES", "").split()] + srcs + [
-               "-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"]  # hiprtc: csrc/jit.cpp
-    subprocess.check_call(cmd)
+    defines = [f"-D{d}" for d in os.environ.get("MRK_DEFINES", "").split()]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-ffp-contract=off"] + defines  # the JVM never fuses a*b+c; parity with the reference is bit-exact
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
+            return obj, True
+        return obj, False
+
+    with ThreadPoolExecutor(max(1, min(len(srcs), os.cpu_count() or 1))) as ex:
+        done = list(ex.map(compile_one, srcs))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
+    objs = [o for o, _ in done]
+    if any(c for _, c in done) or not os.path.exists(LIB_PATH):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs +
+                              ["-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"])  # hiprtc: csrc/jit.cpp
     return LIB_PATH
 
 
@@ -95,6 +115,10 @@ class mrk_request(C.Structure):
                 ("fields", C.POINTER(mrk_field)), ("n_fields", C.c_int32), ("n_items", C.c_int32),
                 ("item_ids", C.POINTER(C.c_char_p)), ("item_field_offsets", C.POINTER(C.c_int32)),
                 ("item_fields", C.POINTER(mrk_field))]
+
+
+class mrk_item_ids(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("offsets", C.c_void_p)]
 
 
 # every symbol include/mrk.h declares: (restype, argtypes)
@@ -133,6 +157,12 @@ SIGNATURES = {
     "mrk_rank_binary": (_I, [_V, _V, _S, _P, C.c_size_t, C.POINTER(C.c_int), _P, _P, _I]),
     "mrk_model_warmup": (_I, [_V, _V, _S, C.POINTER(C.c_int)]),
     "mrk_batch_prepare": (_I, [_V, _S, C.POINTER(mrk_request), _I, C.POINTER(_V)]),
+    "mrk_batch_create": (_I, [_V, C.POINTER(_V)]),
+    "mrk_batch_load": (_I, [_V, _S, C.POINTER(mrk_request), _I, _P]),
+    "mrk_batch_enqueue_fetch": (_I, [_V]),
+    "mrk_batch_host_outputs": (_I, [_V, C.POINTER(_V), C.POINTER(_V), C.POINTER(_V)]),
+    "mrk_host_alloc": (_V, [C.c_size_t]),
+    "mrk_host_free": (None, [_V]),
     "mrk_batch_total_items": (_I, [_V]),
     "mrk_batch_run": (_I, [_V, _V]),
     "mrk_batch_shard_chunk": (_I, [_V, _I]),
@@ -183,6 +213,14 @@ def lib():
                 fn.argtypes = args
             _lib = L
     return _lib
+
+
+def reload_switches():
+    """The library reads its experiment switches (MRK_* environment variables) once; tests and measurement
+    scripts that change one inside a process call this afterwards."""
+    fn = lib().mrk_debug_reload_switches
+    fn.restype, fn.argtypes = None, []
+    fn()
 
 
 def check(status: int):

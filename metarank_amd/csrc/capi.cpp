@@ -1,7 +1,9 @@
 // C ABI (include/mrk.h): lifecycle, model handles, predictMat replacement, profiling.
 // Feature store / rank entry points live in capi_rank.cpp.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "runtime.hpp"
 
@@ -9,6 +11,41 @@ namespace mrk {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+static Switches read_switches() {
+  Switches s;
+  auto flag = [](const char *name, bool dflt) { const char *e = getenv(name); return e ? atoi(e) != 0 : dflt; };
+  auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+  s.rank_fused = flag("MRK_RANK_FUSED", true);
+  s.rank_cells = flag("MRK_RANK_CELLS", true);
+  if (const char *e = getenv("MRK_SCORER")) s.scorer_walk = !strcmp(e, "walk");
+  if (const char *e = getenv("MRK_FUSED_THREADS")) s.fused_threads = std::min(256, std::max(64, atoi(e) / 64 * 64));
+  s.rank_combine = flag("MRK_RANK_COMBINE", true);
+  s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
+  s.table_load_pct = std::max(10, std::min(90, num("MRK_TABLE_LOAD_PCT", 75)));
+  s.host_threads = std::max(0, std::min(256, num("MRK_HOST_THREADS", 0)));
+  if (const char *e = getenv("MRK_RANK_JIT")) s.jit_mode = !strcmp(e, "require") ? 2 : !strcmp(e, "async") ? 3 : atoi(e) != 0 ? 1 : 0;
+  s.jit_waves = num("MRK_JIT_WAVES", 0);
+  if (const char *d = getenv("MRK_JIT_CACHE_DIR")) s.jit_cache_dir = d;
+  else if (const char *x = getenv("XDG_CACHE_HOME")) s.jit_cache_dir = std::string(x) + "/mrk_jit";
+  else if (const char *h = getenv("HOME")) s.jit_cache_dir = std::string(h) + "/.cache/mrk_jit";
+  if (s.jit_cache_dir == "off") s.jit_cache_dir.clear();
+  const int sc = num("MRK_SORT_CHUNK", 1024);
+  s.sort_chunk = sc == 2048 || sc == 4096 ? sc : 1024;
+  s.qs_split = num("MRK_QS_SPLIT", -1);
+  s.qs_kernel = num("MRK_QS_KERNEL", 1);
+  s.qs_r = num("MRK_QS_R", 2);
+  s.qs_leaves = num("MRK_QS_LEAVES", 0);
+  s.encoder_graph = flag("MRK_ENCODER_GRAPH", false);
+  s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
+  return s;
+}
+static Switches &switches_storage() {
+  static Switches s = read_switches();
+  return s;
+}
+const Switches &switches() { return switches_storage(); }
+void reload_switches() { switches_storage() = read_switches(); }
 
 ScopedKernelTimer::ScopedKernelTimer(mrk_ctx *c, const char *n) : ctx(c), name(n) {
   if (!ctx->profile) return;
@@ -123,6 +160,8 @@ mrk_ctx::~mrk_ctx() { mrk::free_rank_state(this); }
 extern "C" {
 
 int mrk_abi_version(void) { return MRK_ABI_VERSION; }
+/* not part of include/mrk.h: tests / measurement scripts that change an experiment switch inside one process */
+void mrk_debug_reload_switches(void) { mrk::reload_switches(); }
 const char *mrk_last_error(void) { return g_last_error.c_str(); }
 
 int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out) {

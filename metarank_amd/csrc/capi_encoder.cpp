@@ -186,8 +186,7 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
   // Opt-in (MRK_ENCODER_GRAPH=1): measured 0.230 vs 0.240 ms for a 9-token query -- the forward pass of a small batch
   // is bound by the dependent-kernel chain, not by launch overhead -- and rocprofv3's kernel tracing crashes inside
   // the HIP runtime when a captured graph is launched.
-  const char *ge = getenv("MRK_ENCODER_GRAPH");
-  const bool use_graphs = ge && atoi(ge) != 0;
+  const bool use_graphs = switches().encoder_graph;
   if (use_graphs && M <= GRAPH_MAX_TOKENS) {
     const std::tuple<int, int, int> key(n, seq, mode);
     auto it = e.graphs.find(key);

@@ -26,6 +26,8 @@ size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
+void launch_resolve_ids(hipStream_t stream, const IdTableDev &tab, const uint8_t *d_bytes, const uint32_t *d_offs, const ReqDev *d_reqs,
+                        int n_req, int total, int32_t *d_item_slot, uint32_t *d_item_req);  // resolve.hip
 
 template <typename F>
 static int guard(F &&f) {
@@ -68,18 +70,24 @@ struct mrk_batch {
   mrk_ctx *ctx = nullptr;
   const Program *prog = nullptr;
   int n_req = 0, total_items = 0;
+  std::mutex bmu;            // a batch is driven by one thread at a time; this makes a mistake a wait instead of a race
   DevBuf d_in, d_prep_out, d_arena, d_matrix;
-  hipStream_t stream = nullptr;   // batches made by mrk_batch_prepare own a stream: several can be in flight on one device
+  hipStream_t stream = nullptr;   // batches made by mrk_batch_prepare / _create own a stream: several can be in flight on one device
   hipStream_t s() const { return stream ? stream : ctx->stream; }
   DevBuf d_out;              // [scores: (T + shard padding) f64][order: T i32][status: n_req i32], fetched with ONE copy
   size_t out_order_off = 0, out_status_off = 0, out_bytes = 0;
   PinBuf h_out;
+  bool fetch_enqueued = false;          // the download of d_out into h_out is on the stream behind the last run
   DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
   DevBuf d_sort_keys, d_sort_idx;       // scratch of the multi-workgroup sort
   std::vector<std::pair<int, int>> big; // (request, n_items) with n_items > SORT_MAX_ITEMS
   PinBuf h_in;
+  HostBatch hb;              // host half of the last load (grow-only scratch)
+  DevBuf d_ids;              // flat item ids of the batch: [offsets: (T + 1) u32][bytes]
+  PinBuf h_ids;              // their staging copy when the caller's memory is not pinned
   BatchDev view{};
   std::vector<int32_t> h_status;
+  std::vector<int32_t> codes;           // mrk_status per request (mrk_batch_host_outputs)
   bool ran = false;
   // one-workgroup-per-request path (tables in LDS)
   bool fused_ok = false;
@@ -106,13 +114,59 @@ void free_rank_state(mrk_ctx *ctx) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// builds the device-resident batch (inputs uploaded, outputs allocated); ctx->mu must be held
-static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *reqs, int n_req, mrk_batch &b) {
+// Access to the feature store for the duration of a call.  Readers (resolving a batch, launching kernels that gather from
+// the device tables) share it; whatever is dirty is flushed first, exclusively.  `exclusive`: the call mutates host-side
+// store state itself (lazily tokenised cross-encoder texts).
+struct StoreAccess {
+  mrk_ctx *ctx;
+  std::shared_lock<std::shared_mutex> shared;
+  std::unique_lock<std::shared_mutex> unique;
+  StoreAccess(mrk_ctx *c, bool exclusive = false, bool flush = true) : ctx(c) {
+    if (!ctx->store) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called first");
+    if (exclusive) {
+      unique = std::unique_lock<std::shared_mutex>(ctx->store_mu);
+      if (flush) do_flush();
+      return;
+    }
+    shared = std::shared_lock<std::shared_mutex>(ctx->store_mu);
+    while (flush && ctx->store->dirty()) {
+      shared.unlock();
+      {
+        std::unique_lock<std::shared_mutex> x(ctx->store_mu);
+        do_flush();
+      }
+      shared.lock();
+    }
+  }
+  void do_flush() {
+    MRK_HIP(hipSetDevice(ctx->device));
+    ctx->store->flush(ctx->stream);
+  }
+};
+
+static bool program_mutates_store(const Program &prog) {
+  for (const HostOp &ho : prog.host_ops)
+    if (ho.def->cross && ho.def->encoder) return true;
+  return false;
+}
+
+static bool is_pinned_host(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc memory: not an error worth keeping
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// (re)builds the device-resident batch (inputs uploaded, outputs allocated, id resolution enqueued); the caller holds
+// the store (StoreAccess) and the batch
+static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *reqs, int n_req, const mrk_item_ids *ids, mrk_batch &b) {
   Store &store = *ctx->store;
   MRK_HIP(hipSetDevice(ctx->device));
-  store.flush(ctx->stream);
-  HostBatch hb;
-  resolve_requests(prog, store, reqs, n_req, hb);
+  HostBatch &hb = b.hb;
+  resolve_requests(prog, store, reqs, n_req, ids, hb);
   b.ctx = ctx;
   b.prog = &prog;
   b.n_req = n_req;
@@ -122,25 +176,50 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   size_t off = 0;
   auto place = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_reqs = place(hb.reqs.size() * sizeof(ReqDev));
-  const size_t o_slot = place((size_t)T * 4);
-  const size_t o_ireq = place((size_t)T * 4);
   const size_t o_consts = place(hb.consts.size() * 8);
   const size_t o_irf = place(hb.irf.size() * 4);
   const size_t o_ov = place(hb.overrides.size() * sizeof(Override));
   const size_t o_prep = place(hb.prep_out.size() * sizeof(PrepOut));
+  const size_t host_bytes = std::max<size_t>(off, 256);  // everything the host fills; the per-item arrays follow
+  const size_t o_slot = place((size_t)T * 4);
+  const size_t o_ireq = place((size_t)T * 4);
   const size_t total_bytes = std::max<size_t>(off, 256);
-  b.h_in.reserve(total_bytes);
+  const size_t up_bytes = hb.device_ids ? host_bytes : total_bytes;  // device-resolved ids: item_slot / item_req are written by a kernel
+  b.h_in.reserve(up_bytes);
   b.d_in.reserve(total_bytes);
   uint8_t *h = b.h_in.as<uint8_t>();
   auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) memcpy(h + o, src, bytes); };
   put(o_reqs, hb.reqs.data(), hb.reqs.size() * sizeof(ReqDev));
-  put(o_slot, hb.item_slot.data(), (size_t)T * 4);
-  put(o_ireq, hb.item_req.data(), (size_t)T * 4);
   put(o_consts, hb.consts.data(), hb.consts.size() * 8);
   put(o_irf, hb.irf.data(), hb.irf.size() * 4);
   put(o_ov, hb.overrides.data(), hb.overrides.size() * sizeof(Override));
   put(o_prep, hb.prep_out.data(), hb.prep_out.size() * sizeof(PrepOut));
-  MRK_HIP(hipMemcpyAsync(b.d_in.p, h, total_bytes, hipMemcpyHostToDevice, b.s()));
+  if (!hb.device_ids) {
+    put(o_slot, hb.item_slot.data(), (size_t)T * 4);
+    put(o_ireq, hb.item_req.data(), (size_t)T * 4);
+  }
+  MRK_HIP(hipMemcpyAsync(b.d_in.p, h, up_bytes, hipMemcpyHostToDevice, b.s()));
+  uint8_t *d = b.d_in.as<uint8_t>();
+  if (hb.device_ids && T > 0) {
+    // the ids as they arrived: [offsets][bytes] in one device buffer; pinned caller memory is read by the copy engine
+    // directly, anything else goes through the batch's pinned staging buffer
+    const size_t off_bytes = ((size_t)T + 1) * 4;
+    const size_t id_bytes = ids->offsets[T];
+    const size_t o_bytes = align_up(off_bytes, 256);
+    b.d_ids.reserve(o_bytes + std::max<size_t>(id_bytes, 1));
+    const void *src_off = ids->offsets, *src_bytes = ids->bytes;
+    if (!is_pinned_host(ids->offsets) || !is_pinned_host(ids->bytes)) {
+      b.h_ids.reserve(o_bytes + std::max<size_t>(id_bytes, 1));
+      memcpy(b.h_ids.p, ids->offsets, off_bytes);
+      memcpy(b.h_ids.as<uint8_t>() + o_bytes, ids->bytes, id_bytes);
+      src_off = b.h_ids.p;
+      src_bytes = b.h_ids.as<uint8_t>() + o_bytes;
+    }
+    MRK_HIP(hipMemcpyAsync(b.d_ids.p, src_off, off_bytes, hipMemcpyHostToDevice, b.s()));
+    if (id_bytes) MRK_HIP(hipMemcpyAsync(b.d_ids.as<uint8_t>() + o_bytes, src_bytes, id_bytes, hipMemcpyHostToDevice, b.s()));
+    launch_resolve_ids(b.s(), store.tables[SC_ITEM].id_table_view(), b.d_ids.as<uint8_t>() + o_bytes, b.d_ids.as<uint32_t>(),
+                       (const ReqDev *)(d + o_reqs), n_req, T, (int32_t *)(d + o_slot), (uint32_t *)(d + o_ireq));
+  }
   b.d_arena.reserve(std::max<size_t>(hb.arena_entries, 1) * 8);
   // outputs in one allocation: one device-to-host copy per fetch (single-request latency)
   const size_t score_slots = (size_t)T + 256 * QS_TILE_ROWS;  // room for the padded chunks of an item-sharded all-gather
@@ -149,7 +228,6 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.out_bytes = b.out_status_off + std::max<size_t>(n_req, 1) * 4;
   b.d_out.reserve(b.out_bytes);
   b.d_matrix.reserve(std::max<size_t>((size_t)T * prog.dim, 1) * 8);
-  uint8_t *d = b.d_in.as<uint8_t>();
   BatchDev &v = b.view;
   v.reqs = (const ReqDev *)(d + o_reqs);
   v.n_req = n_req;
@@ -171,6 +249,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.h_status.assign(n_req, 0);
   b.ran = false;
   b.matrix_valid = false;
+  b.fetch_enqueued = false;
   b.big.clear();
   size_t big_p2 = 0;
   for (int r = 0; r < n_req; ++r)
@@ -188,9 +267,9 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.fused_entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
   b.fused_vals = (int)vals;
   b.fused_threads = std::min(256, std::max(64, (hb.max_items + 63) / 64 * 64));
-  if (const char *e = getenv("MRK_FUSED_THREADS")) b.fused_threads = std::min(256, std::max(64, atoi(e) / 64 * 64));  // experiments
-  const bool fused_enabled = [] { const char *e = getenv("MRK_RANK_FUSED"); return !e || atoi(e) != 0; }();
-  b.fused_ok = fused_enabled && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
+  const Switches &sw = switches();
+  if (sw.fused_threads) b.fused_threads = sw.fused_threads;  // experiments
+  b.fused_ok = sw.rank_fused && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
                hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR) <= 64 * 1024;
 }
 
@@ -205,7 +284,7 @@ static void check_model_fits(mrk_model *model, const Program &prog) {
                                                 "' has " + std::to_string(prog.dim) + " columns");
 }
 
-// pre-pass + assembly into the row-major f64 matrix (ClickthroughQuery's layout); ctx->mu must be held
+// pre-pass + assembly into the row-major f64 matrix (ClickthroughQuery's layout); inside a LaunchOn
 static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &pd) {
   mrk_ctx *ctx = b.ctx;
   if (b.fused_ok) {
@@ -229,30 +308,33 @@ static void sort_batch(mrk_batch &b) {
   for (auto &br : b.big) launch_big_sort(ctx, b.view, br.first, br.second, b.d_sort_keys.as<unsigned long long>(), b.d_sort_idx.as<int>());
 }
 
-// enqueue the pipeline on the context stream for batch items [lo, hi); ctx->mu must be held
-struct LaunchOn {  // routes kernel launches (and their timers) to a batch's stream while ctx->mu is held
+// routes kernel launches (and their timers) to a batch's stream; holds ctx->mu for as long as it lives
+struct LaunchOn {
   mrk_ctx *ctx;
-  LaunchOn(mrk_ctx *c, hipStream_t s) : ctx(c) { ctx->launch = s; }
+  std::lock_guard<std::mutex> lk;
+  LaunchOn(mrk_ctx *c, hipStream_t s) : ctx(c), lk(c->mu) { ctx->launch = s; }
   ~LaunchOn() { ctx->launch = ctx->stream; }
 };
 
+// enqueue the pipeline on the batch's stream for batch items [lo, hi); the caller holds the store (StoreAccess)
 static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort) {
   mrk_ctx *ctx = b.ctx;
   MRK_HIP(hipSetDevice(ctx->device));
-  LaunchOn on(ctx, b.s());
   check_model_fits(model, *b.prog);
+  const Switches &sw = switches();
+  const int rows = hi - lo;
+  // MRK_RANK_CELLS=0 / MRK_SCORER=walk keep the f64 matrix between assembly and scoring (A/B measurements)
+  const bool cells = sw.rank_cells && !sw.scorer_walk && model && model->qs.ok && !b.want_matrix && rows > 0;
+  const bool f64 = model && model->forest.backend == Backend::LightGBM;
+  // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
+  void *jit_fn = cells && b.fused_ok ? jit_rank_function(*b.prog, f64) : nullptr;
+  LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
   MRK_HIP(hipMemsetAsync(b.view.status, 0, std::max<size_t>(b.n_req, 1) * 4, b.s()));
   b.view.item_lo = lo;
   b.view.item_hi = hi;
-  const int rows = hi - lo;
-  // MRK_RANK_CELLS=0 / MRK_SCORER=walk keep the f64 matrix between assembly and scoring (A/B measurements)
-  const bool cells_enabled = [] {
-    const char *e = getenv("MRK_RANK_CELLS"), *w = getenv("MRK_SCORER");
-    return (!e || atoi(e) != 0) && !(w && std::string(w) == "walk");
-  }();
-  const bool cells = cells_enabled && model && model->qs.ok && !b.want_matrix && rows > 0;
+  b.fetch_enqueued = false;
   if (cells) {
     // hot path: the assembled values go straight into the scorer's binned tile; no f64 matrix
     const QsDev q = qs_device_view(model);
@@ -261,10 +343,8 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
     b.d_cells.reserve(std::max<size_t>(n_tiles * tile_bytes, 16));
     if (hi % QS_TILE_ROWS && tile_bytes)  // rows past the last item of the last tile of this range
       MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (size_t)(hi / QS_TILE_ROWS) * tile_bytes, 0, tile_bytes, b.s()));
-    const bool f64 = model->forest.backend == Backend::LightGBM;
     if (b.fused_ok) {
-      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64,
-                        jit_rank_function(*b.prog, f64));
+      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     } else {
       launch_prepass(ctx, st, pd, b.view);
       launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64);
@@ -290,34 +370,44 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
 
 static void run_batch(mrk_batch &b, mrk_model *model) { run_batch(b, model, 0, b.total_items, true); }
 
-static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *matrix) {
-  mrk_ctx *ctx = b.ctx;
-  MRK_HIP(hipSetDevice(ctx->device));
-  LaunchOn on(ctx, b.s());
+// scores + order + status -> the batch's pinned result buffer, one copy (a copy into pageable caller memory is staged by
+// the runtime anyway, and three small copies cost three round trips); asynchronous
+static void enqueue_fetch(mrk_batch &b, bool scores, bool order) {
   const size_t T = (size_t)b.total_items;
-  if (matrix && T && b.prog->dim && !b.matrix_valid) {
-    // the last run assembled straight into the scorer's tile: materialise the f64 matrix now
-    assemble_matrix(b, ctx->store->device_view(), b.prog->device_view());
-  }
-  // scores + order + status: one copy into pinned memory (a copy into pageable caller memory is staged by the
-  // runtime anyway, and three small copies cost three round trips)
-  const size_t tight = (size_t)T * 8 <= 64 * 1024 ? b.out_bytes : 0;  // small batch: copy the whole blob; else the used ranges
   b.h_out.reserve(b.out_bytes);
   uint8_t *h = b.h_out.as<uint8_t>();
   const uint8_t *d = b.d_out.as<uint8_t>();
-  if (tight) {
+  if (T * 8 <= 64 * 1024) {  // small batch: the whole blob
     MRK_HIP(hipMemcpyAsync(h, d, b.out_bytes, hipMemcpyDeviceToHost, b.s()));
-  } else {
+  } else {                   // else the used ranges
     if (scores && T) MRK_HIP(hipMemcpyAsync(h, d, T * 8, hipMemcpyDeviceToHost, b.s()));
     if (order && T) MRK_HIP(hipMemcpyAsync(h + b.out_order_off, d + b.out_order_off, T * 4, hipMemcpyDeviceToHost, b.s()));
     if (b.n_req) MRK_HIP(hipMemcpyAsync(h + b.out_status_off, d + b.out_status_off, (size_t)b.n_req * 4, hipMemcpyDeviceToHost, b.s()));
   }
+}
+
+// the caller holds the store when `matrix` may have to be assembled (StoreAccess), and the batch
+static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *matrix) {
+  mrk_ctx *ctx = b.ctx;
+  MRK_HIP(hipSetDevice(ctx->device));
+  const size_t T = (size_t)b.total_items;
+  if (matrix && T && b.prog->dim && !b.matrix_valid) {
+    // the last run assembled straight into the scorer's tile: materialise the f64 matrix now
+    LaunchOn on(ctx, b.s());
+    assemble_matrix(b, ctx->store->device_view(), b.prog->device_view());
+  }
+  if (!b.fetch_enqueued) enqueue_fetch(b, scores != nullptr, order != nullptr);
+  b.fetch_enqueued = false;
   if (matrix && T && b.prog->dim) MRK_HIP(hipMemcpyAsync(matrix, b.d_matrix.p, T * b.prog->dim * 8, hipMemcpyDeviceToHost, b.s()));
   MRK_HIP(hipStreamSynchronize(b.s()));
+  const uint8_t *h = b.h_out.as<uint8_t>();
   if (scores && T) memcpy(scores, h, T * 8);
   if (order && T) memcpy(order, h + b.out_order_off, T * 4);
   if (b.n_req) memcpy(b.h_status.data(), h + b.out_status_off, (size_t)b.n_req * 4);
-  drain_profile_events(ctx);
+  if (ctx->profile) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_profile_events(ctx);
+  }
 }
 
 }  // namespace mrk
@@ -327,6 +417,7 @@ extern "C" {
 int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len) {
   return guard([&] {
     if (!ctx || !json) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    std::unique_lock<std::shared_mutex> sl(ctx->store_mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "this context already has a configuration");
     MRK_HIP(hipSetDevice(ctx->device));
@@ -373,7 +464,7 @@ int mrk_model_dim(mrk_ctx *ctx, const char *model_name) {
   int dim = -1;
   int rc = guard([&] {
     if (!ctx || !model_name) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::shared_lock<std::shared_mutex> lk(ctx->store_mu);
     if (!ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called first");
     const Program *p = ctx->registry->program(model_name);
     if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
@@ -386,7 +477,7 @@ int mrk_model_dim(mrk_ctx *ctx, const char *model_name) {
   return guard([&] {                                      \
     if (!key) throw StatusError(MRK_ERR_INVALID_ARG, "null key"); \
     Store &st = store_of(ctx);                            \
-    std::lock_guard<std::mutex> lk(ctx->mu);              \
+    std::unique_lock<std::shared_mutex> lk(ctx->store_mu); \
     (void)st.call;                                        \
   })
 
@@ -405,7 +496,7 @@ int mrk_store_put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int *ou
     if (out_records) *out_records = 0;
     if (!bytes && len) throw StatusError(MRK_ERR_INVALID_ARG, "null blob");
     Store &st = store_of(ctx);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
     const int n = load_feature_values(st, bytes, len);
     if (out_records) *out_records = n;
   });
@@ -415,7 +506,7 @@ int mrk_store_increment_periodic_batch(mrk_ctx *ctx, const char *const *keys, co
   return guard([&] {
     if (n < 0 || (n > 0 && (!keys || !ts_ms || !inc))) throw StatusError(MRK_ERR_INVALID_ARG, "bad increment batch");
     Store &st = store_of(ctx);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
     for (int i = 0; i < n; ++i) {
       if (!keys[i]) throw StatusError(MRK_ERR_INVALID_ARG, "null key");
       (void)st.increment_periodic(keys[i], ts_ms[i], inc[i]);
@@ -428,7 +519,7 @@ int mrk_store_append(mrk_ctx *ctx, const char *key, const char *value, int64_t t
 int mrk_store_flush(mrk_ctx *ctx) {
   return guard([&] {
     Store &st = store_of(ctx);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
     MRK_HIP(hipSetDevice(ctx->device));
     st.flush(ctx->stream);
   });
@@ -461,19 +552,26 @@ struct RankTicket {
   bool done = false;
 };
 
-// ranks tickets [0, n) as one batch; fills status / err of each; ctx->mu is taken inside
+// ranks tickets [0, n) as one batch; fills status / err of each.  The scratch batch of the context is owned by the
+// leader of the batching front (one at a time); the store is held shared, the launch lock only while launching.
 void rank_tickets(mrk_ctx *ctx, RankTicket **tk, int n) {
   auto fail_all = [&](int code, const std::string &msg) {
     for (int i = 0; i < n; ++i) { tk[i]->status = code; tk[i]->err = msg; }
   };
   try {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const Program &prog = program_of(ctx, tk[0]->model_name.c_str());
+    std::lock_guard<std::mutex> rl(ctx->rank_mu);
+    const Program *progp;
+    {
+      std::shared_lock<std::shared_mutex> sl(ctx->store_mu);
+      progp = &program_of(ctx, tk[0]->model_name.c_str());
+    }
+    const Program &prog = *progp;
+    StoreAccess access(ctx, program_mutates_store(prog));
     if (!ctx->rank_scratch) ctx->rank_scratch = new mrk_batch();  // grow-only: no hipMalloc / hipFree per request
     mrk_batch &b = *(mrk_batch *)ctx->rank_scratch;
     std::vector<mrk_request> reqs(n);
     for (int i = 0; i < n; ++i) reqs[i] = *tk[i]->req;
-    build_batch(ctx, prog, reqs.data(), n, b);
+    build_batch(ctx, prog, reqs.data(), n, nullptr, b);
     b.want_matrix = tk[0]->matrix != nullptr;
     run_batch(b, tk[0]->model);
     if (n == 1) {
@@ -511,37 +609,47 @@ int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_r
   if (!req || !ctx || !model_name) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
   if (model && model->ctx != ctx) { set_last_error("model belongs to another context"); return MRK_ERR_INVALID_ARG; }
   RankTicket t{model, model_name, req, out_scores, out_order, out_matrix};
-  static const bool combine = [] { const char *e = getenv("MRK_RANK_COMBINE"); return !e || atoi(e) != 0; }();
-  static const int combine_max = [] { const char *e = getenv("MRK_RANK_COMBINE_MAX"); return e ? std::max(1, atoi(e)) : 256; }();
-  if (!combine) {
+  const Switches &sw = switches();
+  if (!sw.rank_combine) {
     RankTicket *one = &t;
     rank_tickets(ctx, &one, 1);
   } else {
+    // Whoever finds no leader becomes one, serves ONE batch (its own ticket is in it: the queue is FIFO and the leader's
+    // ticket is its oldest compatible entry or was taken by the previous leader) and hands leadership to a waiter - a
+    // caller never serves other callers' batches after its own result is ready.
     std::unique_lock<std::mutex> lk(ctx->qmu);
     ctx->rank_queue.push_back(&t);
-    if (!ctx->rank_leader) {
-      ctx->rank_leader = true;
-      while (!ctx->rank_queue.empty()) {
-        // everything queued that is compatible with the oldest ticket
-        std::vector<RankTicket *> take;
-        RankTicket *head = (RankTicket *)ctx->rank_queue.front();
-        std::vector<void *> rest;
-        for (void *p : ctx->rank_queue) {
-          RankTicket *q = (RankTicket *)p;
-          const bool ok = (int)take.size() < combine_max && q->model == head->model && q->model_name == head->model_name &&
-                          (q->matrix != nullptr) == (head->matrix != nullptr);
-          if (ok) take.push_back(q); else rest.push_back(p);
-        }
-        ctx->rank_queue.swap(rest);
-        lk.unlock();
-        rank_tickets(ctx, take.data(), (int)take.size());
-        lk.lock();
-        for (RankTicket *q : take) q->done = true;
-        ctx->qcv.notify_all();
+    while (!t.done) {
+      if (ctx->rank_leader) {
+        ctx->qcv.wait(lk, [&] { return t.done || !ctx->rank_leader; });
+        continue;
       }
-      ctx->rank_leader = false;
-    } else {
-      ctx->qcv.wait(lk, [&] { return t.done; });
+      ctx->rank_leader = true;
+      struct Resign {  // leadership is given up whatever happens in the batch
+        mrk_ctx *c;
+        std::unique_lock<std::mutex> &l;
+        ~Resign() {
+          if (!l.owns_lock()) l.lock();
+          c->rank_leader = false;
+          c->qcv.notify_all();
+        }
+      } resign{ctx, lk};
+      // this caller's ticket plus everything queued that is compatible with it
+      std::vector<RankTicket *> take;
+      std::vector<void *> rest;
+      take.push_back(&t);
+      for (void *p : ctx->rank_queue) {
+        RankTicket *q = (RankTicket *)p;
+        if (q == &t) continue;
+        const bool ok = (int)take.size() < sw.combine_max && q->model == t.model && q->model_name == t.model_name &&
+                        (q->matrix != nullptr) == (t.matrix != nullptr);
+        if (ok) take.push_back(q); else rest.push_back(p);
+      }
+      ctx->rank_queue.swap(rest);
+      lk.unlock();
+      rank_tickets(ctx, take.data(), (int)take.size());
+      lk.lock();
+      for (RankTicket *q : take) q->done = true;
     }
   }
   if (t.status != MRK_OK) set_last_error(t.err);
@@ -581,31 +689,73 @@ int mrk_model_warmup(mrk_ctx *ctx, mrk_model *model, const char *model_name, int
   return MRK_OK;
 }
 
-int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req, mrk_batch **out) {
+static const Program &locked_program(mrk_ctx *ctx, const char *model_name) {
+  std::shared_lock<std::shared_mutex> sl(ctx->store_mu);
+  return program_of(ctx, model_name);
+}
+
+int mrk_batch_create(mrk_ctx *ctx, mrk_batch **out) {
   return guard([&] {
     if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
-    if (!ctx || n_req < 0 || (n_req > 0 && !reqs)) throw StatusError(MRK_ERR_INVALID_ARG, "bad arguments");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const Program &prog = program_of(ctx, model_name);
-    if (ctx->closed) throw StatusError(MRK_ERR_INVALID_ARG, "context is shut down");
+    if (!ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      if (ctx->closed) throw StatusError(MRK_ERR_INVALID_ARG, "context is shut down");
+    }
     std::unique_ptr<mrk_batch> b(new mrk_batch());
+    b->ctx = ctx;
     MRK_HIP(hipSetDevice(ctx->device));
     MRK_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    build_batch(ctx, prog, reqs, n_req, *b);
-    MRK_HIP(hipStreamSynchronize(b->s()));
     ctx_retain(ctx);
     *out = b.release();
   });
 }
 
+int mrk_batch_load(mrk_batch *batch, const char *model_name, const mrk_request *reqs, int n_req, const mrk_item_ids *ids) {
+  return guard([&] {
+    if (!batch || !batch->ctx || n_req < 0 || (n_req > 0 && !reqs)) throw StatusError(MRK_ERR_INVALID_ARG, "bad arguments");
+    mrk_ctx *ctx = batch->ctx;
+    const Program &prog = locked_program(ctx, model_name);
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    MRK_HIP(hipSetDevice(ctx->device));
+    MRK_HIP(hipStreamSynchronize(batch->s()));  // the previous run may still read the staging buffers
+    StoreAccess access(ctx, program_mutates_store(prog));
+    build_batch(ctx, prog, reqs, n_req, ids, *batch);
+  });
+}
+
+int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *reqs, int n_req, mrk_batch **out) {
+  if (!out) { set_last_error("out is null"); return MRK_ERR_INVALID_ARG; }
+  *out = nullptr;
+  mrk_batch *b = nullptr;
+  int rc = mrk_batch_create(ctx, &b);
+  if (rc != MRK_OK) return rc;
+  rc = mrk_batch_load(b, model_name, reqs, n_req, nullptr);
+  if (rc == MRK_OK) rc = guard([&] { MRK_HIP(hipStreamSynchronize(b->s())); });
+  if (rc != MRK_OK) {
+    const std::string msg = mrk_last_error();
+    mrk_batch_free(b);
+    set_last_error(msg);
+    return rc;
+  }
+  *out = b;
+  return MRK_OK;
+}
+
 int mrk_batch_total_items(mrk_batch *batch) { return batch ? batch->total_items : MRK_ERR_INVALID_ARG; }
+
+static void check_batch(mrk_batch *batch, mrk_model *model) {
+  if (!batch || !batch->ctx) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+  if (!batch->prog) throw StatusError(MRK_ERR_INVALID_ARG, "the batch has not been loaded");
+  if (model && model->ctx != batch->ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
+}
 
 int mrk_batch_run(mrk_batch *batch, mrk_model *model) {
   return guard([&] {
-    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
-    if (model && model->ctx != batch->ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
-    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    check_batch(batch, model);
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    StoreAccess access(batch->ctx, false, /*flush=*/false);  // what the batch resolved against stays what it reads
     run_batch(*batch, model);
   });
 }
@@ -617,11 +767,11 @@ int mrk_batch_shard_chunk(mrk_batch *batch, int shard_count) {
 
 int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int shard_count) {
   return guard([&] {
-    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    check_batch(batch, model);
     if (shard_count < 1 || shard_count > 256 || shard_index < 0 || shard_index >= shard_count)
       throw StatusError(MRK_ERR_INVALID_ARG, "bad shard index / count (1..256 shards)");
-    if (model && model->ctx != batch->ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
-    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    StoreAccess access(batch->ctx, false, false);
     const int chunk = shard_chunk(*batch, shard_count);
     const int lo = std::min<long long>((long long)chunk * shard_index, batch->total_items);
     const int hi = std::min<long long>((long long)chunk * (shard_index + 1), batch->total_items);
@@ -631,10 +781,11 @@ int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int
 
 int mrk_batch_sort(mrk_batch *batch) {
   return guard([&] {
-    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
-    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    check_batch(batch, nullptr);
+    std::lock_guard<std::mutex> bl(batch->bmu);
     MRK_HIP(hipSetDevice(batch->ctx->device));
     LaunchOn on(batch->ctx, batch->s());
+    batch->fetch_enqueued = false;
     sort_batch(*batch);
   });
 }
@@ -646,18 +797,20 @@ int mrk_batch_sync(mrk_batch *batch) {
     if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
     MRK_HIP(hipSetDevice(batch->ctx->device));
     MRK_HIP(hipStreamSynchronize(batch->s()));
-    std::lock_guard<std::mutex> lk(batch->ctx->mu);
-    drain_profile_events(batch->ctx);
+    if (batch->ctx->profile) {
+      std::lock_guard<std::mutex> lk(batch->ctx->mu);
+      drain_profile_events(batch->ctx);
+    }
   });
 }
 
 int mrk_batch_device_outputs(mrk_batch *batch, double **d_scores, int32_t **d_order, double **d_matrix) {
   return guard([&] {
-    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
+    check_batch(batch, nullptr);
+    std::lock_guard<std::mutex> bl(batch->bmu);
     if (d_scores) *d_scores = batch->view.scores;
     if (d_order) *d_order = batch->view.order;
     if (d_matrix) {  // from now on every run materialises the f64 matrix
-      std::lock_guard<std::mutex> lk(batch->ctx->mu);
       batch->want_matrix = true;
       *d_matrix = batch->view.matrix;
     }
@@ -666,16 +819,63 @@ int mrk_batch_device_outputs(mrk_batch *batch, double **d_scores, int32_t **d_or
 
 int mrk_batch_fetch(mrk_batch *batch, double *out_scores, int32_t *out_order, double *out_matrix) {
   return guard([&] {
-    if (!batch) throw StatusError(MRK_ERR_INVALID_ARG, "null batch");
-    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    check_batch(batch, nullptr);
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    StoreAccess access(batch->ctx, false, false);
     fetch_batch(*batch, out_scores, out_order, out_matrix);
   });
 }
 
+int mrk_batch_enqueue_fetch(mrk_batch *batch) {
+  return guard([&] {
+    check_batch(batch, nullptr);
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    MRK_HIP(hipSetDevice(batch->ctx->device));
+    enqueue_fetch(*batch, true, true);
+    batch->fetch_enqueued = true;
+  });
+}
+
+int mrk_batch_host_outputs(mrk_batch *batch, const double **scores, const int32_t **order, const int32_t **status) {
+  return guard([&] {
+    check_batch(batch, nullptr);
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    MRK_HIP(hipSetDevice(batch->ctx->device));
+    if (!batch->fetch_enqueued) {  // mrk_batch_enqueue_fetch was not called behind the run: ask for everything now
+      enqueue_fetch(*batch, true, true);
+      batch->fetch_enqueued = true;
+    }
+    fetch_batch(*batch, nullptr, nullptr, nullptr);  // waits for the batch; status words -> h_status
+    const uint8_t *h = batch->h_out.as<uint8_t>();
+    if (scores) *scores = (const double *)h;
+    if (order) *order = (const int32_t *)(h + batch->out_order_off);
+    if (status) {
+      batch->codes.resize((size_t)std::max(batch->n_req, 1));
+      std::string msg;
+      for (int r = 0; r < batch->n_req; ++r) batch->codes[(size_t)r] = status_to_code(batch->h_status[(size_t)r], msg);
+      *status = batch->codes.data();
+    }
+  });
+}
+
+void *mrk_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void mrk_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int mrk_batch_status(mrk_batch *batch, int32_t *out_status) {
   return guard([&] {
-    if (!batch || !out_status) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(batch->ctx->mu);
+    check_batch(batch, nullptr);
+    if (!out_status) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> bl(batch->bmu);
     fetch_batch(*batch, nullptr, nullptr, nullptr);
     for (int r = 0; r < batch->n_req; ++r) {
       std::string msg;
@@ -688,13 +888,10 @@ void mrk_batch_free(mrk_batch *batch) {
   if (!batch) return;
   mrk_ctx *ctx = batch->ctx;
   if (ctx) {
-    {
-      std::lock_guard<std::mutex> lk(ctx->mu);
-      (void)hipSetDevice(ctx->device);
-      (void)hipStreamSynchronize(batch->s());
-      if (batch->stream) (void)hipStreamDestroy(batch->stream);
-      delete batch;
-    }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(batch->s());
+    if (batch->stream) (void)hipStreamDestroy(batch->stream);
+    delete batch;
     ctx_release(ctx);
   } else {
     delete batch;

@@ -49,6 +49,43 @@ struct StoreDev {
   const uint32_t *slot_pool;
 };
 
+// ---- id -> slot table of a scope (store.hpp SlotMap), mirrored to the device for the ITEM table: a request batch
+// hands over the UTF-8 bytes of its item ids and the slots are looked up by a kernel (resolve.hip) instead of by
+// the host.  Open addressing, linear probing, power-of-two capacity; hash 0 = empty entry.
+struct IdEntry { uint64_t hash; uint32_t slot; uint32_t off; };  // off: the id (NUL-terminated) in the arena
+struct IdTableDev {
+  const IdEntry *table;
+  const uint8_t *arena;
+  uint32_t mask;       // capacity - 1; 0 with table == nullptr: no ids yet
+  uint32_t pad;
+};
+
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#define MRK_HD __host__ __device__
+#else
+#define MRK_HD
+#endif
+
+// The hash of an id (bytes [s, s + len)), read a byte at a time so that host and device agree on any alignment:
+// 8-byte little-endian words, the tail zero-padded (the host's SlotMap::hash computes the same with word loads).
+MRK_HD inline uint64_t id_hash_bytes(const uint8_t *s, size_t len) {
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ ((uint64_t)len * 0xff51afd7ed558ccdull);
+  size_t i = 0;
+  for (; i + 8 <= len; i += 8) {
+    uint64_t w = 0;
+    for (int k = 0; k < 8; ++k) w |= (uint64_t)s[i + k] << (8 * k);
+    h = (h ^ w) * 0x9fb21c651e98df25ull;
+    h ^= h >> 29;
+  }
+  uint64_t w = 0;
+  for (int k = 0; i + k < len; ++k) w |= (uint64_t)s[i + k] << (8 * k);
+  h = (h ^ w) * 0x9fb21c651e98df25ull;
+  h ^= h >> 32;
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 29;
+  return h ? h : 1;
+}
+
 // ---- bit-vector forest format (described in forest.hpp)
 constexpr int QS_SLOTS = 16;
 constexpr int QS_LEAVES = 16;

@@ -406,9 +406,8 @@ template <int EPI>
 void launch_gemm(const uint16_t *A, const uint16_t *W, const float *bias, const float *res, void *out, int M, int N, int K, hipStream_t s) {
   // 128x128 tiles once the grid still covers the chip with them, 64x64 tiles otherwise
   const bool big = N % 128 == 0 && (size_t)((M + 127) / 128) * (N / 128) >= 256;
-  const char *sk = getenv("MRK_ENCODER_SKINNY");  // A/B switch (tests pin both kernels to the same bits)
   const int which = EPI == EPI_F16 ? 1 : EPI == EPI_GELU_F16 ? 2 : K == N ? 4 : 8;
-  const bool skinny = !sk || (atoi(sk) & which);
+  const bool skinny = (switches().encoder_skinny & which) != 0;  // MRK_ENCODER_SKINNY: A/B switch (tests pin both kernels to the same bits)
   if (skinny && M <= 32 && launch_skinny<1, EPI>((const _Float16 *)A, (const _Float16 *)W, bias, res, out, M, N, K, s)) return;
   if (skinny && M > 32 && M <= 64 && launch_skinny<2, EPI>((const _Float16 *)A, (const _Float16 *)W, bias, res, out, M, N, K, s)) return;
   auto grid_of = [&](int bm, int bn) { return dim3((unsigned)(8 * (((M + bm - 1) / bm + 7) / 8) * (N / bn))); };

@@ -8,6 +8,7 @@
 #include <limits>
 #include <exception>
 #include <set>
+#include <string_view>
 #include <thread>
 
 #include "encoder.hpp"
@@ -531,7 +532,7 @@ Registry::~Registry() {
 void unbind_encoders(mrk_ctx *ctx) {
   std::vector<mrk_encoder *> drop;
   {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
     if (ctx->registry)
       for (auto &f : ctx->registry->features)
         if (f->encoder) { drop.push_back(f->encoder); f->encoder = nullptr; }
@@ -540,7 +541,7 @@ void unbind_encoders(mrk_ctx *ctx) {
 }
 
 void bind_encoder(mrk_ctx *ctx, const char *feature, mrk_encoder *enc) {
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::unique_lock<std::shared_mutex> lk(ctx->store_mu);  // resolve_requests reads FeatureDef::encoder under the shared lock
   if (!ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_bind_encoder: load a config first");
   for (auto &f : ctx->registry->features)
     if (f->name == feature) {
@@ -743,19 +744,19 @@ double map_datetime(int mapper, const Civil &c) {
 // size sets how many requests a CU works on at once; measured on the Ranklens workload (MRK_TABLE_LOAD_PCT
 // sweep): 75 % -> 0.42 ms per 3840 requests, 50 % -> 0.45, 33 % -> 0.52, 25 % -> 0.60: shorter probe chains do
 // not pay for the lost occupancy.  Even => the 8-byte entries of consecutive tables stay 16-byte aligned.
-static uint64_t table_load_pct() {
-  const char *e = getenv("MRK_TABLE_LOAD_PCT");  // experiments: worst-case load factor in percent
-  return e ? (uint64_t)std::max(10, std::min(90, atoi(e))) : 75;
-}
+static uint64_t table_load_pct() { return (uint64_t)switches().table_load_pct; }  // MRK_TABLE_LOAD_PCT (experiments)
 static uint32_t table_capacity(uint64_t tokens, uint64_t pct) {
-  uint64_t cap = tokens * 100 / pct + 2;
+  // tokens * 100 / pct without the division (nine of them per request are a third of the host's share of a small
+  // request): a 16-bit fixed-point reciprocal rounded UP, so the capacity never falls below the exact quotient
+  const uint64_t inv = (100ull * 65536ull + pct - 1) / pct;  // pct is a per-process constant: hoisted by the compiler's inliner
+  const uint64_t cap = (tokens < (1ull << 40) ? (tokens * inv) >> 16 : tokens * 100 / pct) + 2;
   return (uint32_t)((cap + 1) & ~1ull);
 }
 
 // Host threads of one resolve_requests call: MRK_HOST_THREADS, else min(8, hardware threads).  The per-request work
 // (id -> slot lookups, request constants, table sizing) only READS the store, so requests are independent.
 static int host_threads() {
-  if (const char *e = getenv("MRK_HOST_THREADS")) return std::max(1, std::min(256, atoi(e)));
+  if (switches().host_threads > 0) return switches().host_threads;
   const unsigned hw = std::thread::hardware_concurrency();
   return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
 }
@@ -807,8 +808,40 @@ static bool query_text(const mrk_request &rq, const FeatureDef &f, std::string &
   return false;
 }
 
-void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs, int n_req, HostBatch &hb) {
-  hb = HostBatch();
+void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs, int n_req, const mrk_item_ids *ids, HostBatch &hb) {
+  // `hb` may be a batch's own (grow-only) scratch: everything is re-assigned below, nothing is freed
+  hb.item_slot.clear();
+  hb.item_req.clear();
+  hb.irf.clear();
+  hb.overrides.clear();
+  hb.arena_entries = hb.max_req_entries = 0;
+  hb.max_doubles = hb.max_items = hb.total_items = 0;
+  // first batch item of every request, and where an item's id bytes are
+  std::vector<int> begins((size_t)n_req + 1, 0);
+  for (int r = 0; r < n_req; ++r) {
+    if (reqs[r].n_items < 0 || (reqs[r].n_items > 0 && !ids && !reqs[r].item_ids)) throw StatusError(MRK_ERR_INVALID_ARG, "bad item list");
+    if (reqs[r].n_items > (1 << 27)) throw StatusError(MRK_ERR_UNSUPPORTED, "requests with more than 2^27 items are not supported");
+    if ((long long)begins[r] + reqs[r].n_items > INT32_MAX) throw StatusError(MRK_ERR_UNSUPPORTED, "batches of more than 2^31 items are not supported");
+    begins[r + 1] = begins[r] + reqs[r].n_items;
+  }
+  if (ids && begins[n_req] > 0 && (!ids->bytes || !ids->offsets)) throw StatusError(MRK_ERR_INVALID_ARG, "null id bytes / offsets");
+  auto id_of = [&](int r, int i) -> std::string_view {
+    if (ids) {
+      const uint32_t o0 = ids->offsets[begins[r] + i], o1 = ids->offsets[begins[r] + i + 1];
+      return std::string_view((const char *)ids->bytes + o0, o1 - o0);
+    }
+    const char *s = reqs[r].item_ids[i];
+    return s ? std::string_view(s) : std::string_view("");
+  };
+  // Flat ids: the device resolves the slots and the host sizes the pre-pass tables from bounds.  One exception: a numeric
+  // `diversity` over more candidates than the pre-pass sorts needs the exact count of present values, i.e. the slots.
+  bool device_ids = ids != nullptr;
+  if (device_ids)
+    for (const HostOp &ho : prog.host_ops)
+      if (ho.def->type == FType::Diversity)
+        for (int r = 0; r < n_req && device_ids; ++r)
+          if (std::min(ho.def->div_top, reqs[r].n_items) > PREP_MAX_VALUES) device_ids = false;
+  hb.device_ids = device_ids;
   // queries of encoder-backed bi-encoder columns: every distinct uncached text of the batch goes through the device
   // encoder in one call, before the per-request loop reads them back
   std::map<std::pair<mrk_encoder *, std::string>, std::vector<float>> queries;
@@ -844,7 +877,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
       if (!query_text(reqs[r], f, text)) continue;
       const std::vector<int32_t> q = tk.pieces(text);
       for (int i = 0; i < reqs[r].n_items; ++i) {
-        auto it = texts.find(reqs[r].item_ids[i] ? reqs[r].item_ids[i] : "");
+        auto it = texts.find(std::string(id_of(r, i)));
         if (it == texts.end()) continue;
         if (reqs[r].item_field_offsets && reqs[r].item_fields) {  // a score the caller already has (ScoreCache hit) wins
           bool given = false;
@@ -882,25 +915,32 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
       at = end;
     }
   }
-  int total = 0;
-  for (int r = 0; r < n_req; ++r) {
-    if (reqs[r].n_items < 0 || (reqs[r].n_items > 0 && !reqs[r].item_ids)) throw StatusError(MRK_ERR_INVALID_ARG, "bad item list");
-    if (reqs[r].n_items > (1 << 27)) throw StatusError(MRK_ERR_UNSUPPORTED, "requests with more than 2^27 items are not supported");
-    total += reqs[r].n_items;
-  }
+  const int total = begins[n_req];
   hb.total_items = total;
   hb.reqs.resize(n_req);
-  hb.item_slot.resize(total);
-  hb.item_req.resize(total);
+  if (!device_ids) {
+    hb.item_slot.resize(total);
+    hb.item_req.resize(total);
+  }
   hb.consts.assign((size_t)n_req * prog.n_consts, kNaN);
   hb.irf.assign((size_t)prog.n_irf * total, -1);
   hb.prep_out.assign((size_t)n_req * prog.prep.size(), PrepOut{0, 0, 0.0, 0, 0});
-  {
-    int at = 0;
-    for (int r = 0; r < n_req; ++r) { hb.reqs[r].item_begin = at; at += reqs[r].n_items; }
-  }
+  for (int r = 0; r < n_req; ++r) hb.reqs[r].item_begin = begins[r];
   const uint64_t load_pct = table_load_pct();
-  const int n_workers = total >= 16384 ? host_threads() : 1;  // small batches (one request of mrk_rank): not worth a thread
+  // small batches (one request of mrk_rank) are not worth a thread; neither is a batch whose ids the device resolves
+  const int n_workers = (device_ids ? n_req >= 16384 : total >= 16384) ? host_threads() : 1;
+  // the ops that ask something of the REQUEST (constants, table sizes); plain per-item columns do not
+  std::vector<const HostOp *> request_ops;
+  for (const HostOp &ho : prog.host_ops) {
+    const FeatureDef &f = *ho.def;
+    const bool per_request = (f.type == FType::Number && f.scope == SC_RANKING) || (f.type == FType::WordCount && f.scope == SC_RANKING) ||
+                             (f.type == FType::String && f.field_is_ranking) || f.type == FType::LocalTime || f.type == FType::Position ||
+                             f.type == FType::ExternalRanking || f.type == FType::Biencoder || (f.type == FType::Rate && f.scope == SC_IRF) ||
+                             f.type == FType::InteractedWith || f.type == FType::Diversity;
+    if (per_request) request_ops.push_back(&ho);
+  }
+  const Table &item_table = store.tables[SC_ITEM];
+  auto col_max_len = [&](ColRef c) -> uint64_t { return c.tag >= 0 && c.tag < (int)item_table.cols.size() ? item_table.cols[(size_t)c.tag].max_len : 0u; };
   struct Worker { std::vector<Override> overrides; int max_items = 0, max_doubles = 0; std::vector<double> enc; };
   std::vector<Worker> workers((size_t)std::max(1, n_workers));
   std::vector<uint64_t> req_entries((size_t)n_req, 0);  // hash-table entries of every request (its tables are contiguous)
@@ -912,18 +952,11 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
     std::vector<double> &enc = wk.enc;
     uint64_t arena = 0;  // relative to the request's first table
     rd.n_items = rq.n_items;
-    auto slot_or = [&](ScopeId sc, const char *id) -> int32_t {
-      if (!id) return -1;
-      uint32_t s = store.slot(sc, id, strlen(id), false);
-      return s == Store::NO_SLOT ? -1 : (int32_t)s;
-    };
-    rd.user_slot = slot_or(SC_USER, rq.user);
-    rd.session_slot = slot_or(SC_SESSION, rq.session);
-    rd.ranking_slot = slot_or(SC_RANKING, rq.id ? rq.id : "");
+    // (user / session / ranking slots: resolved for the whole batch before this loop, scope_slots below)
     wk.max_items = std::max(wk.max_items, rq.n_items);
     rd.ts_ms = rq.timestamp_ms;
     // (one request with very many candidates - C4 - spreads its id lookups over the threads instead)
-    parallel_ranges(rq.n_items, rq.n_items >= 16384 ? item_workers : 1, [&](int64_t lo, int64_t hi, int) {
+    if (!device_ids) parallel_ranges(rq.n_items, rq.n_items >= 16384 ? item_workers : 1, [&](int64_t lo, int64_t hi, int) {
       // id -> slot, a block at a time: hash every id and ask for its home entry, then probe (the misses overlap)
       const SlotMap &map = store.tables[SC_ITEM].slot_of;
       constexpr int BLOCK = 64;
@@ -932,13 +965,14 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
       for (int64_t i0 = lo; i0 < hi; i0 += BLOCK) {
         const int nb = (int)std::min<int64_t>(BLOCK, hi - i0);
         for (int k = 0; k < nb; ++k) {
-          const char *id = rq.item_ids[i0 + k] ? rq.item_ids[i0 + k] : "";
-          lens[k] = (uint32_t)strlen(id);
-          hs[k] = SlotMap::hash(id, lens[k]);
+          const std::string_view id = id_of(r, (int)(i0 + k));
+          lens[k] = (uint32_t)id.size();
+          hs[k] = SlotMap::hash(id.data(), lens[k]);
           map.prefetch(hs[k]);
         }
         for (int k = 0; k < nb; ++k) {
-          const char *id = rq.item_ids[i0 + k] ? rq.item_ids[i0 + k] : "";
+          const std::string_view idv = id_of(r, (int)(i0 + k));
+          const char *id = idv.data();
           const uint32_t s = map.find_hashed(hs[k], id, lens[k]);
           hb.item_slot[begin + i0 + k] = s == SlotMap::NONE ? -1 : (int32_t)s;
           hb.item_req[begin + i0 + k] = (uint32_t)r;
@@ -954,7 +988,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
       const uint8_t *rec = t.rows.data() + (size_t)slot * t.stride;
       for (uint32_t o = 0; o < t.stride; o += 64) __builtin_prefetch(rec + o);
     };
-    if (!prog.prep.empty()) {
+    if (!prog.prep.empty() && !device_ids) {
       for (int i = 0; i < std::min(rq.n_items, 48); ++i) prefetch_record(hb.item_slot[begin + i]);
       for (const HostOp &ho : prog.host_ops) {
         if (ho.def->type != FType::InteractedWith) continue;
@@ -964,7 +998,8 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
         for (uint32_t k = 0; k < len; ++k) prefetch_record((int32_t)store.slot_pool.host[off + k]);
       }
     }
-    for (const HostOp &ho : prog.host_ops) {
+    for (const HostOp *hop : request_ops) {
+      const HostOp &ho = *hop;
       const FeatureDef &f = *ho.def;
       switch (f.type) {
         case FType::Number:
@@ -1033,7 +1068,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
             if (fl && fl->type == MRK_FIELD_STRING && fl->str) {
               const std::string prefix = f.scope_field + ":" + fl->str + ":";
               for (int i = 0; i < rq.n_items; ++i) {
-                uint32_t s = store.slot(SC_IRF, prefix + (rq.item_ids[i] ? rq.item_ids[i] : ""), false);
+                uint32_t s = store.slot(SC_IRF, prefix + std::string(id_of(r, i)), false);
                 hb.irf[(size_t)ho.irf_id * total + begin + i] = s == Store::NO_SLOT ? -1 : (int32_t)s;
               }
             }
@@ -1051,9 +1086,13 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
           HostCell lc = host_cell(store, ls, vslot, pe.list_col);
           if (lc.tag != TAG_MISSING) {
             const uint32_t off = (uint32_t)lc.bits, len = (uint32_t)(lc.bits >> 32);
-            for (uint32_t k = 0; k < len; ++k) {
-              HostCell ic = host_cell(store, SC_ITEM, (int32_t)store.slot_pool.host[off + k], pe.item_col);
-              if (ic.tag == TAG_STRING_LIST) count += (uint32_t)(ic.bits >> 32);
+            if (device_ids) {
+              count = (uint64_t)len * col_max_len(pe.item_col);  // bound: every interacted item holds the longest list ever put
+            } else {
+              for (uint32_t k = 0; k < len; ++k) {
+                HostCell ic = host_cell(store, SC_ITEM, (int32_t)store.slot_pool.host[off + k], pe.item_col);
+                if (ic.tag == TAG_STRING_LIST) count += (uint32_t)(ic.bits >> 32);
+              }
             }
           }
           PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base + fi];
@@ -1067,7 +1106,11 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
         uint64_t tokens = 0;
         int taken = 0, doubles = 0;
         int mode = -1;  // -1 undecided, 0 other, 1 string, 2 double
-        for (int i = 0; i < rq.n_items && taken < f.div_top; ++i) {
+        if (device_ids) {  // bounds: the first `top` candidates all present, each with the longest list the column ever held
+          doubles = std::min(f.div_top, rq.n_items);
+          tokens = (uint64_t)doubles * col_max_len(pe.item_col);
+        }
+        for (int i = 0; !device_ids && i < rq.n_items && taken < f.div_top; ++i) {
           HostCell c = host_cell(store, SC_ITEM, hb.item_slot[begin + i], pe.item_col);
           if (c.tag == TAG_MISSING) continue;
           if (mode < 0) mode = (c.tag == TAG_STRING || c.tag == TAG_STRING_LIST) ? 1 : (c.tag == TAG_DOUBLE ? 2 : 0);
@@ -1129,6 +1172,45 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
     }
     req_entries[(size_t)r] = arena;
   };
+  // user / session / ranking ids -> slots, a block of requests at a time: hash every id and ask for its home entry, probe
+  // (the cache misses of a block overlap), then ask for the records the per-request pass reads (the bounded list cell
+  // of interacted_with lives in the session / user record)
+  {
+    constexpr int BLOCK = 32;
+    uint64_t hs[3][BLOCK];
+    uint32_t lens[3][BLOCK];
+    const ScopeId scs[3] = {SC_USER, SC_SESSION, SC_RANKING};
+    for (int r0 = 0; r0 < n_req; r0 += BLOCK) {
+      const int nb = std::min(BLOCK, n_req - r0);
+      for (int k = 0; k < nb; ++k) {
+        const mrk_request &rq = reqs[r0 + k];
+        const char *idp[3] = {rq.user, rq.session, rq.id ? rq.id : ""};
+        for (int j = 0; j < 3; ++j) {
+          if (store.tables[scs[j]].slot_of.n == 0) idp[j] = nullptr;  // a scope nothing was ever put under: no hashing
+          lens[j][k] = idp[j] ? (uint32_t)strlen(idp[j]) : 0u;
+          hs[j][k] = idp[j] ? SlotMap::hash(idp[j], lens[j][k]) : 0;
+          if (idp[j]) store.tables[scs[j]].slot_of.prefetch(hs[j][k]);
+        }
+      }
+      for (int k = 0; k < nb; ++k) {
+        const mrk_request &rq = reqs[r0 + k];
+        const char *idp[3] = {rq.user, rq.session, rq.id ? rq.id : ""};
+        int32_t out[3];
+        for (int j = 0; j < 3; ++j)
+          if (store.tables[scs[j]].slot_of.n == 0) idp[j] = nullptr;
+        for (int j = 0; j < 3; ++j) {
+          const Table &t = store.tables[scs[j]];
+          const uint32_t sl = idp[j] ? t.slot_of.find_hashed(hs[j][k], idp[j], lens[j][k]) : SlotMap::NONE;
+          out[j] = sl == SlotMap::NONE ? -1 : (int32_t)sl;
+          if (out[j] >= 0) __builtin_prefetch(t.rows.data() + (size_t)out[j] * t.stride);
+        }
+        ReqDev &rd = hb.reqs[r0 + k];
+        rd.user_slot = out[0];
+        rd.session_slot = out[1];
+        rd.ranking_slot = out[2];
+      }
+    }
+  }
   if (n_req == 1) {
     resolve_one(0, workers[0], n_workers);
   } else {

@@ -5,6 +5,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,7 @@ struct Program {
   int n_consts = 0;
   int n_irf = 0;
   DevBuf d_ops, d_prep, d_aux;
+  mutable std::mutex jit_mu;        // guards `jit` (the first ranks of a model may come from several threads)
   mutable void *jit = nullptr;      // JitKernels* (jit.cpp): the kernel specialised for this program, built on first use
   mutable bool jit_failed = false;
   ProgramDev device_view() const;
@@ -99,8 +101,13 @@ struct HostBatch {
   int max_doubles = 0;            // most numeric diversity values of any (request, feature)
   int max_items = 0;              // largest request
   int total_items = 0;
+  bool device_ids = false;        // item_slot / item_req are left to the device (resolve.hip): the batch came with flat ids
 };
 
-void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs, int n_req, HostBatch &out);
+// ids == nullptr: the ids are reqs[r].item_ids (NUL-terminated strings), looked up on the host, and the pre-pass tables
+// are sized from exact token counts read from the host mirror.  ids != nullptr: reqs[r].item_ids is ignored, the ids of
+// all requests lie back to back in ids->bytes (request order); their slots are resolved by the device and the tables are
+// sized from upper bounds (list lengths x the longest list a column ever held) - no per-item work on the host.
+void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs, int n_req, const mrk_item_ids *ids, HostBatch &out);
 
 }  // namespace mrk

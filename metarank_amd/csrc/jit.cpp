@@ -86,8 +86,8 @@ std::string jit_source(const Program &prog, bool f64) {
   s += "  JitOps ops;\n  JitPrep prep;\n  JitAux aux;\n};\n}  // namespace\n}  // namespace mrk\n\n";
   // experiments: MRK_JIT_WAVES=n asks the compiler for n wavefronts per SIMD (register cap 512 / n)
   std::string attr;
-  if (const char *w = getenv("MRK_JIT_WAVES"))
-    if (atoi(w) >= 1 && atoi(w) <= 8) attr = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(atoi(w)) + ", " + std::to_string(atoi(w)) + ")))";
+  if (const int w = switches().jit_waves; w >= 1 && w <= 8)
+    attr = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(w) + ", " + std::to_string(w) + ")))";
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
        "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells) {\n"
        "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
@@ -132,25 +132,15 @@ struct JitKernels {
 
 // 0 off; 1 on: the first rank of a model waits for the compile (a failure falls back to the generic kernel with a warning);
 // 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready
-int jit_mode() {
-  const char *e = getenv("MRK_RANK_JIT");
-  if (!e) return 1;
-  if (!strcmp(e, "require")) return 2;
-  if (!strcmp(e, "async")) return 3;
-  return atoi(e) != 0 ? 1 : 0;
-}
+int jit_mode() { return switches().jit_mode; }
 
 namespace {
 
 // code objects are kept on disk between processes: $MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else
 // ~/.cache/mrk_jit; the key covers the whole translation unit and the compiler's version
 std::string cache_path(const std::string &src) {
-  const char *dir = getenv("MRK_JIT_CACHE_DIR");
-  std::string d;
-  if (dir) d = dir;
-  else if (const char *x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/mrk_jit";
-  else if (const char *h = getenv("HOME")) d = std::string(h) + "/.cache/mrk_jit";
-  if (d.empty() || d == "off") return "";
+  const std::string &d = switches().jit_cache_dir;
+  if (d.empty()) return "";
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
   char name[96];
@@ -185,10 +175,12 @@ void write_file(const std::string &path, const std::vector<char> &data) {
 
 }  // namespace
 
-// ctx->mu must be held (the program's cache slot is not otherwise protected)
+// Called WITHOUT the context's launch lock: the first rank of a model compiles for seconds, and other batches keep
+// launching meanwhile.  The program's own mutex serialises callers that want the same kernel.
 void *jit_rank_function(const Program &prog, bool f64) {
   const int mode = jit_mode();
   if (mode == 0) return nullptr;
+  std::lock_guard<std::mutex> lk(prog.jit_mu);
   if (!prog.jit) prog.jit = new JitKernels();
   JitKernels *k = (JitKernels *)prog.jit;
   const int v = f64 ? 1 : 0;

@@ -384,7 +384,7 @@ void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsign
   const int n_pad = (int)big_sort_padded(n_items);
   // chunks sorted in LDS: smaller chunks = more workgroups in the first launch and shallower compare-exchange networks,
   // but more merge passes.  Measured on 100 000 candidates (MRK_SORT_CHUNK): see DESIGN.md
-  static const int chunk = [] { const char *e = getenv("MRK_SORT_CHUNK"); const int c = e ? atoi(e) : 1024; return c == 2048 || c == 4096 ? c : 1024; }();
+  const int chunk = switches().sort_chunk;
   ScopedKernelTimer timer(ctx, "sort");
   const dim3 blk(SORT_THREADS);
   unsigned long long *k0 = keys, *k1 = keys + n_pad;

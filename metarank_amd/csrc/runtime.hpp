@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -88,6 +89,32 @@ struct KernelTimer {
 struct Store;     // store.hpp
 struct Registry;  // features.hpp
 
+// Experiment switches (DESIGN.md "Experiment switches"): environment variables read ONCE, when the library is first
+// used - never on a launch path.  Tests and the measurement scripts that flip a switch inside one process call the
+// exported mrk_debug_reload_switches() afterwards.
+struct Switches {
+  bool rank_fused = true;      // MRK_RANK_FUSED=0: pre-pass and assembly as separate kernels, tables in an HBM arena
+  bool rank_cells = true;      // MRK_RANK_CELLS=0: keep the f64 matrix between assembly and scoring
+  bool scorer_walk = false;    // MRK_SCORER=walk: the tree-walk scorer even where the bit-vector scorer applies
+  int fused_threads = 0;       // MRK_FUSED_THREADS: lanes of the fused kernel's workgroups (0: by request size)
+  bool rank_combine = true;    // MRK_RANK_COMBINE=0: no batching front in mrk_rank
+  int combine_max = 256;       // MRK_RANK_COMBINE_MAX
+  int table_load_pct = 75;     // MRK_TABLE_LOAD_PCT
+  int host_threads = 0;        // MRK_HOST_THREADS (0: min(8, hardware threads))
+  int jit_mode = 1;            // MRK_RANK_JIT: 0 off, 1 on, 2 require, 3 async
+  int jit_waves = 0;           // MRK_JIT_WAVES
+  std::string jit_cache_dir;   // MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else ~/.cache/mrk_jit; "" / "off": none
+  int sort_chunk = 1024;       // MRK_SORT_CHUNK
+  int qs_split = -1;           // MRK_QS_SPLIT
+  int qs_kernel = 1;           // MRK_QS_KERNEL
+  int qs_r = 2;                // MRK_QS_R
+  int qs_leaves = 0;           // MRK_QS_LEAVES: widest bit-vector image a model may get (0: the widest available)
+  bool encoder_graph = false;  // MRK_ENCODER_GRAPH
+  int encoder_skinny = 15;     // MRK_ENCODER_SKINNY
+};
+const Switches &switches();
+void reload_switches();
+
 }  // namespace mrk
 
 struct mrk_ctx {
@@ -101,7 +128,11 @@ struct mrk_ctx {
   hipStream_t launch = nullptr;
   int n_cus = 0;
   size_t lds_per_block = 0;
-  std::mutex mu;  // serialises stream use + scratch buffers (one in-flight call per ctx)
+  std::mutex mu;  // serialises kernel launches (ctx->launch routing, timers) + the context's scratch buffers
+  // The feature store: puts / flushes take it exclusively, everything that reads the host mirror or launches kernels
+  // that read the device tables takes it shared (a flush may reallocate the tables; it waits for the device first).
+  // Lock order: store_mu before mu.
+  std::shared_mutex store_mu;
   // scratch for predict_f64
   mrk::DevBuf d_x, d_out, d_flag;
   mrk::DevBuf d_cells;  // binned tile of the bit-vector scorer (score_qs.hip), grow-only
@@ -114,6 +145,7 @@ struct mrk_ctx {
   mrk::Registry *registry = nullptr;  // owned; freed by mrk::free_rank_state
   mrk::Store *store = nullptr;
   void *rank_scratch = nullptr;       // mrk_batch reused by mrk_rank (owned; freed by mrk::free_rank_state)
+  std::mutex rank_mu;                 // owner of rank_scratch (the leader of the batching front, or a caller with the front off)
   // batching front of mrk_rank: concurrent callers are combined into one device batch by whichever caller
   // finds no leader active (capi_rank.cpp)
   std::mutex qmu;

@@ -299,7 +299,7 @@ void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows,
   if (rows <= 0) return;
   // MRK_SCORER=walk forces the tree-walk kernel (A/B measurements, parity of both kernels); read per call so
   // that a test can flip it
-  const bool walk_only = [] { const char *e = getenv("MRK_SCORER"); return e && std::string(e) == "walk"; }();
+  const bool walk_only = switches().scorer_walk;
   if (!walk_only && launch_score_qs(ctx, m, d_x, rows, cols, d_out, d_status, d_row_req)) return;
   ScopedKernelTimer timer(ctx, "score");
   if (m->forest.backend == Backend::LightGBM) launch_b<true>(ctx, m, d_x, rows, cols, d_out, d_status, d_row_req);

@@ -418,7 +418,7 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
   const int V = (int)q.views.size();
   const long long n_tiles = ((long long)rows + QS_TILE_ROWS - 1) / QS_TILE_ROWS;
   // fewer tiles than the chip has SIMDs (4 per CU): let 2 / 4 / 8 wavefronts split the trees of every tile
-  const int split_env = [] { const char *e = getenv("MRK_QS_SPLIT"); return e ? atoi(e) : -1; }();
+  const int split_env = switches().qs_split;
   const long long simds = 4LL * std::max(ctx->n_cus, 1);
   int nw = 1;
   if (split_env >= 0) nw = split_env;
@@ -500,7 +500,7 @@ template <bool F64>
 bool launch_qs_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out, int *d_flag,
                  const uint32_t *d_row_req) {
   // MRK_QS_KERNEL=0 selects the multi-wave generic kernel with MRK_QS_R rows per lane (A/B measurements)
-  const int variant = [] { const char *e = getenv("MRK_QS_KERNEL"); return e ? atoi(e) : 1; }();
+  const int variant = switches().qs_kernel;
   if (variant != 0) {
     launch_bin<F64>(ctx, m, d_x, rows, cols, QS_TILE_ROWS, d_flag, d_row_req);
     launch_wave<F64>(ctx, m, ctx->d_cells.as<uint16_t>(), rows, d_out);
@@ -510,7 +510,7 @@ bool launch_qs_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int co
   const int leaf_bytes = QS_LEAVES * (F64 ? 8 : 4);
   const int chunk_trees = std::min(m->qs.n_trees, 8 * 1024 / leaf_bytes);
   auto smem = [&](int r) { return (size_t)chunk_trees * leaf_bytes + (size_t)QS_WAVES * V * r * 128; };
-  const int forced = [] { const char *e = getenv("MRK_QS_R"); return e ? atoi(e) : 2; }();
+  const int forced = switches().qs_r;
   const int r = (forced == 4 || forced == 8) ? forced : 2;
   if (smem(r) > 160 * 1024) return false;
   launch_bin<F64>(ctx, m, d_x, rows, cols, r * 64, d_flag, d_row_req);

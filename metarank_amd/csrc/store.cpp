@@ -9,6 +9,7 @@ namespace mrk {
 
 Store::Store() {
   for (int s = 0; s < SC_COUNT; ++s) tables[s].scope = (ScopeId)s;
+  tables[SC_ITEM].slot_of.mirrored = true;  // item ids are resolved on the device (resolve.hip)
   tok_pool.host.push_back(0);   // offset 0 is never a valid list start for a non-empty list; keeps {0,0} == empty
   f64_pool.host.push_back(0.0);
   slot_pool.host.push_back(0);
@@ -201,6 +202,7 @@ bool Store::put_string(const char *key, const char *v) {
     c.c = const_cast<Column *>(col);
   }
   set_tag(c, TAG_STRING);
+  c.c->max_len = std::max<uint32_t>(c.c->max_len, 1u);
   uint64_t cell = (uint64_t)tok | ((uint64_t)link << 32);
   set_val(c, 0, cell);
   return true;
@@ -214,6 +216,7 @@ bool Store::put_string_list(const char *key, const char *const *v, int n) {
   uint32_t off = n ? (uint32_t)tok_pool.host.size() : 0;
   for (int i = 0; i < n; ++i) tok_pool.host.push_back(intern(v[i] ? v[i] : ""));
   set_tag(c, TAG_STRING_LIST);
+  c.c->max_len = std::max<uint32_t>(c.c->max_len, (uint32_t)n);
   uint64_t cell = (uint64_t)off | ((uint64_t)(uint32_t)n << 32);
   set_val(c, 0, cell);
   return true;
@@ -306,14 +309,58 @@ static void flush_pool(Pool<T> &p, hipStream_t stream) {
   }
 }
 
+bool Store::dirty() const {
+  bool d = !pending.empty() || tok_pool.host.size() > tok_pool.uploaded || f64_pool.host.size() > f64_pool.uploaded ||
+           slot_pool.host.size() > slot_pool.uploaded;
+  for (int s = 0; s < SC_COUNT && !d; ++s) {
+    const Table &t = tables[s];
+    d = t.dirty_hi > t.dirty_lo || t.n_slots > t.d_slots_cap ||
+        (t.slot_of.mirrored && (t.slot_of.regrown || !t.slot_of.touched.empty() || t.slot_of.table.size() != t.d_id_entries));
+  }
+  return d;
+}
+
+// device mirror of an id -> slot map: the arena grows at its end; the table is re-sent whole after a rehash, else only
+// the entries placed since the last flush
+void Store::flush_ids(Table &t, hipStream_t stream) {
+  SlotMap &m = t.slot_of;
+  if (!m.mirrored) return;
+  const size_t arena = m.ids.size();
+  if (arena > t.d_arena_cap) {
+    const size_t cap = std::max<size_t>(arena + arena / 2, 4096);
+    t.d_id_arena.release();
+    t.d_id_arena.reserve(cap);
+    t.d_arena_cap = cap;
+    t.d_arena_uploaded = 0;
+  }
+  if (arena > t.d_arena_uploaded) {
+    MRK_HIP(hipMemcpyAsync((uint8_t *)t.d_id_arena.p + t.d_arena_uploaded, m.ids.data() + t.d_arena_uploaded, arena - t.d_arena_uploaded,
+                           hipMemcpyHostToDevice, stream));
+    t.d_arena_uploaded = arena;
+  }
+  const bool whole = m.regrown || m.table.size() != t.d_id_entries || m.touched.size() > 4096;
+  if (whole) {
+    if (m.table.size() != t.d_id_entries) {
+      t.d_id_table.release();
+      t.d_id_table.reserve(std::max<size_t>(m.table.size(), 1) * sizeof(IdEntry));
+      t.d_id_entries = m.table.size();
+    }
+    if (!m.table.empty())
+      MRK_HIP(hipMemcpyAsync(t.d_id_table.p, m.table.data(), m.table.size() * sizeof(IdEntry), hipMemcpyHostToDevice, stream));
+  } else {
+    for (uint32_t i : m.touched)
+      MRK_HIP(hipMemcpyAsync((IdEntry *)t.d_id_table.p + i, &m.table[i], sizeof(IdEntry), hipMemcpyHostToDevice, stream));
+  }
+  m.regrown = false;
+  m.touched.clear();
+}
+
 void Store::flush(hipStream_t stream) {
   // batches run on their own streams: nothing may be reading the tables / pools while they are rewritten or
   // reallocated.  Nothing dirty (the serving steady state between feedback events): no synchronisation at all.
-  bool dirty = !pending.empty() || tok_pool.host.size() > tok_pool.uploaded || f64_pool.host.size() > f64_pool.uploaded ||
-               slot_pool.host.size() > slot_pool.uploaded;
-  for (int s = 0; s < SC_COUNT && !dirty; ++s) dirty = tables[s].dirty_hi > tables[s].dirty_lo || tables[s].n_slots > tables[s].d_slots_cap;
-  if (!dirty) return;
+  if (!dirty()) return;
   MRK_HIP(hipDeviceSynchronize());
+  for (int s = 0; s < SC_COUNT; ++s) flush_ids(tables[s], stream);
   uint32_t uploaded_lo[SC_COUNT], uploaded_hi[SC_COUNT];
   for (int s = 0; s < SC_COUNT; ++s) {
     Table &t = tables[s];

@@ -45,6 +45,9 @@ struct Column {
   int ring_w = 0;                   // ring entries = max(offsets) + 1
   int64_t list_count = INT64_MAX;   // COL_BOUNDED_LIST
   int64_t list_duration_ms = INT64_MAX;
+  // the longest string list ever put into this column (an SString counts 1): upper bound used to size the pre-pass
+  // hash tables of a request without reading item records on the host (features.cpp resolve_requests)
+  uint32_t max_len = 0;
 };
 
 // device descriptor of a periodic column that owns a bucket ring
@@ -65,10 +68,15 @@ constexpr unsigned long long RING_EMPTY = 0x8080808080808080ull;  // memset(0x80
 // misses and a temporary string per lookup, and id lookups are 70 % of the host's share of a rank batch).
 // Slots are assigned densely in insertion order, so slot s's id is the s-th string of the arena.
 struct SlotMap {
-  struct Entry { uint64_t hash; uint32_t slot; uint32_t off; };  // hash 0 = empty; off: the id (NUL-terminated) in `ids`
+  typedef IdEntry Entry;          // {hash, slot, off}: hash 0 = empty; off: the id (NUL-terminated) in `ids`
   std::vector<Entry> table;       // power-of-two capacity, load <= 1/2
   std::string ids;
   size_t n = 0;
+  // device mirror (ITEM table only, store.cpp flush_ids): entries placed since the last upload; `regrown` = the whole
+  // table moved
+  bool mirrored = false;
+  bool regrown = false;
+  std::vector<uint32_t> touched;
   static uint64_t hash(const char *s, size_t len) {
     uint64_t h = 0x9e3779b97f4a7c15ull ^ (len * 0xff51afd7ed558ccdull);
     size_t i = 0;
@@ -120,8 +128,11 @@ struct SlotMap {
     size_t i = (size_t)e.hash & mask;
     while (table[i].hash != 0) i = (i + 1) & mask;
     table[i] = e;
+    if (mirrored && !regrown) touched.push_back((uint32_t)i);
   }
   void grow() {
+    regrown = true;
+    touched.clear();
     std::vector<Entry> old;
     old.swap(table);
     table.assign(old.empty() ? 64 : old.size() * 2, Entry{0, 0, 0});
@@ -150,6 +161,17 @@ struct Table {
   bool ring_used = false;
   uint32_t dirty_lo = UINT32_MAX, dirty_hi = 0;  // slot range to upload
   bool dirty_all = false;
+  // device mirror of slot_of (ITEM table): lets a kernel resolve item ids (resolve.hip)
+  DevBuf d_id_table, d_id_arena;
+  size_t d_id_entries = 0;        // entries allocated = host capacity at the last full upload
+  size_t d_arena_cap = 0, d_arena_uploaded = 0;
+  IdTableDev id_table_view() const {
+    IdTableDev v{};
+    v.table = d_id_entries ? (const IdEntry *)d_id_table.p : nullptr;
+    v.arena = (const uint8_t *)d_id_arena.p;
+    v.mask = d_id_entries ? (uint32_t)(d_id_entries - 1) : 0u;
+    return v;
+  }
   void mark(uint32_t slot) {
     if (slot < dirty_lo) dirty_lo = slot;
     if (slot + 1 > dirty_hi) dirty_hi = slot + 1;
@@ -224,6 +246,8 @@ struct Store {
   // copies everything that changed since the last call to the device (async on stream)
   void flush(hipStream_t stream);
   void flush_writes(hipStream_t stream, const uint32_t *uploaded_lo, const uint32_t *uploaded_hi);
+  bool dirty() const;   // anything flush() would upload
+  void flush_ids(Table &t, hipStream_t stream);
   StoreDev device_view() const;
   size_t device_bytes() const;
 

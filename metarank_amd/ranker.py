@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _native as N
 from .booster import Context, HipBooster, default_context
-from .request import Request, request_array
+from .request import Request, RequestSet, request_array
 
 
 def _strs(vals):
@@ -26,16 +26,54 @@ def _strs(vals):
 class Batch:
     """mrk_batch: a prepared, device-resident batch of requests."""
 
-    def __init__(self, ranker: "HipRanker", model_name: str, events):
+    def __init__(self, ranker: "HipRanker", model_name: str | None = None, events=None):
+        """With events: mrk_batch_prepare (resolve + upload once).  Without: mrk_batch_create - an empty batch for the
+        serving loop, (re)filled with load()."""
         self.ranker = ranker
+        self._h = C.c_void_p()
+        self.requests, self.n_req, self.total_items, self.dim, self.offsets = [], 0, 0, 0, np.zeros(1, dtype=np.int64)
+        if events is None:
+            N.check(N.lib().mrk_batch_create(ranker.ctx.handle, C.byref(self._h)))
+            return
         self.requests = [e if isinstance(e, Request) else Request(e) for e in events]
         arr = request_array(self.requests)
-        self._h = C.c_void_p()
         N.check(N.lib().mrk_batch_prepare(ranker.ctx.handle, model_name.encode(), arr, len(self.requests), C.byref(self._h)))
         self.n_req = len(self.requests)
         self.total_items = N.lib().mrk_batch_total_items(self._h)
         self.dim = ranker.dim(model_name)
         self.offsets = np.concatenate([[0], np.cumsum([r.n_items for r in self.requests])]).astype(np.int64)
+
+    def load(self, model_name: str, rs: "RequestSet | list", flat: bool = True):
+        """mrk_batch_load: (re)fill the batch.  A RequestSet travels as flat id bytes (device-side id resolution) unless
+        flat=False; a list of events / Requests goes through the per-item C strings (host lookups)."""
+        if isinstance(rs, RequestSet):
+            if not flat:
+                raise ValueError("a RequestSet carries no per-item C strings")
+            N.check(N.lib().mrk_batch_load(self._h, model_name.encode(), rs.arr, rs.n_req, C.byref(rs.ids)))
+            self.requests, self.n_req, self.offsets = rs.requests, rs.n_req, rs.offsets_per_request
+            self._keep = rs
+        else:
+            self.requests = [e if isinstance(e, Request) else Request(e) for e in rs]
+            arr = request_array(self.requests)
+            N.check(N.lib().mrk_batch_load(self._h, model_name.encode(), arr, len(self.requests), None))
+            self.n_req = len(self.requests)
+            self.offsets = np.concatenate([[0], np.cumsum([r.n_items for r in self.requests])]).astype(np.int64)
+            self._keep = arr
+        self.total_items = N.lib().mrk_batch_total_items(self._h)
+        self.dim = self.ranker.dim(model_name)
+
+    def enqueue_fetch(self):
+        N.check(N.lib().mrk_batch_enqueue_fetch(self._h))
+
+    def host_outputs(self):
+        """waits for the batch; (scores, order, status) as numpy VIEWS of the batch's pinned result buffer"""
+        s, o, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(N.lib().mrk_batch_host_outputs(self._h, C.byref(s), C.byref(o), C.byref(st)))
+        T, R = max(self.total_items, 1), max(self.n_req, 1)
+        scores = np.ctypeslib.as_array((C.c_double * T).from_address(s.value))[:self.total_items]
+        order = np.ctypeslib.as_array((C.c_int32 * T).from_address(o.value))[:self.total_items]
+        status = np.ctypeslib.as_array((C.c_int32 * R).from_address(st.value))[:self.n_req]
+        return scores, order, status
 
     def run(self, booster: HipBooster | None):
         N.check(N.lib().mrk_batch_run(self._h, booster.handle if booster is not None else None))
@@ -191,6 +229,10 @@ class HipRanker:
 
     def prepare(self, model_name: str, events) -> Batch:
         return Batch(self, model_name, events)
+
+    def new_batch(self) -> Batch:
+        """mrk_batch_create: an empty, reusable batch (own stream) for the serving loop"""
+        return Batch(self)
 
     def close(self):
         if self._own_ctx:

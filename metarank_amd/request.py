@@ -45,7 +45,8 @@ def _fill_field(dst: mrk_field, name: str, value, keep: list):
 class Request:
     """Owns the ctypes memory of one mrk_request."""
 
-    def __init__(self, event: dict):
+    def __init__(self, event: dict, with_ids: bool = True):
+        """with_ids False: item_ids stays NULL (the ids travel as flat bytes, RequestSet / mrk_item_ids)"""
         self.event = event
         self._keep: list = []
         c = mrk_request()
@@ -70,9 +71,12 @@ class Request:
         c.fields, c.n_fields = farr, len(fields)
         items = event["items"]
         ids = [str(it["id"] if isinstance(it, dict) else it).encode() for it in items]
-        idarr = (C.c_char_p * max(len(ids), 1))(*ids)
-        k.extend([ids, idarr])
-        c.item_ids, c.n_items = idarr, len(ids)
+        self.id_bytes = ids
+        if with_ids:
+            idarr = (C.c_char_p * max(len(ids), 1))(*ids)
+            k.extend([ids, idarr])
+            c.item_ids = idarr
+        c.n_items = len(ids)
         per_item = []
         for it in items:
             fl = []
@@ -106,3 +110,58 @@ def request_array(reqs):
     for i, r in enumerate(reqs):
         C.memmove(C.byref(arr, i * C.sizeof(mrk_request)), C.byref(r.c), C.sizeof(mrk_request))
     return arr
+
+
+class RequestSet:
+    """Requests marshalled for the serving loop (mrk_batch_load with mrk_item_ids): the mrk_request array without
+    per-item C strings, and the UTF-8 bytes of all item ids back to back + their offsets - in pinned memory
+    (mrk_host_alloc) unless pinned=False, so that the copy engine reads them where they are."""
+
+    def __init__(self, events, pinned: bool = True):
+        from . import _native as N
+
+        self.requests = [e if isinstance(e, Request) else Request(e, with_ids=False) for e in events]
+        self.arr = request_array(self.requests)
+        ids = [b for r in self.requests for b in r.id_bytes]
+        lens = np.fromiter((len(b) for b in ids), dtype=np.int64, count=len(ids))
+        offs = np.zeros(len(ids) + 1, dtype=np.uint32)
+        np.cumsum(lens, out=offs[1:])
+        blob = b"".join(ids)
+        self.total_items = len(ids)
+        self.n_req = len(self.requests)
+        self.offsets_per_request = np.concatenate([[0], np.cumsum([r.n_items for r in self.requests])]).astype(np.int64)
+        self._pinned = []
+        if pinned:
+            def pin(nbytes):
+                p = N.lib().mrk_host_alloc(max(nbytes, 1))
+                if not p:
+                    raise MemoryError("mrk_host_alloc failed")
+                self._pinned.append(p)
+                return p
+            pb, po = pin(len(blob)), pin(offs.nbytes)
+            C.memmove(pb, blob, len(blob))
+            C.memmove(po, offs.ctypes.data, offs.nbytes)
+            self._blob, self._offs = None, None
+            self.ids = N.mrk_item_ids(pb, po)
+        else:
+            self._blob = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(1, dtype=np.uint8)
+            self._offs = offs
+            self.ids = N.mrk_item_ids(self._blob.ctypes.data, offs.ctypes.data)
+        self.id_bytes_total = len(blob)
+
+    def requests_with_ids(self):
+        """the same requests with per-item C strings (pointer-style mrk_batch_prepare), for cross-checks"""
+        return [Request(r.event) for r in self.requests]
+
+    def close(self):
+        from . import _native as N
+
+        for p in self._pinned:
+            N.lib().mrk_host_free(p)
+        self._pinned = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -12,7 +12,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
 from backends import OracleBackend  # noqa: E402
-from metarank_amd import ranklens, synth  # noqa: E402
+from workloads import ranklens, synth  # noqa: E402
 from metarank_amd.dist import all_gather_padded, all_gather_scores, padded_chunk, shard_range  # noqa: E402
 
 

@@ -15,7 +15,7 @@ import numpy as np
 from sklearn.ensemble import GradientBoostingRegressor
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
-from metarank_amd import synth  # noqa: E402
+from workloads import synth  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

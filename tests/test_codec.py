@@ -38,7 +38,7 @@ def test_roundtrip_of_the_reference_test_values():  # T/fstore/redis/codec/impl/
 @pytest.mark.gpu
 def test_store_loaded_from_binary_ranks_like_typed_puts():
     from backends import HipBackend
-    from metarank_amd import ranklens, synth
+    from workloads import ranklens, synth
 
     cfg = ranklens.c3_config()
     a, b = HipBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
@@ -90,7 +90,7 @@ def test_ranking_event_format_rejects_garbage_without_a_gpu():
 @pytest.mark.gpu
 def test_binary_requests_and_container_warmup():
     from backends import HipBackend
-    from metarank_amd import ranklens, synth
+    from workloads import ranklens, synth
 
     cfg = ranklens.ranklens_config()
     hip = HipBackend(cfg, "xgboost")

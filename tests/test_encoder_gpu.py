@@ -13,7 +13,8 @@ import os
 import numpy as np
 import pytest
 
-from metarank_amd import _native as N, ranklens, synth
+from metarank_amd import _native as N
+from workloads import ranklens, synth
 from metarank_amd.encoder import HipEncoder, HipTokenizer
 from oracle import bert
 from backends import HipBackend, OracleBackend
@@ -130,10 +131,12 @@ def test_a_row_does_not_depend_on_the_batch_it_travels_in(minilm):
     np.testing.assert_array_equal(few[:6], many[:6])
     import os
     os.environ["MRK_ENCODER_GRAPH"] = "1"                      # recorded graph replay vs direct launches
+    N.reload_switches()
     try:
         np.testing.assert_array_equal(enc.hidden_ids(ids[:1], None, mask[:1]), alone)
     finally:
         del os.environ["MRK_ENCODER_GRAPH"]
+        N.reload_switches()
 
 
 def test_head_size_64(minilm):

@@ -22,7 +22,7 @@ def test_one_large_request_spreads_its_lookups(tmp_path):
     dump = str(tmp_path / "one.txt")
     # ranklens.generate_requests draws with replacement when a request is larger than the catalogue
     import json
-    from metarank_amd import ranklens
+    from workloads import ranklens
     host_bench.write_dump(dump, "c2", catalogue=2000, sessions=50, n_req=1)
     lines = open(dump).read().split("\n")
     ev = ranklens.generate_requests(1, 20_000, 2000, 50)[0]

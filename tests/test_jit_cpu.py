@@ -7,7 +7,8 @@ import json
 
 import pytest
 
-from metarank_amd import _native, ranklens
+from metarank_amd import _native
+from workloads import ranklens
 
 
 def specialize(cfg, what, f64=1, model=b"xgboost"):
@@ -65,7 +66,8 @@ def test_compiles_when_torch_brought_its_own_rocm_libraries(tmp_path):
     code = r"""
 import torch, ctypes as C, json, os, sys
 sys.path.insert(0, %r)
-from metarank_amd import _native, ranklens
+from metarank_amd import _native
+from workloads import ranklens
 lib = _native.lib()
 js = json.dumps(ranklens.ranklens_config()).encode()
 need = C.c_size_t(0)

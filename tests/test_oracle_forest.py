@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from metarank_amd import synth
+from workloads import synth
 from oracle.forest import InfInData, OracleForest
 
 NAN = float("nan")

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from backends import HipBackend, OracleBackend
-from metarank_amd import ranklens, synth
+import metarank_amd as M
+from workloads import ranklens, synth
 
 N_ITEMS, N_SESS = 3000, 300
 
@@ -191,6 +192,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
         for fused, cells, jit in (("1", "1", "require"), ("1", "1", "0"), ("1", "0", "0"), ("0", "1", "0"), ("0", "0", "0")):
             if True:
                 os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = fused, cells, jit
+                M.reload_switches()
                 batch = hip.ranker.prepare("xgboost", reqs)
                 batch.run(hip.booster)
                 scores, order, _ = batch.fetch()
@@ -210,6 +212,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
                 batch.close()
         # single requests: mrk_rank without / with the explain matrix
         os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = "1", "1", "require"
+        M.reload_switches()
         for ev, (_, es, eo), m in list(zip(reqs, expected, mats))[:8]:
             _, hs, ho = hip.ranker.rerank("xgboost", ev, hip.booster, explain=False)
             assert same(hs, es) and ho.tolist() == eo.tolist()
@@ -221,6 +224,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        M.reload_switches()
         hip.close()
 
 
@@ -446,6 +450,7 @@ def test_shapes_beyond_the_kernels_batches_and_long_threshold_tables():
         expected = [orc.rerank(ev) for ev in reqs]
         for jit in ("require", "0"):
             os.environ["MRK_RANK_JIT"] = jit
+            M.reload_switches()
             batch = hip.ranker.prepare("m", reqs)
             batch.run(hip.booster)
             scores, order, _ = batch.fetch()
@@ -463,6 +468,7 @@ def test_shapes_beyond_the_kernels_batches_and_long_threshold_tables():
             os.environ.pop("MRK_RANK_JIT", None)
         else:
             os.environ["MRK_RANK_JIT"] = saved
+        M.reload_switches()
         hip.close()
 
 
@@ -477,6 +483,7 @@ def test_background_specialisation_swaps_in_without_changing_results(oracle_c2, 
 
     saved = {k: os.environ.get(k) for k in ("MRK_RANK_JIT", "MRK_JIT_CACHE_DIR")}
     os.environ["MRK_RANK_JIT"], os.environ["MRK_JIT_CACHE_DIR"] = "async", str(tmp_path)
+    M.reload_switches()
     hip = HipBackend(ranklens.ranklens_config(), "xgboost")
     try:
         load(hip)
@@ -513,3 +520,4 @@ def test_background_specialisation_swaps_in_without_changing_results(oracle_c2, 
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        M.reload_switches()

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import metarank_amd as M
-from metarank_amd import synth
+from workloads import synth
 from oracle.forest import OracleForest
 
 pytestmark = pytest.mark.gpu
@@ -153,8 +153,8 @@ def test_full_size_properties_100k(ctx):
 
 # ---------------------------------------------------------------------------------------------
 # The two scorers: bit-vector (trees of <= 16 leaves, score_qs.hip) and tree-walk (score.hip).
-# Both must reproduce the oracle bit for bit on the same model; MRK_SCORER / MRK_QS_KERNEL are read
-# per call by the library, so a test can pin a kernel.
+# Both must reproduce the oracle bit for bit on the same model; the library reads MRK_SCORER / MRK_QS_KERNEL once, so a
+# test that pins a kernel re-reads them (M.reload_switches).
 @pytest.fixture
 def scorer_env():
     saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT")}
@@ -164,26 +164,26 @@ def scorer_env():
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
+    M.reload_switches()
+
+
+def _predict_with(b, X, **env):
+    for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    M.reload_switches()
+    return b.predict(X)
 
 
 def _all_kernels(b, X):
     out = {}
-    os.environ.pop("MRK_SCORER", None)
-    os.environ["MRK_QS_KERNEL"] = "1"
     for nw in ("1", "2", "4", "8"):  # 1 = one wavefront per tile; 2/4/8 = wavefronts splitting the trees of a tile
-        os.environ["MRK_QS_SPLIT"] = nw
-        out[f"bitvector-wave-split{nw}"] = b.predict(X)
-    os.environ.pop("MRK_QS_SPLIT", None)
-    out["bitvector-wave-auto"] = b.predict(X)
+        out[f"bitvector-wave-split{nw}"] = _predict_with(b, X, MRK_QS_KERNEL="1", MRK_QS_SPLIT=nw)
+    out["bitvector-wave-auto"] = _predict_with(b, X, MRK_QS_KERNEL="1")
     for r in ("2", "4", "8"):
-        os.environ["MRK_QS_KERNEL"] = "0"
-        os.environ["MRK_QS_R"] = r
-        out[f"bitvector-generic-r{r}"] = b.predict(X)
-    os.environ.pop("MRK_QS_KERNEL", None)
-    os.environ.pop("MRK_QS_R", None)
-    os.environ["MRK_SCORER"] = "walk"
-    out["walk"] = b.predict(X)
-    os.environ.pop("MRK_SCORER", None)
+        out[f"bitvector-generic-r{r}"] = _predict_with(b, X, MRK_QS_KERNEL="0", MRK_QS_R=r)
+    out["walk"] = _predict_with(b, X, MRK_SCORER="walk")
+    _predict_with(b, X[:1])
     return out
 
 

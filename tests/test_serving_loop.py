@@ -1,0 +1,205 @@
+"""The serving loop of the C ABI (mrk_batch_create / mrk_batch_load with flat item ids / mrk_batch_run /
+mrk_batch_enqueue_fetch / mrk_batch_host_outputs): item ids travel as UTF-8 bytes and are resolved to store slots by a
+kernel (csrc/resolve.hip), pre-pass tables are sized from bounds, results land in pinned memory.  Everything must equal
+the oracle - and the pointer-style path (host lookups, exact table sizes) - bit for bit."""
+import threading
+
+import numpy as np
+import pytest
+
+import metarank_amd as M
+from backends import HipBackend, OracleBackend
+from workloads import ranklens, synth
+
+N_ITEMS, N_SESS = 3000, 300
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.fixture(scope="module")
+def oracle_c2():
+    b = OracleBackend(ranklens.ranklens_config(), "xgboost")
+    ranklens.load_state(b, ranklens.generate_state(N_ITEMS, N_SESS))
+    return b
+
+
+def _requests():
+    reqs = ranklens.generate_requests(40, 100, N_ITEMS, N_SESS, seed=71)
+    reqs += ranklens.generate_requests(3, 1, N_ITEMS, N_SESS, seed=72) + ranklens.generate_requests(2, 300, N_ITEMS, N_SESS, seed=73)
+    # ids the store has never seen, an id that is a prefix / an extension of a known one, an empty id, non-ASCII bytes
+    reqs.append({"id": "odd", "timestamp": ranklens.TS, "user": None, "session": reqs[0]["session"], "fields": [],
+                 "items": [{"id": "nobody"}, {"id": "12"}, {"id": "1"}, {"id": "123456789"}, {"id": ""}, {"id": "фильм-7"}, {"id": "12"}]})
+    reqs.append({"id": "none", "timestamp": ranklens.TS, "user": None, "session": None, "fields": [], "items": []})
+    reqs += ranklens.generate_requests(2, 64, N_ITEMS, N_SESS, seed=74)
+    return reqs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [True, False])
+def test_flat_ids_are_resolved_on_the_device_and_match_the_oracle(oracle_c2, pinned):
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
+        reqs = _requests()
+        mats = [oracle_c2.matrix(ev) for ev in reqs]
+        q = ranklens.column_quantiles(np.concatenate([m for m in mats if len(m)]))
+        blob = synth.synthetic_lgbm_model(n_trees=300, n_features=24, quantiles=q, cat_features=[7], cat_prob=0.05, missing="per_feature")
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        expected = [oracle_c2.rerank(ev) for ev in reqs]
+        rs = M.RequestSet(reqs, pinned=pinned)
+        batch = hip.ranker.new_batch()
+        for rep in range(2):  # the second pass reuses every buffer of the batch
+            batch.load("xgboost", rs)
+            batch.run(hip.booster)
+            batch.enqueue_fetch()
+            scores, order, status = batch.host_outputs()
+            assert (status == 0).all()
+            for r, (_, es, eo) in enumerate(expected):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                assert same(scores[lo:hi], es), (rep, r)
+                assert order[lo:hi].tolist() == eo.tolist(), (rep, r)
+        # the explain matrix of the same batch is the oracle's (slots resolved by the device feed the matrix path too)
+        _, _, mat = batch.fetch(matrix=True)
+        for r in range(len(reqs)):
+            assert same(mat[batch.offsets[r]:batch.offsets[r + 1]], mats[r]), r
+        # and the pointer-style load of the same requests into the same batch object gives the same bytes
+        s1 = np.array(scores)
+        o1 = np.array(order)
+        batch.load("xgboost", reqs)
+        batch.run(hip.booster)
+        s2, o2, _ = batch.fetch()
+        assert same(s1, s2) and (o1 == o2).all()
+        # a smaller and a larger request set through the same batch
+        for sub in (reqs[:3], reqs + reqs):
+            rs2 = M.RequestSet(sub, pinned=pinned)
+            batch.load("xgboost", rs2)
+            batch.run(hip.booster)
+            scores, order, status = batch.host_outputs()  # no enqueue_fetch: host_outputs asks for the download itself
+            exp = [oracle_c2.rerank(ev) for ev in sub]
+            for r, (_, es, eo) in enumerate(exp):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), r
+            rs2.close()
+        batch.close()
+        rs.close()
+    finally:
+        hip.close()
+
+
+@pytest.mark.gpu
+def test_items_put_after_the_first_load_are_found(oracle_c2):
+    """The device mirror of the id table follows the store: a few new ids (entry-wise update), then enough to make the
+    host table rehash (whole-table update)."""
+    cfg = ranklens.ranklens_config()
+    orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+    try:
+        for be in (orc, hip):
+            ranklens.load_state(be, ranklens.generate_state(500, 50))
+        batch = hip.ranker.new_batch()
+        n_known = 500
+        for extra in (3, 2000):
+            for be in (orc, hip):
+                for i in range(n_known, n_known + extra):
+                    be.put_double(f"item={i}/popularity", float(i % 97))
+                    be.put_string_list(f"item={i}/divers_genres", ["drama", "noir"][: 1 + i % 2])
+            n_known += extra
+            reqs = ranklens.generate_requests(6, 80, n_known, 50, seed=90 + extra)
+            rs = M.RequestSet(reqs)
+            batch.load("xgboost", rs)
+            batch.run(None)  # NoopModel: the matrix is what is under test
+            _, _, mat = batch.fetch(matrix=True)
+            for r, ev in enumerate(reqs):
+                assert same(mat[batch.offsets[r]:batch.offsets[r + 1]], orc.matrix(ev)), (extra, r)
+            rs.close()
+        batch.close()
+    finally:
+        hip.close()
+
+
+@pytest.mark.gpu
+def test_batches_in_flight_from_several_threads_with_puts_in_between(oracle_c2):
+    """Three host threads drive their own batches (load -> run -> fetch) while a fourth keeps putting values under keys
+    the requests do not read; every result equals the oracle's."""
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
+        sets = [ranklens.generate_requests(64, 100, N_ITEMS, N_SESS, seed=80 + k) for k in range(3)]
+        q = ranklens.column_quantiles(np.concatenate([oracle_c2.matrix(ev) for ev in sets[0][:16]]))
+        blob = synth.synthetic_lgbm_model(n_trees=100, n_features=24, quantiles=q)
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        expected = [[oracle_c2.rerank(ev) for ev in reqs] for reqs in sets]
+        errors = []
+        stop = threading.Event()
+
+        def writer():
+            i = 0
+            while not stop.is_set():
+                hip.put_double(f"item=new-{i % 50}/popularity", float(i))  # new items: the id table grows under the readers
+                i += 1
+
+        def serve(k):
+            try:
+                rs = M.RequestSet(sets[k])
+                batch = hip.ranker.new_batch()
+                for _ in range(12):
+                    batch.load("xgboost", rs)
+                    batch.run(hip.booster)
+                    batch.enqueue_fetch()
+                    scores, order, status = batch.host_outputs()
+                    assert (status == 0).all()
+                    for r, (_, es, eo) in enumerate(expected[k]):
+                        lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                        assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), (k, r)
+                batch.close()
+                rs.close()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        w = threading.Thread(target=writer)
+        w.start()
+        threads = [threading.Thread(target=serve, args=(k,)) for k in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        stop.set()
+        w.join()
+        assert not errors, errors
+    finally:
+        hip.close()
+
+
+def test_id_hash_of_the_device_equals_the_hosts(tmp_path):
+    """CPU: id_hash_bytes (device_types.hpp, what resolve.hip computes) == SlotMap::hash (store.hpp, what the host's table
+    was built with) on ids of every length 0..40 and random bytes."""
+    import os
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.cpp"
+    src.write_text('''
+#include <cstdio>
+#include <random>
+#include <string>
+#include "store.hpp"
+int main() {
+  std::mt19937_64 g(7);
+  for (int len = 0; len <= 40; ++len)
+    for (int rep = 0; rep < 200; ++rep) {
+      std::string s(len, 0);
+      for (auto &c : s) c = (char)(g() & 0xff);
+      if (mrk::SlotMap::hash(s.data(), s.size()) != mrk::id_hash_bytes((const uint8_t *)s.data(), s.size())) { printf("MISMATCH len %d\\n", len); return 1; }
+    }
+  printf("ok\\n");
+  return 0;
+}
+''')
+    exe = tmp_path / "h"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", str(src), "-o", str(exe),
+                           "-I" + os.path.join(repo, "metarank_amd", "csrc")])
+    assert subprocess.check_output([str(exe)], text=True).strip() == "ok"

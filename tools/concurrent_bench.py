@@ -10,7 +10,7 @@ import numpy as np
 
 sys.path.insert(0, ".")
 import metarank_amd as M
-from metarank_amd import ranklens, synth
+from workloads import ranklens, synth
 
 threads = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 per_thread = int(sys.argv[2]) if len(sys.argv) > 2 else 300

@@ -13,7 +13,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from metarank_amd import synth  # noqa: E402
+from workloads import synth  # noqa: E402
 from metarank_amd.encoder import HipEncoder, HipTokenizer  # noqa: E402
 
 

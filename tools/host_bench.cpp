@@ -88,12 +88,32 @@ int main(int argc, char **argv) {
   const Program *prog = reg->program("xgboost");
   fprintf(stderr, "%zu puts in %.2f s (%.2f M puts/s incl. argument conversion), %zu requests, %zu items\n", puts, put_s, puts / put_s / 1e6, reqs.size(), total);
   HostBatch hb;
-  resolve_requests(*prog, store, reqs.data(), (int)reqs.size(), hb);  // warm
   const int reps = 5;
+  {
+    // the serving loop's form of the same batch: flat id bytes, slots resolved by the device (mrk_batch_load with
+    // mrk_item_ids) - what is left for the host is O(requests)
+    std::string bytes;
+    std::vector<uint32_t> offs(1, 0);
+    for (const Ev &e : evs)
+      for (const std::string &s : e.items) { bytes += s; offs.push_back((uint32_t)bytes.size()); }
+    std::vector<mrk_request> flat(reqs);
+    for (mrk_request &q : flat) q.item_ids = nullptr;
+    mrk_item_ids ids{(const uint8_t *)bytes.data(), offs.data()};
+    resolve_requests(*prog, store, flat.data(), (int)flat.size(), &ids, hb);
+    double fbest = 1e30;
+    for (int i = 0; i < reps; ++i) {
+      auto t0 = std::chrono::steady_clock::now();
+      resolve_requests(*prog, store, flat.data(), (int)flat.size(), &ids, hb);
+      fbest = std::min(fbest, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    printf("flat ids (device-resolved): %.3f ms per batch of %zu requests -> %.1f M items/s of host work; %zu id bytes; arena %llu entries, max per request %llu\n",
+           fbest * 1e3, reqs.size(), total / fbest / 1e6, bytes.size(), (unsigned long long)hb.arena_entries, (unsigned long long)hb.max_req_entries);
+  }
+  resolve_requests(*prog, store, reqs.data(), (int)reqs.size(), nullptr, hb);  // warm
   double best = 1e30;
   for (int i = 0; i < reps; ++i) {
     auto t0 = std::chrono::steady_clock::now();
-    resolve_requests(*prog, store, reqs.data(), (int)reqs.size(), hb);
+    resolve_requests(*prog, store, reqs.data(), (int)reqs.size(), nullptr, hb);
     best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
   printf("resolve_requests: %.1f ms per batch of %zu requests (%zu items) -> %.2f M items/s; arena %llu entries, max per request %llu\n",

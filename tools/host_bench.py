@@ -14,7 +14,8 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-from metarank_amd import _native, ranklens
+from metarank_amd import _native
+from workloads import ranklens
 
 
 def write_dump(path, wl="c2", catalogue=100_000, sessions=10_000, n_req=7680):

@@ -10,7 +10,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metarank_amd as M
-from metarank_amd import _native, ranklens, synth
+from metarank_amd import _native
+from workloads import ranklens, synth
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n_req, n_items = (3840, 100) if wl == "c2" else (384, 1000)

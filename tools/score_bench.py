@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, ".")
 import metarank_amd as M
 from metarank_amd import _native as N
-from metarank_amd import synth
+from workloads import synth
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 409600
 cols = int(sys.argv[2]) if len(sys.argv) > 2 else 24

@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, ".")
 import metarank_amd as M
 from metarank_amd import _native as N
-from metarank_amd import ranklens
+from workloads import ranklens
 
 n_items = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 n_inc = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
