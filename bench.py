@@ -27,6 +27,9 @@ scores / order / status into pinned memory, `--e2e-batches` batches in flight, o
 --workload c4   ONE request with 100 000 candidates (BASELINE config 4), item-sharded over the ranks:
              every rank assembles + scores its slice, one in-place RCCL all-gather of the f64 scores,
              then the sort.  Strong scaling ("scaling": "strong").
+--workload c4x  the out-of-cache form of c4: the generated catalogue is cloned to 8 M items (3 GB of item records, no
+             cache level holds it) and ONE request carries 4 M candidates drawn from all of them - the gather of the
+             assembly kernel against real HBM.  No CPU baseline / latency leg (the oracle does not hold 8 M items).
 
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
   roofline     dominant kernel, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
@@ -58,7 +61,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4x", "c5"], default="c2")
+    ap.add_argument("--clones", type=int, default=79,
+                    help="c4x: deep copies of every generated item (mrk_debug_clone_items): 100 000 x (1 + 79) = 8 M items, a 3 GB item "
+                         "table - far beyond the 256 MB Infinity Cache")
     ap.add_argument("--requests", type=int, default=None, help="requests per step per GPU (c2: 3840, c3: 384, c4: 1)")
     ap.add_argument("--items", type=int, default=None, help="candidate items per request (c2: 100, c3: 1000, c4: 100000)")
     ap.add_argument("--streams", type=int, default=None,
@@ -79,15 +85,17 @@ def main():
     args = ap.parse_args()
     wl = args.workload
     if args.requests is None:
-        args.requests = {"c2": 3840, "c3": 384, "c4": 1, "c5": 3840}[wl]
+        args.requests = {"c2": 3840, "c3": 384, "c4": 1, "c4x": 1, "c5": 3840}[wl]
     if args.items is None:
-        args.items = {"c2": 100, "c3": 1000, "c4": 100_000, "c5": 100}[wl]
-    sharded = wl == "c4"
+        args.items = {"c2": 100, "c3": 1000, "c4": 100_000, "c4x": 4_000_000, "c5": 100}[wl]
+    sharded = wl in ("c4", "c4x")
+    if wl == "c4x":
+        args.cpu_sample, args.latency_requests = 0, 0
     if args.streams is None:
         args.streams = 1 if sharded else 2
     n_streams = max(1, args.streams)
     if args.batches_per_step is None:
-        args.batches_per_step = {"c2": 96, "c3": 96, "c4": 128, "c5": 8}[wl]
+        args.batches_per_step = {"c2": 96, "c3": 96, "c4": 128, "c4x": 4, "c5": 8}[wl]
     bps = max(1, args.batches_per_step)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,13 +167,27 @@ def main():
         if oracle is not None:
             fn_o[kind](key, value)
         n_puts += 1
+    n_catalogue = args.catalogue
+    if wl == "c4x":
+        n_catalogue = ranker.clone_items(args.clones)
     ranker.flush()
-    log(f"state: {n_puts} feature values for {args.catalogue} items / {args.sessions} sessions in {time.perf_counter() - t0:.1f}s")
+    log(f"state: {n_puts} feature values for {args.catalogue} items / {args.sessions} sessions in {time.perf_counter() - t0:.1f}s"
+        + (f"; cloned to {n_catalogue} items" if wl == "c4x" else ""))
 
     # ---- requests (per-rank seeds) and the model
     # item-sharded: every rank holds the same request; else per-rank (and per-stream) requests
-    all_events = [ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
-                                             seed=ranklens.SEED + 1 + (0 if sharded else rank) + 1000 * k) for k in range(n_streams)]
+    if wl == "c4x":  # candidates drawn from the originals and all their clones
+        def big_request(seed):
+            rng = np.random.default_rng(seed)
+            base = rng.integers(0, args.catalogue, args.items)
+            k = rng.integers(0, args.clones + 1, args.items)
+            ev = ranklens.generate_requests(1, 1, args.catalogue, args.sessions, seed=seed)[0]
+            ev["items"] = [{"id": f"{b}#{c}" if c else f"{b}"} for b, c in zip(base.tolist(), k.tolist())]
+            return ev
+        all_events = [[big_request(ranklens.SEED + 1 + 1000 * k)] for k in range(n_streams)]
+    else:
+        all_events = [ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
+                                                 seed=ranklens.SEED + 1 + (0 if sharded else rank) + 1000 * k) for k in range(n_streams)]
     events = all_events[0]
     qtok = None
     if wl == "c5":  # a distinct query per request; the step's forward pass runs over these token ids
@@ -185,7 +207,15 @@ def main():
     booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
     info = booster.info()
     t0 = time.perf_counter()
-    batches = [ranker.prepare(model_name, ev) for ev in all_events]
+    if wl == "c4x":  # millions of ids: the flat form (no per-item C strings), resolved on the device
+        batches = []
+        for ev in all_events:
+            bt = ranker.new_batch()
+            bt.load(model_name, M.RequestSet(ev))
+            bt.sync()
+            batches.append(bt)
+    else:
+        batches = [ranker.prepare(model_name, ev) for ev in all_events]
     batch = batches[0]
     total_items = batch.total_items
     log(f"batch: {args.requests} requests x {args.items} items resolved + uploaded in {time.perf_counter() - t0:.2f}s; "
@@ -497,7 +527,7 @@ def main():
             "ms_per_step": ms_per_step, "ms_per_device_batch": ms_per_batch, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-lightgbm", "requests_per_step_per_gpu": args.requests,
-                       "items_per_request": args.items, "device_batches_per_step": bps, "items_per_device_batch": total_items, "items_per_step_per_gpu": total_items * bps, "catalogue_items": args.catalogue,
+                       "items_per_request": args.items, "device_batches_per_step": bps, "items_per_device_batch": total_items, "items_per_step_per_gpu": total_items * bps, "catalogue_items": n_catalogue, "item_table_bytes": int(n_catalogue) * ranker.item_stride(),
                        "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16,
                        "tile_columns": V, "batches_in_flight": n_streams,
                        "parallelism": (f"item-sharded x{n_gpus}" if sharded else f"request-sharded x{n_gpus}") +

@@ -516,6 +516,29 @@ int mrk_store_increment_periodic_batch(mrk_ctx *ctx, const char *const *keys, co
 int mrk_store_increment(mrk_ctx *ctx, const char *key, int64_t inc) { STORE_PUT(increment(key, inc)); }
 int mrk_store_append(mrk_ctx *ctx, const char *key, const char *value, int64_t ts_ms) { STORE_PUT(append(key, value, ts_ms)); }
 
+/* not part of include/mrk.h (measurement aid, Store::clone_items): grows the ITEM table to (copies + 1) x its size */
+int mrk_debug_clone_items(mrk_ctx *ctx, int copies, int64_t *out_items) {
+  return guard([&] {
+    Store &st = store_of(ctx);
+    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    const uint32_t n = st.clone_items(copies);
+    if (out_items) *out_items = n;
+  });
+}
+
+/* not part of include/mrk.h: layout of one scope's table - out[0..5] = slots, record stride, first byte of the inline heap,
+ * heap bytes, token pool entries, f64 pool entries (benchmarks report bytes per record from it) */
+int mrk_debug_store_info(mrk_ctx *ctx, int scope, int64_t *out) {
+  return guard([&] {
+    Store &st = store_of(ctx);
+    if (scope < 0 || scope >= SC_COUNT || !out) throw StatusError(MRK_ERR_INVALID_ARG, "bad scope");
+    std::shared_lock<std::shared_mutex> lk(ctx->store_mu);
+    const Table &t = st.tables[scope];
+    out[0] = t.n_slots; out[1] = t.stride; out[2] = t.heap_off; out[3] = t.heap_cap;
+    out[4] = (int64_t)st.tok_pool.host.size(); out[5] = (int64_t)st.f64_pool.host.size();
+  });
+}
+
 int mrk_store_flush(mrk_ctx *ctx) {
   return guard([&] {
     Store &st = store_of(ctx);

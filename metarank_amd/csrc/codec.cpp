@@ -65,20 +65,28 @@ struct In {
   }
 };
 
-// Key.encode (model/Key.scala:9) of the key the record carries: "<ScopeCodec.encode(scope)>/<feature>"
-std::string read_key(In &in) {
-  std::string scope;
-  switch (in.byte()) {  // FeatureValueCodec.ScopeCodec :205-235
-    case 0: scope = "user=" + in.utf(); break;
-    case 1: scope = "item=" + in.utf(); break;
-    case 2: scope = "global"; break;
-    case 3: scope = "session=" + in.utf(); break;
-    case 4: { std::string f = in.utf(); scope = "field=" + f + ":" + in.utf(); break; }
-    case 5: { std::string f = in.utf(), v = in.utf(); scope = "irf=" + f + ":" + v + ":" + in.utf(); break; }
-    case 6: scope = "ranking=" + in.utf(); break;
+// The key a record carries (FeatureValueCodec.KeyCodec / ScopeCodec :205-235), kept structured: ids and field values may
+// hold any bytes ('/' included), so they never travel through the Key.encode string form.  `id` is what follows
+// "<kind>=" in ScopeCodec.encode (fstore/codec/impl/ScopeCodec.scala:18-26).
+struct WireKey {
+  ScopeId scope = SC_GLOBAL;
+  std::string id, feature;
+  KeyRef ref() const { return KeyRef{scope, id, feature}; }
+};
+WireKey read_key(In &in) {
+  WireKey k;
+  switch (in.byte()) {
+    case 0: k.scope = SC_USER; k.id = in.utf(); break;
+    case 1: k.scope = SC_ITEM; k.id = in.utf(); break;
+    case 2: k.scope = SC_GLOBAL; break;
+    case 3: k.scope = SC_SESSION; k.id = in.utf(); break;
+    case 4: { std::string f = in.utf(); k.scope = SC_FIELD; k.id = f + ":" + in.utf(); break; }
+    case 5: { std::string f = in.utf(), v = in.utf(); k.scope = SC_IRF; k.id = f + ":" + v + ":" + in.utf(); break; }
+    case 6: k.scope = SC_RANKING; k.id = in.utf(); break;
     default: throw StatusError(MRK_ERR_PARSE, "feature value blob: cannot parse scope index");
   }
-  return scope + "/" + in.utf();
+  k.feature = in.utf();
+  return k;
 }
 
 struct ScalarV {
@@ -106,7 +114,8 @@ ScalarV read_scalar(In &in) {  // ScalarCodec.read
 
 }  // namespace
 
-// decodes every record of the blob into `store`; returns the number of records seen
+// decodes every record of the blob into `store`; returns the number of records seen (records of features the
+// configuration does not use are decoded and dropped, like KVStore values nobody reads)
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len) {
   In in{bytes, bytes + len};
   int n = 0;
@@ -114,26 +123,26 @@ int load_feature_values(Store &store, const uint8_t *bytes, size_t len) {
     const uint8_t tag = in.byte();
     const bool has_ttl = tag >= 7;  // tags 0-6 are the pre-ttl encodings ("compat")
     if (tag > 13) throw StatusError(MRK_ERR_PARSE, "cannot decode fv index " + std::to_string(tag));
-    const std::string key = read_key(in);
+    const WireKey wk = read_key(in);
+    const KeyRef key = wk.ref();
     (void)in.var_long();  // timestamp: the read path does not look at it
     switch (has_ttl ? tag - 7 : tag) {
       case 0: {  // ScalarValue
         ScalarV v = read_scalar(in);
         switch (v.kind) {
-          case 0: store.put_string(key.c_str(), v.s.c_str()); break;
-          case 1: store.put_double(key.c_str(), v.d); break;
-          case 2: store.put_bool(key.c_str(), v.b); break;
+          case 0: store.put_string(key, v.s); break;
+          case 1: store.put_double(key, v.d); break;
+          case 2: store.put_bool(key, v.b); break;
           case 3: {
-            std::vector<const char *> ptrs;
-            for (auto &s : v.sl) ptrs.push_back(s.c_str());
-            store.put_string_list(key.c_str(), ptrs.data(), (int)ptrs.size());
+            std::vector<std::string_view> ptrs(v.sl.begin(), v.sl.end());
+            store.put_string_list(key, ptrs.data(), (int)ptrs.size());
             break;
           }
-          default: store.put_double_list(key.c_str(), v.dl.data(), (int)v.dl.size()); break;
+          default: store.put_double_list(key, v.dl.data(), (int)v.dl.size()); break;
         }
         break;
       }
-      case 1: store.put_counter(key.c_str(), in.var_long()); break;  // CounterValue
+      case 1: store.put_counter(key, in.var_long()); break;  // CounterValue
       case 2: {  // NumStatsValue: not read by /rank
         (void)in.f64(); (void)in.f64();
         int m = in.var_int();
@@ -152,7 +161,7 @@ int load_feature_values(Store &store, const uint8_t *bytes, size_t len) {
           (void)in.var_long(); (void)in.var_long(); (void)in.var_int();
           vals.push_back(in.var_long());
         }
-        store.put_periodic(key.c_str(), vals.data(), (int)vals.size());
+        store.put_periodic(key, vals.data(), (int)vals.size());
         break;
       }
       case 5: {  // FrequencyValue: not read by /rank
@@ -168,9 +177,8 @@ int load_feature_values(Store &store, const uint8_t *bytes, size_t len) {
           ScalarV v = read_scalar(in);
           if (v.kind == 0) ids.push_back(v.s);  // InteractedWithFeature.scala:104-108 collects SString values only
         }
-        std::vector<const char *> ptrs;
-        for (auto &s : ids) ptrs.push_back(s.c_str());
-        store.put_bounded_list(key.c_str(), ptrs.data(), (int)ptrs.size());
+        std::vector<std::string_view> ptrs(ids.begin(), ids.end());
+        store.put_bounded_list(key, ptrs.data(), (int)ptrs.size());
         break;
       }
     }

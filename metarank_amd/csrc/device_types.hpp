@@ -31,10 +31,13 @@ enum Tag : uint8_t {
   TAG_DOUBLE = 1,       // ScalarValue(SDouble): cell = f64
   TAG_BOOL = 2,         // ScalarValue(SBoolean): cell = f64 0/1
   TAG_STRING = 3,       // ScalarValue(SString): cell = {u32 token, u32 linked field slot + 1 (0 = none)}
-  TAG_STRING_LIST = 4,  // ScalarValue(SStringList): cell = {u32 offset into token pool, u32 length}
+  TAG_STRING_LIST = 4,  // ScalarValue(SStringList): cell = {u32 offset, u32 length}; offset & LIST_INLINE_BIT: byte offset of the
+                        // tokens inside the record itself (its inline heap), else an index into the token pool
   TAG_DOUBLE_LIST = 5,  // ScalarValue(SDoubleList): cell = {u32 offset into f64 pool, u32 length}
   TAG_PRESENT = 1,      // counter / bounded list present; periodic: tag = 1 + min(len, 250)
 };
+
+constexpr uint32_t LIST_INLINE_BIT = 0x80000000u;
 
 struct TableDev {          // what kernels see
   const uint8_t *rows;

@@ -333,8 +333,11 @@ void declare_columns(const FeatureDef &f, Store &st) {
     case FType::Number: case FType::WordCount:
       if (f.scope != SC_RANKING || f.type == FType::Number) { if (t != SC_COUNT) st.add_column(t, f.name, COL_SCALAR, 0); }
       break;
-    case FType::Boolean: case FType::Vector: case FType::String:
+    case FType::Boolean: case FType::Vector:
       if (t != SC_COUNT) st.add_column(t, f.name, COL_SCALAR, 0);
+      break;
+    case FType::String:
+      if (t != SC_COUNT) st.add_column(t, f.name, COL_SCALAR, 0, "", /*expect_list=*/true);
       break;
     case FType::InteractionCount:
       if (t != SC_COUNT) st.add_column(t, f.name, COL_COUNTER, 0);
@@ -362,9 +365,12 @@ void declare_columns(const FeatureDef &f, Store &st) {
     case FType::InteractedWith:
       st.add_column(f.scope, f.name + "_interactions", COL_BOUNDED_LIST, 0);
       st.set_list_config(f.scope, f.name + "_interactions", f.list_count, f.list_duration_ms);
-      for (auto &fld : f.values) st.add_column(SC_ITEM, f.name + "_" + fld, COL_SCALAR, 0);
+      for (auto &fld : f.values) st.add_column(SC_ITEM, f.name + "_" + fld, COL_SCALAR, 0, "", /*expect_list=*/true);
       break;
-    case FType::Diversity: case FType::ItemAge: case FType::Biencoder:
+    case FType::Diversity:  // string lists or numbers: the heap is sized as if every one held a list
+      st.add_column(SC_ITEM, f.name, COL_SCALAR, 0, "", /*expect_list=*/true);
+      break;
+    case FType::ItemAge: case FType::Biencoder:
       st.add_column(SC_ITEM, f.name, COL_SCALAR, 0);
       break;
     default: break;

@@ -58,6 +58,12 @@ __device__ __forceinline__ Cell load_cell(const uint8_t *rec, ColRef c, int idx 
   return out;
 }
 
+// the tokens of a string list cell of record `rec`: in the record's own inline heap (same 128-byte lines as the cells:
+// no second trip to memory) or, for lists that did not fit, in the token pool
+__device__ __forceinline__ const uint32_t *list_tokens(const StoreDev &st, const uint8_t *rec, uint32_t off) {
+  return (off & LIST_INLINE_BIT) ? (const uint32_t *)(rec + (off & ~LIST_INLINE_BIT)) : st.tok_pool + off;
+}
+
 __device__ __forceinline__ int scoped_slot(const ReqDev &rq, int scope, int item_slot) {
   switch (scope) {
     case SC_GLOBAL: return 0;
@@ -117,14 +123,14 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
 // probes start: one trip to memory per batch instead of one per token.
 constexpr int TOK_BATCH = 8;
 
-// every token of tok_pool[off, off + len) -> table (pre-pass); len = 0 for lanes without a list.  Returns the
+// every token of toks[0, len) -> table (pre-pass); len = 0 for lanes without a list.  Returns the
 // number of tokens this lane could not insert (table full).
-__device__ __forceinline__ uint32_t table_add_list(const StoreDev &st, unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len) {
+__device__ __forceinline__ uint32_t table_add_list(const uint32_t *toks, unsigned long long *tab, uint32_t cap, uint32_t len) {
   uint32_t failed = 0;
   for (uint32_t j0 = 0; wave_any(j0 < len); j0 += TOK_BATCH) {
     uint32_t tk[TOK_BATCH];
 #pragma unroll
-    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? st.tok_pool[off + j0 + t] : 0u;
+    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? toks[j0 + t] : 0u;
 #pragma unroll
     for (int t = 0; t < TOK_BATCH; ++t) {
       if (!wave_any(j0 + t < len)) break;
@@ -134,14 +140,14 @@ __device__ __forceinline__ uint32_t table_add_list(const StoreDev &st, unsigned 
   return failed;
 }
 
-// sum over the tokens of tok_pool[off, off + len) of their table counts, added as doubles in list order
+// sum over the tokens toks[0, len) of their table counts, added as doubles in list order
 // (InteractedWithFeature.scala:150-160 / DiversityFeature.scala:112-122: integers, exact)
-__device__ __forceinline__ double table_sum_list(const StoreDev &st, const unsigned long long *tab, uint32_t cap, uint32_t off, uint32_t len,
+__device__ __forceinline__ double table_sum_list(const uint32_t *toks, const unsigned long long *tab, uint32_t cap, uint32_t len,
                                                  double cnt = 0.0) {
   for (uint32_t j0 = 0; wave_any(j0 < len); j0 += TOK_BATCH) {
     uint32_t tk[TOK_BATCH];
 #pragma unroll
-    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? st.tok_pool[off + j0 + t] : 0u;
+    for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? toks[j0 + t] : 0u;
 #pragma unroll
     for (int t = 0; t < TOK_BATCH; ++t) {
       if (!wave_any(j0 + t < len)) break;
@@ -345,7 +351,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
         for (int u = 0; u < PREP_GROUP; ++u) {
           if (u < n) {  // uniform
             const bool list = ic[u].tag == TAG_STRING_LIST;
-            if (table_add_list(st, tab[u], cap[u], ic[u].lo(), list ? ic[u].hi() : 0u)) atomicOr(&b.status[r], ST_TABLE_FULL);
+            if (table_add_list(list_tokens(st, irec, ic[u].lo()), tab[u], cap[u], list ? ic[u].hi() : 0u)) atomicOr(&b.status[r], ST_TABLE_FULL);
           }
         }
       }
@@ -381,6 +387,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
     // atomicMin over (index << 8 | tag) finds the first one AND what it holds.  A request that fits one round of the
     // workgroup (the usual case) keeps its cells in registers for passes (b) and (c).
     const bool single = rq.n_items <= nthr;
+    const uint8_t *keep_rec = nullptr;  // ... and the record they came from (inline string lists are read from it)
     Cell keep[PREP_GROUP];
 #pragma unroll
     for (int u = 0; u < PREP_GROUP; ++u) { keep[u].tag = TAG_MISSING; keep[u].bits = 0; }
@@ -400,6 +407,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
           if (u < n && c[u].tag != TAG_MISSING) atomicMin(&s_first[ent[u]], (i << 8) | (int)c[u].tag);
           if (single) keep[u] = c[u];
         }
+        if (single) keep_rec = irec;
       }
       __syncthreads();
       bool all = true;
@@ -434,7 +442,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
         const int i = base + tid;
         Cell c[PREP_GROUP];
         bool cand[PREP_GROUP];
-        const uint8_t *irec = !single && i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr;
+        const uint8_t *irec = single ? keep_rec : (i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr);
 #pragma unroll
         for (int u = 0; u < PREP_GROUP; ++u) {
           c[u].tag = TAG_MISSING;
@@ -451,7 +459,7 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
             const bool one = take && c[u].tag == TAG_STRING;
             const uint32_t tlen = take && !one ? c[u].hi() : 0u;
             uint32_t failed = table_add(tab[u], cap[u], c[u].lo(), one) ? 0u : 1u;
-            failed += table_add_list(st, tab[u], cap[u], c[u].lo(), tlen);
+            failed += table_add_list(list_tokens(st, irec, c[u].lo()), tab[u], cap[u], tlen);
             if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
             if (take) atomicAdd(&s_tokens[u], one ? 1 : (int)tlen);
           }
@@ -685,7 +693,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
         const Cell c = pc;
         double idx = 0.0;
         if (c.tag == TAG_STRING_LIST && c.hi() > 0) {
-          const uint32_t first = st.tok_pool[c.lo()];
+          const uint32_t first = list_tokens(st, primary_record(op), c.lo())[0];
           for (int k = 0; k < op.i1; ++k)
             if (prog.aux[op.i0 + k] == first) idx = (double)(k + 1);  // zipWithIndex.toMap: last duplicate wins
         }
@@ -696,7 +704,8 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
         // OneHotEncoder.fromValues: every token sets the FIRST position whose value equals it (indexOf)
         const Cell c = pc;
         const bool has = c.tag == TAG_STRING_LIST;
-        const uint32_t off = c.lo(), len = has ? c.hi() : 0u;
+        const uint32_t len = has ? c.hi() : 0u;
+        const uint32_t *toks = list_tokens(st, primary_record(op), c.lo());
         for (int k = 0; k < op.dim; ++k) {
           double v = 0.0;
           if (k < op.i1) {
@@ -705,7 +714,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
             for (int k2 = 0; k2 < k; ++k2) first = first && prog.aux[op.i0 + k2] != want;
             if (first)
               for (uint32_t j = 0; j < len; ++j)
-                if (st.tok_pool[off + j] == want) { v = 1.0; break; }
+                if (toks[j] == want) { v = 1.0; break; }
           }
           sink.put(dst + k, v);
         }
@@ -810,8 +819,9 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 #pragma unroll
           for (int u = 0; u < IW_BATCH; ++u) {
             const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
+            const uint32_t *toks = list_tokens(st, irec, fc[u].lo());
 #pragma unroll
-            for (int t = 0; t < IW_TOK; ++t) tk[u][t] = (uint32_t)t < len ? st.tok_pool[fc[u].lo() + t] : 0u;
+            for (int t = 0; t < IW_TOK; ++t) tk[u][t] = (uint32_t)t < len ? toks[t] : 0u;
           }
 #pragma unroll
           for (int u = 0; u < IW_BATCH; ++u) {
@@ -826,7 +836,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
               cnt = cnt + (double)table_get(tab, po.tab_cap, tk[u][t], (uint32_t)t < len);
             }
             if (wave_any(len > (uint32_t)IW_TOK))  // the rest of longer lists, in list order
-              cnt = table_sum_list(st, tab, po.tab_cap, fc[u].lo() + IW_TOK, len > (uint32_t)IW_TOK ? len - IW_TOK : 0u, cnt);
+              cnt = table_sum_list(list_tokens(st, irec, fc[u].lo()) + IW_TOK, tab, po.tab_cap, len > (uint32_t)IW_TOK ? len - IW_TOK : 0u, cnt);
             sink.put(dst + f0 + u, cnt);
           }
         }
@@ -844,7 +854,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
           const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
           const bool one = c.tag == TAG_STRING, list = c.tag == TAG_STRING_LIST;
           const double w1 = 0.0 + (double)table_get(tab, po.tab_cap, c.lo(), one);
-          const double wl = table_sum_list(st, tab, po.tab_cap, c.lo(), list ? c.hi() : 0u);
+          const double wl = table_sum_list(list_tokens(st, irec, c.lo()), tab, po.tab_cap, list ? c.hi() : 0u);
           if (one || list) v = (one ? w1 : wl) / po.scalar;
         }
         sink.put(dst + 0, v);

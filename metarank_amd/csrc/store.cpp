@@ -10,12 +10,15 @@ namespace mrk {
 Store::Store() {
   for (int s = 0; s < SC_COUNT; ++s) tables[s].scope = (ScopeId)s;
   tables[SC_ITEM].slot_of.mirrored = true;  // item ids are resolved on the device (resolve.hip)
-  tok_pool.host.push_back(0);   // offset 0 is never a valid list start for a non-empty list; keeps {0,0} == empty
+  tok_pool.host.push_back(0);   // offset 0 is never handed out: {0, 0} == the empty list
   f64_pool.host.push_back(0.0);
   slot_pool.host.push_back(0);
+  tok_pool.dirty.emplace_back(0, 1);
+  f64_pool.dirty.emplace_back(0, 1);
+  slot_pool.dirty.emplace_back(0, 1);
 }
 
-int Store::add_column(ScopeId scope, const std::string &name, ColKind kind, int periods, const std::string &link_field) {
+int Store::add_column(ScopeId scope, const std::string &name, ColKind kind, int periods, const std::string &link_field, bool expect_list) {
   if (frozen) throw StatusError(MRK_ERR_INVALID_ARG, "store layout is frozen");
   Table &t = tables[scope];
   auto it = t.col_of.find(name);
@@ -24,6 +27,7 @@ int Store::add_column(ScopeId scope, const std::string &name, ColKind kind, int 
     if (c.kind != kind || c.periods != periods)
       throw StatusError(MRK_ERR_INVALID_ARG, "state '" + name + "' is declared twice with different types");
     if (!link_field.empty()) c.link_field = link_field;
+    c.expect_list = c.expect_list || expect_list;
     return it->second;
   }
   Column c;
@@ -31,6 +35,7 @@ int Store::add_column(ScopeId scope, const std::string &name, ColKind kind, int 
   c.kind = kind;
   c.periods = periods;
   c.link_field = link_field;
+  c.expect_list = expect_list;
   t.cols.push_back(c);
   t.col_of[name] = (int)t.cols.size() - 1;
   return (int)t.cols.size() - 1;
@@ -39,14 +44,23 @@ int Store::add_column(ScopeId scope, const std::string &name, ColKind kind, int 
 void Store::freeze_layout() {
   for (int s = 0; s < SC_COUNT; ++s) {
     Table &t = tables[s];
-    uint32_t tag_bytes = ((uint32_t)t.cols.size() + 7u) & ~7u;
-    uint32_t off = tag_bytes;
+    // [tags][u16 heap_used] padded to 8, then the value cells, then the inline heap up to the end of the last line
+    t.heap_used_off = (uint32_t)t.cols.size();
+    t.heap_used_off = (t.heap_used_off + 1u) & ~1u;
+    uint32_t off = (t.heap_used_off + 2u + 7u) & ~7u;
+    uint32_t list_cols = 0;
     for (size_t i = 0; i < t.cols.size(); ++i) {
       t.cols[i].tag_index = (int)i;
       t.cols[i].val_off = (int)off;
       off += 8u * (uint32_t)(t.cols[i].kind == COL_PERIODIC ? std::max(1, t.cols[i].periods) : 1);
+      if (t.cols[i].expect_list) ++list_cols;
     }
-    t.stride = std::max(16u, (off + 15u) & ~15u);
+    // records start on a 128-byte line and end on one (64 for records that fit half a line); the heap gets what the
+    // declared list columns are expected to need (12 bytes each = 3 tokens on average) plus the padding
+    const uint32_t want = off + 12u * list_cols;
+    t.stride = want <= 64 ? 64u : (want + 127u) & ~127u;
+    t.heap_off = off;
+    t.heap_cap = std::min<uint32_t>(t.stride - off, 0xfff0u);
     // bucket rings of the periodic columns that have a write-path config
     t.ring_col_of.assign(t.cols.size(), -1);
     uint32_t roff = 0;
@@ -96,6 +110,7 @@ uint32_t Store::slot(ScopeId scope, const char *id, size_t len, bool create) {
   if (found != SlotMap::NONE) return found;
   if (!create) return NO_SLOT;
   if (!frozen) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called before the store is used");
+  if (memchr(id, 0, len)) throw StatusError(MRK_ERR_INVALID_ARG, "ids containing U+0000 are not supported");
   uint32_t s = t.n_slots++;
   t.slot_of.insert(id, len, s);
   t.rows.resize((size_t)t.n_slots * t.stride, 0);
@@ -103,38 +118,39 @@ uint32_t Store::slot(ScopeId scope, const char *id, size_t len, bool create) {
   return s;
 }
 
-bool Store::split_key(const char *key, ScopeId &scope, std::string &id, std::string &feature) {
+bool Store::parse_key(const char *key, KeyRef &out) {
   if (!key) return false;
-  // ScopeCodec.encode never emits '/', feature names may not either; ids may contain '/', so split on the LAST one?
-  // Key.fromString (model/Key.scala:14-23) splits on the FIRST '/': mirror that.
+  // Key.fromString (model/Key.scala:14-23) splits on the FIRST '/': mirror that
   const char *slash = strchr(key, '/');
   if (!slash || slash == key) return false;
-  std::string sc(key, slash);
-  feature.assign(slash + 1);
-  if (sc == "global") { scope = SC_GLOBAL; id.clear(); return true; }
-  size_t eq = sc.find('=');
-  if (eq == std::string::npos || eq == 0) return false;
-  std::string left = sc.substr(0, eq);
-  id = sc.substr(eq + 1);
-  if (left == "item") scope = SC_ITEM;
-  else if (left == "user") scope = SC_USER;
-  else if (left == "session") scope = SC_SESSION;
-  else if (left == "ranking") scope = SC_RANKING;
-  else if (left == "field") scope = SC_FIELD;
-  else if (left == "irf") scope = SC_IRF;
+  const std::string_view sc(key, (size_t)(slash - key));
+  out.feature = std::string_view(slash + 1);
+  if (sc == "global") { out.scope = SC_GLOBAL; out.id = std::string_view(); return true; }
+  const size_t eq = sc.find('=');
+  if (eq == std::string_view::npos || eq == 0) return false;
+  const std::string_view left = sc.substr(0, eq);
+  out.id = sc.substr(eq + 1);
+  if (left == "item") out.scope = SC_ITEM;
+  else if (left == "user") out.scope = SC_USER;
+  else if (left == "session") out.scope = SC_SESSION;
+  else if (left == "ranking") out.scope = SC_RANKING;
+  else if (left == "field") out.scope = SC_FIELD;
+  else if (left == "irf") out.scope = SC_IRF;
   else return false;
   return true;
 }
 
-bool Store::locate(const char *key, Cell &out) {
-  ScopeId sc;
-  std::string id, feature;
-  if (!split_key(key, sc, id, feature))
-    throw StatusError(MRK_ERR_INVALID_ARG, std::string("malformed key '") + (key ? key : "(null)") + "'");
-  Table &t = tables[sc];
-  auto it = t.col_of.find(feature);
+KeyRef Store::need_key(const char *key) {
+  KeyRef k;
+  if (!parse_key(key, k)) throw StatusError(MRK_ERR_INVALID_ARG, std::string("malformed key '") + (key ? key : "(null)") + "'");
+  return k;
+}
+
+bool Store::locate(const KeyRef &k, Cell &out) {
+  Table &t = tables[k.scope];
+  auto it = t.col_of.find(std::string(k.feature));
   if (it == t.col_of.end()) return false;  // state of a feature this config does not use
-  uint32_t s = slot(sc, id, true);
+  uint32_t s = slot(k.scope, k.id.data() ? k.id.data() : "", k.id.size(), true);
   out.t = &t;
   out.c = &t.cols[it->second];
   out.slot = s;
@@ -144,63 +160,79 @@ bool Store::locate(const char *key, Cell &out) {
   return true;
 }
 
-static void kind_check(const Column *c, ColKind want, const char *key) {
+static void kind_check(const Column *c, ColKind want, const KeyRef &k) {
   if (c->kind != want)
-    throw StatusError(MRK_ERR_INVALID_ARG, std::string("value type does not match the state '") + c->name + "' (key " + key + ")");
+    throw StatusError(MRK_ERR_INVALID_ARG, std::string("value type does not match the state '") + c->name + "' (scope id " + std::string(k.id) + ")");
 }
 
-bool Store::put_double(const char *key, double v) {
+// the pool range a cell's CURRENT value holds goes back to its free list (inline heap bytes are reclaimed by the next
+// re-pack of the record); keep_tok_range: the caller is about to store a new string list and handles the old one itself
+void Store::drop_value(Cell &c, bool keep_tok_range) {
+  const uint8_t tag = c.rec[c.c->tag_index];
+  if (tag == TAG_MISSING) return;
+  uint64_t cell;
+  memcpy(&cell, c.rec + c.c->val_off, 8);
+  const uint32_t off = (uint32_t)cell, len = (uint32_t)(cell >> 32);
+  if (c.c->kind == COL_SCALAR) {
+    if (tag == TAG_STRING_LIST && !keep_tok_range && !(off & LIST_INLINE)) tok_pool.release(off, len);
+    else if (tag == TAG_DOUBLE_LIST) f64_pool.release(off, len);
+  } else if (c.c->kind == COL_BOUNDED_LIST) {
+    slot_pool.release(off, len);
+  }
+}
+
+bool Store::put_double(const KeyRef &k, double v) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_SCALAR, key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_SCALAR, k);
+  drop_value(c);
   set_tag(c, TAG_DOUBLE);
   set_val(c, 0, v);
   return true;
 }
 
-bool Store::put_bool(const char *key, bool v) {
+bool Store::put_bool(const KeyRef &k, bool v) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_SCALAR, key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_SCALAR, k);
+  drop_value(c);
   set_tag(c, TAG_BOOL);
   set_val(c, 0, v ? 1.0 : 0.0);
   return true;
 }
 
 bool Store::put_string(const char *key, const char *v) {
-  if (!texts.empty()) {  // a cross-encoder column's item text
-    ScopeId sc;
-    std::string id, feature;
-    if (split_key(key, sc, id, feature) && sc == SC_ITEM) {
-      auto t = texts.find(feature);
-      if (t != texts.end()) {
-        if (!v) throw StatusError(MRK_ERR_INVALID_ARG, "null string value");
-        ItemText &e = t->second[id];
-        e.text = v;
-        e.pieces.clear();
-        e.tokenized = false;
-        ++version;
-        return true;
-      }
+  if (!v) throw StatusError(MRK_ERR_INVALID_ARG, "null string value");
+  return put_string(need_key(key), std::string_view(v));
+}
+
+bool Store::put_string(const KeyRef &k, std::string_view v) {
+  if (!texts.empty() && k.scope == SC_ITEM) {  // a cross-encoder column's item text
+    auto t = texts.find(std::string(k.feature));
+    if (t != texts.end()) {
+      ItemText &e = t->second[std::string(k.id)];
+      e.text = std::string(v);
+      e.pieces.clear();
+      e.tokenized = false;
+      ++version;
+      return true;
     }
   }
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_SCALAR, key);
-  if (!v) throw StatusError(MRK_ERR_INVALID_ARG, "null string value");
-  uint32_t tok = intern(v);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_SCALAR, k);
+  uint32_t tok = intern(std::string(v));
   uint32_t link = 0;
   if (!c.c->link_field.empty()) {
     // second key hop of the item-field scoped rate, resolved now: ItemFieldScope(field, value)
-    const std::string link_field = c.c->link_field;
     Table *t = c.t;
-    uint32_t sl = c.slot;
-    const Column *col = c.c;
-    uint32_t fs = slot(SC_FIELD, link_field + ":" + v, true);  // may grow another table only
+    const uint32_t sl = c.slot;
+    const std::string fid = c.c->link_field + ":" + std::string(v);
+    uint32_t fs = slot(SC_FIELD, fid, true);  // may grow another table only
     link = fs + 1;
     c.rec = t->rows.data() + (size_t)sl * t->stride;
-    c.c = const_cast<Column *>(col);
   }
+  drop_value(c);
   set_tag(c, TAG_STRING);
   c.c->max_len = std::max<uint32_t>(c.c->max_len, 1u);
   uint64_t cell = (uint64_t)tok | ((uint64_t)link << 32);
@@ -208,46 +240,130 @@ bool Store::put_string(const char *key, const char *v) {
   return true;
 }
 
-bool Store::put_string_list(const char *key, const char *const *v, int n) {
-  Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_SCALAR, key);
-  if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad string list");
-  uint32_t off = n ? (uint32_t)tok_pool.host.size() : 0;
-  for (int i = 0; i < n; ++i) tok_pool.host.push_back(intern(v[i] ? v[i] : ""));
-  set_tag(c, TAG_STRING_LIST);
-  c.c->max_len = std::max<uint32_t>(c.c->max_len, (uint32_t)n);
-  uint64_t cell = (uint64_t)off | ((uint64_t)(uint32_t)n << 32);
-  set_val(c, 0, cell);
+// Places `n` tokens of column `col` in the record's inline heap; false when they do not fit even after the heap has
+// been re-packed (then the caller uses the pool).  The heap is a bump allocator: an in-place rewrite when the column's
+// old inline list was at least as long, else the tokens go to the end; when the end is reached the live lists are
+// compacted (in column order) once.
+bool Store::heap_place(Table &t, uint8_t *rec, const Column *col, const uint32_t *toks, uint32_t n, uint32_t &off_out) {
+  const uint32_t need = n * 4u;
+  if (need > t.heap_cap) return false;
+  uint16_t used;
+  memcpy(&used, rec + t.heap_used_off, 2);
+  uint64_t cur;
+  memcpy(&cur, rec + col->val_off, 8);
+  const bool cur_inline = rec[col->tag_index] == TAG_STRING_LIST && ((uint32_t)cur & LIST_INLINE);
+  if (cur_inline && (uint32_t)(cur >> 32) >= n) {  // rewrite in place
+    off_out = (uint32_t)cur & ~LIST_INLINE;
+    memcpy(rec + off_out, toks, need);
+    return true;
+  }
+  if ((uint32_t)used + need > t.heap_cap) {
+    // compact: every OTHER live inline list, in column order (this column's old list is dropped)
+    std::vector<uint32_t> tmp;
+    std::vector<std::pair<const Column *, std::pair<uint32_t, uint32_t>>> live;
+    for (const Column &c2 : t.cols) {
+      if (c2.kind != COL_SCALAR || &c2 == col || rec[c2.tag_index] != TAG_STRING_LIST) continue;
+      uint64_t cell;
+      memcpy(&cell, rec + c2.val_off, 8);
+      if (!((uint32_t)cell & LIST_INLINE)) continue;
+      const uint32_t o = (uint32_t)cell & ~LIST_INLINE, l = (uint32_t)(cell >> 32);
+      live.push_back({&c2, {(uint32_t)tmp.size(), l}});
+      tmp.resize(tmp.size() + l);
+      memcpy(tmp.data() + tmp.size() - l, rec + o, (size_t)l * 4);
+    }
+    uint32_t at = 0;
+    for (auto &e : live) {
+      const uint32_t l = e.second.second;
+      memcpy(rec + t.heap_off + at, tmp.data() + e.second.first, (size_t)l * 4);
+      const uint64_t cell = (uint64_t)((t.heap_off + at) | LIST_INLINE) | ((uint64_t)l << 32);
+      memcpy(rec + e.first->val_off, &cell, 8);
+      at += l * 4u;
+    }
+    used = (uint16_t)at;
+    if ((uint32_t)used + need > t.heap_cap) {
+      memcpy(rec + t.heap_used_off, &used, 2);
+      return false;
+    }
+  }
+  off_out = t.heap_off + used;
+  memcpy(rec + off_out, toks, need);
+  used = (uint16_t)(used + need);
+  memcpy(rec + t.heap_used_off, &used, 2);
   return true;
 }
 
-bool Store::put_double_list(const char *key, const double *v, int n) {
+// stores a string list (already interned) into the cell: inline when the record's heap has room, else in the pool
+void Store::put_tokens(Cell &c, const uint32_t *toks, uint32_t n) {
+  uint64_t old = 0;
+  const bool had_list = c.rec[c.c->tag_index] == TAG_STRING_LIST;
+  if (had_list) memcpy(&old, c.rec + c.c->val_off, 8);
+  else drop_value(c);
+  const uint32_t old_off = (uint32_t)old, old_len = (uint32_t)(old >> 32);
+  const bool old_pool = had_list && !(old_off & LIST_INLINE);
+  uint32_t off = 0;
+  if (n == 0) {
+    if (old_pool) tok_pool.release(old_off, old_len);
+  } else if (heap_place(*c.t, c.rec, c.c, toks, n, off)) {
+    if (old_pool) tok_pool.release(old_off, old_len);
+    off |= LIST_INLINE;
+  } else {
+    off = tok_pool.realloc(old_pool ? old_off : 0, old_pool ? old_len : 0, n);
+    tok_pool.write(off, toks, n);
+  }
+  set_tag(c, TAG_STRING_LIST);
+  c.c->max_len = std::max<uint32_t>(c.c->max_len, n);
+  const uint64_t cell = (uint64_t)off | ((uint64_t)n << 32);
+  set_val(c, 0, cell);
+}
+
+bool Store::put_string_list(const char *key, const char *const *v, int n) {
+  if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad string list");
+  std::vector<std::string_view> sv((size_t)n);
+  for (int i = 0; i < n; ++i) sv[(size_t)i] = v[i] ? std::string_view(v[i]) : std::string_view("");
+  return put_string_list(need_key(key), sv.data(), n);
+}
+
+bool Store::put_string_list(const KeyRef &k, const std::string_view *v, int n) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_SCALAR, key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_SCALAR, k);
+  if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad string list");
+  std::vector<uint32_t> toks((size_t)n);
+  for (int i = 0; i < n; ++i) toks[(size_t)i] = intern(std::string(v[i]));
+  put_tokens(c, toks.data(), (uint32_t)n);
+  return true;
+}
+
+bool Store::put_double_list(const KeyRef &k, const double *v, int n) {
+  Cell c;
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_SCALAR, k);
   if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad double list");
-  uint32_t off = n ? (uint32_t)f64_pool.host.size() : 0;
-  f64_pool.host.insert(f64_pool.host.end(), v, v + n);
+  uint64_t old = 0;
+  const bool had = c.rec[c.c->tag_index] == TAG_DOUBLE_LIST;
+  if (had) memcpy(&old, c.rec + c.c->val_off, 8);
+  else drop_value(c);
+  const uint32_t off = f64_pool.realloc((uint32_t)old, (uint32_t)(old >> 32), (uint32_t)n);
+  f64_pool.write(off, v, (uint32_t)n);
   set_tag(c, TAG_DOUBLE_LIST);
   uint64_t cell = (uint64_t)off | ((uint64_t)(uint32_t)n << 32);
   set_val(c, 0, cell);
   return true;
 }
 
-bool Store::put_counter(const char *key, int64_t v) {
+bool Store::put_counter(const KeyRef &k, int64_t v) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_COUNTER, key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_COUNTER, k);
   set_tag(c, TAG_PRESENT);
   set_val(c, 0, v);
   return true;
 }
 
-bool Store::put_periodic(const char *key, const int64_t *v, int n) {
+bool Store::put_periodic(const KeyRef &k, const int64_t *v, int n) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_PERIODIC, key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_PERIODIC, k);
   if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad periodic counter");
   // the reference emits NaN when values.length != dim; keep the length in the tag, keep at most `periods` cells
   set_tag(c, (uint8_t)(1 + std::min(n, 250)));
@@ -256,40 +372,100 @@ bool Store::put_periodic(const char *key, const int64_t *v, int n) {
 }
 
 bool Store::put_bounded_list(const char *key, const char *const *v, int n) {
+  if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad bounded list");
+  std::vector<std::string_view> sv((size_t)n);
+  for (int i = 0; i < n; ++i) sv[(size_t)i] = v[i] ? std::string_view(v[i]) : std::string_view("");
+  return put_bounded_list(need_key(key), sv.data(), n);
+}
+
+bool Store::put_bounded_list(const KeyRef &k, const std::string_view *v, int n) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_BOUNDED_LIST, key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_BOUNDED_LIST, k);
   if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad bounded list");
   Table *t = c.t;
-  uint32_t sl = c.slot;
-  Column *col = c.c;
-  uint32_t off = n ? (uint32_t)slot_pool.host.size() : 0;
-  for (int i = 0; i < n; ++i) slot_pool.host.push_back(slot(SC_ITEM, v[i] ? v[i] : "", true));  // may grow the item table
+  const uint32_t sl = c.slot;
+  std::vector<uint32_t> slots((size_t)n);
+  for (int i = 0; i < n; ++i) slots[(size_t)i] = slot(SC_ITEM, v[i].data() ? v[i].data() : "", v[i].size(), true);  // may grow the item table
   c.rec = t->rows.data() + (size_t)sl * t->stride;  // t may BE the item table
-  c.c = col;
+  uint64_t old = 0;
+  if (c.rec[c.c->tag_index] != TAG_MISSING) memcpy(&old, c.rec + c.c->val_off, 8);
+  const uint32_t off = slot_pool.realloc((uint32_t)old, (uint32_t)(old >> 32), (uint32_t)n);
+  slot_pool.write(off, slots.data(), (uint32_t)n);
   set_tag(c, TAG_PRESENT);
   uint64_t cell = (uint64_t)off | ((uint64_t)(uint32_t)n << 32);
   set_val(c, 0, cell);
   return true;
 }
 
-bool Store::erase(const char *key) {
-  ScopeId sc;
-  std::string id, feature;
-  if (!split_key(key, sc, id, feature)) throw StatusError(MRK_ERR_INVALID_ARG, "malformed key");
-  if (sc == SC_ITEM) {
-    auto tx = texts.find(feature);
-    if (tx != texts.end()) { ++version; return tx->second.erase(id) > 0; }
+bool Store::erase(const KeyRef &k) {
+  if (k.scope == SC_ITEM) {
+    auto tx = texts.find(std::string(k.feature));
+    if (tx != texts.end()) { ++version; return tx->second.erase(std::string(k.id)) > 0; }
   }
-  Table &t = tables[sc];
-  auto it = t.col_of.find(feature);
+  Table &t = tables[k.scope];
+  auto it = t.col_of.find(std::string(k.feature));
   if (it == t.col_of.end()) return false;
-  uint32_t s = slot(sc, id, false);
+  uint32_t s = slot(k.scope, k.id.data() ? k.id.data() : "", k.id.size(), false);
   if (s == NO_SLOT) return false;
-  t.rows[(size_t)s * t.stride + t.cols[it->second].tag_index] = TAG_MISSING;
+  Cell c{&t, &t.cols[it->second], s, t.rows.data() + (size_t)s * t.stride};
+  drop_value(c);
+  set_tag(c, TAG_MISSING);
   t.mark(s);
   ++version;
   return true;
+}
+
+uint32_t Store::clone_items(int copies) {
+  Table &t = tables[SC_ITEM];
+  const uint32_t n0 = t.n_slots;
+  if (copies <= 0 || n0 == 0) return n0;
+  if ((uint64_t)n0 * (uint64_t)(copies + 1) > 0x7fffffffull) throw StatusError(MRK_ERR_INVALID_ARG, "too many clones");
+  // the original ids, in slot order (slot s's id is the s-th string of the arena)
+  std::vector<std::string> ids;
+  ids.reserve(n0);
+  for (size_t at = 0; ids.size() < n0;) {
+    const char *p = t.slot_of.ids.data() + at;
+    ids.emplace_back(p);
+    at += ids.back().size() + 1;
+  }
+  std::vector<uint8_t> rec(t.stride);
+  for (int k = 1; k <= copies; ++k) {
+    const std::string suffix = "#" + std::to_string(k);
+    for (uint32_t s0 = 0; s0 < n0; ++s0) {
+      const std::string id = ids[s0] + suffix;
+      const uint32_t s = slot(SC_ITEM, id, true);
+      memcpy(rec.data(), t.rows.data() + (size_t)s0 * t.stride, t.stride);
+      for (const Column &c : t.cols) {  // values that live in a pool get their own range
+        const uint8_t tag = rec[c.tag_index];
+        if (tag == TAG_MISSING) continue;
+        uint64_t cell;
+        memcpy(&cell, rec.data() + c.val_off, 8);
+        const uint32_t off = (uint32_t)cell, len = (uint32_t)(cell >> 32);
+        uint32_t noff = off;
+        if (c.kind == COL_SCALAR && tag == TAG_STRING_LIST && !(off & LIST_INLINE) && len) {
+          noff = tok_pool.alloc(len);
+          std::vector<uint32_t> v(tok_pool.host.begin() + off, tok_pool.host.begin() + off + len);
+          tok_pool.write(noff, v.data(), len);
+        } else if (c.kind == COL_SCALAR && tag == TAG_DOUBLE_LIST && len) {
+          noff = f64_pool.alloc(len);
+          std::vector<double> v(f64_pool.host.begin() + off, f64_pool.host.begin() + off + len);
+          f64_pool.write(noff, v.data(), len);
+        } else if (c.kind == COL_BOUNDED_LIST && len) {
+          noff = slot_pool.alloc(len);
+          std::vector<uint32_t> v(slot_pool.host.begin() + off, slot_pool.host.begin() + off + len);
+          slot_pool.write(noff, v.data(), len);
+        } else {
+          continue;
+        }
+        cell = (uint64_t)noff | ((uint64_t)len << 32);
+        memcpy(rec.data() + c.val_off, &cell, 8);
+      }
+      memcpy(t.rows.data() + (size_t)s * t.stride, rec.data(), t.stride);
+    }
+  }
+  ++version;
+  return t.n_slots;
 }
 
 template <typename T>
@@ -300,18 +476,23 @@ static void flush_pool(Pool<T> &p, hipStream_t stream) {
     p.dev.release();
     p.dev.reserve(cap * sizeof(T));
     p.dev_cap = cap;
-    p.uploaded = 0;
+    p.dirty.clear();
+    p.dirty.emplace_back(0, n);
   }
-  if (n > p.uploaded) {
-    MRK_HIP(hipMemcpyAsync((T *)p.dev.p + p.uploaded, p.host.data() + p.uploaded, (n - p.uploaded) * sizeof(T),
-                           hipMemcpyHostToDevice, stream));
-    p.uploaded = n;
+  if (p.dirty.size() > 256) {  // many scattered rewrites: one copy of their hull
+    size_t lo = n, hi = 0;
+    for (auto &d : p.dirty) { lo = std::min(lo, d.first); hi = std::max(hi, d.second); }
+    p.dirty.clear();
+    p.dirty.emplace_back(lo, hi);
   }
+  for (auto &d : p.dirty)
+    if (d.second > d.first)
+      MRK_HIP(hipMemcpyAsync((T *)p.dev.p + d.first, p.host.data() + d.first, (d.second - d.first) * sizeof(T), hipMemcpyHostToDevice, stream));
+  p.dirty.clear();
 }
 
 bool Store::dirty() const {
-  bool d = !pending.empty() || tok_pool.host.size() > tok_pool.uploaded || f64_pool.host.size() > f64_pool.uploaded ||
-           slot_pool.host.size() > slot_pool.uploaded;
+  bool d = !pending.empty() || !tok_pool.dirty.empty() || !f64_pool.dirty.empty() || !slot_pool.dirty.empty();
   for (int s = 0; s < SC_COUNT && !d; ++s) {
     const Table &t = tables[s];
     d = t.dirty_hi > t.dirty_lo || t.n_slots > t.d_slots_cap ||
@@ -467,8 +648,9 @@ void Store::set_list_config(ScopeId scope, const std::string &name, int64_t coun
 
 bool Store::increment_periodic(const char *key, int64_t ts_ms, int64_t inc) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_PERIODIC, key);
+  const KeyRef k = need_key(key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_PERIODIC, k);
   const int col = (int)(c.c - c.t->cols.data());
   const int rc = c.t->ring_col_of.empty() ? -1 : c.t->ring_col_of[col];
   if (rc < 0) throw StatusError(MRK_ERR_UNSUPPORTED, std::string("state '") + c.c->name + "' has no bucket / periods the device write path supports");
@@ -481,8 +663,9 @@ bool Store::increment_periodic(const char *key, int64_t ts_ms, int64_t inc) {
 
 bool Store::increment(const char *key, int64_t inc) {
   Cell c;
-  if (!locate(key, c)) return false;
-  kind_check(c.c, COL_COUNTER, key);
+  const KeyRef k = need_key(key);
+  if (!locate(k, c)) return false;
+  kind_check(c.c, COL_COUNTER, k);
   // MemCounter.put (fstore/memory/MemCounter.scala): existing + inc, else inc
   int64_t cur = 0;
   if (c.rec[c.c->tag_index] != TAG_MISSING) memcpy(&cur, c.rec + c.c->val_off, 8);
@@ -494,8 +677,9 @@ bool Store::increment(const char *key, int64_t inc) {
 bool Store::append(const char *key, const char *value, int64_t ts_ms) {
   {
     Cell c;
-    if (!locate(key, c)) return false;
-    kind_check(c.c, COL_BOUNDED_LIST, key);
+    const KeyRef k = need_key(key);
+    if (!locate(k, c)) return false;
+    kind_check(c.c, COL_BOUNDED_LIST, k);
     if (!value) throw StatusError(MRK_ERR_INVALID_ARG, "null list element");
     // MemBoundedList.put (fstore/memory/MemBoundedList.scala:18-37): the first element is stored as is; later ones
     // are prepended, then everything older than (this ts - duration) is dropped and `count` elements are kept

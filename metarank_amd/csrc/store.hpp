@@ -5,9 +5,14 @@
 // a table is an array of fixed-stride RECORDS, one per scope instance ("slot"), so that the
 // gather of one candidate item touches a single contiguous record (a few 128-B lines) instead of
 // one line per feature column.  A record is
-//     [tag bytes: one per column][8-byte value cells, one per column (P cells for a P-period counter)]
-// Variable-length values (string lists as interned token ids, double lists, bounded lists as item
-// slots) live in three append-only pools addressed by {offset, length} cells.
+//     [tag bytes: one per column][u16 heap_used][8-byte value cells, one per column (P cells for a P-period counter)]
+//     [inline heap: the interned tokens of the record's own string lists]
+// padded to a whole number of 128-byte lines (64 bytes for tiny records) and starting on one: a candidate costs exactly
+// stride / 128 lines, its tokens included.  A string list cell is {u32 offset, u32 length}; offset has LIST_INLINE
+// set when the tokens live in the record's own heap (byte offset from the record's start), else it indexes the
+// token pool.  Lists that do not fit the heap, double lists and bounded lists (item slots) live in three pools
+// addressed by {offset, length} cells; pool ranges come in power-of-two size classes and are recycled through free
+// lists when a value is replaced, so a long-running store does not grow with the number of puts.
 // Strings are interned host-side (one dictionary for the whole store); the second key hop of the
 // item-field-scoped `rate` (item -> "field=<name>:<value>") is resolved at put time into a direct
 // slot reference.
@@ -18,6 +23,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -37,6 +43,7 @@ struct Column {
   int tag_index = 0;         // byte index of the tag inside the record
   int val_off = 0;           // byte offset of the first value cell inside the record
   std::string link_field;    // SString scalar whose value is also a key into the FIELD table ("field=<link_field>:<value>")
+  bool expect_list = false;  // the feature that reads it stores string lists here: the record's inline heap is sized for it
   // write path (raw state): PeriodicCounterConfig(period, sumPeriodRanges = periods.map(PeriodRange(_, 0))),
   // model/Feature.scala:196-209; BoundedListConfig(count, duration), model/Feature.scala:100-108
   int64_t period_ms = 0;            // COL_PERIODIC: bucket length; 0 = no write-path config (values arrive by put only)
@@ -145,7 +152,10 @@ struct Table {
   ScopeId scope;
   std::vector<Column> cols;
   std::unordered_map<std::string, int> col_of;
-  uint32_t stride = 16;
+  uint32_t stride = 64;
+  uint32_t heap_used_off = 0;     // byte offset of the u16 "inline heap bytes in use" inside the record
+  uint32_t heap_off = 0;          // first byte of the inline heap = end of the value cells
+  uint32_t heap_cap = 0;          // stride - heap_off
   SlotMap slot_of;
   std::vector<uint8_t> rows;      // host mirror, n_slots * stride
   uint32_t n_slots = 0;
@@ -178,14 +188,52 @@ struct Table {
   }
 };
 
+constexpr uint32_t LIST_INLINE = 0x80000000u;  // list cell: the tokens are in the record's own heap (device_types.hpp)
+constexpr uint32_t POOL_MAX = 0x7fffffffu;     // pool offsets keep the top bit free
+
+// A pool of variable-length values.  Ranges are allocated in power-of-two size classes (a range of class c holds 2^c
+// elements) and recycled: replacing a value whose class still fits rewrites it in place, anything else returns the old
+// range to its class's free list.  Element 0 is never handed out ({0, 0} = the empty list).
 template <typename T>
 struct Pool {
   std::vector<T> host;
   DevBuf dev;
-  size_t uploaded = 0;   // elements already on device
-  size_t dev_cap = 0;    // elements allocated on device
+  size_t dev_cap = 0;                                 // elements allocated on device
+  std::vector<std::pair<size_t, size_t>> dirty;      // element ranges [lo, hi) to upload
+  std::vector<uint32_t> free_[32];
+  static int cls(uint32_t n) { return n <= 1 ? 0 : 32 - __builtin_clz(n - 1); }
+  uint32_t alloc(uint32_t n) {  // n >= 1
+    const int c = cls(n);
+    if (!free_[c].empty()) { const uint32_t off = free_[c].back(); free_[c].pop_back(); return off; }
+    const size_t off = host.size(), len = (size_t)1 << c;
+    if (off + len > POOL_MAX) throw std::length_error("feature store: a value pool would exceed 2^31 entries");
+    host.resize(off + len, T());
+    return (uint32_t)off;
+  }
+  void release(uint32_t off, uint32_t n) { if (n && off) free_[cls(n)].push_back(off); }
+  // the range for a value of n elements replacing one of old_n elements at old_off (0, 0: none)
+  uint32_t realloc(uint32_t old_off, uint32_t old_n, uint32_t n) {
+    if (n == 0) { release(old_off, old_n); return 0; }
+    if (old_n && old_off && cls(old_n) == cls(n)) return old_off;
+    release(old_off, old_n);
+    return alloc(n);
+  }
+  void write(uint32_t off, const T *v, uint32_t n) {
+    if (!n) return;
+    std::copy(v, v + n, host.begin() + off);
+    if (!dirty.empty() && dirty.back().second == off) dirty.back().second = off + n;  // consecutive appends coalesce
+    else dirty.emplace_back(off, off + n);
+  }
 };
 
+
+// Key(scope, feature) (model/Key.scala:7-10) with the scope already told apart: `id` is what follows "<kind>=" in
+// ScopeCodec.encode (fstore/codec/impl/ScopeCodec.scala:18-26) - the item / user / session / ranking id, or
+// "<field>:<value>" / "<field>:<value>:<item>" for the field scopes; empty for the global scope.  Views: nothing is copied.
+struct KeyRef {
+  ScopeId scope = SC_GLOBAL;
+  std::string_view id, feature;
+};
 
 struct Store {
   Table tables[SC_COUNT];
@@ -206,7 +254,8 @@ struct Store {
 
   Store();
   // layout (called by the registry while loading the config)
-  int add_column(ScopeId scope, const std::string &name, ColKind kind, int periods, const std::string &link_field = "");
+  int add_column(ScopeId scope, const std::string &name, ColKind kind, int periods, const std::string &link_field = "",
+                 bool expect_list = false);
   void freeze_layout();
 
   uint32_t intern(const std::string &s);
@@ -215,19 +264,31 @@ struct Store {
   uint32_t slot(ScopeId scope, const char *id, size_t len, bool create);
   static constexpr uint32_t NO_SLOT = 0xffffffffu;
 
-  // Key.encode -> (scope, scope id, feature); false if malformed
-  static bool split_key(const char *key, ScopeId &scope, std::string &id, std::string &feature);
+  // Key.encode ("<ScopeCodec.encode(scope)>/<feature>", model/Key.scala:9) -> KeyRef viewing `key`; false if malformed.
+  // Key.fromString splits on the FIRST '/', so an id that itself contains '/' cannot travel in this form - the
+  // structured KeyRef overloads below (used by the binary loader, codec.cpp) take any bytes.
+  static bool parse_key(const char *key, KeyRef &out);
 
   // puts: return false when the key does not belong to any configured column (ignored)
-  bool put_double(const char *key, double v);
-  bool put_bool(const char *key, bool v);
+  bool put_double(const KeyRef &k, double v);
+  bool put_bool(const KeyRef &k, bool v);
+  bool put_string(const KeyRef &k, std::string_view v);
+  bool put_string_list(const KeyRef &k, const std::string_view *v, int n);
+  bool put_double_list(const KeyRef &k, const double *v, int n);
+  bool put_counter(const KeyRef &k, int64_t v);
+  bool put_periodic(const KeyRef &k, const int64_t *v, int n);
+  bool put_bounded_list(const KeyRef &k, const std::string_view *v, int n);
+  bool erase(const KeyRef &k);
+  // the same for Key.encode strings and C strings (the C ABI)
+  bool put_double(const char *key, double v) { return put_double(need_key(key), v); }
+  bool put_bool(const char *key, bool v) { return put_bool(need_key(key), v); }
   bool put_string(const char *key, const char *v);
   bool put_string_list(const char *key, const char *const *v, int n);
-  bool put_double_list(const char *key, const double *v, int n);
-  bool put_counter(const char *key, int64_t v);
-  bool put_periodic(const char *key, const int64_t *v, int n);
+  bool put_double_list(const char *key, const double *v, int n) { return put_double_list(need_key(key), v, n); }
+  bool put_counter(const char *key, int64_t v) { return put_counter(need_key(key), v); }
+  bool put_periodic(const char *key, const int64_t *v, int n) { return put_periodic(need_key(key), v, n); }
   bool put_bounded_list(const char *key, const char *const *v, int n);
-  bool erase(const char *key);
+  bool erase(const char *key) { return erase(need_key(key)); }
 
   // ---- write path (raw Writes of flow/FeatureValueFlow.scala:44-62; the FeatureValue is derived here) ----
   void set_periodic_config(ScopeId scope, const std::string &name, int64_t period_ms, const std::vector<int32_t> &offsets);
@@ -237,6 +298,11 @@ struct Store {
   bool increment_periodic(const char *key, int64_t ts_ms, int64_t inc);
   bool increment(const char *key, int64_t inc);                          // Write.Increment
   bool append(const char *key, const char *value, int64_t ts_ms);        // Write.Append(SString)
+
+  // Measurement aid (mrk_debug_clone_items): every ITEM-scope instance that exists now gets `copies` deep copies under
+  // the ids "<id>#1" .. "<id>#<copies>" - the way bench.py grows a generated catalogue past the Infinity Cache without
+  // generating (and putting) hundreds of millions of values through Python.  Returns the number of items afterwards.
+  uint32_t clone_items(int copies);
 
   // host-side readers (used to size per-request scratch; never to compute features)
   const uint8_t *record(ScopeId scope, uint32_t slot) const {
@@ -253,9 +319,14 @@ struct Store {
 
  private:
   struct Cell { Table *t; Column *c; uint32_t slot; uint8_t *rec; };
-  bool locate(const char *key, Cell &out);
+  static KeyRef need_key(const char *key);
+  bool locate(const KeyRef &k, Cell &out);
   void set_tag(Cell &c, uint8_t tag) { c.rec[c.c->tag_index] = tag; }
   template <typename T> void set_val(Cell &c, int idx, T v) { memcpy(c.rec + c.c->val_off + idx * 8, &v, sizeof(T)); }
+  // returns the pool range / heap bytes a cell's current value holds before the value is replaced
+  void drop_value(Cell &c, bool keep_tok_range = false);
+  void put_tokens(Cell &c, const uint32_t *toks, uint32_t n);
+  bool heap_place(Table &t, uint8_t *rec, const Column *col, const uint32_t *toks, uint32_t n, uint32_t &off_out);
 };
 
 // codec.cpp: a `ranking` event decoded from the reference's binary RankingEventFormat; `req` points into this object

@@ -182,6 +182,25 @@ class HipRanker:
         N.check(N.lib().mrk_store_put_binary(self.ctx.handle, blob, len(blob), C.byref(n)))
         return n.value
 
+    def clone_items(self, copies: int) -> int:
+        """measurement aid (mrk_debug_clone_items): every item gets `copies` deep copies under the ids '<id>#k'"""
+        fn = N.lib().mrk_debug_clone_items
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        n = C.c_int64(0)
+        N.check(fn(self.ctx.handle, int(copies), C.byref(n)))
+        return n.value
+
+    def store_info(self, scope: int = 1) -> dict:
+        """layout of one scope's table (1 = items): slots, record stride, inline heap, pool sizes (mrk_debug_store_info)"""
+        fn = N.lib().mrk_debug_store_info
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        out = (C.c_int64 * 6)()
+        N.check(fn(self.ctx.handle, scope, out))
+        return dict(zip(("slots", "stride", "heap_off", "heap_cap", "tok_pool", "f64_pool"), [int(x) for x in out]))
+
+    def item_stride(self) -> int:
+        return self.store_info(1)["stride"]
+
     def delete(self, key): N.check(N.lib().mrk_store_delete(self.ctx.handle, self._k(key)))
     def flush(self): N.check(N.lib().mrk_store_flush(self.ctx.handle))
 

@@ -203,3 +203,35 @@ int main() {
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", str(src), "-o", str(exe),
                            "-I" + os.path.join(repo, "metarank_amd", "csrc")])
     assert subprocess.check_output([str(exe)], text=True).strip() == "ok"
+
+
+@pytest.mark.gpu
+def test_cloned_items_rank_like_their_originals():
+    """mrk_debug_clone_items (how bench.py --workload c4x grows the catalogue past the Infinity Cache): a clone has its
+    original's state, so inside one request its matrix row equals the original's - a property that holds at any size."""
+    cfg = ranklens.ranklens_config()
+    orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+    try:
+        for be in (orc, hip):
+            ranklens.load_state(be, ranklens.generate_state(400, 30))
+        n = hip.ranker.clone_items(3)
+        assert n >= 1600
+        info = hip.ranker.store_info(1)
+        assert info["stride"] % 128 == 0 and info["slots"] == n
+        ev = ranklens.generate_requests(1, 60, 400, 30, seed=5)[0]
+        originals = [it["id"] for it in ev["items"]]
+        ev["items"] = [{"id": i} for i in originals] + [{"id": f"{i}#{1 + k % 3}"} for k, i in enumerate(originals)]
+        batch = hip.ranker.new_batch()
+        batch.load("xgboost", M.RequestSet([ev]))
+        batch.run(None)
+        _, _, mat = batch.fetch(matrix=True)
+        assert same(mat[:60], mat[60:])
+        # and the originals' rows are the oracle's for the same 120-candidate request with the clones unknown to it:
+        # per-item columns only (diversity / interacted_with see 120 candidates on the device, the oracle sees the
+        # clones as items without state)
+        om = orc.matrix(ev)
+        per_item = [c for c in range(24) if c not in (15, 16, 17, 18, 19)]
+        assert same(mat[:60][:, per_item], om[:60][:, per_item])
+        batch.close()
+    finally:
+        hip.close()
