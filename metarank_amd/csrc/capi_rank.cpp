@@ -19,7 +19,7 @@ size_t big_sort_padded(int n_items);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
-                           uint16_t *cells, bool f64);
+                           uint16_t *cells, bool f64, void *jit_fn);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap);
@@ -327,7 +327,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
   const bool cells = sw.rank_cells && !sw.scorer_walk && model && model->qs.ok && !b.want_matrix && rows > 0;
   const bool f64 = model && model->forest.backend == Backend::LightGBM;
   // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
-  void *jit_fn = cells && b.fused_ok ? jit_rank_function(*b.prog, f64) : nullptr;
+  void *jit_fn = !cells ? nullptr : b.fused_ok ? jit_rank_function(*b.prog, f64) : jit_items_function(*b.prog, f64);
   LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
@@ -347,7 +347,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
       launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     } else {
       launch_prepass(ctx, st, pd, b.view);
-      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64);
+      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     }
     b.matrix_valid = false;
     // lo is a multiple of the tile size: the scorer sees rows [lo, hi) as its rows [0, hi - lo)

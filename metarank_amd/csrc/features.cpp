@@ -379,6 +379,7 @@ void declare_columns(const FeatureDef &f, Store &st) {
 
 void build_program(Program &p, const std::vector<const FeatureDef *> &feats, const Store &st) {
   int dst = 0;
+  p.item_fixed = (int)st.tables[SC_ITEM].heap_off;
   for (const FeatureDef *f : feats) {
     Op op{};
     HostOp ho;

@@ -67,6 +67,7 @@ struct Program {
   int dim = 0;
   int n_consts = 0;
   int n_irf = 0;
+  int item_fixed = 0;   // bytes of tags + value cells of an ITEM record (Table::heap_off): what the specialised kernel keeps in registers
   DevBuf d_ops, d_prep, d_aux;
   mutable std::mutex jit_mu;        // guards `jit` (the first ranks of a model may come from several threads)
   mutable void *jit = nullptr;      // JitKernels* (jit.cpp): the kernel specialised for this program, built on first use

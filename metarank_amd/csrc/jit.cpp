@@ -82,7 +82,7 @@ std::string jit_source(const Program &prog, bool f64) {
   table("JitAux", "uint32_t", prog.aux.size(), rows);
   s += "struct JitProg {\n  static constexpr bool is_static = true;\n";
   s += "  static constexpr int32_t n_ops = " + std::to_string(prog.ops.size()) + ", n_prep = " + std::to_string(prog.prep.size()) +
-       ", dim = " + std::to_string(prog.dim) + ", n_consts = " + std::to_string(prog.n_consts) + ";\n";
+       ", dim = " + std::to_string(prog.dim) + ", n_consts = " + std::to_string(prog.n_consts) + ", item_fixed = " + std::to_string(switches().jit_record_regs ? prog.item_fixed : 0) + ";\n";
   s += "  JitOps ops;\n  JitPrep prep;\n  JitAux aux;\n};\n}  // namespace\n}  // namespace mrk\n\n";
   // experiments: MRK_JIT_WAVES=n asks the compiler for n wavefronts per SIMD (register cap 512 / n)
   std::string attr;
@@ -91,6 +91,10 @@ std::string jit_source(const Program &prog, bool f64) {
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
        "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells) {\n"
        "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
+  // the item-parallel form (requests too large for one workgroup: tables from a previous pre-pass launch, in HBM)
+  s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
+       "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
+       "  mrk::assemble_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, q, cells);\n}\n";
   return s;
 }
 
@@ -121,7 +125,8 @@ std::vector<char> jit_compile(const std::string &source, std::string &log) {
 
 struct JitKernels {
   hipModule_t mod[2] = {nullptr, nullptr};   // [f64]: one module per scorer precision, built when first needed
-  hipFunction_t fn[2] = {nullptr, nullptr};
+  hipFunction_t fn[2] = {nullptr, nullptr};        // mrk_jit_rank_cells
+  hipFunction_t fn_items[2] = {nullptr, nullptr};  // mrk_jit_assemble_cells
   bool failed[2] = {false, false};
   // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
   std::thread worker[2];
@@ -227,6 +232,7 @@ void *jit_rank_function(const Program &prog, bool f64) {
     }
     MRK_HIP(hipModuleLoadData(&k->mod[v], code.data()));
     MRK_HIP(hipModuleGetFunction(&k->fn[v], k->mod[v], "mrk_jit_rank_cells"));
+    MRK_HIP(hipModuleGetFunction(&k->fn_items[v], k->mod[v], "mrk_jit_assemble_cells"));
   } catch (const std::exception &e) {
     k->failed[v] = true;
     if (mode == 2) throw;
@@ -250,6 +256,14 @@ extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *o
   return 0;
 }
 #endif
+
+// the item-parallel kernel of the same module (nullptr under the same conditions as jit_rank_function)
+void *jit_items_function(const Program &prog, bool f64) {
+  if (!jit_rank_function(prog, f64)) return nullptr;
+  std::lock_guard<std::mutex> lk(prog.jit_mu);
+  JitKernels *k = (JitKernels *)prog.jit;
+  return k ? (void *)k->fn_items[f64 ? 1 : 0] : nullptr;
+}
 
 void jit_release(Program &prog) {
   if (!prog.jit) return;

@@ -14,6 +14,8 @@ std::vector<char> jit_compile(const std::string &source, std::string &log);
 // hipFunction_t of the specialised fused kernel for (program, scorer precision), built on first use; nullptr when
 // specialisation is switched off (MRK_RANK_JIT=0) or hiprtc failed (warning on stderr; MRK_RANK_JIT=require throws)
 void *jit_rank_function(const Program &prog, bool f64);
+// the item-parallel assembly kernel of the same specialised module (mrk_jit_assemble_cells), same conditions
+void *jit_items_function(const Program &prog, bool f64);
 void jit_release(Program &prog);
 
 }  // namespace mrk

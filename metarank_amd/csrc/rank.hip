@@ -57,16 +57,7 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
 template <bool F64>
 __global__ void __launch_bounds__(ASM_THREADS)
 assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_t *cells) {
-  __shared__ __align__(16) double s_thr[ASM_THREADS / 64][2 * QS_LDS_THR];
-  const int gi0 = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
-  const bool active = gi0 < b.item_hi;
-  if (!__any(active)) return;
-  const int gi = active ? gi0 : b.item_hi - 1;
-  const int r = (int)b.item_req[gi];
-  const ReqDev rq = b.reqs[r];
-  CellSink<F64> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r],
-                     (qs_lds_double *)s_thr[threadIdx.x >> 6], active};
-  assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
+  assemble_cells_body<F64>(st, prog, b, q, cells);
 }
 
 __global__ void __launch_bounds__(256)
@@ -309,14 +300,21 @@ static void launch_override_cells(mrk_ctx *ctx, const BatchDev &b, const QsDev &
   MRK_HIP(hipGetLastError());
 }
 
-// assembly straight into the scorer's binned tile (tables from a previous launch_prepass)
+// assembly straight into the scorer's binned tile (tables from a previous launch_prepass); jit_fn: the specialised
+// mrk_jit_assemble_cells of this program, or nullptr = the kernel that interprets the program
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
-                           uint16_t *cells, bool f64) {
+                           uint16_t *cells, bool f64, void *jit_fn) {
   if (b.item_hi <= b.item_lo) return;
   {
     ScopedKernelTimer timer(ctx, "assemble");
     const dim3 grid((b.item_hi - b.item_lo + ASM_THREADS - 1) / ASM_THREADS);
-    if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), 0, ctx->launch, st, prog, b, q, cells);
+    if (jit_fn) {  // the kernel specialised for this model's program (jit.cpp)
+      StoreDev a_st = st;
+      BatchDev a_b = b;
+      QsDev a_q = q;
+      void *args[] = {&a_st, &a_b, &a_q, &cells};
+      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, grid.x, 1, 1, ASM_THREADS, 1, 1, 0, ctx->launch, args, nullptr));
+    } else if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), 0, ctx->launch, st, prog, b, q, cells);
     else hipLaunchKernelGGL(assemble_cells_kernel<false>, grid, dim3(ASM_THREADS), 0, ctx->launch, st, prog, b, q, cells);
     MRK_HIP(hipGetLastError());
   }

@@ -641,6 +641,57 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// ---- the candidate's own record, seen two ways.
+// PtrRec reads it from memory cell by cell (the kernels of rank.hip, any program).  RegRec holds its fixed part - tag
+// bytes and value cells, NP 16-byte pieces - in registers: the kernel specialised for one model (jit.cpp) fetches every
+// line of the record exactly once, with all loads in flight together, and every cell an op touches later is a register
+// read with a compile-time offset.  (Measured on 4 M candidates over an 8 M-item table, profiles/r02_b: cell-by-cell
+// loads cost 23 L2 misses per candidate - 1.4 KB for a 384-byte record - because the lines are evicted between ops.)
+struct PtrRec {
+  const uint8_t *p;
+  __device__ __forceinline__ uint32_t tag(int tag_index) const { return p[tag_index]; }
+  __device__ __forceinline__ uint64_t u64(int byte_off) const { return *(const uint64_t *)(p + byte_off); }
+};
+
+template <int NP>
+struct RegRec {
+  const uint8_t *p;   // still needed: inline string lists are read from the record's heap
+  uint4 r[NP];
+  __device__ __forceinline__ uint32_t tag(int tag_index) const {
+    const uint4 v = r[tag_index >> 4];
+    const int w = (tag_index >> 2) & 3;
+    const uint32_t word = w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w;
+    return (word >> (8 * (tag_index & 3))) & 0xffu;
+  }
+  __device__ __forceinline__ uint64_t u64(int byte_off) const {
+    const uint4 v = r[byte_off >> 4];
+    return (byte_off & 8) ? ((uint64_t)v.w << 32) | v.z : ((uint64_t)v.y << 32) | v.x;
+  }
+};
+
+template <int NP>
+__device__ __forceinline__ RegRec<NP> load_record_regs(const uint8_t *p) {
+  RegRec<NP> R;
+  R.p = p;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    R.r[i] = make_uint4(0u, 0u, 0u, 0u);          // no record: every tag reads TAG_MISSING
+    if (p != nullptr) R.r[i] = ((const uint4 *)p)[i];
+  }
+  return R;
+}
+
+template <typename IR>
+__device__ __forceinline__ Cell rec_cell(const IR &ir, ColRef c, int idx = 0) {
+  Cell out;
+  out.tag = TAG_MISSING;
+  out.bits = 0;
+  if (ir.p == nullptr || c.tag < 0) return out;
+  out.tag = ir.tag(c.tag);
+  out.bits = ir.u64(c.val + idx * 8);
+  return out;
+}
+
 // ops whose first load is the cell of their primary column op.c0
 __device__ __forceinline__ constexpr bool op_has_primary(const Op &op) {
   const int kind = op.kind;
@@ -648,24 +699,150 @@ __device__ __forceinline__ constexpr bool op_has_primary(const Op &op) {
   return kind == OP_SCALAR_DOUBLE || kind == OP_SCALAR_BOOL || kind == OP_VECTOR || kind == OP_STRING_INDEX || kind == OP_STRING_ONEHOT ||
          kind == OP_COUNTER || kind == OP_WINDOW || kind == OP_DIVERSITY || kind == OP_ITEM_AGE || kind == OP_BIENCODER;
 }
+// ... and whether that column lives in the candidate's own record
+__device__ __forceinline__ constexpr bool op_primary_in_item(const Op &op) {
+  const int kind = op.kind;
+  if (kind == OP_DIVERSITY || kind == OP_BIENCODER || kind == OP_RATE) return true;
+  return op.scope == SC_ITEM;
+}
+
+constexpr int IW_BATCH = 4, IW_TOK = 4;   // interacted_with: fields handled together, tokens per field fetched ahead
+constexpr int RATE_BATCH = 4;             // rate: periods fetched together
+constexpr int PRE_TOK = IW_BATCH * IW_TOK;
+constexpr int PRE_F64 = 8;
+
+// What an op needs from memory BEYOND the candidate's record, fetched ahead of the arithmetic (second trip): the first
+// tokens of its string lists, the counters of the record a scoped rate points to, the global counters of a normalised
+// rate, the head of a stored vector.  In the specialised kernel the fetches of ALL ops are issued together, before the
+// first op computes anything; the interpreting kernels fetch op by op.  Fields an op kind does not use are never
+// assigned and cost nothing.
+struct OpPre {
+  Cell fc[IW_BATCH];                    // interacted_with: the field cells
+  uint32_t tok[PRE_TOK];                // interacted_with: token t of field u at [u * IW_TOK + t]; string / diversity: the list's first tokens
+  long long tv[RATE_BATCH], bv[RATE_BATCH], gtv[RATE_BATCH], gbv[RATE_BATCH];
+  uint32_t ttag, btag, gttag, gbtag;
+  double d[PRE_F64];                    // vector: the first stored values
+};
 
 // Evaluates the model program for batch item gi of request r.  Hash tables: tab_base + (po.tab_off - tab_sub).
-template <typename Prog, typename Sink>
-__device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &prog, const BatchDev &b, int gi, int r,
-                                              const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
-                                              const PrepOut *pos, const Sink &sink) {
-  const int islot = sink.active ? b.item_slot[gi] : -1;  // lanes without an item: a missing record
-  const uint8_t *irec = record(st, SC_ITEM, islot);
+template <typename Prog, typename Sink, typename IR>
+__device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog &prog, const BatchDev &b, int gi, int r,
+                                                  const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
+                                                  const PrepOut *pos, const Sink &sink, int islot, const IR &ir) {
+  const uint8_t *irec = ir.p;
   const double NaN = d_nan();
 
-  // the record an op's primary column (op.c0) lives in
-  auto primary_record = [&](const Op &op) -> const uint8_t * {
-    if (op.kind == OP_DIVERSITY || op.kind == OP_BIENCODER || op.kind == OP_RATE) return irec;
-    if (op.kind == OP_ITEM_AGE) return op.scope == SC_ITEM ? irec : nullptr;
+  // the record an op's primary column (op.c0) lives in, when that is not the candidate's own
+  auto other_record = [&](const Op &op) -> const uint8_t * {
+    if (op.kind == OP_ITEM_AGE) return nullptr;
     return record(st, op.scope, scoped_slot(rq, op.scope, islot));
   };
-  // one op, given its primary cell `pc` (missing for the kinds without one: op_has_primary)
-  auto run_op = [&](const Op &op, const Cell &pc) __attribute__((always_inline)) {
+  auto primary_cell = [&](const Op &op) -> Cell {
+    Cell pc;
+    pc.tag = TAG_MISSING;
+    pc.bits = 0;
+    if (!op_has_primary(op)) return pc;
+    return op_primary_in_item(op) ? rec_cell(ir, op.c0) : load_cell(other_record(op), op.c0);
+  };
+  // the record the tokens of the op's primary string list live in
+  auto primary_list_record = [&](const Op &op) -> const uint8_t * { return op_primary_in_item(op) ? irec : other_record(op); };
+
+  // ---- second trip to memory of one op (see OpPre)
+  auto prefetch_op = [&](const Op &op, const Cell &pc, OpPre &pre) __attribute__((always_inline)) {
+    switch (op.kind) {
+      case OP_VECTOR: {
+        const bool has = pc.tag == TAG_DOUBLE_LIST;
+#pragma unroll
+        for (int k = 0; k < PRE_F64; ++k) {
+          pre.d[k] = 0.0;
+          if (k < op.dim && has && (uint32_t)k < pc.hi()) pre.d[k] = st.f64_pool[pc.lo() + k];
+        }
+        break;
+      }
+      case OP_STRING_INDEX: {
+        pre.tok[0] = 0u;
+        if (pc.tag == TAG_STRING_LIST && pc.hi() > 0) pre.tok[0] = list_tokens(st, primary_list_record(op), pc.lo())[0];
+        break;
+      }
+      case OP_DIVERSITY: {
+        const uint32_t len = pc.tag == TAG_STRING_LIST ? pc.hi() : 0u;
+        const uint32_t *toks = list_tokens(st, irec, pc.lo());
+#pragma unroll
+        for (int t = 0; t < TOK_BATCH; ++t) pre.tok[t] = (uint32_t)t < len ? toks[t] : 0u;
+        break;
+      }
+      case OP_INTERACTED: {
+#pragma unroll
+        for (int u = 0; u < IW_BATCH; ++u) {
+          pre.fc[u].tag = TAG_MISSING;
+          pre.fc[u].bits = 0;
+          if (u < op.dim) {
+            ColRef col;
+            col.tag = (int32_t)prog.aux[op.i0 + 2 * u];
+            col.val = (int32_t)prog.aux[op.i0 + 2 * u + 1];
+            pre.fc[u] = rec_cell(ir, col);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < IW_BATCH; ++u) {
+          const uint32_t len = pre.fc[u].tag == TAG_STRING_LIST ? pre.fc[u].hi() : 0u;
+          const uint32_t *toks = list_tokens(st, irec, pre.fc[u].lo());
+#pragma unroll
+          for (int t = 0; t < IW_TOK; ++t) pre.tok[u * IW_TOK + t] = (uint32_t)t < len ? toks[t] : 0u;
+        }
+        break;
+      }
+      case OP_RATE: {
+        // every value present with exactly `dim` periods, else NaN x dim (RateFeature.scala:318-350).  All counters of
+        // the op are requested together; the value cells of a column exist whatever its tag says.
+        ColRef top = op.c0, bot = op.c1;
+        const uint8_t *trec = nullptr;  // the record holding the target-scope counters, when it is not the candidate's
+        if (op.i0 == RATE_ITEM_FIELD) {
+          if (pc.tag == TAG_STRING && pc.hi() != 0) trec = record(st, SC_FIELD, (int)pc.hi() - 1);  // item=<id>/<name>_field -> field slot
+          top = op.c4;
+          bot = op.c5;
+        } else if (op.i0 == RATE_RANKING_FIELD) {
+          trec = record(st, SC_IRF, b.irf[(size_t)op.i2 * b.total_items + gi]);
+          top = op.c4;
+          bot = op.c5;
+        }
+        const bool cols = top.tag >= 0 && bot.tag >= 0;
+        pre.ttag = pre.btag = pre.gttag = pre.gbtag = TAG_MISSING;
+#pragma unroll
+        for (int u = 0; u < RATE_BATCH; ++u) pre.tv[u] = pre.bv[u] = pre.gtv[u] = pre.gbv[u] = 0;
+        if (op.i0 == RATE_ITEM) {
+          if (irec != nullptr && cols) {
+            pre.ttag = ir.tag(top.tag);
+            pre.btag = ir.tag(bot.tag);
+#pragma unroll
+            for (int u = 0; u < RATE_BATCH; ++u)
+              if (u < op.dim) { pre.tv[u] = (long long)ir.u64(top.val + u * 8); pre.bv[u] = (long long)ir.u64(bot.val + u * 8); }
+          }
+        } else if (trec != nullptr && cols) {
+          pre.ttag = trec[top.tag];
+          pre.btag = trec[bot.tag];
+#pragma unroll
+          for (int u = 0; u < RATE_BATCH; ++u)
+            if (u < op.dim) { pre.tv[u] = *(const long long *)(trec + top.val + u * 8); pre.bv[u] = *(const long long *)(trec + bot.val + u * 8); }
+        }
+        if (op.i3 != 0 && op.c2.tag >= 0 && op.c3.tag >= 0) {
+          const uint8_t *grec = record(st, SC_GLOBAL, 0);
+          if (grec != nullptr) {
+            pre.gttag = grec[op.c2.tag];
+            pre.gbtag = grec[op.c3.tag];
+#pragma unroll
+            for (int u = 0; u < RATE_BATCH; ++u)
+              if (u < op.dim) { pre.gtv[u] = *(const long long *)(grec + op.c2.val + u * 8); pre.gbv[u] = *(const long long *)(grec + op.c3.val + u * 8); }
+          }
+        }
+        break;
+      }
+      default: break;
+    }
+  };
+
+  // ---- one op, given its primary cell `pc` (missing for the kinds without one) and what prefetch_op fetched
+  auto run_op = [&](const Op &op, const Cell &pc, const OpPre &pre) __attribute__((always_inline)) {
     const int dst = op.dst;
     switch (op.kind) {
       case OP_SCALAR_DOUBLE: {
@@ -682,7 +859,12 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
         const Cell c = pc;
         const bool has = c.tag == TAG_DOUBLE_LIST;
         const uint32_t off = c.lo(), len = c.hi();
-        for (int k = 0; k < op.dim; ++k) {  // every put at a wavefront-uniform point (CellSink stages tables cooperatively)
+#pragma unroll
+        for (int k = 0; k < PRE_F64; ++k) {  // every put at a wavefront-uniform point (CellSink stages tables cooperatively)
+          if (k >= op.dim) break;
+          sink.put(dst + k, has ? pre.d[k] : NaN);
+        }
+        for (int k = PRE_F64; k < op.dim; ++k) {
           double v = NaN;
           if (has) v = (uint32_t)k < len ? st.f64_pool[off + k] : 0.0;
           sink.put(dst + k, v);
@@ -693,7 +875,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
         const Cell c = pc;
         double idx = 0.0;
         if (c.tag == TAG_STRING_LIST && c.hi() > 0) {
-          const uint32_t first = list_tokens(st, primary_record(op), c.lo())[0];
+          const uint32_t first = pre.tok[0];
           for (int k = 0; k < op.i1; ++k)
             if (prog.aux[op.i0 + k] == first) idx = (double)(k + 1);  // zipWithIndex.toMap: last duplicate wins
         }
@@ -705,7 +887,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
         const Cell c = pc;
         const bool has = c.tag == TAG_STRING_LIST;
         const uint32_t len = has ? c.hi() : 0u;
-        const uint32_t *toks = list_tokens(st, primary_record(op), c.lo());
+        const uint32_t *toks = list_tokens(st, primary_list_record(op), c.lo());
         for (int k = 0; k < op.dim; ++k) {
           double v = 0.0;
           if (k < op.i1) {
@@ -726,56 +908,58 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
         break;
       }
       case OP_WINDOW: {
-        const uint8_t *rec = primary_record(op);
         const Cell c = pc;
         const bool ok = c.tag != TAG_MISSING && (int)c.tag - 1 == op.dim;
-        for (int k = 0; k < op.dim; ++k) sink.put(dst + k, ok ? (double)load_cell(rec, op.c0, k).i64() : NaN);
+        const bool in_item = op_primary_in_item(op);
+        const uint8_t *rec = in_item ? nullptr : other_record(op);
+#pragma unroll 8
+        for (int k = 0; k < op.dim; ++k) {
+          const Cell ck = in_item ? rec_cell(ir, op.c0, k) : load_cell(rec, op.c0, k);
+          sink.put(dst + k, ok ? (double)ck.i64() : NaN);
+        }
         break;
       }
       case OP_RATE: {
-        const uint8_t *trec = nullptr;  // record holding the target-scope counters
+        const bool norm = op.i3 != 0;
+        const uint32_t ttag = pre.ttag, btag = pre.btag, gttag = pre.gttag, gbtag = pre.gbtag;
+        bool valid = ttag != TAG_MISSING && btag != TAG_MISSING && (int)ttag - 1 == op.dim && (int)btag - 1 == op.dim;
+        if (norm) valid = valid && gttag != TAG_MISSING && gbtag != TAG_MISSING && (int)gttag - 1 == op.dim && (int)gbtag - 1 == op.dim;
+        bool thrown = false;  // java.lang.ArithmeticException: / by zero aborts the request
+        // periods beyond the first RATE_BATCH: fetched here, batch by batch (the record pointers are re-derived)
         ColRef top = op.c0, bot = op.c1;
-        if (op.i0 == RATE_ITEM) {
-          trec = irec;
-        } else if (op.i0 == RATE_ITEM_FIELD) {
-          const Cell link = pc;  // item=<id>/<name>_field : SString -> field slot (the op's primary cell)
-          if (link.tag == TAG_STRING && link.hi() != 0) trec = record(st, SC_FIELD, (int)link.hi() - 1);
+        const uint8_t *trec = nullptr;
+        if (op.i0 == RATE_ITEM_FIELD) {
+          if (pc.tag == TAG_STRING && pc.hi() != 0) trec = record(st, SC_FIELD, (int)pc.hi() - 1);
           top = op.c4;
           bot = op.c5;
-        } else {
-          const int s = b.irf[(size_t)op.i2 * b.total_items + gi];
-          trec = record(st, SC_IRF, s);
+        } else if (op.i0 == RATE_RANKING_FIELD) {
+          if (op.dim > RATE_BATCH) trec = record(st, SC_IRF, b.irf[(size_t)op.i2 * b.total_items + gi]);
           top = op.c4;
           bot = op.c5;
         }
-        // every value present with exactly `dim` periods, else NaN x dim (RateFeature.scala:318-350).  All cells of
-        // the op are requested before the first one is looked at (one trip to memory, not one per cell); the value
-        // cells of a column exist whatever its tag says.
-        const bool norm = op.i3 != 0;
-        const bool has = trec != nullptr && top.tag >= 0 && bot.tag >= 0;
-        const uint8_t *grec = norm ? record(st, SC_GLOBAL, 0) : nullptr;
-        const bool ghas = grec != nullptr && op.c2.tag >= 0 && op.c3.tag >= 0;
-        uint32_t ttag = TAG_MISSING, btag = TAG_MISSING, gttag = TAG_MISSING, gbtag = TAG_MISSING;
-        if (has) { ttag = trec[top.tag]; btag = trec[bot.tag]; }
-        if (ghas) { gttag = grec[op.c2.tag]; gbtag = grec[op.c3.tag]; }
-        constexpr int RATE_BATCH = 4;  // periods fetched together
-        bool thrown = false;  // java.lang.ArithmeticException: / by zero aborts the request
+        const uint8_t *grec = norm && op.dim > RATE_BATCH ? record(st, SC_GLOBAL, 0) : nullptr;
         for (int k0 = 0; k0 < op.dim; k0 += RATE_BATCH) {
           long long tv[RATE_BATCH], bv[RATE_BATCH], gtv[RATE_BATCH], gbv[RATE_BATCH];
 #pragma unroll
           for (int u = 0; u < RATE_BATCH; ++u) {
-            tv[u] = bv[u] = gtv[u] = gbv[u] = 0;
-            if (k0 + u < op.dim && has) {
-              tv[u] = *(const long long *)(trec + top.val + (k0 + u) * 8);
-              bv[u] = *(const long long *)(trec + bot.val + (k0 + u) * 8);
-            }
-            if (k0 + u < op.dim && ghas) {
-              gtv[u] = *(const long long *)(grec + op.c2.val + (k0 + u) * 8);
-              gbv[u] = *(const long long *)(grec + op.c3.val + (k0 + u) * 8);
+            tv[u] = pre.tv[u]; bv[u] = pre.bv[u]; gtv[u] = pre.gtv[u]; gbv[u] = pre.gbv[u];
+            if (k0 > 0) {
+              tv[u] = bv[u] = gtv[u] = gbv[u] = 0;
+              if (k0 + u < op.dim && ttag != TAG_MISSING) {
+                if (op.i0 == RATE_ITEM) {
+                  tv[u] = (long long)ir.u64(top.val + (k0 + u) * 8);
+                  bv[u] = (long long)ir.u64(bot.val + (k0 + u) * 8);
+                } else if (trec != nullptr) {
+                  tv[u] = *(const long long *)(trec + top.val + (k0 + u) * 8);
+                  bv[u] = *(const long long *)(trec + bot.val + (k0 + u) * 8);
+                }
+              }
+              if (k0 + u < op.dim && grec != nullptr && gttag != TAG_MISSING) {
+                gtv[u] = *(const long long *)(grec + op.c2.val + (k0 + u) * 8);
+                gbv[u] = *(const long long *)(grec + op.c3.val + (k0 + u) * 8);
+              }
             }
           }
-          bool valid = ttag != TAG_MISSING && btag != TAG_MISSING && (int)ttag - 1 == op.dim && (int)btag - 1 == op.dim;
-          if (norm) valid = valid && gttag != TAG_MISSING && gbtag != TAG_MISSING && (int)gttag - 1 == op.dim && (int)gbtag - 1 == op.dim;
 #pragma unroll
           for (int u = 0; u < RATE_BATCH; ++u) {
             if (k0 + u >= op.dim) break;
@@ -801,27 +985,34 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
       case OP_INTERACTED: {
         // per field: sum over the candidate's tokens of the session histogram.  IW_BATCH fields at a time: their
         // cells are requested together, then the first tokens of all their lists, then the tables are probed.
-        constexpr int IW_BATCH = 4, IW_TOK = 4;
         for (int f0 = 0; f0 < op.dim; f0 += IW_BATCH) {
           Cell fc[IW_BATCH];
-#pragma unroll
-          for (int u = 0; u < IW_BATCH; ++u) {
-            fc[u].tag = TAG_MISSING;
-            fc[u].bits = 0;
-            if (f0 + u < op.dim) {
-              ColRef col;
-              col.tag = (int32_t)prog.aux[op.i0 + 2 * (f0 + u)];
-              col.val = (int32_t)prog.aux[op.i0 + 2 * (f0 + u) + 1];
-              fc[u] = load_cell(irec, col);
-            }
-          }
           uint32_t tk[IW_BATCH][IW_TOK];
 #pragma unroll
           for (int u = 0; u < IW_BATCH; ++u) {
-            const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
-            const uint32_t *toks = list_tokens(st, irec, fc[u].lo());
+            fc[u] = pre.fc[u];
 #pragma unroll
-            for (int t = 0; t < IW_TOK; ++t) tk[u][t] = (uint32_t)t < len ? toks[t] : 0u;
+            for (int t = 0; t < IW_TOK; ++t) tk[u][t] = pre.tok[u * IW_TOK + t];
+          }
+          if (f0 > 0) {  // later groups of fields: fetched here
+#pragma unroll
+            for (int u = 0; u < IW_BATCH; ++u) {
+              fc[u].tag = TAG_MISSING;
+              fc[u].bits = 0;
+              if (f0 + u < op.dim) {
+                ColRef col;
+                col.tag = (int32_t)prog.aux[op.i0 + 2 * (f0 + u)];
+                col.val = (int32_t)prog.aux[op.i0 + 2 * (f0 + u) + 1];
+                fc[u] = rec_cell(ir, col);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < IW_BATCH; ++u) {
+              const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
+              const uint32_t *toks = list_tokens(st, irec, fc[u].lo());
+#pragma unroll
+              for (int t = 0; t < IW_TOK; ++t) tk[u][t] = (uint32_t)t < len ? toks[t] : 0u;
+            }
           }
 #pragma unroll
           for (int u = 0; u < IW_BATCH; ++u) {
@@ -854,7 +1045,16 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
           const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
           const bool one = c.tag == TAG_STRING, list = c.tag == TAG_STRING_LIST;
           const double w1 = 0.0 + (double)table_get(tab, po.tab_cap, c.lo(), one);
-          const double wl = table_sum_list(list_tokens(st, irec, c.lo()), tab, po.tab_cap, list ? c.hi() : 0u);
+          // the list's first TOK_BATCH tokens were fetched ahead; longer lists continue from memory, in list order
+          const uint32_t len = list ? c.hi() : 0u;
+          double wl = 0.0;
+#pragma unroll
+          for (int t = 0; t < TOK_BATCH; ++t) {
+            if (!wave_any((uint32_t)t < len)) break;
+            wl = wl + (double)table_get(tab, po.tab_cap, pre.tok[t], (uint32_t)t < len);
+          }
+          if (wave_any(len > (uint32_t)TOK_BATCH))
+            wl = table_sum_list(list_tokens(st, irec, c.lo()) + TOK_BATCH, tab, po.tab_cap, len > (uint32_t)TOK_BATCH ? len - TOK_BATCH : 0u, wl);
           if (one || list) v = (one ? w1 : wl) / po.scalar;
         }
         sink.put(dst + 0, v);
@@ -912,23 +1112,27 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 
   sink.begin();
   if constexpr (prog_is_static<Prog>(0)) {
-    // compile-time program: the loops unroll, every `op` is a constant, and the primary cells of ALL ops are requested
-    // before the first op runs - one trip to memory instead of one per op
+    // compile-time program: the loops unroll, every `op` is a constant.  Trip 1 (the record) has been issued by the
+    // caller; trip 2 - what the ops need beyond it - is issued here for ALL ops before the first op computes anything.
     Cell pc[Prog::n_ops > 0 ? Prog::n_ops : 1];
+    OpPre pre[Prog::n_ops > 0 ? Prog::n_ops : 1];
 #ifdef MRK_PHASE_CLOCKS
     unsigned long long t_op = clock64(), op_acc[Prog::n_ops > 0 ? Prog::n_ops : 1] = {};
 #endif
     static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
       constexpr int oi = decltype(ic)::value;
       constexpr Op op = Prog{}.ops[oi];
-      pc[oi].tag = TAG_MISSING;
-      pc[oi].bits = 0;
-      if constexpr (op_has_primary(op)) pc[oi] = load_cell(primary_record(op), op.c0);
+      pc[oi] = primary_cell(op);
     });
     static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
       constexpr int oi = decltype(ic)::value;
       constexpr Op op = Prog{}.ops[oi];
-      run_op(op, pc[oi]);
+      prefetch_op(op, pc[oi], pre[oi]);
+    });
+    static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int oi = decltype(ic)::value;
+      constexpr Op op = Prog{}.ops[oi];
+      run_op(op, pc[oi], pre[oi]);
       MRK_PHASE(t_op, op_acc[oi]);
     });
 #ifdef MRK_PHASE_CLOCKS
@@ -938,12 +1142,33 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
   } else {
     for (int oi = 0; oi < prog.n_ops; ++oi) {
       const Op op = prog.ops[oi];
-      Cell pc;
-      pc.tag = TAG_MISSING;
-      pc.bits = 0;
-      if (op_has_primary(op)) pc = load_cell(primary_record(op), op.c0);
-      run_op(op, pc);
+      const Cell pc = primary_cell(op);
+      OpPre pre;
+      prefetch_op(op, pc, pre);
+      run_op(op, pc, pre);
     }
+  }
+}
+
+// the record pieces the specialised kernel keeps in registers: the whole fixed part of the candidate's record when the
+// program says how long it is and it is not too long (24 pieces = 96 registers); else cell-by-cell loads
+template <typename P> __device__ __forceinline__ constexpr auto prog_item_pieces(int) -> decltype(P::item_fixed) { return (P::item_fixed + 15) / 16; }
+template <typename P> __device__ __forceinline__ constexpr int prog_item_pieces(...) { return 0; }
+constexpr int REC_MAX_PIECES = 24;
+
+template <typename Prog, typename Sink>
+__device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &prog, const BatchDev &b, int gi, int r,
+                                              const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
+                                              const PrepOut *pos, const Sink &sink) {
+  const int islot = sink.active ? b.item_slot[gi] : -1;  // lanes without an item: a missing record
+  const uint8_t *irec = record(st, SC_ITEM, islot);
+  constexpr int NP = prog_item_pieces<Prog>(0);
+  if constexpr (NP > 0 && NP <= REC_MAX_PIECES) {
+    const RegRec<NP> ir = load_record_regs<NP>(irec);
+    assemble_item_rec(st, prog, b, gi, r, rq, tab_base, tab_sub, pos, sink, islot, ir);
+  } else {
+    const PtrRec ir{irec};
+    assemble_item_rec(st, prog, b, gi, r, rq, tab_base, tab_sub, pos, sink, islot, ir);
   }
 }
 
@@ -988,6 +1213,22 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
 #endif
 }
 
+
+// One lane per candidate across many workgroups (requests too large for one workgroup, tables that do not fit LDS):
+// tables in the HBM arena, written by a previous pre-pass launch.  Straight into the scorer's binned tile.
+template <bool F64, typename Prog>
+__device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, const QsDev &q, uint16_t *cells) {
+  __shared__ __align__(16) double s_thr[ASM_THREADS / 64][2 * QS_LDS_THR];
+  const int gi0 = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
+  const bool active = gi0 < b.item_hi;
+  if (!__any(active)) return;                      // whole wavefront past the end
+  const int gi = active ? gi0 : b.item_hi - 1;     // lanes without an item ride along on a missing record
+  const int r = (int)b.item_req[gi];
+  const ReqDev rq = b.reqs[r];
+  CellSink<F64> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r],
+                     (qs_lds_double *)s_thr[threadIdx.x >> 6], active};
+  assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
+}
 
 // the hot-path instance of rank_fused_body: straight into the scorer's binned tile
 template <bool F64, typename Prog>

@@ -103,6 +103,7 @@ struct Switches {
   int host_threads = 0;        // MRK_HOST_THREADS (0: min(8, hardware threads))
   int jit_mode = 1;            // MRK_RANK_JIT: 0 off, 1 on, 2 require, 3 async
   int jit_waves = 0;           // MRK_JIT_WAVES
+  bool jit_record_regs = true; // MRK_JIT_REGS=0: the specialised kernel reads the candidate's record cell by cell instead of keeping it in registers
   std::string jit_cache_dir;   // MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else ~/.cache/mrk_jit; "" / "off": none
   int sort_chunk = 1024;       // MRK_SORT_CHUNK
   int qs_split = -1;           // MRK_QS_SPLIT
