@@ -84,10 +84,15 @@ std::string jit_source(const Program &prog, bool f64) {
   s += "  static constexpr int32_t n_ops = " + std::to_string(prog.ops.size()) + ", n_prep = " + std::to_string(prog.prep.size()) +
        ", dim = " + std::to_string(prog.dim) + ", n_consts = " + std::to_string(prog.n_consts) + ", item_fixed = " + std::to_string(switches().jit_record_regs ? prog.item_fixed : 0) + ";\n";
   s += "  JitOps ops;\n  JitPrep prep;\n  JitAux aux;\n};\n}  // namespace\n}  // namespace mrk\n\n";
-  // experiments: MRK_JIT_WAVES=n asks the compiler for n wavefronts per SIMD (register cap 512 / n)
+  // Wavefronts per SIMD the compiler must leave room for (register cap 512 / n).  With the candidate's record and the
+  // second trip of every op in registers the kernel would take ~200 VGPRs = 2 wavefronts per SIMD; measured on c2
+  // (profiles/r02_c): 2 -> 0.436 ms, 3 -> 0.351, 4 -> 0.286 - the kernel hides its trips to memory with resident
+  // wavefronts, so 4 is asked for (128 VGPRs).  MRK_JIT_WAVES=n overrides (experiments).
   std::string attr;
-  if (const int w = switches().jit_waves; w >= 1 && w <= 8)
+  {
+    const int w = switches().jit_waves >= 1 && switches().jit_waves <= 8 ? switches().jit_waves : 4;
     attr = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(w) + ", " + std::to_string(w) + ")))";
+  }
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
        "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells) {\n"
        "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
