@@ -79,7 +79,12 @@ def main():
     ap.add_argument("--drop-features", default="", help="experiments only: comma-separated features removed from the model")
     ap.add_argument("--catalogue", type=int, default=100_000)
     ap.add_argument("--sessions", type=int, default=10_000)
-    ap.add_argument("--trees", type=int, default=500)
+    ap.add_argument("--trees", type=int, default=None, help="default 500 (lightgbm) / 100 (xgboost)")
+    ap.add_argument("--backend", choices=["lightgbm", "xgboost"], default="lightgbm",
+                    help="booster format of the synthetic forest.  lightgbm (default): 500 leaf-wise 16-leaf trees, f64 - the Ranklens "
+                         "stock model's backend.  xgboost: complete depth-`--depth` trees, f32 - BASELINE config #2 as written is "
+                         "`--backend xgboost --trees 100 --depth 6`")
+    ap.add_argument("--depth", type=int, default=6, help="xgboost: tree depth (Metarank's XGBoost default maxDepth is 8)")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="requests timed on the CPU oracle (0 = skip)")
     ap.add_argument("--latency-requests", type=int, default=300, help="single-request latency samples (0 = skip)")
     args = ap.parse_args()
@@ -91,6 +96,8 @@ def main():
     sharded = wl in ("c4", "c4x")
     if wl == "c4x":
         args.cpu_sample, args.latency_requests = 0, 0
+    if args.trees is None:
+        args.trees = 500 if args.backend == "lightgbm" else 100
     if args.streams is None:
         args.streams = 1 if sharded else 2
     n_streams = max(1, args.streams)
@@ -201,10 +208,15 @@ def main():
     sample.run(None)
     _, _, sm = sample.fetch(matrix=True)
     sample.close()
-    blob = synth.synthetic_lgbm_model(n_trees=args.trees, n_features=dim, num_leaves=16, max_depth=8,
-                                      quantiles=ranklens.column_quantiles(sm), cat_features=[7] if not args.drop_features else None, cat_prob=0.007,  # ~ one categorical split per 10 trees
-                                      missing="per_feature")  # one missing type per column, as LightGBM's bin mappers produce
-    booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
+    if args.backend == "lightgbm":
+        blob = synth.synthetic_lgbm_model(n_trees=args.trees, n_features=dim, num_leaves=16, max_depth=8,
+                                          quantiles=ranklens.column_quantiles(sm), cat_features=[7] if not args.drop_features else None, cat_prob=0.007,  # ~ one categorical split per 10 trees
+                                          missing="per_feature")  # one missing type per column, as LightGBM's bin mappers produce
+        booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
+    else:  # complete depth-d trees, f32 thresholds / leaves, one categorical split per ~10 trees
+        blob = synth.synthetic_xgb_model(n_trees=args.trees, n_features=dim, depth=args.depth, quantiles=ranklens.column_quantiles(sm),
+                                         cat_features=[7] if not args.drop_features else None, cat_prob=0.1 / max(1, 2 ** args.depth - 1))
+        booster = M.HipBooster(blob, M.XGBOOST, ctx)
     info = booster.info()
     t0 = time.perf_counter()
     if wl == "c4x":  # millions of ids: the flat form (no per-item C strings), resolved on the device
@@ -329,7 +341,7 @@ def main():
     V = info["tile_columns"]                  # u16 cells per item in the scorer's tile
     my_items = min(chunk, total_items) if sharded else total_items
     b_item = 8 * dim + 48 + 4 + 8 + (384 * 8 if wl == "c5" else 0)
-    model_bytes = info["n_trees"] * (15 * 16 + 16 * 8)
+    model_bytes = int(info["n_nodes"]) * 16 + int(info["n_leaves"]) * (8 if args.backend == "lightgbm" else 4)
     alg_path = my_items * b_item + model_bytes      # the whole fused path (8d)
     alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass")}
     alg["sort"] = total_items * (8 + 4)
@@ -341,7 +353,7 @@ def main():
     traffic = None
     # the assembly kernel of the hot path is the one specialised for the model at run time (csrc/jit.cpp)
     jit_on = os.environ.get("MRK_RANK_JIT", "1") not in ("0",)
-    pmc_kernel = {"score": "qs_score_wave_kernel", "assemble": "mrk_jit_rank_cells" if jit_on else "rank_fused_cells_kernel"}.get(dominant)
+    pmc_kernel = None if args.backend != "lightgbm" else {"score": "qs_score_wave_kernel", "assemble": "mrk_jit_rank_cells" if jit_on else "rank_fused_cells_kernel"}.get(dominant)
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")), reverse=True):
@@ -463,7 +475,7 @@ def main():
     # ---- CPU baseline: the oracle (scalar C++ port of the reference read path + forest walk), 1 thread
     cpu = None
     if do_cpu:
-        forest = OracleForest.from_lightgbm_text(blob)
+        forest = OracleForest.from_lightgbm_text(blob) if args.backend == "lightgbm" else OracleForest.from_xgboost(blob)
         n = min(args.cpu_sample, len(events), max(1, 400_000 // args.items))  # bounded: ~10 s of CPU work
         cpu_events = events[:n]
         if enc is not None:  # the oracle has no transformer: it is handed the device embeddings (its figure excludes the encoder)
@@ -525,10 +537,11 @@ def main():
             "metric": f"ranked items/sec (feature assembly + {args.trees}-tree LambdaMART + ordering), Ranklens-shaped {args.items}-item requests",
             "value": value, "unit": "items/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_device_batch": ms_per_batch, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-lightgbm", "requests_per_step_per_gpu": args.requests,
+            "dtype": "f64" if args.backend == "lightgbm" else "f32", "data": "synthetic",
+            "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-" + (args.backend if args.backend == "lightgbm" else f"xgboost-depth{args.depth}"), "requests_per_step_per_gpu": args.requests,
                        "items_per_request": args.items, "device_batches_per_step": bps, "items_per_device_batch": total_items, "items_per_step_per_gpu": total_items * bps, "catalogue_items": n_catalogue, "item_table_bytes": int(n_catalogue) * ranker.item_stride(),
-                       "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16,
+                       "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16 if args.backend == "lightgbm" else 2 ** args.depth, "backend": args.backend,
+                       "scorer": "bit-vector" if info["bitvector"] else "tree walk",
                        "tile_columns": V, "batches_in_flight": n_streams,
                        "parallelism": (f"item-sharded x{n_gpus}" if sharded else f"request-sharded x{n_gpus}") +
                                       (", RCCL all-gather of scores" if n_gpus > 1 else "")},

@@ -648,6 +648,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 // read with a compile-time offset.  (Measured on 4 M candidates over an 8 M-item table, profiles/r02_b: cell-by-cell
 // loads cost 23 L2 misses per candidate - 1.4 KB for a 384-byte record - because the lines are evicted between ops.)
 struct PtrRec {
+  static constexpr bool in_regs = false;
   const uint8_t *p;
   __device__ __forceinline__ uint32_t tag(int tag_index) const { return p[tag_index]; }
   __device__ __forceinline__ uint64_t u64(int byte_off) const { return *(const uint64_t *)(p + byte_off); }
@@ -655,6 +656,7 @@ struct PtrRec {
 
 template <int NP>
 struct RegRec {
+  static constexpr bool in_regs = true;
   const uint8_t *p;   // still needed: inline string lists are read from the record's heap
   uint4 r[NP];
   __device__ __forceinline__ uint32_t tag(int tag_index) const {
@@ -723,6 +725,41 @@ struct OpPre {
   uint32_t ttag, btag, gttag, gbtag;
   double d[PRE_F64];                    // vector: the first stored values
 };
+
+// Registers (32-bit) the fetched-ahead state of one op occupies, roughly: what decides how many ops share a group
+__device__ __forceinline__ constexpr int op_pre_weight(const Op &op) {
+  switch (op.kind) {
+    case OP_INTERACTED: return 8 * (op.dim < IW_BATCH ? op.dim : IW_BATCH) + IW_TOK * (op.dim < IW_BATCH ? op.dim : IW_BATCH);
+    case OP_DIVERSITY: return TOK_BATCH;
+    case OP_RATE: return 4 * (op.dim < RATE_BATCH ? op.dim : RATE_BATCH) * (op.i3 != 0 ? 2 : 1) + 4;
+    case OP_VECTOR: return 2 * (op.dim < PRE_F64 ? op.dim : PRE_F64);
+    case OP_STRING_INDEX: return 1;
+    default: return 0;
+  }
+}
+constexpr int PRE_GROUP_BUDGET = 72;  // registers of fetched-ahead state per group (c2's 19 ops: 2 groups)
+// end of the group of ops that starts at `lo` (in_regs: the candidate's record is held in registers, so a primary cell
+// that lives in it costs nothing more)
+template <typename Prog, bool IN_REGS>
+__device__ __forceinline__ constexpr int op_group_end(int lo) {
+  int w = 0, hi = lo;
+  while (hi < Prog::n_ops) {
+    const Op op = Prog{}.ops[hi];
+    const int wi = op_pre_weight(op) + (op_has_primary(op) && !(IN_REGS && op_primary_in_item(op)) ? 3 : 0);
+    if (hi > lo && w + wi > PRE_GROUP_BUDGET) break;
+    w += wi;
+    ++hi;
+  }
+  return hi;
+}
+template <typename Prog, bool IN_REGS, int LO, typename F>
+__device__ __forceinline__ void run_groups(F &&f) {
+  if constexpr (LO < Prog::n_ops) {
+    constexpr int HI = op_group_end<Prog, IN_REGS>(LO);
+    f(IntC<LO>{}, IntC<HI>{});
+    run_groups<Prog, IN_REGS, HI>(f);
+  }
+}
 
 // Evaluates the model program for batch item gi of request r.  Hash tables: tab_base + (po.tab_off - tab_sub).
 template <typename Prog, typename Sink, typename IR>
@@ -1113,27 +1150,34 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
   sink.begin();
   if constexpr (prog_is_static<Prog>(0)) {
     // compile-time program: the loops unroll, every `op` is a constant.  Trip 1 (the record) has been issued by the
-    // caller; trip 2 - what the ops need beyond it - is issued here for ALL ops before the first op computes anything.
+    // caller; trip 2 - what the ops need beyond it - is issued here for a whole group of ops before the first of them
+    // computes anything.
     Cell pc[Prog::n_ops > 0 ? Prog::n_ops : 1];
     OpPre pre[Prog::n_ops > 0 ? Prog::n_ops : 1];
 #ifdef MRK_PHASE_CLOCKS
     unsigned long long t_op = clock64(), op_acc[Prog::n_ops > 0 ? Prog::n_ops : 1] = {};
 #endif
-    static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int oi = decltype(ic)::value;
-      constexpr Op op = Prog{}.ops[oi];
-      pc[oi] = primary_cell(op);
-    });
-    static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int oi = decltype(ic)::value;
-      constexpr Op op = Prog{}.ops[oi];
-      prefetch_op(op, pc[oi], pre[oi]);
-    });
-    static_for<0, Prog::n_ops>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int oi = decltype(ic)::value;
-      constexpr Op op = Prog{}.ops[oi];
-      run_op(op, pc[oi], pre[oi]);
-      MRK_PHASE(t_op, op_acc[oi]);
+    // Ops run in groups whose fetched-ahead state fits the register file: a group's primary cells (register reads when the
+    // record is held in registers, else its first trip to memory), then its second trip, then its arithmetic.
+    constexpr bool in_regs = IR::in_regs;
+    run_groups<Prog, in_regs, 0>([&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
+      constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+      static_for<lo, hi>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int oi = decltype(ic)::value;
+        constexpr Op op = Prog{}.ops[oi];
+        pc[oi] = primary_cell(op);
+      });
+      static_for<lo, hi>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int oi = decltype(ic)::value;
+        constexpr Op op = Prog{}.ops[oi];
+        prefetch_op(op, pc[oi], pre[oi]);
+      });
+      static_for<lo, hi>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int oi = decltype(ic)::value;
+        constexpr Op op = Prog{}.ops[oi];
+        run_op(op, pc[oi], pre[oi]);
+        MRK_PHASE(t_op, op_acc[oi]);
+      });
     });
 #ifdef MRK_PHASE_CLOCKS
     if (threadIdx.x == 0)

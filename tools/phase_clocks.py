@@ -36,7 +36,8 @@ out = (C.c_uint64 * 64)()
 for _ in range(3):
     batch.run(booster)
 batch.sync()
-assert lib.mrk_debug_phase(ctx._h, b"xgboost", out) == 0
+rc = lib.mrk_debug_phase(ctx._h, b"xgboost", out)
+assert rc == 0, f"mrk_debug_phase -> {rc}"
 reps = 5
 for _ in range(reps):
     batch.run(booster)
