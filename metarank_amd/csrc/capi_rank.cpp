@@ -285,10 +285,10 @@ static void check_model_fits(mrk_model *model, const Program &prog) {
 }
 
 // pre-pass + assembly into the row-major f64 matrix (ClickthroughQuery's layout); inside a LaunchOn
-static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &pd) {
+static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &pd, void *jit_matrix_fn = nullptr) {
   mrk_ctx *ctx = b.ctx;
   if (b.fused_ok) {
-    launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, nullptr, nullptr, true, nullptr);
+    launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, nullptr, nullptr, true, jit_matrix_fn);
   } else {
     launch_prepass(ctx, st, pd, b.view);
     launch_assemble(ctx, st, pd, b.view);
@@ -327,7 +327,8 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
   const bool cells = sw.rank_cells && !sw.scorer_walk && model && model->qs.ok && !b.want_matrix && rows > 0;
   const bool f64 = model && model->forest.backend == Backend::LightGBM;
   // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
-  void *jit_fn = !cells ? nullptr : b.fused_ok ? jit_rank_function(*b.prog, f64) : jit_items_function(*b.prog, f64);
+  void *jit_fn = !cells ? (b.fused_ok && model ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too
+                        : b.fused_ok ? jit_rank_function(*b.prog, f64) : jit_items_function(*b.prog, f64);
   LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
@@ -353,7 +354,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
     // lo is a multiple of the tile size: the scorer sees rows [lo, hi) as its rows [0, hi - lo)
     launch_score_qs_cells(ctx, model, b.d_cells.as<uint16_t>() + (size_t)(lo / QS_TILE_ROWS) * (tile_bytes / 2), rows, b.view.scores + lo);
   } else {
-    assemble_matrix(b, st, pd);
+    assemble_matrix(b, st, pd, jit_fn);
     b.matrix_valid = lo == 0 && hi == b.total_items;
     if (model && rows > 0) {
       launch_score_batch(ctx, model, b.view.matrix + (size_t)lo * pd.dim, rows, pd.dim, b.view.scores + lo, b.view.status, b.view.item_req + lo);

@@ -96,6 +96,11 @@ std::string jit_source(const Program &prog, bool f64) {
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
        "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells) {\n"
        "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
+  // the same workgroup-per-request kernel writing the row-major f64 matrix (models scored by the tree walk, explain)
+  if (f64)  // one copy per module: the matrix does not depend on the scorer's precision
+    s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_matrix"
+         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap) {\n"
+         "  mrk::rank_fused_matrix_body(st, mrk::JitProg{}, b, tab_entries, vals_cap);\n}\n";
   // the item-parallel form (requests too large for one workgroup: tables from a previous pre-pass launch, in HBM)
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
        "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
@@ -132,6 +137,7 @@ struct JitKernels {
   hipModule_t mod[2] = {nullptr, nullptr};   // [f64]: one module per scorer precision, built when first needed
   hipFunction_t fn[2] = {nullptr, nullptr};        // mrk_jit_rank_cells
   hipFunction_t fn_items[2] = {nullptr, nullptr};  // mrk_jit_assemble_cells
+  hipFunction_t fn_matrix = nullptr;               // mrk_jit_rank_matrix (module [1])
   bool failed[2] = {false, false};
   // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
   std::thread worker[2];
@@ -154,7 +160,12 @@ std::string cache_path(const std::string &src) {
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
   char name[96];
-  snprintf(name, sizeof name, "/%016llx-%zu-rtc%d.%d-gfx950.co", (unsigned long long)fnv1a(src), src.size(), major, minor);
+#ifdef MRK_PHASE_CLOCKS
+  const char *flavour = "-clk";  // the measurement build compiles the same text with -DMRK_PHASE_CLOCKS
+#else
+  const char *flavour = "";
+#endif
+  snprintf(name, sizeof name, "/%016llx-%zu-rtc%d.%d-gfx950%s.co", (unsigned long long)fnv1a(src), src.size(), major, minor, flavour);
   return d + name;
 }
 
@@ -238,6 +249,7 @@ void *jit_rank_function(const Program &prog, bool f64) {
     MRK_HIP(hipModuleLoadData(&k->mod[v], code.data()));
     MRK_HIP(hipModuleGetFunction(&k->fn[v], k->mod[v], "mrk_jit_rank_cells"));
     MRK_HIP(hipModuleGetFunction(&k->fn_items[v], k->mod[v], "mrk_jit_assemble_cells"));
+    if (v == 1) MRK_HIP(hipModuleGetFunction(&k->fn_matrix, k->mod[v], "mrk_jit_rank_matrix"));
   } catch (const std::exception &e) {
     k->failed[v] = true;
     if (mode == 2) throw;
@@ -268,6 +280,14 @@ void *jit_items_function(const Program &prog, bool f64) {
   std::lock_guard<std::mutex> lk(prog.jit_mu);
   JitKernels *k = (JitKernels *)prog.jit;
   return k ? (void *)k->fn_items[f64 ? 1 : 0] : nullptr;
+}
+
+// the f64-matrix form of the fused kernel (it lives in the f64 module)
+void *jit_matrix_function(const Program &prog) {
+  if (!jit_rank_function(prog, true)) return nullptr;
+  std::lock_guard<std::mutex> lk(prog.jit_mu);
+  JitKernels *k = (JitKernels *)prog.jit;
+  return k ? (void *)k->fn_matrix : nullptr;
 }
 
 void jit_release(Program &prog) {

@@ -62,8 +62,7 @@ assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_
 
 __global__ void __launch_bounds__(256)
 rank_fused_matrix_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap) {
-  rank_fused_body(st, prog, b, tab_entries, vals_cap, 0u,
-                  [&](int gi, int, bool active, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
+  rank_fused_matrix_body(st, prog, b, tab_entries, vals_cap);
 }
 
 template <bool F64>
@@ -344,7 +343,13 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
       MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       configured = true;
     }
-    if (cells && jit_fn) {
+    if (!cells && jit_fn) {  // mrk_jit_rank_matrix
+      StoreDev a_st = st;
+      BatchDev a_b = b;
+      int a_vals = vals_cap;
+      void *args[] = {&a_st, &a_b, &tab_entries, &a_vals};
+      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
+    } else if (cells && jit_fn) {
       StoreDev a_st = st;
       BatchDev a_b = b;
       QsDev a_q = *q;

@@ -1274,6 +1274,13 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
   assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
 }
 
+// rank_fused_body writing ClickthroughQuery's row-major f64 matrix
+template <typename Prog>
+__device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap) {
+  rank_fused_body(st, prog, b, tab_entries, vals_cap, 0u,
+                  [&](int gi, int, bool active, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
+}
+
 // the hot-path instance of rank_fused_body: straight into the scorer's binned tile
 template <bool F64, typename Prog>
 __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,

@@ -189,7 +189,8 @@ def test_assembly_paths_agree(oracle_c2, kind):
         expected = [oracle_c2.rerank(ev) for ev in reqs]
         # (fused, cells, jit): the hot path runs the kernel specialised for this model's feature list at run time
         # ("require": a hiprtc failure is an error, not a fall-back); "0" = the generic kernel that interprets the program
-        for fused, cells, jit in (("1", "1", "require"), ("1", "1", "0"), ("1", "0", "0"), ("0", "1", "0"), ("0", "0", "0")):
+        # cells "0" + jit "require": the specialised kernel's f64-matrix form (the path of models scored by the tree walk)
+        for fused, cells, jit in (("1", "1", "require"), ("1", "1", "0"), ("1", "0", "require"), ("1", "0", "0"), ("0", "1", "require"), ("0", "1", "0"), ("0", "0", "0")):
             if True:
                 os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = fused, cells, jit
                 M.reload_switches()
