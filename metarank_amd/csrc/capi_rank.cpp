@@ -14,6 +14,7 @@ namespace mrk {
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_sort(mrk_ctx *ctx, const BatchDev &b);
+void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode);
 void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx);
 size_t big_sort_padded(int n_items);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
@@ -57,6 +58,7 @@ int status_to_code(int st, std::string &msg) {
   if (st & ST_DIM) { msg = "dim mismatch: item embedding is shorter than the query embedding"; return MRK_ERR_DIM_MISMATCH; }
   if (st & ST_ILLEGAL_ARG) { msg = "requirement failed: Duration is limited to +-(2^63-1)ns (ca. 292 years)"; return MRK_ERR_INVALID_ARG; }
   if (st & 32) { msg = "Input data contains `inf` or a value too large, while `missing` is not set to `inf`"; return MRK_ERR_INVALID_ARG; }
+  if (st & ST_NORM_TOO_MANY) { msg = "norm: position over more than 4096 candidates is not supported on the device"; return MRK_ERR_UNSUPPORTED; }
   if (st & ST_TOO_MANY) { msg = "diversity over more values than the device pre-pass supports: set `top`"; return MRK_ERR_UNSUPPORTED; }
   if (st & ST_TABLE_FULL) { msg = "internal: pre-pass hash table under-sized (store changed between prepare and run?)"; return MRK_ERR_DEVICE; }
   return MRK_OK;
@@ -293,6 +295,8 @@ static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &
     launch_prepass(ctx, st, pd, b.view);
     launch_assemble(ctx, st, pd, b.view);
   }
+  for (const Program::NormCol &nc : b.prog->norm_cols)  // schema.norm.scale over the request's column (Normalize.scala:13-45)
+    if (!nc.cross || nc.cross->encoder) launch_normalize(ctx, b.view, pd.dim, nc.col, nc.mode);
   b.matrix_valid = true;
 }
 
@@ -324,7 +328,12 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
   const Switches &sw = switches();
   const int rows = hi - lo;
   // MRK_RANK_CELLS=0 / MRK_SCORER=walk keep the f64 matrix between assembly and scoring (A/B measurements)
-  const bool cells = sw.rank_cells && !sw.scorer_walk && model && model->qs.ok && !b.want_matrix && rows > 0;
+  // a column normalised across the request (bi- / cross-encoder `norm`) needs every raw value of the request before
+  // any of them can be binned: such models go through the f64 matrix
+  const bool normalises = b.prog->normalises();
+  if (normalises && (lo != 0 || hi != b.total_items))
+    throw StatusError(MRK_ERR_UNSUPPORTED, "item-sharded runs of a model with a normalised (norm: linear | position) column are not supported");
+  const bool cells = sw.rank_cells && !sw.scorer_walk && model && model->qs.ok && !b.want_matrix && rows > 0 && !normalises;
   const bool f64 = model && model->forest.backend == Backend::LightGBM;
   // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
   void *jit_fn = !cells ? (b.fused_ok && model ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too

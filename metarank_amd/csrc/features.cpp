@@ -298,7 +298,7 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
         const std::string &s = n->as_string();
         if (s == "noop") f->norm = NORM_NOOP;
         else if (s == "linear") f->norm = NORM_MINMAX;
-        else if (s == "position") throw StatusError(MRK_ERR_UNSUPPORTED, "feature '" + nm + "': norm 'position' is not implemented for cross-encoder columns");
+        else if (s == "position") f->norm = NORM_POSITION;
         else bad("normalizer " + s + " is not supported");
       }
   } else if (type == "field_match" || type == "random") {
@@ -484,9 +484,12 @@ void build_program(Program &p, const std::vector<const FeatureDef *> &feats, con
         break;
       case FType::LocalTime: case FType::Position: as_const(1); break;
       case FType::ExternalRanking: as_const(f->dim); break;
-      case FType::Relevancy: case FType::ExternalItem: op.kind = OP_FILL_NAN; break;
+      case FType::Relevancy: case FType::ExternalItem:
+        op.kind = OP_FILL_NAN;
+        if (f->cross && f->norm != NORM_NOOP) p.norm_cols.push_back({dst, f->norm, f});  // FieldMatchCrossEncoderFeature.scala:111
+        break;
       case FType::Biencoder:
-        if (f->norm != NORM_NOOP) throw StatusError(MRK_ERR_UNSUPPORTED, "feature '" + f->name + "': norm other than noop is not implemented on the device yet");
+        if (f->norm != NORM_NOOP) p.norm_cols.push_back({dst, f->norm, nullptr});  // schema.norm.scale(raw), FieldMatchBiencoderFeature.scala:107
         op.kind = OP_BIENCODER;
         op.scope = SC_ITEM;
         op.c0 = col_ref(st, SC_ITEM, f->name);
@@ -902,25 +905,9 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
     std::vector<float> logits(rows.size());
     encoder_score_rows(f.encoder, rows, logits.data());
     size_t at = 0;
-    while (at < where.size()) {  // one request at a time: Normalize.scale over the request's values
-      size_t end = at;
-      while (end < where.size() && where[end].first == where[at].first) ++end;
-      double lo = 0, hi = 0;
-      bool any = false;
-      for (size_t k = at; k < end; ++k) {
-        const double v = (double)logits[k];
-        if (v != v) continue;
-        lo = any ? std::min(lo, v) : v;
-        hi = any ? std::max(hi, v) : v;
-        any = true;
-      }
-      for (size_t k = at; k < end; ++k) {
-        double v = (double)logits[k];  // SingleValue(name, score: Float) widens
-        if (f.norm == NORM_MINMAX && any) v = (v - lo) / (hi - lo);  // Normalize.scala:14-22
-        cross_values.push_back({where[k].first, where[k].second, ho.dst, v});
-      }
-      at = end;
-    }
+    // raw logits (SingleValue(name, score: Float) widens); schema.norm.scale runs on the device over the request's whole
+    // column - these, the scores the caller already had, NaN for the rest (FieldMatchCrossEncoderFeature.scala:104-111)
+    for (size_t k = 0; k < where.size(); ++k) cross_values.push_back({where[k].first, where[k].second, ho.dst, (double)logits[k]});
   }
   const int total = begins[n_req];
   hb.total_items = total;

@@ -67,6 +67,16 @@ struct Program {
   int dim = 0;
   int n_consts = 0;
   int n_irf = 0;
+  // matrix columns normalised across the request after assembly and overrides (ml/onnx/Normalize.scala:13-45).  A
+  // cross-encoder column is normalised here only while an encoder is bound to it (the library then produces the raw
+  // logits; without one the host supplies finished values): `cross` points at its definition.
+  struct NormCol { int col; int mode; const FeatureDef *cross; };
+  std::vector<NormCol> norm_cols;
+  bool normalises() const {
+    for (const NormCol &n : norm_cols)
+      if (!n.cross || n.cross->encoder) return true;
+    return false;
+  }
   int item_fixed = 0;   // bytes of tags + value cells of an ITEM record (Table::heap_off): what the specialised kernel keeps in registers
   DevBuf d_ops, d_prep, d_aux;
   mutable std::mutex jit_mu;        // guards `jit` (the first ranks of a model may come from several threads)

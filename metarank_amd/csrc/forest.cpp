@@ -73,6 +73,21 @@ static void validate_tree(const Tree &t, int n_features_hint) {
     if (t.feat[i] < 0) throw std::runtime_error("negative split feature");
     (void)n_features_hint;
   }
+  // a TREE: every internal node but the root and every leaf hangs under exactly one parent.  (Shared children pass
+  // the index checks above but make the in-order walk of pack_forest_qs visit more leaves than the tree has.)
+  std::vector<uint8_t> node_refs((size_t)nn, 0), leaf_refs((size_t)nl, 0);
+  for (int i = 0; i < nn; ++i)
+    for (int c : {t.left[i], t.right[i]}) {
+      uint8_t &r = c >= 0 ? node_refs[(size_t)c] : leaf_refs[(size_t)~c];
+      if (++r > 1) throw std::runtime_error("malformed tree: a node has two parents");
+    }
+  if (nn > 0) {
+    if (node_refs[0] != 0) throw std::runtime_error("malformed tree: the root is somebody's child");
+    for (int i = 1; i < nn; ++i)
+      if (node_refs[(size_t)i] != 1) throw std::runtime_error("malformed tree: an internal node is not reachable from the root");
+    for (int i = 0; i < nl; ++i)
+      if (leaf_refs[(size_t)i] != 1) throw std::runtime_error("malformed tree: a leaf is not reachable from the root");
+  }
 }
 
 // ------------------------------------------------------------------ LightGBM text model
@@ -238,26 +253,209 @@ Forest parse_lightgbm_text(const char *text, size_t len) {
 
 // ------------------------------------------------------------------ XGBoost JSON / UBJSON
 
-static uint64_t f32_bits_widen(float v) {
-  double d = (double)v;
-  uint64_t b;
-  memcpy(&b, &d, 8);
-  return b;
+namespace {
+
+// one XGBoost tree as the library keeps it: leaves and internal nodes in one array
+struct XgbRawTree {
+  std::vector<int32_t> lc, rc, split_index;   // children (-1 = leaf), split feature
+  std::vector<float> cond;                    // split condition, or the leaf value of a leaf
+  std::vector<uint8_t> default_left, split_type;
+  std::map<int, std::vector<int64_t>> categories;  // categorical node -> its categories
+};
+
+void check_objective(const std::string &objective) {
+  if (objective.empty()) return;
+  // Only identity-link objectives keep base_score == base margin and need no output transform.
+  const char *ok[] = {"rank:pairwise", "rank:ndcg", "rank:map", "reg:squarederror", "reg:linear"};
+  bool found = false;
+  for (auto o : ok) found = found || objective == o;
+  if (!found) throw std::runtime_error("xgboost: objective '" + objective + "' is not supported (need an identity-link objective such as rank:ndcg)");
 }
+
+// Renumber (internal nodes and leaves get their own index spaces, deleted nodes drop out) and append to the forest
+void add_xgb_tree(Forest &f, const XgbRawTree &r) {
+  const size_t n = r.lc.size();
+  if (r.rc.size() != n || r.split_index.size() != n || r.cond.size() != n || r.default_left.size() != n)
+    throw std::runtime_error("xgboost: node array length mismatch");
+  if (n == 0) throw std::runtime_error("xgboost: empty tree");
+  std::vector<int> inner_id(n, -1), leaf_id(n, -1);
+  // reachability from root 0 (deleted nodes may linger in the arrays)
+  std::vector<int> order;
+  {
+    std::vector<int> st{0};
+    std::vector<char> seen(n, 0);
+    while (!st.empty()) {
+      int u = st.back();
+      st.pop_back();
+      if (u < 0 || (size_t)u >= n) throw std::runtime_error("xgboost: child index out of range");
+      if (seen[u]) throw std::runtime_error("xgboost: tree has a cycle");
+      seen[u] = 1;
+      order.push_back(u);
+      if (r.lc[u] != -1) {
+        st.push_back(r.rc[u]);
+        st.push_back(r.lc[u]);
+      }
+    }
+  }
+  Tree t;
+  for (int u : order) {
+    if (r.lc[u] == -1) {
+      leaf_id[u] = (int)t.leaf.size();
+      t.leaf.push_back((double)r.cond[u]);
+    } else {
+      inner_id[u] = (int)t.feat.size();
+      t.feat.push_back(0);
+    }
+  }
+  const size_t nn = t.feat.size();
+  t.thr.assign(nn, 0.0);
+  t.flags.assign(nn, 0);
+  t.left.assign(nn, 0);
+  t.right.assign(nn, 0);
+  t.cat_begin.assign(nn, 0);
+  t.cat_words.assign(nn, 0);
+  for (int u : order) {
+    int id = inner_id[u];
+    if (id < 0) continue;
+    const int l = r.lc[u], rr = r.rc[u];
+    t.feat[id] = r.split_index[u];
+    t.left[id] = inner_id[l] >= 0 ? inner_id[l] : ~leaf_id[l];
+    t.right[id] = inner_id[rr] >= 0 ? inner_id[rr] : ~leaf_id[rr];
+    uint8_t fl = NF_MISS_NAN;
+    if (r.default_left[u]) fl |= NF_DEFAULT_LEFT;
+    if (u < (int)r.split_type.size() && r.split_type[u] == 1) {
+      fl |= NF_CATEGORICAL;
+      auto it = r.categories.find(u);
+      if (it == r.categories.end()) throw std::runtime_error("xgboost: categorical node without categories");
+      int64_t maxc = -1;
+      for (int64_t c : it->second) maxc = std::max<int64_t>(maxc, c);
+      uint32_t words = (uint32_t)(maxc < 0 ? 0 : (maxc / 32 + 1));
+      t.cat_begin[id] = (uint32_t)f.cat_bits.size();
+      t.cat_words[id] = words;
+      f.cat_bits.resize(f.cat_bits.size() + words, 0u);
+      for (int64_t c : it->second) {
+        if (c < 0) throw std::runtime_error("xgboost: negative category");
+        f.cat_bits[t.cat_begin[id] + (size_t)(c / 32)] |= 1u << (c % 32);
+      }
+    } else {
+      t.thr[id] = (double)r.cond[u];
+    }
+    t.flags[id] = fl;
+  }
+  validate_tree(t, f.n_features);
+  t.depth = tree_depth(t);
+  f.trees.push_back(std::move(t));
+}
+
+// ---- the legacy binary serialisation (what Booster.toByteArray() of xgboost4j before 2.0 emits by default; still
+// read by every later version: learner.cc LearnerImpl::LoadModel, gbtree_model.cc GBTreeModel::Load, tree_model.cc
+// RegTree::Load).  Raw little-endian structs:
+//   ["binf"]                                   optional 4-byte header
+//   LearnerModelParamLegacy  136 B             f32 base_score, u32 num_feature, i32 num_class, i32 contain_extra_attrs,
+//                                              i32 contain_eval_metrics, u32 major_version, u32 minor_version, ...
+//   u64 n + n bytes                            objective name;  the same for the booster name ("gbtree")
+//   GBTreeModelParam         160 B             i32 num_trees, ..., i32 size_leaf_vector at +28
+//   per tree: TreeParam      148 B             i32 num_roots, i32 num_nodes, i32 num_deleted, i32 max_depth, i32 num_feature,
+//                                              i32 size_leaf_vector, i32 reserved[31]
+//             num_nodes x Node        20 B     i32 parent, i32 cleft, i32 cright, u32 sindex (bit 31 = default_left),
+//                                              f32 leaf_value | split_cond
+//             num_nodes x NodeStat    16 B     skipped
+//             [u64 n + n x f32]                leaf vector, only when size_leaf_vector != 0 (pre-1.0 files)
+//   num_trees x i32                            tree_info (output group; must be 0)
+// The format has no categorical splits.  Stated from the published source of XGBoost 1.x; no file written by the real
+// library is available in this environment (tests/golden/README.md: `make_real_goldens.py` writes one where it is).
+struct LegacyIn {
+  const uint8_t *p, *end;
+  void need(size_t n) const { if ((size_t)(end - p) < n) throw std::runtime_error("xgboost legacy model: truncated"); }
+  template <typename T> T get() { need(sizeof(T)); T v; memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+  void skip(size_t n) { need(n); p += n; }
+  std::string str() {
+    const uint64_t n = get<uint64_t>();
+    if (n > (uint64_t)(end - p)) throw std::runtime_error("xgboost legacy model: bad string length");
+    std::string s((const char *)p, (size_t)n);
+    p += n;
+    return s;
+  }
+};
+
+Forest parse_xgboost_legacy(const uint8_t *bytes, size_t len) {
+  LegacyIn in{bytes, bytes + len};
+  if (len >= 4 && memcmp(bytes, "binf", 4) == 0) in.skip(4);
+  if (len >= 4 && memcmp(bytes, "bs64", 4) == 0) throw std::runtime_error("xgboost: base64 models are not supported");
+  Forest f;
+  f.backend = Backend::XGBoost;
+  const uint8_t *mp = in.p;
+  in.skip(136);
+  float base_score;
+  uint32_t num_feature, major;
+  int32_t num_class;
+  memcpy(&base_score, mp, 4);
+  memcpy(&num_feature, mp + 4, 4);
+  memcpy(&num_class, mp + 8, 4);
+  memcpy(&major, mp + 20, 4);
+  if (num_class > 1) throw std::runtime_error("xgboost: multi-class models are not supported");
+  if (num_feature > (1u << 24)) throw std::runtime_error("xgboost: not a legacy binary model (num_feature out of range)");
+  f.n_features = (int)num_feature;
+  f.objective = in.str();
+  const std::string booster = in.str();
+  if (booster != "gbtree") throw std::runtime_error("xgboost: only gbtree boosters are supported (found '" + booster.substr(0, 32) + "')");
+  check_objective(f.objective);
+  f.base_score = (double)base_score;  // identity-link objectives: ProbToMargin (applied to pre-1.0 files) is the identity
+  (void)major;
+  const uint8_t *gp = in.p;
+  in.skip(160);
+  int32_t num_trees, gb_leaf_vec;
+  memcpy(&num_trees, gp, 4);
+  memcpy(&gb_leaf_vec, gp + 28, 4);
+  if (num_trees < 0 || num_trees > (1 << 24)) throw std::runtime_error("xgboost legacy model: bad tree count");
+  for (int t = 0; t < num_trees; ++t) {
+    const uint8_t *tp = in.p;
+    in.skip(148);
+    int32_t num_nodes, leaf_vec;
+    memcpy(&num_nodes, tp + 4, 4);
+    memcpy(&leaf_vec, tp + 20, 4);
+    if (num_nodes <= 0 || (uint64_t)num_nodes * 36 > (uint64_t)(in.end - in.p)) throw std::runtime_error("xgboost legacy model: bad node count");
+    XgbRawTree r;
+    r.lc.resize(num_nodes); r.rc.resize(num_nodes); r.split_index.resize(num_nodes);
+    r.cond.resize(num_nodes); r.default_left.resize(num_nodes);
+    for (int i = 0; i < num_nodes; ++i) {
+      (void)in.get<int32_t>();  // parent
+      r.lc[i] = in.get<int32_t>();
+      r.rc[i] = in.get<int32_t>();
+      const uint32_t sindex = in.get<uint32_t>();
+      r.cond[i] = in.get<float>();
+      r.split_index[i] = (int32_t)(sindex & 0x7fffffffu);
+      r.default_left[i] = (uint8_t)(sindex >> 31);
+    }
+    in.skip((size_t)num_nodes * 16);
+    if (leaf_vec != 0) {
+      const uint64_t n = in.get<uint64_t>();
+      if (n > (uint64_t)(in.end - in.p) / 4) throw std::runtime_error("xgboost legacy model: bad leaf vector");
+      in.skip((size_t)n * 4);
+    }
+    add_xgb_tree(f, r);
+  }
+  for (int t = 0; t < num_trees; ++t)
+    if (in.get<int32_t>() != 0) throw std::runtime_error("xgboost: multi-group models are not supported");
+  for (auto &t : f.trees)
+    for (auto ft : t.feat) f.n_features = std::max(f.n_features, ft + 1);
+  return f;
+}
+
+}  // namespace
 
 Forest parse_xgboost(const uint8_t *bytes, size_t len) {
   if (len == 0) throw std::runtime_error("xgboost: empty model");
   json::Value root;
-  // JSON text starts with '{' followed by whitespace or '"'; UBJSON starts with '{' followed by a
-  // length marker.  Legacy binary ("binf" / raw struct) is not supported.
+  // JSON text starts with '{' followed by whitespace or '"'; UBJSON starts with '{' followed by a length marker;
+  // anything else is the legacy binary serialisation ("binf" header or the raw parameter struct).
   bool is_json = false;
   if (bytes[0] == '{') {
     size_t k = 1;
     while (k < len && (bytes[k] == ' ' || bytes[k] == '\n' || bytes[k] == '\r' || bytes[k] == '\t')) ++k;
     is_json = k < len && (bytes[k] == '"' || bytes[k] == '}');
   } else {
-    throw std::runtime_error(
-        "xgboost: unsupported serialisation (legacy binary format); re-save the booster as JSON or UBJSON");
+    return parse_xgboost_legacy(bytes, len);
   }
   root = is_json ? json::parse((const char *)bytes, len) : json::parse_ubjson(bytes, len);
 
@@ -271,13 +469,7 @@ Forest parse_xgboost(const uint8_t *bytes, size_t len) {
     if (nc->as_int() > 1) throw std::runtime_error("xgboost: multi-class models are not supported");
   if (const json::Value *obj = learner.find("objective"))
     if (const json::Value *nm = obj->find("name")) f.objective = nm->as_string();
-  if (!f.objective.empty()) {
-    // Only identity-link objectives keep base_score == base margin and need no output transform.
-    const char *ok[] = {"rank:pairwise", "rank:ndcg", "rank:map", "reg:squarederror", "reg:linear"};
-    bool found = false;
-    for (auto o : ok) found = found || f.objective == o;
-    if (!found) throw std::runtime_error("xgboost: objective '" + f.objective + "' is not supported (need an identity-link objective such as rank:ndcg)");
-  }
+  check_objective(f.objective);
   const json::Value &gb = learner.at("gradient_booster");
   if (const json::Value *nm = gb.find("name"))
     if (nm->as_string() != "gbtree") throw std::runtime_error("xgboost: only gbtree boosters are supported");
@@ -294,92 +486,31 @@ Forest parse_xgboost(const uint8_t *bytes, size_t len) {
     const size_t n = lc.size();
     if (rc.size() != n || si.size() != n || sc.size() != n || dl.size() != n)
       throw std::runtime_error("xgboost: node array length mismatch");
-    if (n == 0) throw std::runtime_error("xgboost: empty tree");
-    std::vector<int> split_type(n, 0);
+    XgbRawTree r;
+    r.lc.resize(n); r.rc.resize(n); r.split_index.resize(n); r.cond.resize(n); r.default_left.resize(n);
+    r.split_type.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      r.lc[i] = (int32_t)lc[i].as_int();
+      r.rc[i] = (int32_t)rc[i].as_int();
+      r.split_index[i] = (int32_t)si[i].as_int();
+      r.cond[i] = sc[i].as_float();
+      r.default_left[i] = dl[i].as_bool() ? 1 : 0;
+    }
     if (const json::Value *st = jt.find("split_type"))
-      for (size_t i = 0; i < n && i < st->arr.size(); ++i) split_type[i] = (int)st->arr[i].as_int();
+      for (size_t i = 0; i < n && i < st->arr.size(); ++i) r.split_type[i] = (uint8_t)st->arr[i].as_int();
     // categorical side tables
-    std::map<int, std::pair<size_t, size_t>> cat_of_node;  // node -> (segment begin, size) in `categories`
     const json::Value *cats = jt.find("categories");
     if (const json::Value *cn = jt.find("categories_nodes")) {
       const auto &segs = jt.at("categories_segments").arr;
       const auto &sizes = jt.at("categories_sizes").arr;
-      for (size_t k = 0; k < cn->arr.size(); ++k)
-        cat_of_node[(int)cn->arr[k].as_int()] = {(size_t)segs.at(k).as_int(), (size_t)sizes.at(k).as_int()};
-    }
-    // Renumber: XGBoost keeps leaves and internal nodes in one array; split them.
-    std::vector<int> inner_id(n, -1), leaf_id(n, -1);
-    // reachability from root 0 (deleted nodes may linger in the arrays)
-    std::vector<int> order;
-    {
-      std::vector<int> st{0};
-      std::vector<char> seen(n, 0);
-      while (!st.empty()) {
-        int u = st.back();
-        st.pop_back();
-        if (u < 0 || (size_t)u >= n) throw std::runtime_error("xgboost: child index out of range");
-        if (seen[u]) throw std::runtime_error("xgboost: tree has a cycle");
-        seen[u] = 1;
-        order.push_back(u);
-        int l = (int)lc[u].as_int(), r = (int)rc[u].as_int();
-        if (l != -1) {
-          st.push_back(r);
-          st.push_back(l);
-        }
+      for (size_t k = 0; k < cn->arr.size(); ++k) {
+        const size_t b = (size_t)segs.at(k).as_int(), sz = (size_t)sizes.at(k).as_int();
+        if (!cats || b + sz > cats->arr.size()) throw std::runtime_error("xgboost: categories segment out of range");
+        std::vector<int64_t> &v = r.categories[(int)cn->arr[k].as_int()];
+        for (size_t j = 0; j < sz; ++j) v.push_back(cats->arr[b + j].as_int());
       }
     }
-    Tree t;
-    for (int u : order) {
-      if ((int)lc[u].as_int() == -1) {
-        leaf_id[u] = (int)t.leaf.size();
-        t.leaf.push_back((double)sc[u].as_float());
-      } else {
-        inner_id[u] = (int)t.feat.size();
-        t.feat.push_back(0);
-      }
-    }
-    const size_t nn = t.feat.size();
-    t.thr.assign(nn, 0.0);
-    t.flags.assign(nn, 0);
-    t.left.assign(nn, 0);
-    t.right.assign(nn, 0);
-    t.cat_begin.assign(nn, 0);
-    t.cat_words.assign(nn, 0);
-    for (int u : order) {
-      int id = inner_id[u];
-      if (id < 0) continue;
-      int l = (int)lc[u].as_int(), r = (int)rc[u].as_int();
-      t.feat[id] = (int32_t)si[u].as_int();
-      t.left[id] = inner_id[l] >= 0 ? inner_id[l] : ~leaf_id[l];
-      t.right[id] = inner_id[r] >= 0 ? inner_id[r] : ~leaf_id[r];
-      uint8_t fl = NF_MISS_NAN;
-      if (dl[u].as_bool()) fl |= NF_DEFAULT_LEFT;
-      if (split_type[u] == 1) {
-        fl |= NF_CATEGORICAL;
-        auto it = cat_of_node.find(u);
-        if (it == cat_of_node.end() || !cats) throw std::runtime_error("xgboost: categorical node without categories");
-        size_t b = it->second.first, sz = it->second.second;
-        if (b + sz > cats->arr.size()) throw std::runtime_error("xgboost: categories segment out of range");
-        int64_t maxc = -1;
-        for (size_t k = 0; k < sz; ++k) maxc = std::max<int64_t>(maxc, cats->arr[b + k].as_int());
-        uint32_t words = (uint32_t)(maxc < 0 ? 0 : (maxc / 32 + 1));
-        t.cat_begin[id] = (uint32_t)f.cat_bits.size();
-        t.cat_words[id] = words;
-        f.cat_bits.resize(f.cat_bits.size() + words, 0u);
-        for (size_t k = 0; k < sz; ++k) {
-          int64_t c = cats->arr[b + k].as_int();
-          if (c < 0) throw std::runtime_error("xgboost: negative category");
-          f.cat_bits[t.cat_begin[id] + (size_t)(c / 32)] |= 1u << (c % 32);
-        }
-      } else {
-        t.thr[id] = (double)sc[u].as_float();
-      }
-      t.flags[id] = fl;
-    }
-    (void)f32_bits_widen;
-    validate_tree(t, f.n_features);
-    t.depth = tree_depth(t);
-    f.trees.push_back(std::move(t));
+    add_xgb_tree(f, r);
   }
   if (const json::Value *ti = model.find("tree_info"))
     for (auto &g : ti->arr)
@@ -605,6 +736,7 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
     uint32_t *nd = pf.nodes.data() + ti * QS_TREE_WORDS;  // zero: mask 0 never changes the bit vector
     uint8_t *lv = pf.leaves.data() + ti * QS_LEAVES * leaf_sz;
     auto put_leaf = [&](int pos, double v) {
+      if (pos < 0 || pos >= QS_LEAVES) throw std::runtime_error("malformed tree: more leaf positions than leaves");  // (validate_tree rules it out)
       if (f64) memcpy(lv + (size_t)pos * 8, &v, 8);
       else { float x = (float)v; memcpy(lv + (size_t)pos * 4, &x, 4); }
     };

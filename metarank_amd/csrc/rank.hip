@@ -140,6 +140,86 @@ sort_kernel(BatchDev b) {
   for (int i = tid; i < n; i += SORT_THREADS) b.order[rq.item_begin + i] = s_idx[i];
 }
 
+// ---------------------------------------------------------------- Normalize.scale over one matrix column
+// ml/onnx/Normalize.scala:13-45, applied by the bi-/cross-encoder field_match features to the request's raw values
+// (FieldMatchBiencoderFeature.scala:107, FieldMatchCrossEncoderFeature.scala:111).  One workgroup per request.
+//   linear    (v - min) / (max - min) with min / max over the non-NaN values (scala Ordering.Double = Double.compare:
+//             -0.0 < +0.0); nothing changes when every value is NaN; max == min gives NaN (0 / 0) like the reference
+//   position  sortedIndex / size after a stable ascending sort of ALL values (NaN last); NaN values stay NaN
+__device__ __forceinline__ unsigned long long asc_key(double v) {  // monotone in java.lang.Double.compare order
+  unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  if (v != v) bits = 0x7ff8000000000000ULL;
+  return (bits & 0x8000000000000000ULL) ? ~bits : (bits | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double asc_value(unsigned long long key) {
+  const unsigned long long bits = (key & 0x8000000000000000ULL) ? (key & 0x7fffffffffffffffULL) : ~key;
+  return __longlong_as_double((long long)bits);
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+normalize_kernel(BatchDev b, int dim, int col, int mode) {
+  __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
+  __shared__ int s_idx[SORT_MAX_ITEMS];
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x;
+  const ReqDev rq = b.reqs[r];
+  const int n = rq.n_items;
+  if (n <= 0) return;
+  double *colp = b.matrix + (size_t)rq.item_begin * dim + col;
+  if (mode == NORM_MINMAX) {
+    if (tid == 0) { s_key[0] = ~0ull; s_key[1] = 0ull; }
+    __syncthreads();
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int i = tid; i < n; i += SORT_THREADS) {
+      const double v = colp[(size_t)i * dim];
+      if (v != v) continue;
+      const unsigned long long k = asc_key(v);
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+    }
+    if (lo != ~0ull) { atomicMin(&s_key[0], lo); atomicMax(&s_key[1], hi); }  // (no double maps to key ~0: that is a NaN pattern)
+    __syncthreads();
+    if (s_key[0] == ~0ull) return;  // scores.minOption == None: values unchanged
+    const double mn = asc_value(s_key[0]), mx = asc_value(s_key[1]);
+    const double span = __dsub_rn(mx, mn);
+    for (int i = tid; i < n; i += SORT_THREADS) {
+      double *p = colp + (size_t)i * dim;
+      *p = __ddiv_rn(__dsub_rn(*p, mn), span);
+    }
+    return;
+  }
+  if (n > SORT_MAX_ITEMS) {
+    if (tid == 0) atomicOr(&b.status[r], ST_NORM_TOO_MANY);
+    return;
+  }
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  for (int i = tid; i < p2; i += SORT_THREADS) {
+    s_key[i] = i < n ? asc_key(colp[(size_t)i * dim]) : ~0ull;
+    s_idx[i] = i < n ? i : 0x7fffffff;
+  }
+  __syncthreads();
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < p2; i += SORT_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long ka = s_key[i], kb = s_key[ixj];
+          const int ia = s_idx[i], ib = s_idx[ixj];
+          const bool gt = ka > kb || (ka == kb && ia > ib);
+          const bool up = (i & k) == 0;
+          if (gt == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const unsigned long long nan_key = asc_key(d_nan());
+  const double size = (double)n;
+  for (int s = tid; s < n; s += SORT_THREADS)
+    if (s_key[s] != nan_key) colp[(size_t)s_idx[s] * dim] = __ddiv_rn((double)s, size);
+}
+
 // ---- requests with more than SORT_MAX_ITEMS candidates (C4: 100 000): merge sort.  Chunks of SORT_MAX_ITEMS
 // (key, index) pairs are sorted in LDS (bitonic), then log2(chunks) merge passes; in a pass every workgroup
 // produces SORT_MAX_ITEMS consecutive outputs of one pair of runs: merge-path binary searches find its input
@@ -370,6 +450,14 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
   } else {
     launch_override_cells(ctx, b, *q, cells, f64);
   }
+}
+
+// Normalize.scale over matrix column `col` of every request of the batch (after assembly and overrides)
+void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode) {
+  if (b.n_req <= 0 || mode == NORM_NOOP) return;
+  ScopedKernelTimer timer(ctx, "normalize");
+  hipLaunchKernelGGL(normalize_kernel, dim3(b.n_req), dim3(SORT_THREADS), 0, ctx->launch, b, dim, col, mode);
+  MRK_HIP(hipGetLastError());
 }
 
 void launch_sort(mrk_ctx *ctx, const BatchDev &b) {

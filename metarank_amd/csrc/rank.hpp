@@ -85,6 +85,8 @@ enum : int32_t {
   ST_TABLE_FULL = 4,    // a hash table was under-sized (store changed after prepare)
   ST_TOO_MANY = 8,      // diversity over more values than the pre-pass supports
   ST_DIM = 16,          // embedding shorter than the query
+  ST_XGB_INF = 32,      // XGBoost: a value that is +-inf after the Double -> Float narrowing
+  ST_NORM_TOO_MANY = 64,  // norm: position over more candidates than the device sorts in one workgroup
 };
 
 struct ProgramDev {

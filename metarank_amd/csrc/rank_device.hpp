@@ -601,7 +601,14 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
 
   // `col` is uniform across the wavefront; every lane of the wavefront takes part (lanes without an item write nothing)
   __device__ __forceinline__ void put(int col, double v) const {
-    if (col >= q.n_feats) return;
+    if (col >= q.n_feats) {  // a column the forest does not know: nothing to bin, but still part of XGBoost's DMatrix row
+      if constexpr (!F64) {
+        bool fin;
+        (void)qs_prep<F64>(v, fin);
+        if (!fin && active) atomicOr(status, ST_XGB_INF);
+      }
+      return;
+    }
     if (col != next_col) restart(col);  // a column out of order
     const QsFeature ft = ft_cur;
     if (!landed) wait_landed();  // the item's first column only: later tables are waited for at the end of the previous put
@@ -610,9 +617,11 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     ft_next = feature(col + 2);
     next_col = col + 1;
     landed = false;
-    if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
     bool ok;
     const double x = qs_prep<F64>(v, ok);
+    // XGBoost's DMatrix rejects the whole row for an inf in ANY column, split on or not - every scorer path does the same
+    if (!ok && active) atomicOr(status, ST_XGB_INF);
+    if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
     const uint32_t pos = staged(ft) ? qs_bin_search<F64>(thr_lds + (size_t)(col & 1) * q.thr_cap, ft.thr_len, x)
                                     : qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
     // vmcnt counts loads and stores alike, in order: waiting for the next table AFTER this column's cell stores would
@@ -623,7 +632,6 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     uint16_t *d = dst;
     const bool act = active;
     qs_emit_views<F64>(x, pos, ft, q.views, [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; });
-    if (!ok && act) atomicOr(status, 32);
   }
 };
 

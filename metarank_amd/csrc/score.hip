@@ -132,6 +132,11 @@ score_kernel(const uint8_t *__restrict__ image, const TreeRef *__restrict__ tree
     // tail lanes keep walking (uniform control flow); give them zeros
     for (int e = tile_rows + tid; e < TILE; e += TILE)
       for (int c = 0; c < cols; ++c) s_rows[c * TILE + e] = (row_t)0;
+  } else if constexpr (!F64) {
+    // rows read from global memory on demand (matrices too wide for the LDS tile): XGBoost's DMatrix rejects a row for
+    // an inf in ANY column, visited by the walk or not - the same inputs fail on every scorer path
+    if (row < rows)
+      for (int c = 0; c < cols; ++c) (void)(row_req ? prep<false>(X[row * cols + c], flag + row_req[row], 32) : prep<false>(X[row * cols + c], flag));
   }
 
   double acc64 = 0.0;

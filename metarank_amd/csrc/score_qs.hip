@@ -48,12 +48,25 @@ qs_bin_kernel(const double *__restrict__ X, int rows, int cols, QsDev q, uint16_
   const bool valid = row < rows;
   const double *xr = X + (valid ? row : 0) * cols;
   const int nf = q.n_feats < cols ? q.n_feats : cols;
+  if constexpr (!F64)  // columns beyond the last one the forest knows are part of the DMatrix row too
+    for (int c = nf; c < cols; ++c) {
+      bool ok;
+      (void)qs_prep<F64>(xr[c], ok);
+      if (!ok && valid) {
+        if (row_req) atomicOr(flag + row_req[row], 32);
+        else atomicOr(flag, 1);
+      }
+    }
   for (int c = 0; c < nf; ++c) {
     const QsFeature ft = q.feats[c];  // uniform: scalar loads
-    if (ft.view_begin == ft.view_end) continue;
-    const bool ok = qs_bin_column<F64>(xr[c], ft, q.views, q.thr, [&](uint32_t v, uint32_t cell) {
-      dst[(size_t)v * tile_rows] = valid ? (uint16_t)cell : (uint16_t)0;
-    });
+    bool ok = true;
+    if (ft.view_begin == ft.view_end) {
+      if constexpr (!F64) (void)qs_prep<F64>(xr[c], ok);  // XGBoost rejects an inf in any column, split on or not
+    } else {
+      ok = qs_bin_column<F64>(xr[c], ft, q.views, q.thr, [&](uint32_t v, uint32_t cell) {
+        dst[(size_t)v * tile_rows] = valid ? (uint16_t)cell : (uint16_t)0;
+      });
+    }
     if (!ok && valid) {
       if (row_req) atomicOr(flag + row_req[row], 32);
       else atomicOr(flag, 1);

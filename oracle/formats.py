@@ -183,12 +183,59 @@ def _num(x) -> float:
     return float(x)
 
 
+def parse_xgboost_legacy(blob: bytes) -> dict:
+    """XGBoost's legacy binary serialisation (learner.cc LearnerImpl::LoadModel -> gbtree_model.cc GBTreeModel::Load ->
+    tree_model.cc RegTree::Load of XGBoost 1.x): ["binf"], LearnerModelParamLegacy (136 B: f32 base_score, u32
+    num_feature, ...), two u64-length-prefixed names (objective, booster), GBTreeModelParam (160 B: i32 num_trees first,
+    i32 size_leaf_vector at +28), per tree TreeParam (148 B: i32 num_nodes at +4, i32 size_leaf_vector at +20) +
+    num_nodes x Node {i32 parent, i32 cleft, i32 cright, u32 sindex, f32 info} + num_nodes x 16 B stats [+ leaf vector],
+    then num_trees x i32 tree_info."""
+    import struct
+
+    at = 4 if blob[:4] == b"binf" else 0
+    base_score, num_feature = struct.unpack_from("<fI", blob, at)
+    at += 136
+    names = []
+    for _ in range(2):
+        (n,) = struct.unpack_from("<Q", blob, at)
+        names.append(blob[at + 8:at + 8 + n].decode())
+        at += 8 + n
+    if names[1] != "gbtree":
+        raise ValueError("only gbtree boosters")
+    (num_trees,) = struct.unpack_from("<i", blob, at)
+    at += 160
+    trees = []
+    for _ in range(num_trees):
+        (num_nodes,) = struct.unpack_from("<i", blob, at + 4)
+        (leaf_vec,) = struct.unpack_from("<i", blob, at + 20)
+        at += 148
+        t = {"left": [], "right": [], "split_index": [], "split_cond": [], "default_left": [], "split_type": [0] * num_nodes,
+             "categories": [[] for _ in range(num_nodes)]}
+        for _i in range(num_nodes):
+            _parent, cl, cr, sindex, info = struct.unpack_from("<iiiIf", blob, at)
+            at += 20
+            t["left"].append(cl)
+            t["right"].append(cr)
+            t["split_index"].append(sindex & 0x7fffffff)
+            t["default_left"].append(sindex >> 31)
+            t["split_cond"].append(info)
+        at += 16 * num_nodes
+        if leaf_vec:
+            (n,) = struct.unpack_from("<Q", blob, at)
+            at += 8 + 4 * n
+        trees.append(t)
+    info = struct.unpack_from("<%di" % num_trees, blob, at) if num_trees else ()
+    if any(info):
+        raise ValueError("multi-group models are not supported")
+    return {"base_score": float(base_score), "trees": trees, "num_feature": int(num_feature), "objective": names[0]}
+
+
 def parse_xgboost(blob: bytes) -> dict:
     k = 1
     while k < len(blob) and blob[k:k + 1] in (b" ", b"\n", b"\r", b"\t"):
         k += 1
     if blob[:1] != b"{":
-        raise ValueError("legacy binary XGBoost models are not supported")
+        return parse_xgboost_legacy(blob)
     if blob[k:k + 1] in (b'"', b"}"):
         # float32 fields must go decimal -> f32 directly; keep the decimal text via parse_float
         doc = json.loads(blob.decode("utf-8"), parse_float=lambda s: _F(s))

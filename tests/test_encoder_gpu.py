@@ -241,11 +241,26 @@ def test_c5_query_encoded_on_the_device(minilm):
 def test_cross_encoder_column(minilm):
     """FieldMatchCrossEncoderFeature end to end: item texts are stored (Put SString under the item scope), the request
     carries the query text, the device scores every (query, item text) pair; items without a text are NaN, requests
-    without a query are NaN, a score the caller supplies ("__ext:<name>", the ScoreCache hit) wins.  The matrix, scores
+    without a query are NaN, a score the caller supplies ("__ext:<name>", the ScoreCache hit) wins; `norm` (noop | linear
+    | position) is applied on the device over the request's whole column.  The matrix, scores
     and order must equal the assembly oracle's when it is handed the same logits; the logits themselves are checked
     against oracle/bert.py."""
     w, enc, tok = minilm
-    for norm in ("noop", "linear"):
+    def scale(vals, norm):  # ml/onnx/Normalize.scala:13-45 over one request's column (NaN = missing)
+        v = np.array(vals, dtype=np.float64)
+        ok = ~np.isnan(v)
+        if norm == "linear" and ok.any():
+            v = (v - v[ok].min()) / (v[ok].max() - v[ok].min())
+        elif norm == "position":
+            order = sorted(range(len(v)), key=lambda i: (bool(np.isnan(v[i])), 0.0 if np.isnan(v[i]) else v[i], i))  # stable, NaN last
+            out = v.copy()
+            for s_, i in enumerate(order):
+                if ok[i]:
+                    out[i] = s_ / len(v)
+            v = out
+        return v
+
+    for norm in ("noop", "linear", "position"):
         cfg = ranklens.ranklens_config()
         cfg["features"].append({"name": "title_cross", "type": "field_match", "itemField": "item.title", "rankingField": "ranking.query",
                                 "method": {"type": "cross-encoder", "model": "metarank/ce-msmarco-MiniLM-L6-v2"}, "norm": norm})
@@ -274,20 +289,16 @@ def test_cross_encoder_column(minilm):
                     known = [it["id"] for it in ev["items"] if it["id"].isdigit() and has_text[int(it["id"])]]
                     logits = enc.score_pairs([queries[k]] * len(known), [titles[int(i)] for i in known])
                     all_logits.append((queries[k], [titles[int(i)] for i in known], logits))
-                    vals = logits.astype(np.float64)
-                    if norm == "linear":  # Normalize.scala:14-22
-                        vals = (vals - vals.min()) / (vals.max() - vals.min())
-                    by_id = dict(zip(known, vals))
-                    e["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": float(by_id[it["id"]])}]) if it["id"] in by_id else it
-                                  for it in ev["items"]]
-                if k == 2:  # ScoreCache hit for the first item: the given score is used, the pair is not encoded
-                    first = ev["items"][0]["id"]
-                    t["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": 0.125}]) if it["id"] == first else it for it in ev["items"]]
-                    if norm == "noop":
-                        e["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": 0.125}]) if it["id"] == first else it for it in e["items"]]
+                    raw = dict(zip(known, logits.astype(np.float64)))
+                    if k == 2:  # ScoreCache hit for the first item: the given raw score is used, the pair is not encoded
+                        first = ev["items"][0]["id"]
+                        raw[first] = 0.125
+                        t["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": 0.125}]) if it["id"] == first else it for it in ev["items"]]
+                    # schema.norm.scale over the request's whole column: encoded logits + given scores, NaN for the rest
+                    vals = scale([raw.get(it["id"], np.nan) for it in ev["items"]], norm)
+                    e["items"] = [dict(it, fields=[{"name": "__ext:title_cross", "value": float(v)}]) if v == v else it
+                                  for it, v in zip(ev["items"], vals)]
                 text_reqs.append(t); ext_reqs.append(e)
-            if norm == "linear":  # min/max of request 2 would be taken over the encoded pairs only; keep that case to noop
-                text_reqs[2] = dict(text_reqs[2], items=reqs[2]["items"])
             mats = [orc.matrix(ev) for ev in ext_reqs]
             col = np.concatenate(mats)[:, 24]
             assert np.isnan(col).any() and np.isfinite(col).sum() > 200

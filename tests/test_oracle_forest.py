@@ -141,6 +141,24 @@ def test_xgb_json_and_ubjson_agree():
     assert np.array_equal(a, b)
 
 
+def test_xgb_legacy_binary_agrees_with_json():
+    """The legacy binary serialisation (xgboost4j < 2.0's Booster.toByteArray()) of a model predicts like its JSON form:
+    the writer (workloads/synth.py) and the oracle's reader (oracle/formats.py) restate learner.cc / gbtree_model.cc /
+    tree_model.cc independently of the product's reader (csrc/forest.cpp), with and without the "binf" header and the
+    pre-1.0 leaf vector."""
+    rng = np.random.default_rng(2)
+    trees = [synth.random_xgb_tree(np.random.Generator(np.random.PCG64(k)), 5, 4, None, None, 0.0, 16, k % 2 == 0) for k in range(9)]
+    doc = synth.xgboost_document(trees, 5, 0.5)
+    X = rng.normal(size=(300, 5))
+    X[rng.random(X.shape) < 0.05] = NAN
+    want = OracleForest.from_xgboost(synth.write_xgboost_json(doc)).predict(X)
+    for binf in (False, True):
+        for lv in (False, True):
+            blob = synth.write_xgboost_legacy(doc, binf=binf, leaf_vector=lv)
+            assert blob[:1] != b"{"
+            assert np.array_equal(OracleForest.from_xgboost(blob).predict(X), want), (binf, lv)
+
+
 def test_container_roundtrip():
     inner = synth.synthetic_lgbm_model(n_trees=3, n_features=4, seed=5)
     blob = synth.write_container(["a", "b", "c"], 0, inner, version=3)

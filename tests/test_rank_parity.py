@@ -273,11 +273,14 @@ def test_c4_100k_candidates_sharded_and_sorted(oracle_c2):
 
 
 @pytest.mark.gpu
-def test_c5_biencoder_column():
+@pytest.mark.parametrize("norm", ["noop", "linear", "position"])
+def test_c5_biencoder_column(norm):
     """BASELINE config C5 minus the ONNX forward (the query embedding arrives as a request field): 24 Ranklens
     columns + the bi-encoder cosine column (f32 query x f64 item, f64 accumulators, no epsilon,
-    FieldMatchBiencoderFeature.scala:80-109 / DistanceFunction.scala:14-26), 500-tree LambdaMART."""
+    FieldMatchBiencoderFeature.scala:80-109 / DistanceFunction.scala:14-26), then schema.norm.scale over the request's
+    column (ml/onnx/Normalize.scala:13-45: noop | linear = min-max | position = rank / size), 500-tree LambdaMART."""
     cfg = ranklens.c5_config()
+    cfg["features"][-1]["norm"] = norm
     orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
     try:
         for b in (orc, hip):
@@ -289,9 +292,13 @@ def test_c5_biencoder_column():
             if k % 4 != 3:  # every fourth request has no query: the column is NaN for all its items
                 ev["fields"] = [{"name": "__embedding:title_match", "value": ranklens.c5_query(seed=k)}]
         reqs[0]["items"][0]["id"] = "7"  # the all-zero embedding: 0 / (x * 0) = NaN
+        reqs[1]["items"][5] = dict(reqs[1]["items"][4])  # the same item twice: equal cosines (a tie for the position rank)
+        reqs.append(dict(reqs[2], id="one", items=reqs[2]["items"][:1]))  # a single candidate: linear gives 0 / 0 = NaN
         mats = [orc.matrix(ev) for ev in reqs]
         col = np.concatenate(mats)[:, 24]
         assert np.isfinite(col).any() and np.isnan(col).any() and np.nanmax(np.abs(col)) <= 1.0 + 1e-12
+        if norm != "noop":
+            assert np.nanmin(col) == 0.0 and (norm == "position" or np.nanmax(col) == 1.0)
         blob = synth.synthetic_lgbm_model(n_trees=500, n_features=25, quantiles=ranklens.column_quantiles(np.concatenate(mats)),
                                           cat_features=[7], cat_prob=0.01, missing="per_feature")
         orc.load_model(blob, 0)

@@ -69,6 +69,23 @@ def test_xgboost(ctx, fmt, n_trees, depth, cols, rows):
     assert_same(b.predict(X), exp)
 
 
+@pytest.mark.parametrize("binf", [False, True])
+def test_xgboost_legacy_binary(ctx, binf):
+    """XGBoostBooster(bytes) of a model stored by xgboost4j < 2.0 (LambdaMARTRanker.scala:229-230 hands the booster
+    whatever toByteArray() wrote): the legacy binary serialisation loads and scores like the same model as JSON."""
+    rng = np.random.default_rng(12)
+    X = make_X(rng, 500, 20)
+    trees = [synth.random_xgb_tree(np.random.Generator(np.random.PCG64(k)), 20, 6, quantiles_of(X), None, 0.0, 16, k % 3 != 0) for k in range(60)]
+    doc = synth.xgboost_document(trees, 20, 0.5)
+    js = synth.write_xgboost_json(doc)
+    blob = synth.write_xgboost_legacy(doc, binf=binf, leaf_vector=binf)
+    exp = OracleForest.from_xgboost(js).predict(X)
+    b = M.HipBooster(blob, M.XGBOOST, ctx)
+    assert b.info()["is_f64"] == 0 and b.info()["base_score"] == 0.5 and b.info()["n_trees"] == 60
+    assert_same(b.predict(X), exp)
+    assert_same(M.HipBooster(js, M.XGBOOST, ctx).predict(X), exp)
+
+
 def test_lightgbm_c3_shape_64_columns(ctx):
     rng = np.random.default_rng(3)
     X = make_X(rng, 1000, 64)
@@ -251,3 +268,27 @@ def test_bitvector_special_values(ctx, scorer_env):
     with pytest.raises(M.MrkError) as e:
         bx.predict(Xi)
     assert "inf" in e.value.message
+
+
+def test_xgboost_rejects_inf_in_a_column_the_forest_never_splits_on(ctx, scorer_env):
+    """XGBoost's DMatrix rejects a row for an inf in ANY column, so every scorer path must too - also for a column no
+    tree uses and for one beyond the model's num_feature (bit-vector binning, tree walk with the LDS tile, tree walk over
+    a matrix too wide for it)."""
+    trees = [synth.random_xgb_tree(np.random.Generator(np.random.PCG64(k)), 3, 3, None, None, 0.0, 16, True) for k in range(5)]
+    for shallow in (True, False):  # <= 16 leaves: bit-vector image; deeper: tree walk only
+        if not shallow:
+            trees = [synth.random_xgb_tree(np.random.Generator(np.random.PCG64(k)), 3, 6, None, None, 0.0, 16, True) for k in range(5)]
+        for cols in (6, 3000):     # 3000 columns: the rows do not fit the walk's LDS tile
+            blob = synth.write_xgboost_json(synth.xgboost_document(trees, 3, 0.5))   # splits on columns 0..2 only
+            b = M.HipBooster(blob, M.XGBOOST, ctx)
+            X = np.zeros((5, cols))
+            assert np.isfinite(b.predict(X)).all()
+            for col in (4, cols - 1):
+                Xi = X.copy()
+                Xi[3, col] = -math.inf
+                for env in ({}, {"MRK_SCORER": "walk"}):
+                    with pytest.raises(M.MrkError) as e:
+                        _predict_with(b, Xi, **env)
+                    assert "inf" in e.value.message, (shallow, cols, col, env)
+            _predict_with(b, X)
+            b.close()
