@@ -112,20 +112,22 @@ def main():
         log(f"WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     n_gpus = max(world, 1)
 
-    torch = dist = None
-    use_dist = n_gpus > 1 or bool(os.environ.get("MRK_BENCH_FORCE_DIST"))  # the env var exercises the RCCL leg on 1 GPU
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # multi-GPU: one process per GPU (the driver's torchrun launch provides RANK / WORLD_SIZE / MASTER_*), the RCCL
+    # communicator lives inside the library (csrc/comm.cpp) - no torch anywhere.  MRK_BENCH_FORCE_DIST=1 exercises the
+    # collective leg on one GPU (a world of one goes through RCCL all the same).
+    use_dist = n_gpus > 1 or bool(os.environ.get("MRK_BENCH_FORCE_DIST"))
 
     import metarank_amd as M
     from workloads import ranklens, synth
 
     ctx = M.Context(local_rank)
+    if use_dist:
+        from metarank_amd.dist import exchange_unique_id_file
+
+        # rank 0's ncclUniqueId to the other ranks of this node (all are children of the same launcher process)
+        comm_key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+        uid = exchange_unique_id_file(rank, n_gpus, M.Context.comm_unique_id, comm_key)
+        ctx.comm_init(uid, rank, n_gpus)
     cfg = ranklens.c3_config() if wl == "c3" else ranklens.c5_config() if wl == "c5" else ranklens.ranklens_config()
     if args.drop_features:
         drop = set(args.drop_features.split(","))
@@ -233,57 +235,27 @@ def main():
     log(f"batch: {args.requests} requests x {args.items} items resolved + uploaded in {time.perf_counter() - t0:.2f}s; "
         f"model {info['n_trees']} trees, {info['n_nodes']} nodes, {info['device_bytes']} B on device")
 
-    # ---- multi-GPU merge buffers (scores of every rank) ----
-    gathers = [None] * n_streams
     chunk = batch.shard_chunk(n_gpus) if sharded else total_items
-    if use_dist:
-        from metarank_amd.dist import all_gather_padded
-
-        def make_gather(bt):
-            d_scores, _, _ = bt.device_outputs()
-            n_view = chunk * n_gpus if sharded else total_items  # the library's score buffer has room for the padded chunks
-
-            class _Arr:  # __cuda_array_interface__ view of the library-owned score buffer
-                __cuda_array_interface__ = {"shape": (n_view,), "typestr": "<f8", "data": (d_scores, False), "version": 3}
-
-            scores_t = torch.as_tensor(_Arr(), device=f"cuda:{local_rank}")
-            merged = None if sharded else torch.empty(n_gpus * total_items, dtype=torch.float64, device=f"cuda:{local_rank}")
-            ext = torch.cuda.ExternalStream(bt.stream, device=f"cuda:{local_rank}")  # the collective follows the batch on its stream
-
-            def gather():
-                with torch.cuda.stream(ext):
-                    if sharded:
-                        all_gather_padded(scores_t, chunk)  # in place: every rank ends up with every slice
-                    else:
-                        dist.all_gather_into_tensor(merged, scores_t)
-            return gather
-
-        gathers = [make_gather(bt) for bt in batches]
 
     def sync_all():
         for bt in batches:
             bt.sync()
         ctx.sync()
-        if torch is not None:
-            torch.cuda.synchronize()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if use_dist:
+            ctx.comm_barrier()
 
     def run_one(i):
-        bt, gather = batches[i % n_streams], gathers[i % n_streams]
+        bt = batches[i % n_streams]
         if qtok is not None:
             enc.embed_ids(*qtok[i % n_streams])
-        if sharded:  # this rank's slice -> merge -> order
-            bt.run_shard(booster, rank, n_gpus)
-            if gather is not None:
-                gather()
-            bt.sort()
+        if sharded:   # this rank's slice -> one in-place RCCL all-gather of the f64 scores -> order (csrc/comm.cpp)
+            bt.run_sharded(booster) if use_dist else bt.run(booster)
         else:
             bt.run(booster)
-            if gather is not None:
-                gather()
+            if use_dist:   # replicas: the ranks' scores merged on every rank, inside the timed region
+                bt.gather_scores()
 
     def step(i):
         for j in range(bps):
@@ -301,10 +273,8 @@ def main():
     barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    if use_dist:
+        elapsed = ctx.comm_max(elapsed)
     for bt in batches:
         st = bt.status()
         assert (st == 0).all(), f"requests failed: {st[st != 0][:5]}"
@@ -558,9 +528,13 @@ def main():
     for bt in batches:
         bt.close()
     booster.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if use_dist:
+        ctx.comm_barrier()
+        if rank == 0 and n_gpus > 1:
+            try:
+                os.remove(f"/tmp/mrk_comm_{comm_key}.id")
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":

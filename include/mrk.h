@@ -65,7 +65,8 @@ typedef struct mrk_batch mrk_batch;   /* a prepared, device-resident request bat
 int mrk_abi_version(void);
 const char *mrk_last_error(void);
 
-/* device_ids: HIP ordinals this context may use; n_devices >= 1.  Round 1 uses device_ids[0]. */
+/* device_ids[0]: the HIP ordinal this context drives; n_devices must be 1 - multi-GPU is one context per device (one
+ * process per GPU), joined into an RCCL communicator by mrk_comm_init below. */
 int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out);
 void mrk_shutdown(mrk_ctx *ctx);
 
@@ -295,6 +296,31 @@ int mrk_batch_fetch(mrk_batch *batch, double *out_scores, int32_t *out_order, do
  * exception for that request maps to (e.g. MRK_ERR_ARITHMETIC); results of failed requests are undefined */
 int mrk_batch_status(mrk_batch *batch, int32_t *out_status);
 void mrk_batch_free(mrk_batch *batch);
+
+/* ------------------------------------------------ multi-GPU (RCCL over xGMI) */
+
+/* The path shards without a data-path collective except one: merging score slices (the reference has
+ * no counterpart - one rerank per JVM thread, M/ml/Ranker.scala:27-83).  One process per GPU, one context each; rank
+ * 0 draws an id (ncclGetUniqueId) and hands its 128 bytes to the other ranks over any channel the host has, then
+ * every rank calls mrk_comm_init (ncclCommInitRank: collective, blocks until all `world` ranks have called it). */
+#define MRK_COMM_ID_BYTES 128
+int mrk_comm_unique_id(uint8_t *out_id /* MRK_COMM_ID_BYTES */);
+int mrk_comm_init(mrk_ctx *ctx, const uint8_t *id, int rank, int world);
+int mrk_comm_rank(mrk_ctx *ctx);   /* 0 without a communicator */
+int mrk_comm_world(mrk_ctx *ctx);  /* 1 without a communicator */
+/* host-value collectives for drivers: max over the ranks (in place), and a barrier */
+int mrk_comm_max_f64(mrk_ctx *ctx, double *value);
+int mrk_comm_barrier(mrk_ctx *ctx);
+/* Item-sharded rank of a batch over the communicator's ranks (every rank holds the same batch and a replica of the
+ * store): this rank's slice is assembled and scored (mrk_batch_run_shard with the communicator's rank / world), ONE
+ * in-place ncclAllGather of the score slices on the batch's stream, then the sort - every rank ends up with all scores
+ * and the order.  Asynchronous like mrk_batch_run.  Without a communicator it is mrk_batch_run. */
+int mrk_batch_run_sharded(mrk_batch *batch, mrk_model *model);
+/* the all-gather step alone: after mrk_batch_run_shard(batch, model, mrk_comm_rank, mrk_comm_world) on every rank */
+int mrk_batch_allgather_scores(mrk_batch *batch);
+/* Request-sharded replicas (every rank ranks its own batch of the same size): the scores of all ranks in one device
+ * buffer owned by the batch, rank r's at [r * total_items, (r + 1) * total_items); asynchronous on the batch's stream. */
+int mrk_batch_gather_scores(mrk_batch *batch, double **d_all_scores);
 
 /* -------------------------------------------------------------- utilities */
 

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
-SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "jit.cpp", "score.hip", "score_qs.hip", "rank.hip", "resolve.hip", "writes.hip", "encoder.hip"]
+SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "comm.cpp", "jit.cpp", "score.hip", "score_qs.hip", "rank.hip", "resolve.hip", "writes.hip", "encoder.hip"]
 HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
 
 MRK_OK = 0
@@ -89,7 +89,7 @@ def build(force: bool = False) -> str:
     objs = [o for o, _ in done]
     if any(c for _, c in done) or not os.path.exists(LIB_PATH):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs +
-                              ["-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"])  # hiprtc: csrc/jit.cpp
+                              ["-L/opt/rocm/lib", "-lhiprtc", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])  # hiprtc: csrc/jit.cpp; rccl: csrc/comm.cpp
     return LIB_PATH
 
 
@@ -174,6 +174,15 @@ SIGNATURES = {
     "mrk_batch_fetch": (_I, [_V, _P, _P, _P]),
     "mrk_batch_status": (_I, [_V, _P]),
     "mrk_batch_free": (None, [_V]),
+    "mrk_comm_unique_id": (_I, [_P]),
+    "mrk_comm_init": (_I, [_V, _P, _I, _I]),
+    "mrk_comm_rank": (_I, [_V]),
+    "mrk_comm_world": (_I, [_V]),
+    "mrk_comm_max_f64": (_I, [_V, C.POINTER(C.c_double)]),
+    "mrk_comm_barrier": (_I, [_V]),
+    "mrk_batch_run_sharded": (_I, [_V, _V]),
+    "mrk_batch_allgather_scores": (_I, [_V]),
+    "mrk_batch_gather_scores": (_I, [_V, C.POINTER(_V)]),
     "mrk_sync": (_I, [_V]),
     "mrk_stream": (_V, [_V]),
     "mrk_profile_enable": (_I, [_V, _I]),

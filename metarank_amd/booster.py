@@ -44,6 +44,34 @@ class Context:
         N.check(N.lib().mrk_profile_get(self.handle, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    # ---- multi-GPU: the RCCL communicator lives inside the library (csrc/comm.cpp)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: rank 0 draws it and hands the 128 bytes to the other ranks"""
+        buf = (C.c_uint8 * 128)()
+        N.check(N.lib().mrk_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        """ncclCommInitRank on this context's device: collective over all `world` ranks"""
+        N.check(N.lib().mrk_comm_init(self.handle, uid, rank, world))
+
+    @property
+    def comm_rank(self) -> int:
+        return N.lib().mrk_comm_rank(self.handle)
+
+    @property
+    def comm_world(self) -> int:
+        return N.lib().mrk_comm_world(self.handle)
+
+    def comm_max(self, v: float) -> float:
+        x = C.c_double(v)
+        N.check(N.lib().mrk_comm_max_f64(self.handle, C.byref(x)))
+        return x.value
+
+    def comm_barrier(self):
+        N.check(N.lib().mrk_comm_barrier(self.handle))
+
     def close(self):
         if self._h:
             N.lib().mrk_shutdown(self._h)

@@ -82,6 +82,7 @@ void ctx_retain(mrk_ctx *ctx) { ctx->refs.fetch_add(1); }
 void ctx_release(mrk_ctx *ctx) {
   if (ctx->refs.fetch_sub(1) != 1) return;
   (void)hipSetDevice(ctx->device);
+  comm_destroy(ctx);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_profile_events(ctx);
@@ -176,6 +177,9 @@ int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out) {
       throw StatusError(MRK_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
     if (device_ids[0] < 0 || device_ids[0] >= count)
       throw StatusError(MRK_ERR_INVALID_ARG, "device id out of range");
+    if (n_devices > 1)
+      throw StatusError(MRK_ERR_UNSUPPORTED, "a context drives one device: create one context per device (one process per GPU) and "
+                                             "join them with mrk_comm_unique_id / mrk_comm_init");
     std::unique_ptr<mrk_ctx> ctx(new mrk_ctx());
     ctx->device = device_ids[0];
     MRK_HIP(hipSetDevice(ctx->device));

@@ -82,6 +82,7 @@ struct mrk_batch {
   bool fetch_enqueued = false;          // the download of d_out into h_out is on the stream behind the last run
   DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
   DevBuf d_sort_keys, d_sort_idx;       // scratch of the multi-workgroup sort
+  DevBuf d_gather;                      // mrk_batch_gather_scores: the scores of every rank
   std::vector<std::pair<int, int>> big; // (request, n_items) with n_items > SORT_MAX_ITEMS
   PinBuf h_in;
   HostBatch hb;              // host half of the last load (grow-only scratch)
@@ -809,6 +810,44 @@ int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int
     const int lo = std::min<long long>((long long)chunk * shard_index, batch->total_items);
     const int hi = std::min<long long>((long long)chunk * (shard_index + 1), batch->total_items);
     run_batch(*batch, model, lo, hi, false);
+  });
+}
+
+int mrk_batch_allgather_scores(mrk_batch *batch) {
+  return guard([&] {
+    check_batch(batch, nullptr);
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    mrk_ctx *ctx = batch->ctx;
+    if (!ctx->comm) return;  // no communicator: a world of one, nothing to merge
+    MRK_HIP(hipSetDevice(ctx->device));
+    // the score buffer has room for the padded chunks of up to 256 shards (build_batch)
+    comm_allgather_f64_inplace(ctx, batch->view.scores, (size_t)shard_chunk(*batch, ctx->comm_world), batch->s());
+    batch->fetch_enqueued = false;
+  });
+}
+
+int mrk_batch_run_sharded(mrk_batch *batch, mrk_model *model) {
+  if (!batch || !batch->ctx) { set_last_error("null batch"); return MRK_ERR_INVALID_ARG; }
+  mrk_ctx *ctx = batch->ctx;
+  if (!ctx->comm) return mrk_batch_run(batch, model);
+  int rc = mrk_batch_run_shard(batch, model, ctx->comm_rank, ctx->comm_world);
+  if (rc == MRK_OK) rc = mrk_batch_allgather_scores(batch);
+  if (rc == MRK_OK) rc = mrk_batch_sort(batch);
+  return rc;
+}
+
+int mrk_batch_gather_scores(mrk_batch *batch, double **d_all_scores) {
+  return guard([&] {
+    check_batch(batch, nullptr);
+    if (!d_all_scores) throw StatusError(MRK_ERR_INVALID_ARG, "null output");
+    std::lock_guard<std::mutex> bl(batch->bmu);
+    mrk_ctx *ctx = batch->ctx;
+    const size_t T = (size_t)batch->total_items;
+    MRK_HIP(hipSetDevice(ctx->device));
+    if (!ctx->comm) { *d_all_scores = batch->view.scores; return; }
+    batch->d_gather.reserve(std::max<size_t>(T * (size_t)ctx->comm_world, 1) * 8);
+    comm_allgather_f64(ctx, batch->view.scores, batch->d_gather.as<double>(), T, batch->s());
+    *d_all_scores = batch->d_gather.as<double>();
   });
 }
 

@@ -146,6 +146,10 @@ struct mrk_ctx {
   mrk::Registry *registry = nullptr;  // owned; freed by mrk::free_rank_state
   mrk::Store *store = nullptr;
   void *rank_scratch = nullptr;       // mrk_batch reused by mrk_rank (owned; freed by mrk::free_rank_state)
+  // multi-GPU (comm.cpp): the RCCL communicator this context's device belongs to (ncclComm_t), nullptr = a world of one
+  void *comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  mrk::DevBuf d_comm;                 // scratch of the host-value collectives
   std::mutex rank_mu;                 // owner of rank_scratch (the leader of the batching front, or a caller with the front off)
   // batching front of mrk_rank: concurrent callers are combined into one device batch by whichever caller
   // finds no leader active (capi_rank.cpp)
@@ -188,6 +192,10 @@ void ctx_release(mrk_ctx *ctx);
 
 // capi_rank.cpp: releases ctx->registry / ctx->store
 void free_rank_state(mrk_ctx *ctx);
+// comm.cpp
+void comm_destroy(mrk_ctx *ctx);
+void comm_allgather_f64_inplace(mrk_ctx *ctx, double *buf, size_t chunk, hipStream_t stream);
+void comm_allgather_f64(mrk_ctx *ctx, const double *send, double *recv, size_t count, hipStream_t stream);
 // features.cpp: drops the encoder references mrk_config_bind_encoder took
 void unbind_encoders(mrk_ctx *ctx);
 

@@ -88,6 +88,19 @@ class Batch:
             N.check(c)
         return c
 
+    def run_sharded(self, booster: HipBooster | None):
+        """mrk_batch_run_sharded: this rank's slice -> one in-place RCCL all-gather of the scores -> sort"""
+        N.check(N.lib().mrk_batch_run_sharded(self._h, booster.handle if booster is not None else None))
+
+    def allgather_scores(self):
+        N.check(N.lib().mrk_batch_allgather_scores(self._h))
+
+    def gather_scores(self) -> int:
+        """mrk_batch_gather_scores: device pointer of world x total_items f64 (every rank's scores)"""
+        p = C.c_void_p()
+        N.check(N.lib().mrk_batch_gather_scores(self._h, C.byref(p)))
+        return p.value
+
     def sort(self):
         N.check(N.lib().mrk_batch_sort(self._h))
 

@@ -235,3 +235,52 @@ def test_cloned_items_rank_like_their_originals():
         batch.close()
     finally:
         hip.close()
+
+
+@pytest.mark.gpu
+def test_rccl_code_path_with_a_world_of_one(oracle_c2):
+    """The library's own RCCL communicator (csrc/comm.cpp) on one GPU: ncclGetUniqueId -> ncclCommInitRank(world 1) ->
+    mrk_batch_run_sharded (slice, in-place ncclAllGather of the scores, sort) and mrk_batch_gather_scores give exactly
+    what the plain run gives; the host-value collectives are the identity."""
+    ctx = M.Context(0)
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost", ctx)
+    try:
+        ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
+        assert ctx.comm_world == 1 and ctx.comm_rank == 0
+        uid = M.Context.comm_unique_id()
+        assert len(uid) == 128
+        ctx.comm_init(uid, 0, 1)
+        assert ctx.comm_world == 1 and ctx.comm_rank == 0
+        assert ctx.comm_max(2.5) == 2.5
+        ctx.comm_barrier()
+        with pytest.raises(M.MrkError):
+            ctx.comm_init(uid, 0, 1)   # one communicator per context
+        reqs = ranklens.generate_requests(5, 100, N_ITEMS, N_SESS, seed=91) + ranklens.generate_requests(1, 6000, N_ITEMS, N_SESS, seed=92)
+        q = ranklens.column_quantiles(np.concatenate([oracle_c2.matrix(ev) for ev in reqs[:5]]))
+        blob = synth.synthetic_lgbm_model(n_trees=120, n_features=24, quantiles=q)
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        batch = hip.ranker.prepare("xgboost", reqs)
+        batch.run(hip.booster)
+        s0, o0, _ = batch.fetch()
+        b2 = hip.ranker.prepare("xgboost", reqs)
+        b2.run_sharded(hip.booster)
+        s1, o1, _ = b2.fetch()
+        assert same(s0, s1) and (o0 == o1).all()
+        for r, ev in enumerate(reqs):
+            _, es, eo = oracle_c2.rerank(ev)
+            lo, hi = b2.offsets[r], b2.offsets[r + 1]
+            assert same(s1[lo:hi], es) and o1[lo:hi].tolist() == eo.tolist(), r
+        # the explicit three-step form, and the replica merge
+        b2.run_shard(hip.booster, ctx.comm_rank, ctx.comm_world)
+        b2.allgather_scores()
+        b2.sort()
+        s2, o2, _ = b2.fetch()
+        assert same(s0, s2) and (o0 == o2).all()
+        assert b2.gather_scores() not in (None, 0)   # ncclAllGather into the batch's merge buffer (one rank: a copy)
+        b2.sync()
+        batch.close()
+        b2.close()
+    finally:
+        hip.close()
+        ctx.close()
