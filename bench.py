@@ -126,8 +126,19 @@ def main():
 
         # rank 0's ncclUniqueId to the other ranks of this node (all are children of the same launcher process)
         comm_key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
-        uid = exchange_unique_id_file(rank, n_gpus, M.Context.comm_unique_id, comm_key)
-        ctx.comm_init(uid, rank, n_gpus)
+        # (RCCL prints a version banner on stdout when the first communicator comes up: stdout carries the ONE JSON line
+        # of the contract, so file descriptor 1 points at stderr while the communicator is built)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = exchange_unique_id_file(rank, n_gpus, M.Context.comm_unique_id, comm_key)
+            ctx.comm_init(uid, rank, n_gpus)
+            ctx.comm_barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     cfg = ranklens.c3_config() if wl == "c3" else ranklens.c5_config() if wl == "c5" else ranklens.ranklens_config()
     if args.drop_features:
         drop = set(args.drop_features.split(","))

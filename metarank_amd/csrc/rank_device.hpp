@@ -87,12 +87,40 @@ __device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t cap) { retur
 // false) - ride along on selects.  A per-lane `while` costs ~25 scalar exec-mask instructions per probe.
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
+// A probe is a dependent trip to LDS, and a wave-uniform loop runs as long as its slowest lane: measured (phase clocks,
+// profiles/r02_f) a token lookup cost ~5 k cycles - a third of the assembly phase went into these loops.  So both
+// primitives first read the next PROBE_W entries of the probe sequence TOGETHER (independent reads, one wait); the
+// loop behind it only runs for the rare lane whose key lies deeper.
+constexpr int PROBE_W = 4;
+
 __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   // tab / cap may differ between lanes (item-parallel kernel: lanes of several requests in one wavefront)
   uint32_t idx = tok_home(tok, cap);
-  bool open = want, full = false;
   const unsigned long long fresh = (unsigned long long)tok | (1ull << 32);
-  for (uint32_t probe = 1; wave_any(open); ++probe) {
+  // look before the first atomic: entries that hold OTHER keys can be skipped for good (a key, once set, never changes)
+  unsigned long long e[PROBE_W];
+  uint32_t pos[PROBE_W];
+  {
+    uint32_t ix = idx;
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      pos[k] = ix;
+      e[k] = tab[ix];  // every lane reads: ix stays inside its table
+      ix = ix + 1 == cap ? 0 : ix + 1;
+    }
+  }
+  uint32_t skipped = PROBE_W;     // entries known to hold other keys
+  bool at_key = false;
+#pragma unroll
+  for (int k = PROBE_W - 1; k >= 0; --k) {  // the FIRST entry that holds tok or was empty wins
+    const uint32_t key = (uint32_t)e[k];
+    if (key == tok || key == 0u) { skipped = (uint32_t)k; at_key = key == tok; }
+  }
+  if (skipped < (uint32_t)PROBE_W) idx = pos[skipped];
+  else idx = pos[PROBE_W - 1] + 1 == cap ? 0 : pos[PROBE_W - 1] + 1;
+  if (want && at_key) atomicAdd(&tab[idx], 1ull << 32);  // the key is there already: one atomic, no compare-and-swap
+  bool open = want && !at_key && skipped < cap, full = want && !at_key && skipped >= cap;
+  for (uint32_t probe = skipped + 1; wave_any(open); ++probe) {
     unsigned long long prev = ~0ull;  // riding lanes: a foreign key
     if (open) prev = atomicCAS(&tab[idx], 0ull, fresh);  // empty -> {tok, 1}
     const bool same = open && (uint32_t)prev == tok;
@@ -107,13 +135,25 @@ __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap,
 
 __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   uint32_t idx = tok_home(tok, cap);
+  unsigned long long e[PROBE_W];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    e[k] = tab[idx];  // every lane reads: idx stays inside its table
+    idx = idx + 1 == cap ? 0 : idx + 1;
+  }
   uint32_t res = 0;
   bool open = want;
-  for (uint32_t probe = 1; wave_any(open); ++probe) {
-    const unsigned long long cur = tab[idx];  // every lane reads: idx stays inside its table
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t key = (uint32_t)e[k];
+    res = open && key == tok ? (uint32_t)(e[k] >> 32) : res;
+    open = open && key != tok && key != 0u && (uint32_t)(k + 1) < cap;  // keys are token ids >= 1: key 0 = empty entry
+  }
+  for (uint32_t probe = PROBE_W + 1; wave_any(open); ++probe) {  // rare: PROBE_W entries in a row hold other keys
+    const unsigned long long cur = tab[idx];
     const uint32_t key = (uint32_t)cur;
     res = open && key == tok ? (uint32_t)(cur >> 32) : res;
-    open = open && key != tok && key != 0u && probe < cap;  // keys are token ids >= 1: key 0 = empty entry
+    open = open && key != tok && key != 0u && probe < cap;
     idx = idx + 1 == cap ? 0 : idx + 1;
   }
   return res;
