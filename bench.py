@@ -327,28 +327,32 @@ def main():
     alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass")}
     alg["sort"] = total_items * (8 + 4)
     alg["override"] = 0
-    # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE, KB per
-    # launch, collected in separate runs: tools/gpu/pmc_bench.sh).  MI355X_MICROARCH.md: FETCH_SIZE counts half of
-    # the bytes of wide coalesced reads (the scorer's slab copy: x2); narrow scattered loads (assembly) are
-    # reported uncorrected.  Only filled when the profiled launch had this run's item count.
-    traffic = None
-    # the assembly kernel of the hot path is the one specialised for the model at run time (csrc/jit.cpp)
+    # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE, KB per launch,
+    # collected in separate runs: tools/gpu/r02_final.sh).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half of the
+    # bytes of 16-byte-per-lane reads - which is what both hot kernels issue (the assembly kernel's record pieces, the
+    # scorer's slab copy) - so the fetch side is doubled; `traffic_raw` is the counter as reported.  For the assembly
+    # kernel the truth lies between the two (DESIGN.md "Roofline accounting").  Only filled when the profiled launch had
+    # this run's shape.
+    traffic = traffic_raw = None
     jit_on = os.environ.get("MRK_RANK_JIT", "1") not in ("0",)
-    pmc_kernel = None if args.backend != "lightgbm" else {"score": "qs_score_wave_kernel", "assemble": "mrk_jit_rank_cells" if jit_on else "rank_fused_cells_kernel"}.get(dominant)
+    pmc_kernel = None if args.backend != "lightgbm" else {
+        "score": "qs_score_wave_kernel",
+        "assemble": ("mrk_jit_assemble_cells" if sharded else "mrk_jit_rank_cells") if jit_on else "rank_fused_cells_kernel"}.get(dominant)
     try:
         import glob
-        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")), reverse=True):
+        shape_ok = n_gpus == 1 and ((wl == "c2" and args.requests == 3840) or (wl == "c4x" and args.items == 4_000_000 and args.clones == 79))
+        for f in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_{wl}_summary.json")), reverse=True):
             d = json.load(open(f)).get(pmc_kernel or "", {})
-            if "FETCH_SIZE" in d and "WRITE_SIZE" in d and wl == "c2" and args.requests == 3840 and n_gpus == 1:
-                corr = 2.0 if dominant == "score" else 1.0
-                traffic = (d["FETCH_SIZE"]["mean"] * corr + d["WRITE_SIZE"]["mean"]) * 1024.0
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d and shape_ok:
+                traffic_raw = (d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
+                traffic = (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
                 break
     except Exception:
-        traffic = None
+        traffic = traffic_raw = None
     dur_s = kernels[dominant]["avg_ms"] * 1e-3
     achieved = alg[dominant] / dur_s / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dominant],
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "algorithmic_bytes_per_launch": alg[dominant],
                 "bytes_per_item": b_item, "items_per_launch": my_items, "model_bytes_per_launch": model_bytes,
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
                 "whole_path": {"achieved": alg_path / (ms_per_batch * 1e-3) / 1e9, "frac": alg_path / (ms_per_batch * 1e-3) / 1e9 / HBM_PEAK_GBS,
