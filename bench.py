@@ -428,9 +428,11 @@ def main():
             t1 = time.perf_counter(); enc.embed_ids(ids, types, mask); ts.append(time.perf_counter() - t1)
         ems = float(np.median(ts) * 1e3)
         L, H, I, S = enc.info["layers"], enc.info["hidden"], enc.info["intermediate"], ids.shape[1]
-        fl = ids.shape[0] * S * L * (2 * (4 * H * H + 2 * H * I) + 4 * S * H)
+        lens = np.asarray(mask).sum(axis=1).astype(np.int64)   # the forward pass runs over the real tokens only (packed batches)
+        fl = int(lens.sum()) * L * 2 * (4 * H * H + 2 * H * I) + int((lens * lens).sum()) * L * 4 * H
         encoder_out = {"model": f"bert {L}x{H}, {enc.info['heads']} heads, ffn {I} (all-MiniLM-L6-v2 shape), random weights, fp16 operands / f32 accumulate",
-                       "queries_per_step": int(ids.shape[0]), "padded_tokens_per_query": int(S), "ms_per_step": ems,
+                       "queries_per_step": int(ids.shape[0]), "padded_tokens_per_query": int(S), "real_tokens_per_query": float(lens.mean()),
+                       "layout": "packed: real tokens back to back, no padding", "ms_per_step": ems,
                        "tflops": fl / ems / 1e9, "mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": fl / ems / 1e9 / 2500.0,
                        "includes": "H2D of token ids and D2H of the embeddings (host-buffer API)"}
     latency = None

@@ -39,6 +39,7 @@ static Switches read_switches() {
   s.qs_leaves = num("MRK_QS_LEAVES", 0);
   s.encoder_graph = flag("MRK_ENCODER_GRAPH", false);
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
+  s.encoder_packed = flag("MRK_ENCODER_PACKED", true);
   return s;
 }
 static Switches &switches_storage() {

@@ -150,34 +150,72 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
                                           std::to_string(sh.max_pos) + " positions");
   if (mode == MODE_LOGIT && !sh.classifier) throw StatusError(MRK_ERR_UNSUPPORTED, "encoder: the model has no pooler/classifier head (not a cross-encoder)");
   MRK_HIP(hipSetDevice(e.ctx->device));
-  const size_t M = (size_t)n * seq;
+  // Per-sequence results (pooled embeddings, logits) do not care where a sequence's tokens sit, so the batch runs PACKED:
+  // real tokens back to back, no padding anywhere - every matrix product, LayerNorm and GELU touches real tokens only
+  // (a batch of 3 840 search queries padded to its longest is 48 % padding).  A row's bits are the same either way
+  // (tests/test_encoder_gpu.py pins padded == packed).  Hidden states (n x seq x H, parity checks) keep the padded layout,
+  // and so does a mask that is not a prefix of ones.
+  std::vector<int> lens;
+  bool packed = mode != MODE_HIDDEN && switches().encoder_packed;
+  size_t Mp = 0;
+  int max_len = 0;
+  if (packed) {
+    lens.resize((size_t)n);
+    for (int b = 0; b < n && packed; ++b) {
+      int l = 0;
+      while (l < seq && mask[(size_t)b * seq + l] != 0) ++l;
+      for (int j = l; j < seq; ++j) packed = packed && mask[(size_t)b * seq + j] == 0;
+      packed = packed && l > 0;
+      lens[(size_t)b] = l;
+      Mp += (size_t)l;
+      max_len = std::max(max_len, l);
+    }
+  }
+  const size_t M = packed ? Mp : (size_t)n * seq;
   const size_t out_n = mode == MODE_HIDDEN ? M * sh.hidden : mode == MODE_POOL ? (size_t)n * sh.hidden : (size_t)n;
+  const size_t id_words = 3 * M + (packed ? (size_t)n + 1 : 0);
   // every buffer is sized before anything is enqueued: a captured graph holds raw pointers, so a buffer that
   // moves invalidates the graphs recorded so far
   const void *before[] = {e.h_ids.p, e.h_out.p, e.scratch.ids.p, e.scratch.x.p, e.scratch.xh.p, e.scratch.qkv.p,
                           e.scratch.ctx.p, e.scratch.mid.p, e.scratch.y.p, e.scratch.out.p};
-  e.h_ids.reserve(3 * M * 4);
+  e.h_ids.reserve(id_words * 4);
   e.h_out.reserve(out_n * 4);
-  e.scratch.ids.reserve(3 * M * 4);
+  e.scratch.ids.reserve(id_words * 4);
   e.scratch.out.reserve(out_n * 4);
-  encoder_reserve(e.dev, e.scratch, n, seq);
+  encoder_reserve(e.dev, e.scratch, 1, (int)M);
   const void *after[] = {e.h_ids.p, e.h_out.p, e.scratch.ids.p, e.scratch.x.p, e.scratch.xh.p, e.scratch.qkv.p,
                          e.scratch.ctx.p, e.scratch.mid.p, e.scratch.y.p, e.scratch.out.p};
   if (memcmp(before, after, sizeof before) != 0) drop_graphs(e);
 
   int32_t *h = e.h_ids.as<int32_t>();
-  memcpy(h, ids, M * 4);
-  if (types) memcpy(h + M, types, M * 4); else memset(h + M, 0, M * 4);
-  memcpy(h + 2 * M, mask, M * 4);
+  if (packed) {  // [ids | type_ids | position ids] x M, then cu x (n + 1)
+    int32_t *cu = h + 3 * M;
+    size_t at = 0;
+    for (int b = 0; b < n; ++b) {
+      cu[b] = (int32_t)at;
+      const int l = lens[(size_t)b];
+      memcpy(h + at, ids + (size_t)b * seq, (size_t)l * 4);
+      if (types) memcpy(h + M + at, types + (size_t)b * seq, (size_t)l * 4); else memset(h + M + at, 0, (size_t)l * 4);
+      for (int j = 0; j < l; ++j) h[2 * M + at + (size_t)j] = j;
+      at += (size_t)l;
+    }
+    cu[n] = (int32_t)at;
+  } else {
+    memcpy(h, ids, M * 4);
+    if (types) memcpy(h + M, types, M * 4); else memset(h + M, 0, M * 4);
+    memcpy(h + 2 * M, mask, M * 4);
+  }
+  const int f_seq = packed ? max_len : seq, f_packed = packed ? (int)M : 0;
 
   auto enqueue = [&]() {
-    MRK_HIP(hipMemcpyAsync(e.scratch.ids.p, h, 3 * M * 4, hipMemcpyHostToDevice, e.stream));
-    encoder_forward(e.dev, e.scratch, n, seq, e.stream);
+    MRK_HIP(hipMemcpyAsync(e.scratch.ids.p, h, id_words * 4, hipMemcpyHostToDevice, e.stream));
+    if (packed) encoder_forward_packed(e.dev, e.scratch, n, f_seq, f_packed, e.stream);
+    else encoder_forward(e.dev, e.scratch, n, seq, e.stream);
     const float *src = e.scratch.x.as<float>();
     if (mode != MODE_HIDDEN) {
       src = e.scratch.out.as<float>();
-      if (mode == MODE_POOL) encoder_meanpool(e.dev, e.scratch, n, seq, e.scratch.out.as<float>(), e.stream);
-      else encoder_classify(e.dev, e.scratch, n, seq, e.scratch.out.as<float>(), e.stream);
+      if (mode == MODE_POOL) encoder_meanpool(e.dev, e.scratch, n, f_seq, f_packed, e.scratch.out.as<float>(), e.stream);
+      else encoder_classify(e.dev, e.scratch, n, f_seq, f_packed, e.scratch.out.as<float>(), e.stream);
     }
     MRK_HIP(hipMemcpyAsync(e.h_out.p, src, out_n * 4, hipMemcpyDeviceToHost, e.stream));
   };
@@ -188,7 +226,8 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
   // the HIP runtime when a captured graph is launched.
   const bool use_graphs = switches().encoder_graph;
   if (use_graphs && M <= GRAPH_MAX_TOKENS) {
-    const std::tuple<int, int, int> key(n, seq, mode);
+    // (a packed batch's launch geometry depends on its token count and its longest sequence)
+    const std::tuple<int, int, int> key(n, packed ? -(int)M : seq, mode * 4096 + (packed ? max_len : 0));
     auto it = e.graphs.find(key);
     if (it == e.graphs.end()) {
       if (e.graphs.size() >= GRAPH_MAX_CACHED) drop_graphs(e);

@@ -56,7 +56,9 @@ __device__ __forceinline__ void layer_norm_row(float (&v)[LN_MAX_PER_LANE], int 
 }
 
 // word + position + token-type embeddings, then LayerNorm: one wavefront per token
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *ids, const int32_t *types, int M, int seq, int H, int vocab, int type_vocab,
+// (pos_ids != nullptr: the tokens are PACKED - sequences back to back without padding - and pos_ids[t] is the token's
+// position inside its sequence; else the batch is padded to `seq` tokens per row)
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *ids, const int32_t *types, const int32_t *pos_ids, int M, int seq, int H, int vocab, int type_vocab,
                                                        const _Float16 *word, const _Float16 *pos, const _Float16 *type, const float *g, const float *b,
                                                        float eps, float *x, _Float16 *xh) {
   const int lane = threadIdx.x & 63;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *ids, const
   int id = ids[t], ty = types[t];
   id = id < 0 ? 0 : id >= vocab ? vocab - 1 : id;
   ty = ty < 0 ? 0 : ty >= type_vocab ? type_vocab - 1 : ty;
-  const int p = t % seq;
+  const int p = pos_ids ? pos_ids[t] : t % seq;
   float v[LN_MAX_PER_LANE];
 #pragma unroll
   for (int e = 0; e < LN_MAX_PER_LANE; ++e) {
@@ -279,15 +281,21 @@ bool launch_skinny(const _Float16 *A, const _Float16 *W, const float *bias, cons
 // ---- attention: one wavefront per (32 queries, head, sequence); scores are computed transposed (keys x queries)
 // so that every lane owns one query column: the row-wise softmax is then a per-lane reduction plus one exchange
 // with lane^32, and the probabilities already sit in B-fragment order for O^T = V^T P^T.
+// Padded batches (cu == nullptr): sequence b owns rows [b * seq_pad, (b + 1) * seq_pad), `mask` says which keys are live.
+// Packed batches (cu != nullptr): sequence b owns rows [cu[b], cu[b + 1]), every one of them live.  The arithmetic of a
+// query row is the same in both: dead keys contribute exact zeros, whole dead key blocks leave the running state untouched.
 template <int DH>
-__global__ __launch_bounds__(64) void attention_kernel(const _Float16 *__restrict__ qkv, const int32_t *__restrict__ mask, int seq, int H,
-                                                      float scale, _Float16 *__restrict__ ctx) {
+__global__ __launch_bounds__(64) void attention_kernel(const _Float16 *__restrict__ qkv, const int32_t *__restrict__ mask, const int32_t *__restrict__ cu,
+                                                      int seq_pad, int H, float scale, _Float16 *__restrict__ ctx) {
   constexpr int KC = DH / 16, DT = DH / 32;
   const int lane = threadIdx.x, q = lane & 31, g = lane >> 5;
   const int q0 = blockIdx.x * 32, head = blockIdx.y, b = blockIdx.z;
   const size_t row = (size_t)3 * H;
-  const _Float16 *base = qkv + (size_t)b * seq * row + head * DH;
-  const int32_t *mrow = mask + (size_t)b * seq;
+  const size_t first = cu ? (size_t)cu[b] : (size_t)b * seq_pad;
+  const int seq = cu ? cu[b + 1] - cu[b] : seq_pad;
+  if (q0 >= seq) return;  // (packed: the grid covers the longest sequence)
+  const _Float16 *base = qkv + first * row + head * DH;
+  const int32_t *mrow = mask ? mask + first : nullptr;
 
   const int qi = q0 + q < seq ? q0 + q : seq - 1;
   half8 qf[KC];
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const _Float16 *__restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      const bool live = key < seq && mrow[key < seq ? key : seq - 1] != 0;
+      const bool live = key < seq && (mrow == nullptr || mrow[key < seq ? key : seq - 1] != 0);
       p[r] = live ? st[r] * scale : -FLT_MAX;
       bm = fmaxf(bm, p[r]);
     }
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const _Float16 *__restric
   }
   if (q0 + q >= seq) return;
   const float inv = 1.0f / l_run;
-  _Float16 *dst = ctx + ((size_t)b * seq + q0 + q) * H + head * DH;
+  _Float16 *dst = ctx + (first + q0 + q) * H + head * DH;
 #pragma unroll
   for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -370,23 +378,26 @@ __global__ __launch_bounds__(64) void attention_kernel(const _Float16 *__restric
 }
 
 // OnnxBiEncoder.avgpool (OnnxBiEncoder.scala:36-60): f64 sum of the first sum(mask) tokens in token order
-__global__ void meanpool_kernel(const float *x, const int32_t *mask, int seq, int H, float *out) {
+__global__ void meanpool_kernel(const float *x, const int32_t *mask, const int32_t *cu, int seq, int H, float *out) {
   const int b = blockIdx.x;
+  const size_t first = cu ? (size_t)cu[b] : (size_t)b * seq;
   int cnt = 0;
-  for (int j = 0; j < seq; ++j) cnt += mask[(size_t)b * seq + j];
+  if (cu) cnt = cu[b + 1] - cu[b];
+  else for (int j = 0; j < seq; ++j) cnt += mask[(size_t)b * seq + j];
+  const int rows = cu ? cnt : seq;
   for (int d = threadIdx.x; d < H; d += blockDim.x) {
     double acc = 0.0;
-    for (int j = 0; j < cnt && j < seq; ++j) acc += (double)x[((size_t)b * seq + j) * H + d];
+    for (int j = 0; j < cnt && j < rows; ++j) acc += (double)x[(first + j) * H + d];
     out[(size_t)b * H + d] = (float)(acc / (double)cnt);
   }
 }
 
 // BertPooler (dense + tanh on the [CLS] row) and the 1-logit classifier: one workgroup per sequence
-__global__ __launch_bounds__(256) void classify_kernel(const float *x, int seq, int H, const _Float16 *pw, const float *pb, const float *cw,
+__global__ __launch_bounds__(256) void classify_kernel(const float *x, const int32_t *cu, int seq, int H, const _Float16 *pw, const float *pb, const float *cw,
                                                        const float *cb, float *out) {
   extern __shared__ float sm[];  // H inputs | 4 partials
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float *cls = x + (size_t)b * seq * H;
+  const float *cls = x + (cu ? (size_t)cu[b] : (size_t)b * seq) * H;
   for (int c = tid; c < H; c += 256) sm[c] = cls[c];
   __syncthreads();
   float part = 0.f;
@@ -427,22 +438,27 @@ void encoder_reserve(const EncoderDev &enc, EncoderScratch &sc, int n, int seq) 
   sc.y.reserve(M * H * 4);
 }
 
-void encoder_forward(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, hipStream_t s) {
+// Padded: sc.ids = [ids | type_ids | mask], 3 x n x seq.  Packed (M_packed > 0): sc.ids = [ids | type_ids | position ids],
+// 3 x M_packed, then cu, n + 1 - the sequences' tokens back to back, no padding anywhere: every per-token kernel (the
+// matrix products, LayerNorm, GELU) runs over real tokens only.
+static void forward_impl(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, int M_packed, hipStream_t s) {
   const EncoderShape &sh = enc.shape;
-  const int M = n * seq, H = sh.hidden, I = sh.inter, DH = H / sh.heads;
+  const bool packed = M_packed > 0;
+  const int M = packed ? M_packed : n * seq, H = sh.hidden, I = sh.inter, DH = H / sh.heads;
   if (M <= 0) return;
-  const int32_t *ids = sc.ids.as<int32_t>(), *types = ids + M, *mask = ids + 2 * (size_t)M;
+  const int32_t *ids = sc.ids.as<int32_t>(), *types = ids + M, *third = ids + 2 * (size_t)M;
+  const int32_t *mask = packed ? nullptr : third, *pos_ids = packed ? third : nullptr, *cu = packed ? ids + 3 * (size_t)M : nullptr;
   float *x = sc.x.as<float>(), *y = sc.y.as<float>();
   uint16_t *xh = sc.xh.as<uint16_t>(), *qkv = sc.qkv.as<uint16_t>(), *ctx = sc.ctx.as<uint16_t>(), *mid = sc.mid.as<uint16_t>();
   const int row_blocks = (M + 3) / 4;
-  hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids, types, M, seq, H, sh.vocab, sh.type_vocab, (const _Float16 *)enc.word,
+  hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids, types, pos_ids, M, seq, H, sh.vocab, sh.type_vocab, (const _Float16 *)enc.word,
                      (const _Float16 *)enc.pos, (const _Float16 *)enc.type, enc.embg, enc.embb, sh.eps, x, (_Float16 *)xh);
   const float scale = 1.0f / sqrtf((float)DH);
   for (const LayerDev &L : enc.layers) {
     launch_gemm<EPI_F16>(xh, L.wqkv, L.bqkv, nullptr, qkv, M, 3 * H, H, s);
-    dim3 ag((seq + 31) / 32, sh.heads, n);
-    if (DH == 32) hipLaunchKernelGGL((attention_kernel<32>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, seq, H, scale, (_Float16 *)ctx);
-    else hipLaunchKernelGGL((attention_kernel<64>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, seq, H, scale, (_Float16 *)ctx);
+    dim3 ag((seq + 31) / 32, sh.heads, n);  // packed: seq = the longest sequence
+    if (DH == 32) hipLaunchKernelGGL((attention_kernel<32>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, cu, seq, H, scale, (_Float16 *)ctx);
+    else hipLaunchKernelGGL((attention_kernel<64>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, cu, seq, H, scale, (_Float16 *)ctx);
     launch_gemm<EPI_RES_F32>(ctx, L.wo, L.bo, x, y, M, H, H, s);
     hipLaunchKernelGGL(ln_kernel, dim3(row_blocks), dim3(256), 0, s, (const float *)y, M, H, L.ln1g, L.ln1b, sh.eps, x, (_Float16 *)xh);
     launch_gemm<EPI_GELU_F16>(xh, L.w1, L.b1, nullptr, mid, M, I, H, s);
@@ -452,17 +468,22 @@ void encoder_forward(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, 
   MRK_HIP(hipGetLastError());
 }
 
-void encoder_meanpool(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, float *d_out, hipStream_t s) {
+void encoder_forward(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, hipStream_t s) { forward_impl(enc, sc, n, seq, 0, s); }
+void encoder_forward_packed(const EncoderDev &enc, EncoderScratch &sc, int n, int max_len, int M, hipStream_t s) { forward_impl(enc, sc, n, max_len, M, s); }
+
+void encoder_meanpool(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, int M_packed, float *d_out, hipStream_t s) {
   if (n <= 0) return;
-  const int32_t *mask = sc.ids.as<int32_t>() + 2 * (size_t)n * seq;
-  hipLaunchKernelGGL(meanpool_kernel, dim3(n), dim3(128), 0, s, (const float *)sc.x.as<float>(), mask, seq, enc.shape.hidden, d_out);
+  const int32_t *base = sc.ids.as<int32_t>();
+  const int32_t *mask = M_packed > 0 ? nullptr : base + 2 * (size_t)n * seq, *cu = M_packed > 0 ? base + 3 * (size_t)M_packed : nullptr;
+  hipLaunchKernelGGL(meanpool_kernel, dim3(n), dim3(128), 0, s, (const float *)sc.x.as<float>(), mask, cu, seq, enc.shape.hidden, d_out);
   MRK_HIP(hipGetLastError());
 }
 
-void encoder_classify(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, float *d_out, hipStream_t s) {
+void encoder_classify(const EncoderDev &enc, EncoderScratch &sc, int n, int seq, int M_packed, float *d_out, hipStream_t s) {
   if (n <= 0) return;
   const int H = enc.shape.hidden;
-  hipLaunchKernelGGL(classify_kernel, dim3(n), dim3(256), (H + 4) * sizeof(float), s, (const float *)sc.x.as<float>(), seq, H,
+  const int32_t *cu = M_packed > 0 ? sc.ids.as<int32_t>() + 3 * (size_t)M_packed : nullptr;
+  hipLaunchKernelGGL(classify_kernel, dim3(n), dim3(256), (H + 4) * sizeof(float), s, (const float *)sc.x.as<float>(), cu, seq, H,
                      (const _Float16 *)enc.pool_w, enc.pool_b, enc.cls_w, enc.cls_b, d_out);
   MRK_HIP(hipGetLastError());
 }

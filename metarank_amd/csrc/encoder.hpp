@@ -61,10 +61,13 @@ struct EncoderScratch {
 // sizes the activation buffers for n x seq tokens (never called while a graph is being captured)
 void encoder_reserve(const EncoderDev &enc, EncoderScratch &s, int n, int seq);
 void encoder_forward(const EncoderDev &enc, EncoderScratch &s, int n, int seq, hipStream_t stream);
-// OnnxBiEncoder.avgpool: scratch.x -> out f32 [n, H] (device)
-void encoder_meanpool(const EncoderDev &enc, EncoderScratch &s, int n, int seq, float *d_out, hipStream_t stream);
+// the same over PACKED tokens: d_ids = [ids | type_ids | position ids] (3 x M) then cu (n + 1 offsets); the sequences lie
+// back to back without padding, max_len = the longest one.  Leaves the hidden states packed in scratch.x (f32 [M, H]).
+void encoder_forward_packed(const EncoderDev &enc, EncoderScratch &s, int n, int max_len, int M, hipStream_t stream);
+// OnnxBiEncoder.avgpool: scratch.x -> out f32 [n, H] (device); M_packed > 0: after encoder_forward_packed
+void encoder_meanpool(const EncoderDev &enc, EncoderScratch &s, int n, int seq, int M_packed, float *d_out, hipStream_t stream);
 // pooler + classifier on the [CLS] row: -> out f32 [n] (device)
-void encoder_classify(const EncoderDev &enc, EncoderScratch &s, int n, int seq, float *d_out, hipStream_t stream);
+void encoder_classify(const EncoderDev &enc, EncoderScratch &s, int n, int seq, int M_packed, float *d_out, hipStream_t stream);
 
 // capi_encoder.cpp / features.cpp
 void encoder_retain(mrk_encoder *e);

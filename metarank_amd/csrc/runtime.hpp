@@ -112,6 +112,7 @@ struct Switches {
   int qs_leaves = 0;           // MRK_QS_LEAVES: widest bit-vector image a model may get (0: the widest available)
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY
+  bool encoder_packed = true;  // MRK_ENCODER_PACKED=0: padded batches for pooled / logit calls too
 };
 const Switches &switches();
 void reload_switches();

@@ -139,6 +139,37 @@ def test_a_row_does_not_depend_on_the_batch_it_travels_in(minilm):
         N.reload_switches()
 
 
+def test_packed_batches_give_the_padded_bits(minilm):
+    """Pooled embeddings and pair logits run over PACKED tokens (no padding: csrc/capi_encoder.cpp run_encoder); the bits
+    equal those of the padded batch (MRK_ENCODER_PACKED=0) for ragged lengths 1..seq, a batch without padding, and one
+    whose mask is not a prefix (which stays padded)."""
+    import os
+    w, enc, _ = minilm
+    rng = np.random.default_rng(5)
+    n, seq = 333, 29
+    ids = rng.integers(5, 2000, size=(n, seq)).astype(np.int32)
+    types = (np.arange(seq)[None, :] >= rng.integers(1, seq, size=(n, 1))).astype(np.int32)
+    lens = rng.integers(1, seq + 1, size=n); lens[:3] = [1, seq, 2]
+    mask = (np.arange(seq)[None, :] < lens[:, None]).astype(np.int32)
+    got = {}
+    for packed in ("1", "0"):
+        os.environ["MRK_ENCODER_PACKED"] = packed
+        N.reload_switches()
+        try:
+            got[packed] = (enc.embed_ids(ids, types, mask), enc.score_ids(ids, types, mask),
+                           enc.embed_ids(ids[:, :7], types[:, :7], np.ones((n, 7), dtype=np.int32)))
+        finally:
+            del os.environ["MRK_ENCODER_PACKED"]
+            N.reload_switches()
+    for a, b in zip(got["1"], got["0"]):
+        np.testing.assert_array_equal(a, b)
+    holes = mask.copy(); holes[5, :4] = [1, 0, 1, 1]   # row 5's mask is not a prefix of ones: the whole batch stays padded
+    e = enc.embed_ids(ids, types, holes)
+    keep = np.arange(n) != 5
+    np.testing.assert_array_equal(e[keep], got["0"][0][keep])
+    assert np.isfinite(e[5]).all()
+
+
 def test_head_size_64(minilm):
     """BERT-base style heads (64 wide): 2 layers x 128, 2 heads"""
     w = synth.synthetic_bert(layers=2, hidden=128, heads=2, inter=256, vocab=300, max_pos=64, seed=4)
