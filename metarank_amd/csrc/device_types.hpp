@@ -33,11 +33,15 @@ enum Tag : uint8_t {
   TAG_STRING = 3,       // ScalarValue(SString): cell = {u32 token, u32 linked field slot + 1 (0 = none)}
   TAG_STRING_LIST = 4,  // ScalarValue(SStringList): cell = {u32 offset, u32 length}; offset & LIST_INLINE_BIT: byte offset of the
                         // tokens inside the record itself (its inline heap), else an index into the token pool
-  TAG_DOUBLE_LIST = 5,  // ScalarValue(SDoubleList): cell = {u32 offset into f64 pool, u32 length}
+  TAG_DOUBLE_LIST = 5,  // ScalarValue(SDoubleList): cell = {u32 offset, u32 length}; offset & LIST_F32_BIT: the values are kept as
+                        // f32 in the f32 pool (every one of them is exactly a float: embeddings are f32 values widened at
+                        // ingest, model/Scalar.scala:24-32 - half the bytes per candidate, the same doubles), else f64 pool
   TAG_PRESENT = 1,      // counter / bounded list present; periodic: tag = 1 + min(len, 250)
 };
 
 constexpr uint32_t LIST_INLINE_BIT = 0x80000000u;
+constexpr uint32_t LIST_F32_BIT = 0x80000000u;
+constexpr uint32_t LIST_F32_MIN = 16;   // shorter double lists stay f64 (nothing to gain)
 
 struct TableDev {          // what kernels see
   const uint8_t *rows;
@@ -50,6 +54,7 @@ struct StoreDev {
   const uint32_t *tok_pool;
   const double *f64_pool;
   const uint32_t *slot_pool;
+  const float *f32_pool;
 };
 
 // ---- id -> slot table of a scope (store.hpp SlotMap), mirrored to the device for the ITEM table: a request batch

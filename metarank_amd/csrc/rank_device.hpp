@@ -64,6 +64,11 @@ __device__ __forceinline__ const uint32_t *list_tokens(const StoreDev &st, const
   return (off & LIST_INLINE_BIT) ? (const uint32_t *)(rec + (off & ~LIST_INLINE_BIT)) : st.tok_pool + off;
 }
 
+// element k of a double list cell {off, len}: from the f32 pool (LIST_F32_BIT: every value is exactly a float) or the f64 pool
+__device__ __forceinline__ double list_f64(const StoreDev &st, uint32_t off, uint32_t k) {
+  return (off & LIST_F32_BIT) ? (double)st.f32_pool[(off & ~LIST_F32_BIT) + k] : st.f64_pool[off + k];
+}
+
 __device__ __forceinline__ int scoped_slot(const ReqDev &rq, int scope, int item_slot) {
   switch (scope) {
     case SC_GLOBAL: return 0;
@@ -840,7 +845,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
 #pragma unroll
         for (int k = 0; k < PRE_F64; ++k) {
           pre.d[k] = 0.0;
-          if (k < op.dim && has && (uint32_t)k < pc.hi()) pre.d[k] = st.f64_pool[pc.lo() + k];
+          if (k < op.dim && has && (uint32_t)k < pc.hi()) pre.d[k] = list_f64(st, pc.lo(), (uint32_t)k);
         }
         break;
       }
@@ -951,7 +956,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
         }
         for (int k = PRE_F64; k < op.dim; ++k) {
           double v = NaN;
-          if (has) v = (uint32_t)k < len ? st.f64_pool[off + k] : 0.0;
+          if (has) v = (uint32_t)k < len ? list_f64(st, off, (uint32_t)k) : 0.0;
           sink.put(dst + k, v);
         }
         break;
@@ -1177,13 +1182,30 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
           if ((int)c.hi() < qn) {
             if (sink.active) atomicOr(&b.status[r], ST_DIM);
           } else {
-            const double *item = st.f64_pool + c.lo();
+            // the products and sums of DistanceFunction.scala:14-26, in element order: f32 query x f64 item, f64 accumulators
             double top = 0.0, a = 0.0, bs = 0.0;
-            for (int k = 0; k < qn; ++k) {
+            auto step = [&](int k, double x) {
               const float q = (float)cs[1 + k];
-              top = __dadd_rn(top, __dmul_rn((double)q, item[k]));
+              top = __dadd_rn(top, __dmul_rn((double)q, x));
               a = __dadd_rn(a, (double)__fmul_rn(q, q));  // Float * Float is a Float product
-              bs = __dadd_rn(bs, __dmul_rn(item[k], item[k]));
+              bs = __dadd_rn(bs, __dmul_rn(x, x));
+            };
+            if (c.lo() & LIST_F32_BIT) {
+              // stored as f32 (exactly the values the reference holds as doubles): 16 bytes = 4 elements per load, half the
+              // bytes of the f64 form (the pool keeps ranges 16-byte aligned)
+              const float *item = st.f32_pool + (c.lo() & ~LIST_F32_BIT);
+              int k = 0;
+              for (; k + 4 <= qn; k += 4) {
+                const float4 x4 = *(const float4 *)(item + k);
+                step(k, (double)x4.x);
+                step(k + 1, (double)x4.y);
+                step(k + 2, (double)x4.z);
+                step(k + 3, (double)x4.w);
+              }
+              for (; k < qn; ++k) step(k, (double)item[k]);
+            } else {
+              const double *item = st.f64_pool + c.lo();
+              for (int k = 0; k < qn; ++k) step(k, item[k]);
             }
             v = top / (sqrt(a) * sqrt(bs));
           }

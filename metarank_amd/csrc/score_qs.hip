@@ -338,7 +338,7 @@ qs_score_wave_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restri
     if (row0 + j < rows) out[row0 + j] = F64 ? acc64[j] : (double)acc32[j];
 }
 
-// Few tiles (a single request, a 100 000-candidate request on 256 CUs): NW wavefronts share ONE tile and split
+// Few tiles (a single request, a 100 000-candidate request on 256 CUs): NW (2 / 4 / 8 / 16) wavefronts share ONE tile and split
 // its trees, so the forest is walked NW times faster.  The scores stay bit-identical because only the exit
 // LEAF INDICES are computed in parallel: per chunk of 8 * NW trees every wavefront writes the indices of its
 // trees (tree w, w + NW, ...) to LDS, then the rows' owners add the chunk's leaf values in tree order - the same
@@ -435,10 +435,11 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
   const long long simds = 4LL * std::max(ctx->n_cus, 1);
   int nw = 1;
   if (split_env >= 0) nw = split_env;
+  else if (n_tiles * 16 <= simds / 2) nw = 16;  // a single request: every tree-walking wavefront it can get
   else if (n_tiles * 8 <= 2 * simds) nw = 8;
   else if (n_tiles * 4 <= 2 * simds) nw = 4;
   else if (n_tiles * 2 <= 2 * simds) nw = 2;
-  if (nw == 2 || nw == 4 || nw == 8) {
+  if (nw == 2 || nw == 4 || nw == 8 || nw == 16) {
     const size_t lds = (size_t)V * 256 + (size_t)8 * nw * (QS_LEAVES * (F64 ? 8 : 4) + QS_TILE_ROWS);
     if (lds <= 160 * 1024) {
       ScopedKernelTimer timer(ctx, "score");
@@ -454,7 +455,7 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
                            m->d_qs_leaves.as<uint8_t>(), m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(), d_cells, \
                            q.n_trees, V, rows, m->forest.base_score, d_out);                                                  \
       }
-      if (nw == 8) MRK_SPLIT(8) else if (nw == 4) MRK_SPLIT(4) else MRK_SPLIT(2)
+      if (nw == 16) MRK_SPLIT(16) else if (nw == 8) MRK_SPLIT(8) else if (nw == 4) MRK_SPLIT(4) else MRK_SPLIT(2)
 #undef MRK_SPLIT
       MRK_HIP(hipGetLastError());
       return;

@@ -13,6 +13,9 @@ Store::Store() {
   tok_pool.host.push_back(0);   // offset 0 is never handed out: {0, 0} == the empty list
   f64_pool.host.push_back(0.0);
   slot_pool.host.push_back(0);
+  f32_pool.host.assign(4, 0.f);
+  f32_pool.align = 4;
+  f32_pool.dirty.emplace_back(0, 4);
   tok_pool.dirty.emplace_back(0, 1);
   f64_pool.dirty.emplace_back(0, 1);
   slot_pool.dirty.emplace_back(0, 1);
@@ -175,7 +178,7 @@ void Store::drop_value(Cell &c, bool keep_tok_range) {
   const uint32_t off = (uint32_t)cell, len = (uint32_t)(cell >> 32);
   if (c.c->kind == COL_SCALAR) {
     if (tag == TAG_STRING_LIST && !keep_tok_range && !(off & LIST_INLINE)) tok_pool.release(off, len);
-    else if (tag == TAG_DOUBLE_LIST) f64_pool.release(off, len);
+    else if (tag == TAG_DOUBLE_LIST) { if (off & LIST_F32_BIT) f32_pool.release(off & ~LIST_F32_BIT, len); else f64_pool.release(off, len); }
   } else if (c.c->kind == COL_BOUNDED_LIST) {
     slot_pool.release(off, len);
   }
@@ -339,12 +342,29 @@ bool Store::put_double_list(const KeyRef &k, const double *v, int n) {
   if (!locate(k, c)) return false;
   kind_check(c.c, COL_SCALAR, k);
   if (n < 0 || (n > 0 && !v)) throw StatusError(MRK_ERR_INVALID_ARG, "bad double list");
+  // long lists whose values are all exactly floats (embeddings: f32 widened at ingest) are kept as f32
+  bool as_f32 = (uint32_t)n >= LIST_F32_MIN;
+  for (int i = 0; i < n && as_f32; ++i) as_f32 = (double)(float)v[i] == v[i] || v[i] != v[i];
+  for (int i = 0; i < n && as_f32; ++i) as_f32 = v[i] == v[i];   // (a NaN's payload would not survive: keep such lists f64)
   uint64_t old = 0;
   const bool had = c.rec[c.c->tag_index] == TAG_DOUBLE_LIST;
   if (had) memcpy(&old, c.rec + c.c->val_off, 8);
   else drop_value(c);
-  const uint32_t off = f64_pool.realloc((uint32_t)old, (uint32_t)(old >> 32), (uint32_t)n);
-  f64_pool.write(off, v, (uint32_t)n);
+  const uint32_t old_off = (uint32_t)old, old_len = (uint32_t)(old >> 32);
+  const bool old_f32 = had && (old_off & LIST_F32_BIT);
+  uint32_t off;
+  if (as_f32) {
+    if (had && !old_f32) f64_pool.release(old_off, old_len);
+    off = f32_pool.realloc(old_f32 ? old_off & ~LIST_F32_BIT : 0, old_f32 ? old_len : 0, (uint32_t)n);
+    std::vector<float> f((size_t)n);
+    for (int i = 0; i < n; ++i) f[(size_t)i] = (float)v[i];
+    f32_pool.write(off, f.data(), (uint32_t)n);
+    off |= LIST_F32_BIT;
+  } else {
+    if (old_f32) f32_pool.release(old_off & ~LIST_F32_BIT, old_len);
+    off = f64_pool.realloc(had && !old_f32 ? old_off : 0, had && !old_f32 ? old_len : 0, (uint32_t)n);
+    f64_pool.write(off, v, (uint32_t)n);
+  }
   set_tag(c, TAG_DOUBLE_LIST);
   uint64_t cell = (uint64_t)off | ((uint64_t)(uint32_t)n << 32);
   set_val(c, 0, cell);
@@ -447,6 +467,12 @@ uint32_t Store::clone_items(int copies) {
           noff = tok_pool.alloc(len);
           std::vector<uint32_t> v(tok_pool.host.begin() + off, tok_pool.host.begin() + off + len);
           tok_pool.write(noff, v.data(), len);
+        } else if (c.kind == COL_SCALAR && tag == TAG_DOUBLE_LIST && len && (off & LIST_F32_BIT)) {
+          const uint32_t o = off & ~LIST_F32_BIT;
+          noff = f32_pool.alloc(len);
+          std::vector<float> v(f32_pool.host.begin() + o, f32_pool.host.begin() + o + len);
+          f32_pool.write(noff, v.data(), len);
+          noff |= LIST_F32_BIT;
         } else if (c.kind == COL_SCALAR && tag == TAG_DOUBLE_LIST && len) {
           noff = f64_pool.alloc(len);
           std::vector<double> v(f64_pool.host.begin() + off, f64_pool.host.begin() + off + len);
@@ -492,7 +518,7 @@ static void flush_pool(Pool<T> &p, hipStream_t stream) {
 }
 
 bool Store::dirty() const {
-  bool d = !pending.empty() || !tok_pool.dirty.empty() || !f64_pool.dirty.empty() || !slot_pool.dirty.empty();
+  bool d = !pending.empty() || !tok_pool.dirty.empty() || !f64_pool.dirty.empty() || !slot_pool.dirty.empty() || !f32_pool.dirty.empty();
   for (int s = 0; s < SC_COUNT && !d; ++s) {
     const Table &t = tables[s];
     d = t.dirty_hi > t.dirty_lo || t.n_slots > t.d_slots_cap ||
@@ -568,6 +594,7 @@ void Store::flush(hipStream_t stream) {
   flush_pool(tok_pool, stream);
   flush_pool(f64_pool, stream);
   flush_pool(slot_pool, stream);
+  flush_pool(f32_pool, stream);
   flush_writes(stream, uploaded_lo, uploaded_hi);
   // the host vectors may be reallocated by later puts: finish the copies before returning
   MRK_HIP(hipStreamSynchronize(stream));
@@ -712,13 +739,14 @@ StoreDev Store::device_view() const {
   d.tok_pool = (const uint32_t *)tok_pool.dev.p;
   d.f64_pool = (const double *)f64_pool.dev.p;
   d.slot_pool = (const uint32_t *)slot_pool.dev.p;
+  d.f32_pool = (const float *)f32_pool.dev.p;
   return d;
 }
 
 size_t Store::device_bytes() const {
   size_t b = 0;
   for (int s = 0; s < SC_COUNT; ++s) b += (size_t)tables[s].n_slots * tables[s].stride;
-  return b + tok_pool.host.size() * 4 + f64_pool.host.size() * 8 + slot_pool.host.size() * 4;
+  return b + tok_pool.host.size() * 4 + f64_pool.host.size() * 8 + slot_pool.host.size() * 4 + f32_pool.host.size() * 4;
 }
 
 }  // namespace mrk

@@ -202,9 +202,11 @@ struct Pool {
   std::vector<std::pair<size_t, size_t>> dirty;      // element ranges [lo, hi) to upload
   std::vector<uint32_t> free_[32];
   static int cls(uint32_t n) { return n <= 1 ? 0 : 32 - __builtin_clz(n - 1); }
+  uint32_t align = 1;            // ranges start on a multiple of this many elements
   uint32_t alloc(uint32_t n) {  // n >= 1
     const int c = cls(n);
     if (!free_[c].empty()) { const uint32_t off = free_[c].back(); free_[c].pop_back(); return off; }
+    if (host.size() % align) host.resize((host.size() + align - 1) / align * align, T());
     const size_t off = host.size(), len = (size_t)1 << c;
     if (off + len > POOL_MAX) throw std::length_error("feature store: a value pool would exceed 2^31 entries");
     host.resize(off + len, T());
@@ -239,6 +241,7 @@ struct Store {
   Table tables[SC_COUNT];
   Pool<uint32_t> tok_pool;   // interned token ids of string lists
   Pool<double> f64_pool;
+  Pool<float> f32_pool;      // double lists whose values are all exactly floats (LIST_F32), ranges 16-byte aligned
   Pool<uint32_t> slot_pool;  // item slots of bounded lists
   std::unordered_map<std::string, uint32_t> token_of;  // string -> token id (>= 1)
   struct PendingInc { uint8_t table; uint32_t slot; uint32_t ring_col; int64_t bucket, inc; };

@@ -57,8 +57,10 @@ int main() {
       }
       case 4: {  // a double list whose length changes
         const std::string key = "item=" + item + "/vec";
-        std::vector<double> v((size_t)(rnd() % 12));
-        for (auto &x : v) x = (double)(rnd() % 1000) / 7.0;
+        // short lists stay f64; long ones whose values are all exactly floats (x / 8) go to the f32 pool, the others (x / 7) do not
+        std::vector<double> v((size_t)(rnd() % 3 == 0 ? rnd() % 41 : rnd() % 12));
+        const double div = rnd() % 2 ? 8.0 : 7.0;
+        for (auto &x : v) x = (double)(rnd() % 1000) / div;
         st.put_double_list(key.c_str(), v.data(), (int)v.size());
         ref_vecs[key] = v;
         break;
@@ -79,7 +81,7 @@ int main() {
       }
       default: st.put_double(("item=" + item + "/pop").c_str(), (double)round); break;
     }
-    if (round == 20000) { tok_hi = st.tok_pool.host.size(); f64_hi = st.f64_pool.host.size(); slot_hi = st.slot_pool.host.size(); }
+    if (round == 20000) { tok_hi = st.tok_pool.host.size(); f64_hi = st.f64_pool.host.size() + st.f32_pool.host.size(); slot_hi = st.slot_pool.host.size(); }
   }
   // read back through the mirror exactly like the device does
   auto cell_of = [&](ScopeId sc, const std::string &id, const std::string &col, uint8_t &tag, uint64_t &bits, const uint8_t *&rec) {
@@ -114,8 +116,15 @@ int main() {
     uint8_t tag = 0; uint64_t bits = 0; const uint8_t *rec = nullptr;
     cell_of(SC_ITEM, id, "vec", tag, bits, rec);
     if (tag != TAG_DOUBLE_LIST || (uint32_t)(bits >> 32) != kv.second.size()) { ++bad; continue; }
-    for (size_t i = 0; i < kv.second.size(); ++i)
-      if (st.f64_pool.host[(uint32_t)bits + i] != kv.second[i]) { ++bad; break; }
+    const uint32_t off = (uint32_t)bits;
+    bool exact = kv.second.size() >= LIST_F32_MIN;
+    for (double x : kv.second) exact = exact && (double)(float)x == x;
+    if (((off & LIST_F32_BIT) != 0) != exact && !kv.second.empty()) ++bad;   // the right pool
+    if ((off & LIST_F32_BIT) && (off & 3u)) ++bad;                           // 16-byte aligned for float4 loads
+    for (size_t i = 0; i < kv.second.size(); ++i) {
+      const double got = (off & LIST_F32_BIT) ? (double)st.f32_pool.host[(off & ~LIST_F32_BIT) + i] : st.f64_pool.host[off + i];
+      if (got != kv.second[i]) { ++bad; break; }
+    }
   }
   for (auto &kv : ref_sessions) {
     const std::string id = kv.first.substr(8, kv.first.find('/') - 8);
@@ -127,7 +136,7 @@ int main() {
   }
   // two thirds of the churn happened after the high-water marks were taken: a store that appended for ever would have
   // tripled; recycling keeps the growth small
-  const size_t tok_end = st.tok_pool.host.size(), f64_end = st.f64_pool.host.size(), slot_end = st.slot_pool.host.size();
+  const size_t tok_end = st.tok_pool.host.size(), f64_end = st.f64_pool.host.size() + st.f32_pool.host.size(), slot_end = st.slot_pool.host.size();
   printf("pools after 20000 / 60000 rounds: tokens %zu / %zu, doubles %zu / %zu, slots %zu / %zu\n", tok_hi, tok_end, f64_hi, f64_end, slot_hi, slot_end);
   const bool bounded = tok_end <= tok_hi * 3 / 2 + 256 && f64_end <= f64_hi * 3 / 2 + 256 && slot_end <= slot_hi * 3 / 2 + 512;
   printf("lists %zu vecs %zu sessions %zu bad %d bounded %d\n", ref_lists.size(), ref_vecs.size(), ref_sessions.size(), bad, (int)bounded);

@@ -194,7 +194,7 @@ def _predict_with(b, X, **env):
 
 def _all_kernels(b, X):
     out = {}
-    for nw in ("1", "2", "4", "8"):  # 1 = one wavefront per tile; 2/4/8 = wavefronts splitting the trees of a tile
+    for nw in ("1", "2", "4", "8", "16"):  # 1 = one wavefront per tile; 2/4/8/16 = wavefronts splitting the trees of a tile
         out[f"bitvector-wave-split{nw}"] = _predict_with(b, X, MRK_QS_KERNEL="1", MRK_QS_SPLIT=nw)
     out["bitvector-wave-auto"] = _predict_with(b, X, MRK_QS_KERNEL="1")
     for r in ("2", "4", "8"):
