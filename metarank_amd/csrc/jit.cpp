@@ -94,13 +94,18 @@ std::string jit_source(const Program &prog, bool f64) {
     attr = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(w) + ", " + std::to_string(w) + ")))";
   }
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
-       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells) {\n"
-       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
+       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int op_split) {\n"
+       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
+  // the same for a handful of requests (mrk_rank): up to 512 lanes per workgroup, the item lanes in op_split copies that
+  // share the program's ops between them (rank_device.hpp op_owner)
+  s += "extern \"C\" __global__ void __launch_bounds__(512)" + attr + "\nmrk_jit_rank_cells_split"
+       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int op_split) {\n"
+       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", true>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, op_split);\n}\n";
   // the same workgroup-per-request kernel writing the row-major f64 matrix (models scored by the tree walk, explain)
   if (f64)  // one copy per module: the matrix does not depend on the scorer's precision
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_matrix"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap) {\n"
-         "  mrk::rank_fused_matrix_body(st, mrk::JitProg{}, b, tab_entries, vals_cap);\n}\n";
+         "  mrk::rank_fused_matrix_body<false>(st, mrk::JitProg{}, b, tab_entries, vals_cap);\n}\n";
   // the item-parallel form (requests too large for one workgroup: tables from a previous pre-pass launch, in HBM)
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
        "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
@@ -138,6 +143,7 @@ struct JitKernels {
   hipFunction_t fn[2] = {nullptr, nullptr};        // mrk_jit_rank_cells
   hipFunction_t fn_items[2] = {nullptr, nullptr};  // mrk_jit_assemble_cells
   hipFunction_t fn_matrix = nullptr;               // mrk_jit_rank_matrix (module [1])
+  hipFunction_t fn_split[2] = {nullptr, nullptr};  // mrk_jit_rank_cells_split
   bool failed[2] = {false, false};
   // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
   std::thread worker[2];
@@ -249,6 +255,7 @@ void *jit_rank_function(const Program &prog, bool f64) {
     MRK_HIP(hipModuleLoadData(&k->mod[v], code.data()));
     MRK_HIP(hipModuleGetFunction(&k->fn[v], k->mod[v], "mrk_jit_rank_cells"));
     MRK_HIP(hipModuleGetFunction(&k->fn_items[v], k->mod[v], "mrk_jit_assemble_cells"));
+    MRK_HIP(hipModuleGetFunction(&k->fn_split[v], k->mod[v], "mrk_jit_rank_cells_split"));
     if (v == 1) MRK_HIP(hipModuleGetFunction(&k->fn_matrix, k->mod[v], "mrk_jit_rank_matrix"));
   } catch (const std::exception &e) {
     k->failed[v] = true;
@@ -280,6 +287,14 @@ void *jit_items_function(const Program &prog, bool f64) {
   std::lock_guard<std::mutex> lk(prog.jit_mu);
   JitKernels *k = (JitKernels *)prog.jit;
   return k ? (void *)k->fn_items[f64 ? 1 : 0] : nullptr;
+}
+
+// the op-split form of the fused kernel (small batches)
+void *jit_split_function(const Program &prog, bool f64) {
+  if (!jit_rank_function(prog, f64)) return nullptr;
+  std::lock_guard<std::mutex> lk(prog.jit_mu);
+  JitKernels *k = (JitKernels *)prog.jit;
+  return k ? (void *)k->fn_split[f64 ? 1 : 0] : nullptr;
 }
 
 // the f64-matrix form of the fused kernel (it lives in the f64 module)

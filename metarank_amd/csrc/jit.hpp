@@ -16,6 +16,8 @@ std::vector<char> jit_compile(const std::string &source, std::string &log);
 void *jit_rank_function(const Program &prog, bool f64);
 // the item-parallel assembly kernel of the same specialised module (mrk_jit_assemble_cells), same conditions
 void *jit_items_function(const Program &prog, bool f64);
+// the fused kernel whose workgroups split the program's ops over copies of the item lanes (mrk_jit_rank_cells_split)
+void *jit_split_function(const Program &prog, bool f64);
 // the fused kernel writing the row-major f64 matrix (mrk_jit_rank_matrix), same conditions
 void *jit_matrix_function(const Program &prog);
 void jit_release(Program &prog);

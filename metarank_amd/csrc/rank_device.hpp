@@ -206,7 +206,8 @@ __device__ __forceinline__ double table_sum_list(const uint32_t *toks, const uns
 constexpr int PREP_THREADS = 256;
 constexpr int FUSED_MAX_PREP = 32;  // pre-pass entries of one model (PrepOut copies + `first` slots kept in LDS)
 constexpr int PREP_GROUP = 4;       // entries handled by one merged pass (their loads are issued together)
-constexpr int PREP_INTS = 96;       // ints of LDS scratch: wave_tot[4][PREP_GROUP] | first[FUSED_MAX_PREP] | misc[4] | tokens[PREP_GROUP]
+constexpr int PREP_WAVES = 8;       // most wavefronts of a workgroup that runs a pre-pass (512 lanes: a single request split over op groups)
+constexpr int PREP_INTS = 96;       // ints of LDS scratch: wave_tot[PREP_WAVES][PREP_GROUP] | first[FUSED_MAX_PREP] | misc[4] | tokens[PREP_GROUP]
 
 struct PrepScratch {   // LDS scratch of one workgroup
   double *vals;        // vals_cap doubles: diversity median
@@ -214,13 +215,13 @@ struct PrepScratch {   // LDS scratch of one workgroup
   int *ints;           // PREP_INTS
   mutable unsigned long long clk;  // MRK_PHASE_CLOCKS builds: time of the previous phase boundary
   mutable unsigned long long acc[6];
-  __device__ __forceinline__ int *wave_tot() const { return ints; }                              // [4][PREP_GROUP]
-  __device__ __forceinline__ int *first() const { return ints + 4 * PREP_GROUP; }                // [FUSED_MAX_PREP]
-  __device__ __forceinline__ int *misc() const { return ints + 4 * PREP_GROUP + FUSED_MAX_PREP; }   // [4]
+  __device__ __forceinline__ int *wave_tot() const { return ints; }                              // [PREP_WAVES][PREP_GROUP]
+  __device__ __forceinline__ int *first() const { return ints + PREP_WAVES * PREP_GROUP; }       // [FUSED_MAX_PREP]
+  __device__ __forceinline__ int *misc() const { return ints + PREP_WAVES * PREP_GROUP + FUSED_MAX_PREP; }   // [4]
   __device__ __forceinline__ int *tokens() const { return misc() + 4; }                          // [PREP_GROUP]
 };
 
-// exclusive prefix sum of a 0/1 flag over the workgroup + total (blockDim.x <= 256 = 4 waves of 64)
+// exclusive prefix sum of a 0/1 flag over the workgroup + total (blockDim.x <= 64 * PREP_WAVES)
 __device__ __forceinline__ int block_scan_flag(bool flag, int *s_wave_tot, int &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_waves = (blockDim.x + 63) >> 6;
@@ -805,6 +806,33 @@ __device__ __forceinline__ constexpr int op_group_end(int lo) {
   }
   return hi;
 }
+// A small batch (a single request) has too few workgroups to fill a CU, let alone the chip: its workgroups then carry
+// OP_SPLIT_MAX copies of the item lanes and every copy evaluates a quarter of the program ("op split": the assembly phase
+// of a request shortens by the split factor; the pre-pass runs once, on all lanes).  Which copy owns an op: greedy
+// balancing of a rough cost, fixed per program.
+constexpr int OP_SPLIT_MAX = 4;
+__device__ __forceinline__ constexpr int op_cost(const Op &op) {
+  switch (op.kind) {
+    case OP_INTERACTED: return 5 * op.dim;
+    case OP_DIVERSITY: return 7;
+    case OP_RATE: return (op.i0 == RATE_ITEM ? 3 : 6) * op.dim;
+    case OP_BIENCODER: return 40;
+    default: return op.dim > 0 ? op.dim : 1;
+  }
+}
+template <typename Prog>
+__device__ __forceinline__ constexpr int op_owner(int oi) {
+  int load[OP_SPLIT_MAX] = {0, 0, 0, 0};
+  int owner = 0;
+  for (int k = 0; k <= oi && k < Prog::n_ops; ++k) {
+    owner = 0;
+    for (int g = 1; g < OP_SPLIT_MAX; ++g)
+      if (load[g] < load[owner]) owner = g;
+    load[owner] += op_cost(Prog{}.ops[k]);
+  }
+  return owner;
+}
+
 template <typename Prog, bool IN_REGS, int LO, typename F>
 __device__ __forceinline__ void run_groups(F &&f) {
   if constexpr (LO < Prog::n_ops) {
@@ -815,10 +843,12 @@ __device__ __forceinline__ void run_groups(F &&f) {
 }
 
 // Evaluates the model program for batch item gi of request r.  Hash tables: tab_base + (po.tab_off - tab_sub).
-template <typename Prog, typename Sink, typename IR>
+// (og, G): op split - this wavefront evaluates the ops whose owner & (G - 1) == og; G = 1: all of them
+template <bool SPLIT, typename Prog, typename Sink, typename IR>
 __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog &prog, const BatchDev &b, int gi, int r,
                                                   const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
-                                                  const PrepOut *pos, const Sink &sink, int islot, const IR &ir) {
+                                                  const PrepOut *pos, const Sink &sink, int islot, const IR &ir, int og, int G_arg) {
+  const int G = SPLIT ? G_arg : 1;  // the hot kernels are instantiated without the split: every guard below folds away
   const uint8_t *irec = ir.p;
   const double NaN = d_nan();
 
@@ -1235,17 +1265,20 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
       static_for<lo, hi>([&](auto ic) __attribute__((always_inline)) {
         constexpr int oi = decltype(ic)::value;
         constexpr Op op = Prog{}.ops[oi];
-        pc[oi] = primary_cell(op);
+        constexpr int own = op_owner<Prog>(oi);
+        if (G == 1 || (own & (G - 1)) == og) pc[oi] = primary_cell(op);
       });
       static_for<lo, hi>([&](auto ic) __attribute__((always_inline)) {
         constexpr int oi = decltype(ic)::value;
         constexpr Op op = Prog{}.ops[oi];
-        prefetch_op(op, pc[oi], pre[oi]);
+        constexpr int own = op_owner<Prog>(oi);
+        if (G == 1 || (own & (G - 1)) == og) prefetch_op(op, pc[oi], pre[oi]);
       });
       static_for<lo, hi>([&](auto ic) __attribute__((always_inline)) {
         constexpr int oi = decltype(ic)::value;
         constexpr Op op = Prog{}.ops[oi];
-        run_op(op, pc[oi], pre[oi]);
+        constexpr int own = op_owner<Prog>(oi);
+        if (G == 1 || (own & (G - 1)) == og) run_op(op, pc[oi], pre[oi]);
         MRK_PHASE(t_op, op_acc[oi]);
       });
     });
@@ -1255,6 +1288,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
 #endif
   } else {
     for (int oi = 0; oi < prog.n_ops; ++oi) {
+      if (G > 1 && (oi & (G - 1)) != og) continue;  // interpreting kernels: ops dealt round-robin
       const Op op = prog.ops[oi];
       const Cell pc = primary_cell(op);
       OpPre pre;
@@ -1270,19 +1304,19 @@ template <typename P> __device__ __forceinline__ constexpr auto prog_item_pieces
 template <typename P> __device__ __forceinline__ constexpr int prog_item_pieces(...) { return 0; }
 constexpr int REC_MAX_PIECES = 24;
 
-template <typename Prog, typename Sink>
+template <bool SPLIT = false, typename Prog, typename Sink>
 __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &prog, const BatchDev &b, int gi, int r,
                                               const ReqDev &rq, const unsigned long long *tab_base, uint32_t tab_sub,
-                                              const PrepOut *pos, const Sink &sink) {
+                                              const PrepOut *pos, const Sink &sink, int og = 0, int G = 1) {
   const int islot = sink.active ? b.item_slot[gi] : -1;  // lanes without an item: a missing record
   const uint8_t *irec = record(st, SC_ITEM, islot);
   constexpr int NP = prog_item_pieces<Prog>(0);
   if constexpr (NP > 0 && NP <= REC_MAX_PIECES) {
     const RegRec<NP> ir = load_record_regs<NP>(irec);
-    assemble_item_rec(st, prog, b, gi, r, rq, tab_base, tab_sub, pos, sink, islot, ir);
+    assemble_item_rec<SPLIT>(st, prog, b, gi, r, rq, tab_base, tab_sub, pos, sink, islot, ir, og, G);
   } else {
     const PtrRec ir{irec};
-    assemble_item_rec(st, prog, b, gi, r, rq, tab_base, tab_sub, pos, sink, islot, ir);
+    assemble_item_rec<SPLIT>(st, prog, b, gi, r, rq, tab_base, tab_sub, pos, sink, islot, ir, og, G);
   }
 }
 
@@ -1290,9 +1324,11 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 // Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
 // Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][PREP_INTS ints]
 //              [threshold staging: 2 buffers x thr_cap x 8 B per wavefront]
-template <typename Prog, typename SinkMaker>
+// op_split (1 | 2 | 4): the workgroup's lanes are op_split copies of the item lanes (see op_owner)
+template <bool SPLIT, typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
-                                                int vals_cap, uint32_t thr_cap, const SinkMaker &make_sink) {
+                                                int vals_cap, uint32_t thr_cap, int op_split_arg, const SinkMaker &make_sink) {
+  const int op_split = SPLIT ? op_split_arg : 1;
   extern __shared__ __align__(16) uint8_t smem[];
   unsigned long long *s_tab = (unsigned long long *)smem;
   double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
@@ -1310,13 +1346,15 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
   sc.clk = clock64();
 #endif
   prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
-  for (int base = 0; base < rq.n_items; base += blockDim.x) {
-    const int i = base + (int)threadIdx.x;
+  const int item_lanes = (int)blockDim.x / op_split;       // a whole number of wavefronts (the host sizes the workgroup)
+  const int og = (int)threadIdx.x / item_lanes, il = (int)threadIdx.x % item_lanes;
+  for (int base = 0; base < rq.n_items; base += item_lanes) {
+    const int i = base + il;
     const int gi0 = rq.item_begin + i;
     const bool active = i < rq.n_items && gi0 >= b.item_lo && gi0 < b.item_hi;
     if (!__any(active)) continue;  // wavefront-uniform
     const int gi = active ? gi0 : rq.item_begin;
-    assemble_item(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr));
+    assemble_item<SPLIT>(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr), og, op_split);
   }
   MRK_PHASE(sc.clk, sc.acc[5]);
 #ifdef MRK_PHASE_CLOCKS
@@ -1345,17 +1383,17 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
 }
 
 // rank_fused_body writing ClickthroughQuery's row-major f64 matrix
-template <typename Prog>
-__device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap) {
-  rank_fused_body(st, prog, b, tab_entries, vals_cap, 0u,
+template <bool SPLIT = false, typename Prog>
+__device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap, int op_split = 1) {
+  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, 0u, op_split,
                   [&](int gi, int, bool active, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
 }
 
 // the hot-path instance of rank_fused_body: straight into the scorer's binned tile
-template <bool F64, typename Prog>
+template <bool F64, bool SPLIT = false, typename Prog>
 __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
-                                                      int vals_cap, const QsDev &q, uint16_t *cells) {
-  rank_fused_body(st, prog, b, tab_entries, vals_cap, q.thr_cap, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
+                                                      int vals_cap, const QsDev &q, uint16_t *cells, int op_split = 1) {
+  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, q.thr_cap, op_split, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
     return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
   });
 }

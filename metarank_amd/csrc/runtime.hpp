@@ -96,7 +96,8 @@ struct Switches {
   bool rank_fused = true;      // MRK_RANK_FUSED=0: pre-pass and assembly as separate kernels, tables in an HBM arena
   bool rank_cells = true;      // MRK_RANK_CELLS=0: keep the f64 matrix between assembly and scoring
   bool scorer_walk = false;    // MRK_SCORER=walk: the tree-walk scorer even where the bit-vector scorer applies
-  int fused_threads = 0;       // MRK_FUSED_THREADS: lanes of the fused kernel's workgroups (0: by request size)
+  int fused_threads = 0;       // MRK_FUSED_THREADS: item lanes of the fused kernel's workgroups (0: by request size)
+  int fused_split = 0;         // MRK_FUSED_SPLIT=1|2|4: op split of the fused kernel's workgroups (0: 4 / 2 for batches of <= 16 requests)
   bool rank_combine = true;    // MRK_RANK_COMBINE=0: no batching front in mrk_rank
   int combine_max = 256;       // MRK_RANK_COMBINE_MAX
   int table_load_pct = 75;     // MRK_TABLE_LOAD_PCT

@@ -167,7 +167,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
     import os
 
     hip = HipBackend(ranklens.ranklens_config(), "xgboost")
-    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT")}
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT", "MRK_FUSED_SPLIT")}
     try:
         load(hip)
         reqs = ranklens.generate_requests(30, 100, N_ITEMS, N_SESS, seed=21)
@@ -211,6 +211,22 @@ def test_assembly_paths_agree(oracle_c2, kind):
                 s2, o2, _ = batch.fetch()
                 assert same(s2, scores) and (o2 == order).all()
                 batch.close()
+        # op split (what a handful of requests gets by itself): the item lanes in 2 / 4 copies that share the ops,
+        # specialised kernel (tile), interpreting kernels (tile and f64 matrix)
+        for split in ("2", "4"):
+            for cells, jit in (("1", "require"), ("1", "0"), ("0", "0")):
+                os.environ["MRK_FUSED_SPLIT"], os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = split, "1", cells, jit
+                M.reload_switches()
+                batch = hip.ranker.prepare("xgboost", reqs)
+                batch.run(hip.booster)
+                scores, order, mat = batch.fetch(matrix=True)
+                assert (batch.status() == 0).all()
+                for r, (_, es, eo) in enumerate(expected):
+                    lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                    assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), (split, cells, jit, r)
+                    assert same(mat[lo:hi], mats[r]), (split, cells, jit, r)
+                batch.close()
+        os.environ.pop("MRK_FUSED_SPLIT", None)
         # single requests: mrk_rank without / with the explain matrix
         os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = "1", "1", "require"
         M.reload_switches()
