@@ -32,7 +32,7 @@ def test_source_carries_the_program_as_constants():
     assert "n_ops = 18, n_prep = 9, dim = 24" in text
     assert "struct JitOps" in text and "rank_fused_cells_body<true, false>" in text and "mrk_jit_rank_cells_split" in text and "#include" not in text
     rc, src32 = specialize(cfg, 0, f64=0)
-    assert rc == 0 and b"rank_fused_cells_body<false>" in src32
+    assert rc == 0 and b"rank_fused_cells_body<false, false>" in src32
     # the normalised rate's weight travels as an exact hexadecimal literal (10.0)
     assert "0x1.4p+3" in text
 
