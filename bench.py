@@ -12,7 +12,8 @@ HIP stream.  `value` is that device-resident throughput (the contract: inputs in
 
 The JSON line also carries "e2e": the serving loop with FRESH requests every device batch - mrk_batch_load (host part
 of the request + upload of the id bytes; item ids are resolved to store slots by a kernel) -> run -> download of
-scores / order / status into pinned memory, `--e2e-batches` batches in flight, one host thread, >= 1 s of timed work.
+scores / order / status into pinned memory, `--e2e-threads` host threads (default 2) with `--e2e-batches` batches in
+flight each, >= 1 s of timed work.
 
 --workload c2 (default)  the configuration BASELINE.json's metric is quoted on: 100-item requests, the
              24 Ranklens columns (stock Ranklens model), 500-tree LightGBM-format LambdaMART;
@@ -74,7 +75,8 @@ def main():
     ap.add_argument("--batches-per-step", type=int, default=None,
                     help="device batches one step runs (default: c2 / c3 96, c4 128, c5 8: a step is about 50 ms of device work)")
     ap.add_argument("--e2e-seconds", type=float, default=1.5, help="timed length of the end-to-end serving loop (0 = skip)")
-    ap.add_argument("--e2e-batches", type=int, default=3, help="batches in flight in the end-to-end loop")
+    ap.add_argument("--e2e-batches", type=int, default=3, help="batches in flight per host thread in the end-to-end loop")
+    ap.add_argument("--e2e-threads", type=int, default=2, help="host threads driving the end-to-end loop (each its own batches)")
     ap.add_argument("--e2e-sets", type=int, default=6, help="distinct request sets the end-to-end loop cycles through")
     ap.add_argument("--drop-features", default="", help="experiments only: comma-separated features removed from the model")
     ap.add_argument("--catalogue", type=int, default=100_000)
@@ -369,35 +371,63 @@ def main():
         sets = [M.RequestSet(ranklens.generate_requests(args.requests, args.items, args.catalogue, args.sessions,
                                                         seed=ranklens.SEED + 5000 + k)) for k in range(n_sets)]
         nb = max(1, args.e2e_batches)
-        eb = [ranker.new_batch() for _ in range(nb)]
+        n_thr = max(1, args.e2e_threads)
         results = [None] * n_sets
+        import threading
 
-        def serve(i, keep=False):
-            b = eb[i % nb]
-            if i >= nb:
-                sc, od, st = b.host_outputs()           # waits for the batch's previous round
-                assert (st == 0).all()
-                if keep:
-                    results[(i - nb) % n_sets] = (sc.copy(), od.copy())
-            b.load(model_name, sets[i % n_sets])
-            b.run(booster)
-            b.enqueue_fetch()
+        class Server:   # one host thread's share of the loop: its own batches, every n_thr-th request set
+            def __init__(self, k):
+                self.k, self.eb, self.n_done, self.err = k, [ranker.new_batch() for _ in range(nb)], 0, None
 
-        for i in range(2 * nb + n_sets):
-            serve(i, keep=True)
-        for b in eb:
-            b.sync()
+            def serve(self, i, keep=False):
+                b = self.eb[i % nb]
+                if i >= nb:
+                    sc, od, st = b.host_outputs()           # waits for the batch's previous round
+                    assert (st == 0).all()
+                    if keep:
+                        results[((i - nb) * n_thr + self.k) % n_sets] = (sc.copy(), od.copy())
+                b.load(model_name, sets[(i * n_thr + self.k) % n_sets])
+                b.run(booster)
+                b.enqueue_fetch()
+
+            def warm(self):
+                for i in range(2 * nb + n_sets):
+                    self.serve(i, keep=True)
+                for b in self.eb:
+                    b.sync()
+
+            def timed(self, go, seconds):
+                try:
+                    go.wait()
+                    t = time.perf_counter()
+                    while True:
+                        for _ in range(16):
+                            self.serve(self.n_done)
+                            self.n_done += 1
+                        if time.perf_counter() - t >= seconds:
+                            break
+                    for b in self.eb:
+                        b.host_outputs()
+                except Exception as e:  # noqa: BLE001
+                    self.err = e
+
+        servers = [Server(k) for k in range(n_thr)]
+        for sv in servers:
+            sv.warm()
+        go = threading.Event()
+        threads = [threading.Thread(target=sv.timed, args=(go, args.e2e_seconds)) for sv in servers]
+        for t in threads:
+            t.start()
         t1 = time.perf_counter()
-        n_done = 0
-        while True:
-            for _ in range(16):
-                serve(n_done)
-                n_done += 1
-            if time.perf_counter() - t1 >= args.e2e_seconds:
-                break
-        for b in eb:
-            b.host_outputs()
+        go.set()
+        for t in threads:
+            t.join()
         e2e_s = time.perf_counter() - t1
+        for sv in servers:
+            if sv.err is not None:
+                raise sv.err
+        n_done = sum(sv.n_done for sv in servers)
+        eb = [b for sv in servers for b in sv.eb]
         e2e_items = n_done * sets[0].total_items
         # what the loop returned equals the device-resident path on the same requests (bit for bit)
         chk = ranker.prepare(model_name, sets[0].requests_with_ids())
@@ -407,10 +437,10 @@ def main():
         assert results[0] is not None and np.array_equal(results[0][0], cs) and np.array_equal(results[0][1], co), "e2e results differ from the resident path"
         e2e = {"value": e2e_items / e2e_s, "unit": "items/s", "seconds": e2e_s, "device_batches": n_done,
                "ms_per_batch": e2e_s / n_done * 1e3, "frac_of_value": (e2e_items / e2e_s) / value,
-               "batches_in_flight": nb, "host_threads": 1, "distinct_request_sets": n_sets,
+               "batches_in_flight": nb * n_thr, "host_threads": n_thr, "distinct_request_sets": n_sets,
                "h2d_bytes_per_batch": int(sets[0].id_bytes_total + 4 * (sets[0].total_items + 1)),
                "d2h_bytes_per_batch": int(12 * sets[0].total_items + 4 * sets[0].n_req),
-               "includes": "per device batch: mrk_batch_load (user/session slots, request constants, table sizing on one host thread; "
+               "includes": "per device batch: mrk_batch_load (user/session slots, request constants, table sizing - one host thread per batch; "
                            "upload of the raw id bytes; id -> slot resolution by a kernel) + mrk_batch_run (assembly, scoring, sort) + "
                            "download of scores / order / status into pinned memory",
                "excludes": "JSON decoding of the events (the host's HTTP layer) - the requests are pre-marshalled mrk_request structs + flat id bytes"}
