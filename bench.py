@@ -378,17 +378,24 @@ def main():
         class Server:   # one host thread's share of the loop: its own batches, every n_thr-th request set
             def __init__(self, k):
                 self.k, self.eb, self.n_done, self.err = k, [ranker.new_batch() for _ in range(nb)], 0, None
+                self.t = [0.0, 0.0, 0.0, 0.0]   # seconds in: waiting for results, mrk_batch_load, mrk_batch_run, enqueue of the download
 
             def serve(self, i, keep=False):
                 b = self.eb[i % nb]
+                t0_ = time.perf_counter()
                 if i >= nb:
                     sc, od, st = b.host_outputs()           # waits for the batch's previous round
                     assert (st == 0).all()
                     if keep:
                         results[((i - nb) * n_thr + self.k) % n_sets] = (sc.copy(), od.copy())
+                t1_ = time.perf_counter()
                 b.load(model_name, sets[(i * n_thr + self.k) % n_sets])
+                t2_ = time.perf_counter()
                 b.run(booster)
+                t3_ = time.perf_counter()
                 b.enqueue_fetch()
+                t4_ = time.perf_counter()
+                self.t[0] += t1_ - t0_; self.t[1] += t2_ - t1_; self.t[2] += t3_ - t2_; self.t[3] += t4_ - t3_
 
             def warm(self):
                 for i in range(2 * nb + n_sets):
@@ -399,6 +406,7 @@ def main():
             def timed(self, go, seconds):
                 try:
                     go.wait()
+                    self.t = [0.0, 0.0, 0.0, 0.0]
                     t = time.perf_counter()
                     while True:
                         for _ in range(16):
@@ -438,6 +446,8 @@ def main():
         e2e = {"value": e2e_items / e2e_s, "unit": "items/s", "seconds": e2e_s, "device_batches": n_done,
                "ms_per_batch": e2e_s / n_done * 1e3, "frac_of_value": (e2e_items / e2e_s) / value,
                "batches_in_flight": nb * n_thr, "host_threads": n_thr, "distinct_request_sets": n_sets,
+               "host_ms_per_batch": {k: 1e3 * sum(sv.t[j] for sv in servers) / max(n_done, 1)
+                                     for j, k in enumerate(("wait_results", "load", "run", "enqueue_fetch"))},
                "h2d_bytes_per_batch": int(sets[0].id_bytes_total + 4 * (sets[0].total_items + 1)),
                "d2h_bytes_per_batch": int(12 * sets[0].total_items + 4 * sets[0].n_req),
                "includes": "per device batch: mrk_batch_load (user/session slots, request constants, table sizing - one host thread per batch; "

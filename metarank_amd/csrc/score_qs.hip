@@ -446,7 +446,7 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
   } else {
     int best_waves = 0;
     for (int n : {1, 4, 8}) {  // (16 is kept for single requests: measured 5 % behind 4 on a full batch)
-      const size_t lds_n = split_lds(n);
+      const size_t lds_n = std::max<size_t>(split_lds(n), 256);  // (a forest of single-leaf trees has no views: V = 0)
       if (lds_n > 160 * 1024) break;
       const int resident = std::min<int>(32, n * (int)((160 * 1024) / lds_n));  // wavefronts per CU (32 slots)
       if (resident > best_waves) { best_waves = resident; nw = n; }
