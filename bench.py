@@ -12,7 +12,7 @@ HIP stream.  `value` is that device-resident throughput (the contract: inputs in
 
 The JSON line also carries "e2e": the serving loop with FRESH requests every device batch - mrk_batch_load (host part
 of the request + upload of the id bytes; item ids are resolved to store slots by a kernel) -> run -> download of
-scores / order / status into pinned memory, `--e2e-threads` host threads (default 2) with `--e2e-batches` batches in
+scores / order / status into pinned memory, `--e2e-threads` host threads (default 1) with `--e2e-batches` batches in
 flight each, >= 1 s of timed work.
 
 --workload c2 (default)  the configuration BASELINE.json's metric is quoted on: 100-item requests, the
@@ -76,7 +76,10 @@ def main():
                     help="device batches one step runs (default: c2 / c3 96, c4 128, c5 8: a step is about 50 ms of device work)")
     ap.add_argument("--e2e-seconds", type=float, default=1.5, help="timed length of the end-to-end serving loop (0 = skip)")
     ap.add_argument("--e2e-batches", type=int, default=3, help="batches in flight per host thread in the end-to-end loop")
-    ap.add_argument("--e2e-threads", type=int, default=2, help="host threads driving the end-to-end loop (each its own batches)")
+    ap.add_argument("--e2e-threads", type=int, default=1,
+                    help="host threads driving the end-to-end loop (each its own batches).  One keeps up with the device (0.28 ms of host "
+                         "work per device batch); through Python more threads only add GIL hand-overs (measured: 683 / 592 / 636 M items/s "
+                         "with 1 / 2 / 3)")
     ap.add_argument("--e2e-sets", type=int, default=6, help="distinct request sets the end-to-end loop cycles through")
     ap.add_argument("--drop-features", default="", help="experiments only: comma-separated features removed from the model")
     ap.add_argument("--catalogue", type=int, default=100_000)
