@@ -110,7 +110,7 @@ struct Switches {
   int qs_split = -1;           // MRK_QS_SPLIT
   int qs_kernel = 1;           // MRK_QS_KERNEL
   int qs_r = 2;                // MRK_QS_R
-  int qs_leaves = 0;           // MRK_QS_LEAVES: widest bit-vector image a model may get (0: the widest available)
+  int walk_tile = 0;           // MRK_WALK_TILE=256: the tree-walk scorer's rows per workgroup (default: 512 where the tile fits)
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY
   bool encoder_packed = true;  // MRK_ENCODER_PACKED=0: padded batches for pooled / logit calls too

@@ -286,7 +286,10 @@ void launch_b(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols,
   // Prefer the tile that still leaves room for two workgroups per CU (more waves to hide LDS
   // latency); fall back to smaller tiles, then to reading rows from global memory.
   const size_t half = 78 * 1024;
-  if (rows > 128 && smem(256) <= half) launch_t<F64, 256, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(256));
+  // (512-row tiles: the forest chunk is shared by twice the rows, so two such workgroups hold 16 wavefronts per CU where
+  // three 256-row ones hold 12 - MRK_WALK_TILE=256 keeps the smaller tile for A/B runs)
+  if (rows > 256 && smem(512) <= half && switches().walk_tile != 256) launch_t<F64, 512, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(512));
+  else if (rows > 128 && smem(256) <= half) launch_t<F64, 256, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(256));
   else if (rows > 64 && smem(128) <= half) launch_t<F64, 128, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(128));
   else if (smem(64) <= half) launch_t<F64, 64, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(64));
   else if (fits(256) && rows > 128) launch_t<F64, 256, true>(ctx, m, d_x, rows, cols, d_out, d_flag, d_row_req, chunk_cap, ref_cap, smem(256));

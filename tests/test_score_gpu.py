@@ -174,7 +174,7 @@ def test_full_size_properties_100k(ctx):
 # test that pins a kernel re-reads them (M.reload_switches).
 @pytest.fixture
 def scorer_env():
-    saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT")}
+    saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT", "MRK_WALK_TILE")}
     yield
     for k, v in saved.items():
         if v is None:
@@ -185,7 +185,7 @@ def scorer_env():
 
 
 def _predict_with(b, X, **env):
-    for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT"):
+    for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT", "MRK_WALK_TILE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     M.reload_switches()
@@ -200,6 +200,7 @@ def _all_kernels(b, X):
     for r in ("2", "4", "8"):
         out[f"bitvector-generic-r{r}"] = _predict_with(b, X, MRK_QS_KERNEL="0", MRK_QS_R=r)
     out["walk"] = _predict_with(b, X, MRK_SCORER="walk")
+    out["walk-256-row-tiles"] = _predict_with(b, X, MRK_SCORER="walk", MRK_WALK_TILE="256")
     _predict_with(b, X[:1])
     return out
 
