@@ -9,7 +9,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libmrk_hip.so")
+LIB_PATH = os.environ.get("MRK_LIB") or os.path.join(HERE, "libmrk_hip.so")  # MRK_LIB: another build of the library (same-box A/B runs)
 SOURCES = ["forest.cpp", "store.cpp", "features.cpp", "codec.cpp", "tokenizer.cpp", "weights.cpp", "capi.cpp", "capi_rank.cpp", "capi_encoder.cpp", "comm.cpp", "jit.cpp", "score.hip", "score_qs.hip", "rank.hip", "resolve.hip", "writes.hip", "encoder.hip"]
 HEADERS = ["json.hpp", "forest.hpp", "runtime.hpp"]
 

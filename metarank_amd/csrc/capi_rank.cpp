@@ -22,7 +22,7 @@ void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows,
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
                            uint16_t *cells, bool f64, void *jit_fn);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
-                       int vals_cap, int threads, int op_split, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
+                       int vals_cap, int threads, int op_split, int slices, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap);
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
@@ -96,6 +96,7 @@ struct mrk_batch {
   bool fused_ok = false;
   uint32_t fused_entries = 0;
   int fused_vals = 1, fused_threads = 64;
+  int fused_slices = 1;      // workgroups per request of the fused kernel (rank_device.hpp rank_fused_body)
   int fused_split = 1;       // op split of the fused kernel's workgroups (1 | 2 | 4; rank_device.hpp op_owner)
   // the f64 matrix is materialised only on demand (explain / parity / models without a bit-vector image)
   bool want_matrix = false;
@@ -281,6 +282,18 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
     if (sw.fused_split) b.fused_split = std::min(fit, sw.fused_split);
     else if (n_req <= 16) b.fused_split = fit;
   }
+  // Few LARGE requests (c3: 384 x 1 000 candidates = 1.5 workgroups per CU, each looping 4 times over its 256 lanes): cover
+  // a request with several workgroups as long as the launch stays within ONE residency of the chip (4 096 wavefronts at
+  // the 4 per SIMD the specialised kernel runs with) - measured (profiles/r02_r_slices.txt): 384 requests 0.62 -> 0.43 ms
+  // with 2 slices (0.47 / 0.48 with 3 / 4: a second wave of workgroups pays the pre-pass again for nothing), 96 requests
+  // 0.52 -> 0.21 ms with 4.  MRK_FUSED_SLICES forces a count (1 = off).
+  b.fused_slices = 1;
+  {
+    const int waves = b.fused_threads / 64;
+    const int rounds = (hb.max_items + b.fused_threads - 1) / std::max(b.fused_threads, 1);
+    if (sw.fused_slices) b.fused_slices = std::max(1, std::min(rounds, sw.fused_slices));
+    else if (b.fused_split == 1 && rounds > 1) b.fused_slices = std::max(1, std::min(rounds, 4096 / std::max(1, n_req * waves)));
+  }
   b.fused_threads *= b.fused_split;
   b.fused_ok = sw.rank_fused && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
                hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR) <= 64 * 1024;
@@ -301,7 +314,7 @@ static void check_model_fits(mrk_model *model, const Program &prog) {
 static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &pd, void *jit_matrix_fn = nullptr) {
   mrk_ctx *ctx = b.ctx;
   if (b.fused_ok) {
-    launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, nullptr, nullptr, true, jit_matrix_fn);
+    launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, jit_matrix_fn ? 1 : b.fused_slices, nullptr, nullptr, true, jit_matrix_fn);
   } else {
     launch_prepass(ctx, st, pd, b.view);
     launch_assemble(ctx, st, pd, b.view);
@@ -348,9 +361,9 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
   const bool f64 = model && model->forest.backend == Backend::LightGBM;
   // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
   // (the specialised matrix kernel has no op-split form: a split batch of a matrix-scored model runs the interpreting kernel)
-  void *jit_fn = !cells ? (b.fused_ok && model && b.fused_split == 1 ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too
+  void *jit_fn = !cells ? (b.fused_ok && model && b.fused_split == 1 && b.fused_slices == 1 ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too
                         : !b.fused_ok ? jit_items_function(*b.prog, f64)
-                        : b.fused_split > 1 ? jit_split_function(*b.prog, f64) : jit_rank_function(*b.prog, f64);
+                        : b.fused_split > 1 || b.fused_slices > 1 ? jit_split_function(*b.prog, f64) : jit_rank_function(*b.prog, f64);
   LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
@@ -367,7 +380,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
     if (hi % QS_TILE_ROWS && tile_bytes)  // rows past the last item of the last tile of this range
       MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (size_t)(hi / QS_TILE_ROWS) * tile_bytes, 0, tile_bytes, b.s()));
     if (b.fused_ok) {
-      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
+      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, b.fused_slices, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     } else {
       launch_prepass(ctx, st, pd, b.view);
       launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn);

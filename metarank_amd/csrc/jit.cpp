@@ -94,18 +94,18 @@ std::string jit_source(const Program &prog, bool f64) {
     attr = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(w) + ", " + std::to_string(w) + ")))";
   }
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
-       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int op_split) {\n"
-       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells);\n}\n";
+       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
+       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
   // the same for a handful of requests (mrk_rank): up to 512 lanes per workgroup, the item lanes in op_split copies that
   // share the program's ops between them (rank_device.hpp op_owner)
   s += "extern \"C\" __global__ void __launch_bounds__(512)" + attr + "\nmrk_jit_rank_cells_split"
-       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int op_split) {\n"
-       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", true>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, op_split);\n}\n";
+       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
+       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", true>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
   // the same workgroup-per-request kernel writing the row-major f64 matrix (models scored by the tree walk, explain)
   if (f64)  // one copy per module: the matrix does not depend on the scorer's precision
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_matrix"
-         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap) {\n"
-         "  mrk::rank_fused_matrix_body<false>(st, mrk::JitProg{}, b, tab_entries, vals_cap);\n}\n";
+         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, int mode) {\n"
+         "  mrk::rank_fused_matrix_body<false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, mode);\n}\n";
   // the item-parallel form (requests too large for one workgroup: tables from a previous pre-pass launch, in HBM)
   s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
        "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"

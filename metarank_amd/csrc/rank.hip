@@ -62,14 +62,14 @@ assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_
 
 // (the interpreting kernels always carry the op split: they are the fall-back, not the hot path)
 __global__ void __launch_bounds__(512)
-rank_fused_matrix_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, int op_split) {
-  rank_fused_matrix_body<true>(st, prog, b, tab_entries, vals_cap, op_split);
+rank_fused_matrix_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, int mode) {
+  rank_fused_matrix_body<true>(st, prog, b, tab_entries, vals_cap, mode);
 }
 
 template <bool F64>
 __global__ void __launch_bounds__(512)
-rank_fused_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, QsDev q, uint16_t *cells, int op_split) {
-  rank_fused_cells_body<F64, true>(st, prog, b, tab_entries, vals_cap, q, cells, op_split);
+rank_fused_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, QsDev q, uint16_t *cells, int mode) {
+  rank_fused_cells_body<F64, true>(st, prog, b, tab_entries, vals_cap, q, cells, mode);
 }
 
 __global__ void override_kernel(BatchDev b, int dim) {
@@ -412,8 +412,10 @@ int fused_max_prep() { return FUSED_MAX_PREP; }
 // cells == nullptr: write the f64 matrix; else write the binned tile.
 // jit_fn: the hipFunction_t of the kernel specialised for this program (jit.cpp), or nullptr = the generic kernel.
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
-                       int vals_cap, int threads, int op_split, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn) {
+                       int vals_cap, int threads, int op_split, int slices, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn) {
   if (b.n_req <= 0) return;
+  int mode = (op_split > 1 ? op_split : 1) | ((slices > 1 ? slices : 1) << 8);  // rank_device.hpp rank_fused_body
+  const unsigned grid = (unsigned)b.n_req * (unsigned)(slices > 1 ? slices : 1);
   const size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u);
   {
     ScopedKernelTimer timer(ctx, "assemble");
@@ -428,18 +430,18 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
       StoreDev a_st = st;
       BatchDev a_b = b;
       int a_vals = vals_cap;
-      void *args[] = {&a_st, &a_b, &tab_entries, &a_vals};   // mrk_jit_rank_matrix: no op split (the caller asked for none)
-      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
+      void *args[] = {&a_st, &a_b, &tab_entries, &a_vals, &mode};   // mrk_jit_rank_matrix (no op-split form: the caller asked for none)
+      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
     } else if (cells && jit_fn) {
       StoreDev a_st = st;
       BatchDev a_b = b;
       QsDev a_q = *q;
       int a_vals = vals_cap;
-      void *args[] = {&a_st, &a_b, &tab_entries, &a_vals, &a_q, &cells, &op_split};  // (op_split is read by mrk_jit_rank_cells_split only)
-      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
-    } else if (!cells) hipLaunchKernelGGL(rank_fused_matrix_kernel, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, op_split);
-    else if (f64) hipLaunchKernelGGL(rank_fused_cells_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, *q, cells, op_split);
-    else hipLaunchKernelGGL(rank_fused_cells_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, *q, cells, op_split);
+      void *args[] = {&a_st, &a_b, &tab_entries, &a_vals, &a_q, &cells, &mode};
+      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
+    } else if (!cells) hipLaunchKernelGGL(rank_fused_matrix_kernel, dim3(grid), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, mode);
+    else if (f64) hipLaunchKernelGGL(rank_fused_cells_kernel<true>, dim3(grid), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, *q, cells, mode);
+    else hipLaunchKernelGGL(rank_fused_cells_kernel<false>, dim3(grid), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, *q, cells, mode);
     MRK_HIP(hipGetLastError());
   }
   if (!cells) {

@@ -1324,11 +1324,17 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 // Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
 // Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][PREP_INTS ints]
 //              [threshold staging: 2 buffers x thr_cap x 8 B per wavefront]
-// op_split (1 | 2 | 4): the workgroup's lanes are op_split copies of the item lanes (see op_owner)
+// `mode` = op_split | slices << 8.
+//   op_split (1 | 2 | 4; SPLIT kernels only): the workgroup's lanes are op_split copies of the item lanes (see op_owner).
+//   slices (>= 1; SPLIT kernels only): a request is covered by `slices` workgroups; each runs the request's pre-pass (its tables are private,
+//     in its own LDS) and assembles one slice of the candidates.  A batch of few large requests - 384 requests x 1 000
+//     candidates is 1.5 workgroups per CU, each looping four times over its lanes - fills the chip this way: the
+//     pre-pass is paid `slices` times, the dependent chain of a workgroup shrinks by the same factor.
 template <bool SPLIT, typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
-                                                int vals_cap, uint32_t thr_cap, int op_split_arg, const SinkMaker &make_sink) {
-  const int op_split = SPLIT ? op_split_arg : 1;
+                                                int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink) {
+  const int op_split = SPLIT ? ((mode & 255) > 1 ? (mode & 255) : 1) : 1;
+  const int slices = SPLIT ? ((mode >> 8) > 1 ? (mode >> 8) : 1) : 1;   // (the plain kernel keeps its registers for the ops)
   extern __shared__ __align__(16) uint8_t smem[];
   unsigned long long *s_tab = (unsigned long long *)smem;
   double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
@@ -1336,9 +1342,14 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
   int *s_int = (int *)(s_po + FUSED_MAX_PREP);
   const size_t thr_at = ((size_t)((uint8_t *)(s_int + PREP_INTS) - smem) + 15) & ~(size_t)15;  // LDS-DMA writes 16 B per lane
   qs_lds_double *s_thr = (qs_lds_double *)(smem + thr_at) + (size_t)(threadIdx.x >> 6) * 2 * thr_cap;
-  const int r = blockIdx.x;
+  const int r = (int)blockIdx.x / slices, sl = (int)blockIdx.x % slices;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
+  const int item_lanes = (int)blockDim.x / op_split;       // a whole number of wavefronts (the host sizes the workgroup)
+  // this workgroup's slice of the candidates: whole rounds of the item lanes
+  const int per = ((rq.n_items + slices - 1) / slices + item_lanes - 1) / item_lanes * item_lanes;
+  const int slice_lo = sl * per, slice_hi = min(rq.n_items, slice_lo + per);
+  if (sl > 0 && slice_lo >= rq.n_items) return;            // a shorter request than the batch's longest: nothing left for this slice
   for (int e = threadIdx.x; e < prog.n_prep; e += blockDim.x) s_po[e] = b.prep_out[(size_t)r * prog.n_prep + e];
   __syncthreads();
   PrepScratch sc{s_vals, vals_cap, s_int, 0ull, {0, 0, 0, 0, 0, 0}};
@@ -1346,12 +1357,11 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
   sc.clk = clock64();
 #endif
   prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
-  const int item_lanes = (int)blockDim.x / op_split;       // a whole number of wavefronts (the host sizes the workgroup)
   const int og = (int)threadIdx.x / item_lanes, il = (int)threadIdx.x % item_lanes;
-  for (int base = 0; base < rq.n_items; base += item_lanes) {
+  for (int base = slice_lo; base < slice_hi; base += item_lanes) {
     const int i = base + il;
     const int gi0 = rq.item_begin + i;
-    const bool active = i < rq.n_items && gi0 >= b.item_lo && gi0 < b.item_hi;
+    const bool active = i < slice_hi && gi0 >= b.item_lo && gi0 < b.item_hi;
     if (!__any(active)) continue;  // wavefront-uniform
     const int gi = active ? gi0 : rq.item_begin;
     assemble_item<SPLIT>(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr), og, op_split);
@@ -1384,16 +1394,16 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
 
 // rank_fused_body writing ClickthroughQuery's row-major f64 matrix
 template <bool SPLIT = false, typename Prog>
-__device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap, int op_split = 1) {
-  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, 0u, op_split,
+__device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap, int mode = 1) {
+  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, 0u, mode,
                   [&](int gi, int, bool active, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
 }
 
 // the hot-path instance of rank_fused_body: straight into the scorer's binned tile
 template <bool F64, bool SPLIT = false, typename Prog>
 __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
-                                                      int vals_cap, const QsDev &q, uint16_t *cells, int op_split = 1) {
-  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, q.thr_cap, op_split, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
+                                                      int vals_cap, const QsDev &q, uint16_t *cells, int mode = 1) {
+  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, q.thr_cap, mode, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
     return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
   });
 }

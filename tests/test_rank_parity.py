@@ -167,7 +167,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
     import os
 
     hip = HipBackend(ranklens.ranklens_config(), "xgboost")
-    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT", "MRK_FUSED_SPLIT")}
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT", "MRK_FUSED_SPLIT", "MRK_FUSED_SLICES", "MRK_FUSED_THREADS")}
     try:
         load(hip)
         reqs = ranklens.generate_requests(30, 100, N_ITEMS, N_SESS, seed=21)
@@ -227,6 +227,24 @@ def test_assembly_paths_agree(oracle_c2, kind):
                     assert same(mat[lo:hi], mats[r]), (split, cells, jit, r)
                 batch.close()
         os.environ.pop("MRK_FUSED_SPLIT", None)
+        # slices (what a batch of few LARGE requests gets by itself): several workgroups per request, each with its own
+        # pre-pass tables and a slice of the candidates; with 64 item lanes the 300-candidate requests take 5 rounds, so
+        # up to 5 slices, the 100-candidate ones 2, the single-candidate ones 1 (the other workgroups leave at once)
+        for slices, split in (("2", "1"), ("5", "1"), ("3", "2")):
+            for cells, jit in (("1", "require"), ("1", "0"), ("0", "0")):
+                os.environ.update(MRK_FUSED_SLICES=slices, MRK_FUSED_SPLIT=split, MRK_FUSED_THREADS="64", MRK_RANK_FUSED="1", MRK_RANK_CELLS=cells, MRK_RANK_JIT=jit)
+                M.reload_switches()
+                batch = hip.ranker.prepare("xgboost", reqs)
+                batch.run(hip.booster)
+                scores, order, mat = batch.fetch(matrix=True)
+                assert (batch.status() == 0).all()
+                for r, (_, es, eo) in enumerate(expected):
+                    lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                    assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), (slices, split, cells, jit, r)
+                    assert same(mat[lo:hi], mats[r]), (slices, split, cells, jit, r)
+                batch.close()
+        for k in ("MRK_FUSED_SLICES", "MRK_FUSED_SPLIT", "MRK_FUSED_THREADS"):
+            os.environ.pop(k, None)
         # single requests: mrk_rank without / with the explain matrix
         os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = "1", "1", "require"
         M.reload_switches()
