@@ -107,8 +107,72 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 // ---- C[M,N] = A[M,K] * W[N,K]^T + bias, fused epilogue -------------------------------------------------
+// With K = 384 (6 k tiles) a workgroup's life is prologue latency + epilogue, not MFMA issue: what pays is MANY resident
+// workgroups (3 wavefronts per SIMD here) and a short epilogue.  Measured on the c5 batch (33.7 k tokens,
+// profiles/r02_v_encoder_tiles.txt): LDS-DMA double-buffered variants of this kernel with 128x128, 128x192, 256x192 and
+// 256x256 tiles - fewer, longer-lived workgroups - were all 7-9 % SLOWER than this one and were removed again; batching
+// the residual loads of the epilogue and dropping the per-element bounds checks from full tiles was worth 20 %.
 enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_RES_F32 = 2 };
 constexpr int BK = 64, LDS_PAD = 8;
+
+
+// f32 -> f16 of a FINISHED f32 value.  Without the (empty) asm the compiler may fold the last f32 multiply / add into
+// `v_fma_mixlo_f16`, which rounds ONCE - and does so in some instantiations of an epilogue and not in others, so a value
+// would depend on which kernel produced it (caught by the packed-vs-padded test: one f16 ulp in one `mid` element).
+__device__ __forceinline__ _Float16 to_half(float v) {
+  asm("" : "+v"(v));
+  return (_Float16)v;
+}
+
+// a global-memory pointer the compiler keeps in scalar registers (then `p[lane_offset]` is one `global_load … v_off, s[base]`)
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *scalar_ptr(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (__attribute__((address_space(1))) T *)(((unsigned long long)hi << 32) | lo);
+}
+
+// One 32 x 32 accumulator block out: bias, then GELU / residual, then f16 / f32.  (m_blk, n_blk) = the block's corner,
+// uniform across the wavefront; the lane owns column `col` and rows rbase + (r & 3) + 8 (r >> 2).  RAGGED = the tile may
+// run past row M.  Addresses are a scalar base per row + ONE per-lane 32-bit offset (16 address pairs in registers cost
+// the kernel a wavefront per SIMD).  The residual values of a block are fetched together BEFORE its first store (a load
+// per element between the stores is a trip to memory each: measured, the K = 384 product with the residual epilogue
+// took 57 us for 4 us of MFMA work).
+template <int EPI, bool RAGGED>
+__device__ __forceinline__ void store_block(const floatx16 &acc, int m_blk, int n_blk, int rbase, int col, int M, int N, float bv,
+                                            const float *__restrict__ res, void *__restrict__ out) {
+  const size_t corner = (size_t)m_blk * N + n_blk;            // uniform
+  const uint32_t lane_off = (uint32_t)rbase * (uint32_t)N + (uint32_t)col;
+  const int m_lane = m_blk + rbase;
+  if constexpr (EPI == EPI_RES_F32) {
+    const float *rrow = res + corner;
+    float *orow = (float *)out + corner;
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      const bool live = !RAGGED || m_lane + dr < M;
+      rv[r] = live ? scalar_ptr(rrow + (size_t)dr * N)[lane_off] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      if (RAGGED && m_lane + dr >= M) continue;
+      scalar_ptr(orow + (size_t)dr * N)[lane_off] = (acc[r] + bv) + rv[r];
+    }
+    asm volatile("" ::: "memory");  // one block's 16 loads in flight at a time
+  } else {
+    _Float16 *orow = (_Float16 *)out + corner;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      if (RAGGED && m_lane + dr >= M) continue;
+      float v = acc[r] + bv;
+      if (EPI == EPI_GELU_F16) v = gelu_erf(v);
+      scalar_ptr(orow + (size_t)dr * N)[lane_off] = to_half(v);
+    }
+  }
+}
 
 template <int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, const float *__restrict__ bias,
@@ -116,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const _Float16 *__restrict__ 
   constexpr int BM = 64 * WM, BN = 64 * WN;
   __shared__ _Float16 As[BM][BK + LDS_PAD];
   __shared__ _Float16 Bs[BN][BK + LDS_PAD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The 1-D grid is folded so that the
   // workgroups of one XCD walk the N tiles of the same rows of A back to back: A is then fetched from HBM by one L2
@@ -181,21 +245,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const _Float16 *__restrict__ 
   }
 
   const int col = lane & 31, rbase = 4 * (lane >> 5);
+  const bool ragged = m0 + BM > M;  // uniform: only the last row tile pays for the bounds checks
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int n = n0 + (wc * WN + j) * 32 + col;
-      const float bv = bias[n];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wr * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        if (m >= M) continue;
-        float v = acc[i][j][r] + bv;
-        if (EPI == EPI_GELU_F16) v = gelu_erf(v);
-        if (EPI == EPI_RES_F32) ((float *)out)[(size_t)m * N + n] = v + res[(size_t)m * N + n];
-        else ((_Float16 *)out)[(size_t)m * N + n] = (_Float16)v;
-      }
+      const int n_blk = n0 + (wc * WN + j) * 32, m_blk = m0 + (wr * WM + i) * 32;
+      const float bv = bias[n_blk + col];
+      if (ragged) store_block<EPI, true>(acc[i][j], m_blk, n_blk, rbase, col, M, N, bv, res, out);
+      else store_block<EPI, false>(acc[i][j], m_blk, n_blk, rbase, col, M, N, bv, res, out);
     }
 }
 
@@ -260,7 +318,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const _Float16 *__rest
       float v = acc[i][r] + bv;
       if (EPI == EPI_GELU_F16) v = gelu_erf(v);
       if (EPI == EPI_RES_F32) ((float *)out)[(size_t)m * N + n] = v + res[(size_t)m * N + n];
-      else ((_Float16 *)out)[(size_t)m * N + n] = (_Float16)v;
+      else ((_Float16 *)out)[(size_t)m * N + n] = to_half(v);
     }
 }
 
