@@ -322,11 +322,11 @@ def main():
     # processes (+ the model, read once per launch).  B_item for the configuration as built (f64 columns, LightGBM):
     #   store read  8 B x D matrix columns + ~48 B of list tokens (12 tokens x 4 B)
     #   ids / slot in 4 B, score out 8 B
-    #   c5: + the item's stored embedding, 384 x 8 B (kept f64, as stored)
+    #   c5: + the item's stored embedding, 384 x 4 B (float-exact double lists are kept - and read - as f32)
     # No intermediate tile, no pre-pass tokens: what the fused path would move at best.
     V = info["tile_columns"]                  # u16 cells per item in the scorer's tile
     my_items = min(chunk, total_items) if sharded else total_items
-    b_item = 8 * dim + 48 + 4 + 8 + (384 * 8 if wl == "c5" else 0)
+    b_item = 8 * dim + 48 + 4 + 8 + (384 * 4 if wl == "c5" else 0)
     model_bytes = int(info["n_nodes"]) * 16 + int(info["n_leaves"]) * (8 if args.backend == "lightgbm" else 4)
     alg_path = my_items * b_item + model_bytes      # the whole fused path (8d)
     alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass")}
@@ -340,24 +340,29 @@ def main():
     # this run's shape.
     traffic = traffic_raw = None
     jit_on = os.environ.get("MRK_RANK_JIT", "1") not in ("0",)
-    pmc_kernel = None if args.backend != "lightgbm" else {
-        "score": "qs_score_wave_kernel",
-        "assemble": ("mrk_jit_assemble_cells" if sharded else "mrk_jit_rank_cells") if jit_on else "rank_fused_cells_kernel"}.get(dominant)
+    # the kernel behind `dominant` in the newest committed summary of this workload (names change with the batch shape:
+    # mrk_jit_rank_cells / _split / mrk_jit_assemble_cells; qs_score_wave_kernel / qs_score_split_kernel)
+    prefixes = {"score": ("qs_score",), "assemble": ("mrk_jit_rank_cells", "mrk_jit_assemble_cells") if jit_on else ("rank_fused_cells", "assemble_cells")}
+    pmc_kernel = None
     try:
         import glob
-        shape_ok = n_gpus == 1 and ((wl == "c2" and args.requests == 3840) or (wl == "c4x" and args.items == 4_000_000 and args.clones == 79))
-        for f in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_{wl}_summary.json")), reverse=True):
-            d = json.load(open(f)).get(pmc_kernel or "", {})
-            if "FETCH_SIZE" in d and "WRITE_SIZE" in d and shape_ok:
-                traffic_raw = (d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
-                traffic = (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
-                break
+        shape_ok = n_gpus == 1 and args.backend == "lightgbm" and (
+            (wl == "c2" and args.requests == 3840) or (wl == "c3" and args.requests == 384) or (wl == "c4x" and args.items == 4_000_000 and args.clones == 79))
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_{wl}_summary.json")), reverse=True)
+        if files and shape_ok:
+            summary = json.load(open(files[0]))
+            for name, d in summary.items():
+                if name.startswith(prefixes.get(dominant, ())) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                    pmc_kernel = name
+                    traffic_raw = (d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
+                    traffic = (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
+                    break
     except Exception:
         traffic = traffic_raw = None
     dur_s = kernels[dominant]["avg_ms"] * 1e-3
     achieved = alg[dominant] / dur_s / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "algorithmic_bytes_per_launch": alg[dominant],
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "traffic_kernel": pmc_kernel, "algorithmic_bytes_per_launch": alg[dominant],
                 "bytes_per_item": b_item, "items_per_launch": my_items, "model_bytes_per_launch": model_bytes,
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
                 "whole_path": {"achieved": alg_path / (ms_per_batch * 1e-3) / 1e9, "frac": alg_path / (ms_per_batch * 1e-3) / 1e9 / HBM_PEAK_GBS,

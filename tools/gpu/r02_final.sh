@@ -24,7 +24,7 @@ timeout 900 python bench.py --backend xgboost --trees 100 --depth 8 --cpu-sample
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o s -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0 > $O/stats_c2.log 2>&1
 PMC="--steps 3 --warmup 1 --batches-per-step 1 --streams 1 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0"
 run() { w=$1; name=$2; shift 2; timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_${w}_$name -o s -- python bench.py --workload $w $PMC > $O/pmc_${w}_$name.log 2>&1; }
-for w in c2 c4x; do
+for w in c2 c3 c4x; do
 run $w fetch FETCH_SIZE
 run $w write WRITE_SIZE
 run $w wait SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
