@@ -22,6 +22,7 @@ static Switches read_switches() {
   if (const char *e = getenv("MRK_FUSED_THREADS")) s.fused_threads = std::min(256, std::max(64, atoi(e) / 64 * 64));
   { const int fs = num("MRK_FUSED_SPLIT", 0); s.fused_split = fs == 1 || fs == 2 || fs == 4 ? fs : 0; }
   s.fused_slices = std::max(0, num("MRK_FUSED_SLICES", 0));
+  s.prepass_lds = flag("MRK_PREPASS_LDS", true);
   s.rank_combine = flag("MRK_RANK_COMBINE", true);
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
   s.table_load_pct = std::max(10, std::min(90, num("MRK_TABLE_LOAD_PCT", 75)));

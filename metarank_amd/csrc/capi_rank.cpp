@@ -11,7 +11,7 @@
 
 namespace mrk {
 
-void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
+void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries);
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_sort(mrk_ctx *ctx, const BatchDev &b);
 void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode);
@@ -316,7 +316,7 @@ static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &
   if (b.fused_ok) {
     launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, jit_matrix_fn ? 1 : b.fused_slices, nullptr, nullptr, true, jit_matrix_fn);
   } else {
-    launch_prepass(ctx, st, pd, b.view);
+    launch_prepass(ctx, st, pd, b.view, b.fused_entries);
     launch_assemble(ctx, st, pd, b.view);
   }
   for (const Program::NormCol &nc : b.prog->norm_cols)  // schema.norm.scale over the request's column (Normalize.scala:13-45)
@@ -382,7 +382,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
     if (b.fused_ok) {
       launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, b.fused_slices, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     } else {
-      launch_prepass(ctx, st, pd, b.view);
+      launch_prepass(ctx, st, pd, b.view, b.fused_entries);
       launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     }
     b.matrix_valid = false;

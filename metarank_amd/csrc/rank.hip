@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <utility>
 
 #include "rank_device.hpp"
@@ -31,15 +32,30 @@ namespace mrk {
 
 namespace {
 
+// The pre-pass alone (requests too large for one workgroup's assembly - C4 - or whose tables exceed the fused kernel's
+// LDS budget).  The item-parallel kernels that follow read the tables from the HBM arena, but a request's tables depend
+// on its session and `top`, not on its candidate count: when they fit the `lds_entries` of dynamic LDS they are BUILT
+// there (every insert / probe a `ds_cmpst` instead of a global atomic round trip) and copied out once.
 __global__ void __launch_bounds__(PREP_THREADS)
-prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
+prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t lds_entries) {
   __shared__ double s_vals[PREP_MAX_VALUES];
   __shared__ int s_ints[PREP_INTS];
+  extern __shared__ __align__(16) unsigned long long s_tables[];
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
   PrepScratch sc{s_vals, PREP_MAX_VALUES, s_ints, 0ull, {0, 0, 0, 0, 0, 0}};
-  prepass_request(st, prog, b, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sc);
+  PrepOut *po = &b.prep_out[(size_t)r * prog.n_prep];
+  uint32_t n_ent = 0;  // this request's table entries: [arena_begin, arena_begin + n_ent)
+  for (int e = 0; e < prog.n_prep; ++e) n_ent = max(n_ent, po[e].tab_off - rq.arena_begin + po[e].tab_cap);
+  const bool in_lds = n_ent <= lds_entries;  // uniform
+  if (!in_lds) {
+    prepass_request(st, prog, b, r, rq, b.arena, 0u, po, sc);
+  } else {  // (two instantiations: with a selected pointer the table accesses would be flat instead of ds operations)
+    prepass_request(st, prog, b, r, rq, s_tables, rq.arena_begin, po, sc);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_ent; i += blockDim.x) b.arena[(size_t)rq.arena_begin + i] = s_tables[i];
+  }
 }
 
 __global__ void __launch_bounds__(ASM_THREADS)
@@ -349,10 +365,15 @@ bigsort_store_kernel(BatchDev b, int r, const int *idx) {
 
 }  // namespace
 
-void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b) {
+void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries) {
   if (b.n_req <= 0 || prog.n_prep <= 0) return;
+  // tables in LDS when the largest request's fit next to the kernel's 33 KB of static scratch (MRK_PREPASS_LDS=0: HBM arena)
+  constexpr uint32_t LDS_TABLE_BUDGET = 96 * 1024;
+  const uint32_t lds_entries = switches().prepass_lds && (uint64_t)max_req_entries * 8 <= LDS_TABLE_BUDGET ? max_req_entries : 0;
+  static std::once_flag once;
+  std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TABLE_BUDGET)); });  // static + dynamic <= 160 KB
   ScopedKernelTimer timer(ctx, "prepass");
-  hipLaunchKernelGGL(prepass_kernel, dim3(b.n_req), dim3(PREP_THREADS), 0, ctx->launch, st, prog, b);
+  hipLaunchKernelGGL(prepass_kernel, dim3(b.n_req), dim3(PREP_THREADS), (size_t)lds_entries * 8, ctx->launch, st, prog, b, lds_entries);
   MRK_HIP(hipGetLastError());
 }
 

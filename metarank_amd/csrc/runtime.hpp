@@ -97,6 +97,7 @@ struct Switches {
   bool rank_cells = true;      // MRK_RANK_CELLS=0: keep the f64 matrix between assembly and scoring
   bool scorer_walk = false;    // MRK_SCORER=walk: the tree-walk scorer even where the bit-vector scorer applies
   int fused_threads = 0;       // MRK_FUSED_THREADS: item lanes of the fused kernel's workgroups (0: by request size)
+  bool prepass_lds = true;     // MRK_PREPASS_LDS=0: the stand-alone pre-pass kernel builds its hash tables in the HBM arena
   int fused_slices = 0;        // MRK_FUSED_SLICES=n: workgroups per request of the fused kernel (0: by batch shape; 1: off)
   int fused_split = 0;         // MRK_FUSED_SPLIT=1|2|4: op split of the fused kernel's workgroups (0: 4 / 2 for batches of <= 16 requests)
   bool rank_combine = true;    // MRK_RANK_COMBINE=0: no batching front in mrk_rank
