@@ -342,12 +342,16 @@ bool launch_skinny(const _Float16 *A, const _Float16 *W, const float *bias, cons
 // Padded batches (cu == nullptr): sequence b owns rows [b * seq_pad, (b + 1) * seq_pad), `mask` says which keys are live.
 // Packed batches (cu != nullptr): sequence b owns rows [cu[b], cu[b + 1]), every one of them live.  The arithmetic of a
 // query row is the same in both: dead keys contribute exact zeros, whole dead key blocks leave the running state untouched.
+// A workgroup is ATT_HEADS independent wavefronts, one head each (no LDS, no barrier): a batch of 3 840 nine-token
+// queries is 46 080 wavefronts, and dispatching them four to a workgroup is cheaper than one by one.
+constexpr int ATT_HEADS = 4;
 template <int DH>
-__global__ __launch_bounds__(64) void attention_kernel(const _Float16 *__restrict__ qkv, const int32_t *__restrict__ mask, const int32_t *__restrict__ cu,
-                                                      int seq_pad, int H, float scale, _Float16 *__restrict__ ctx) {
+__global__ __launch_bounds__(64 * ATT_HEADS) void attention_kernel(const _Float16 *__restrict__ qkv, const int32_t *__restrict__ mask, const int32_t *__restrict__ cu,
+                                                                  int seq_pad, int H, int heads, float scale, _Float16 *__restrict__ ctx) {
   constexpr int KC = DH / 16, DT = DH / 32;
-  const int lane = threadIdx.x, q = lane & 31, g = lane >> 5;
-  const int q0 = blockIdx.x * 32, head = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, q = lane & 31, g = lane >> 5;
+  const int q0 = blockIdx.x * 32, head = blockIdx.y * ATT_HEADS + ((int)threadIdx.x >> 6), b = blockIdx.z;
+  if (head >= heads) return;
   const size_t row = (size_t)3 * H;
   const size_t first = cu ? (size_t)cu[b] : (size_t)b * seq_pad;
   const int seq = cu ? cu[b + 1] - cu[b] : seq_pad;
@@ -514,9 +518,9 @@ static void forward_impl(const EncoderDev &enc, EncoderScratch &sc, int n, int s
   const float scale = 1.0f / sqrtf((float)DH);
   for (const LayerDev &L : enc.layers) {
     launch_gemm<EPI_F16>(xh, L.wqkv, L.bqkv, nullptr, qkv, M, 3 * H, H, s);
-    dim3 ag((seq + 31) / 32, sh.heads, n);  // packed: seq = the longest sequence
-    if (DH == 32) hipLaunchKernelGGL((attention_kernel<32>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, cu, seq, H, scale, (_Float16 *)ctx);
-    else hipLaunchKernelGGL((attention_kernel<64>), ag, dim3(64), 0, s, (const _Float16 *)qkv, mask, cu, seq, H, scale, (_Float16 *)ctx);
+    dim3 ag((seq + 31) / 32, (sh.heads + ATT_HEADS - 1) / ATT_HEADS, n);  // packed: seq = the longest sequence
+    if (DH == 32) hipLaunchKernelGGL((attention_kernel<32>), ag, dim3(64 * ATT_HEADS), 0, s, (const _Float16 *)qkv, mask, cu, seq, H, sh.heads, scale, (_Float16 *)ctx);
+    else hipLaunchKernelGGL((attention_kernel<64>), ag, dim3(64 * ATT_HEADS), 0, s, (const _Float16 *)qkv, mask, cu, seq, H, sh.heads, scale, (_Float16 *)ctx);
     launch_gemm<EPI_RES_F32>(ctx, L.wo, L.bo, x, y, M, H, H, s);
     hipLaunchKernelGGL(ln_kernel, dim3(row_blocks), dim3(256), 0, s, (const float *)y, M, H, L.ln1g, L.ln1b, sh.eps, x, (_Float16 *)xh);
     launch_gemm<EPI_GELU_F16>(xh, L.w1, L.b1, nullptr, mid, M, I, H, s);

@@ -121,6 +121,7 @@ __device__ __forceinline__ unsigned long long sort_key(double score) {
 }
 
 constexpr int SORT_THREADS = 256;
+constexpr int SORT_COUNT_MAX = 256;  // requests up to this size are ordered by counting (sort_kernel)
 
 __global__ void __launch_bounds__(SORT_THREADS)
 sort_kernel(BatchDev b) {
@@ -131,6 +132,23 @@ sort_kernel(BatchDev b) {
   const ReqDev rq = b.reqs[r];
   const int n = rq.n_items;
   if (n <= 0 || n > SORT_MAX_ITEMS) return;  // larger requests: the multi-workgroup sort below
+  if (n <= SORT_COUNT_MAX) {
+    // A request of the usual size (100 candidates): every lane counts the elements that precede its own - the keys are
+    // read from LDS at one address per instruction (a broadcast), there is one barrier instead of 28 bitonic steps, and
+    // (key, index) pairs are distinct, so the count IS the position in the stable order.
+    for (int i = tid; i < n; i += SORT_THREADS) s_key[i] = sort_key(b.scores[rq.item_begin + i]);
+    __syncthreads();
+    for (int i = tid; i < n; i += SORT_THREADS) {
+      const unsigned long long mine = s_key[i];
+      int before = 0;
+      for (int j = 0; j < n; ++j) {
+        const unsigned long long kj = s_key[j];
+        before += (kj < mine || (kj == mine && j < i)) ? 1 : 0;
+      }
+      b.order[rq.item_begin + before] = i;
+    }
+    return;
+  }
   int p2 = 1;
   while (p2 < n) p2 <<= 1;
   for (int i = tid; i < p2; i += SORT_THREADS) {
@@ -138,18 +156,17 @@ sort_kernel(BatchDev b) {
     s_idx[i] = i < n ? i : 0x7fffffff;
   }
   __syncthreads();
-  // bitonic sort on (key, index): the index makes every pair distinct => equals the stable order
+  // bitonic sort on (key, index): the index makes every pair distinct => equals the stable order.  One compare-exchange
+  // per lane and step: pair p of a step with stride j is (i, i | j) with i = p's bits spread around bit j.
   for (int k = 2; k <= p2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < p2; i += SORT_THREADS) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long ka = s_key[i], kb = s_key[ixj];
-          const int ia = s_idx[i], ib = s_idx[ixj];
-          const bool gt = ka > kb || (ka == kb && ia > ib);
-          const bool up = (i & k) == 0;
-          if (gt == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
-        }
+      for (int p = tid; p < p2 / 2; p += SORT_THREADS) {
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+        const unsigned long long ka = s_key[i], kb = s_key[ixj];
+        const int ia = s_idx[i], ib = s_idx[ixj];
+        const bool gt = ka > kb || (ka == kb && ia > ib);
+        const bool up = (i & k) == 0;
+        if (gt == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
       }
       __syncthreads();
     }
@@ -264,14 +281,12 @@ msort_chunk_kernel(BatchDev b, int r, unsigned long long *keys, int *idx) {
   __syncthreads();
   for (int k = 2; k <= CHUNK; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < CHUNK; i += SORT_THREADS) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long ka = s_key[i], kb = s_key[ixj];
-          const int ia = s_idx[i], ib = s_idx[ixj];
-          const bool up = (i & k) == 0;
-          if (pair_lt(kb, ib, ka, ia) == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
-        }
+      for (int p = tid; p < CHUNK / 2; p += SORT_THREADS) {  // one compare-exchange per lane (see sort_kernel)
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+        const unsigned long long ka = s_key[i], kb = s_key[ixj];
+        const int ia = s_idx[i], ib = s_idx[ixj];
+        const bool up = (i & k) == 0;
+        if (pair_lt(kb, ib, ka, ia) == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
       }
       __syncthreads();
     }
