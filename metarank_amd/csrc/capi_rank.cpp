@@ -5,6 +5,7 @@
 
 #include "features.hpp"
 #include "jit.hpp"
+#include "launch_shape.hpp"
 #include "qs_device.hpp"
 #include "rank.hpp"
 #include "runtime.hpp"
@@ -271,30 +272,11 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   while ((int)vals < hb.max_doubles) vals <<= 1;
   b.fused_entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
   b.fused_vals = (int)vals;
-  b.fused_threads = std::min(256, std::max(64, (hb.max_items + 63) / 64 * 64));
   const Switches &sw = switches();
-  if (sw.fused_threads) b.fused_threads = sw.fused_threads;  // experiments
-  // A handful of requests cannot fill the chip with one or two wavefronts each: their workgroups get copies of the item
-  // lanes that split the program's ops between them (<= 512 lanes per workgroup).  MRK_FUSED_SPLIT forces 1 | 2 | 4.
-  b.fused_split = 1;
-  if (b.fused_threads <= 256) {
-    const int fit = b.fused_threads <= 128 ? 4 : 2;
-    if (sw.fused_split) b.fused_split = std::min(fit, sw.fused_split);
-    else if (n_req <= 16) b.fused_split = fit;
-  }
-  // Few LARGE requests (c3: 384 x 1 000 candidates = 1.5 workgroups per CU, each looping 4 times over its 256 lanes): cover
-  // a request with several workgroups as long as the launch stays within ONE residency of the chip (4 096 wavefronts at
-  // the 4 per SIMD the specialised kernel runs with) - measured (profiles/r02_r_slices.txt): 384 requests 0.62 -> 0.43 ms
-  // with 2 slices (0.47 / 0.48 with 3 / 4: a second wave of workgroups pays the pre-pass again for nothing), 96 requests
-  // 0.52 -> 0.21 ms with 4.  MRK_FUSED_SLICES forces a count (1 = off).
-  b.fused_slices = 1;
-  {
-    const int waves = b.fused_threads / 64;
-    const int rounds = (hb.max_items + b.fused_threads - 1) / std::max(b.fused_threads, 1);
-    if (sw.fused_slices) b.fused_slices = std::max(1, std::min(rounds, sw.fused_slices));
-    else if (b.fused_split == 1 && rounds > 1) b.fused_slices = std::max(1, std::min(rounds, 4096 / std::max(1, n_req * waves)));
-  }
-  b.fused_threads *= b.fused_split;
+  const FusedShape shape = fused_launch_shape(n_req, hb.max_items, sw.fused_threads, sw.fused_split, sw.fused_slices);  // launch_shape.hpp
+  b.fused_split = shape.split;
+  b.fused_slices = shape.slices;
+  b.fused_threads = shape.threads();
   b.fused_ok = sw.rank_fused && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
                hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR) <= 64 * 1024;
 }
@@ -553,6 +535,18 @@ int mrk_store_increment(mrk_ctx *ctx, const char *key, int64_t inc) { STORE_PUT(
 int mrk_store_append(mrk_ctx *ctx, const char *key, const char *value, int64_t ts_ms) { STORE_PUT(append(key, value, ts_ms)); }
 
 /* not part of include/mrk.h (measurement aid, Store::clone_items): grows the ITEM table to (copies + 1) x its size */
+// launch_shape.hpp through the C ABI, for tests without a device: out = {lanes per workgroup, op split, slices}
+int mrk_debug_fused_shape(int n_req, int max_items, int *out3) {
+  const mrk::FusedShape s = mrk::fused_launch_shape(n_req, max_items);
+  out3[0] = s.threads();
+  out3[1] = s.split;
+  out3[2] = s.slices;
+  return MRK_OK;
+}
+int mrk_debug_scorer_split(int rows, int views, int f64, int n_cus) {
+  return mrk::scorer_waves_per_tile(((long long)rows + mrk::QS_TILE_ROWS - 1) / mrk::QS_TILE_ROWS, views, f64 != 0, n_cus, mrk::QS_LEAVES, mrk::QS_TILE_ROWS);
+}
+
 int mrk_debug_clone_items(mrk_ctx *ctx, int copies, int64_t *out_items) {
   return guard([&] {
     Store &st = store_of(ctx);

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "launch_shape.hpp"
 #include "qs_device.hpp"
 #include "runtime.hpp"
 
@@ -430,35 +431,9 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
   const PackedForestQS &q = m->qs;
   const int V = (int)q.views.size();
   const long long n_tiles = ((long long)rows + QS_TILE_ROWS - 1) / QS_TILE_ROWS;
-  // Wavefronts per tile.  (1) Few tiles (a single request, a 100 000-candidate request on 256 CUs): more wavefronts per
-  // tile walk the forest that many times faster.  (2) Full batches: a tile's slab (V x 256 B) is what limits how many
-  // one-wavefront workgroups a CU holds - 15 at V = 41, 6 at V = 100 - and the kernel needs ~8 wavefronts per SIMD to
-  // keep the VALU fed; NW wavefronts SHARING one slab multiply the residency.  Measured on 384 000 rows x 500 trees
-  // (profiles/r02_l): V = 41: 1 -> 0.283 ms, 2 -> 0.317, 4 -> 0.218, 8 -> 0.220, 16 -> 0.230; 64 columns (V ~ 100):
-  // 1 -> 0.547, 4 -> 0.280, 8 -> 0.248.  So: the smallest NW whose workgroups fill a CU's wavefront slots, else the
-  // NW with the most resident wavefronts.
+  // wavefronts per tile: by residency and fill (launch_shape.hpp has the rule and the measurements behind it)
   const int split_env = switches().qs_split;
-  const long long simds = 4LL * std::max(ctx->n_cus, 1);
-  auto split_lds = [&](int n) { return (size_t)V * 256 + (n > 1 ? (size_t)8 * n * (QS_LEAVES * (F64 ? 8 : 4) + QS_TILE_ROWS) : 0); };
-  int nw = 1;
-  if (split_env >= 0) {
-    nw = split_env;
-  } else {
-    int best_waves = 0;
-    for (int n : {1, 4, 8}) {  // (16 is kept for single requests: measured 5 % behind 4 on a full batch)
-      const size_t lds_n = std::max<size_t>(split_lds(n), 256);  // (a forest of single-leaf trees has no views: V = 0)
-      if (lds_n > 160 * 1024) break;
-      const int resident = std::min<int>(32, n * (int)((160 * 1024) / lds_n));  // wavefronts per CU (32 slots)
-      if (resident > best_waves) { best_waves = resident; nw = n; }
-      if (resident >= 28) break;
-    }
-    int fill = 1;  // few tiles: fill the chip
-    if (n_tiles * 16 <= simds / 2) fill = 16;
-    else if (n_tiles * 8 <= 2 * simds) fill = 8;
-    else if (n_tiles * 4 <= 2 * simds) fill = 4;
-    else if (n_tiles * 2 <= 2 * simds) fill = 2;
-    nw = std::max(nw, fill);
-  }
+  const int nw = split_env >= 0 ? split_env : scorer_waves_per_tile(n_tiles, V, F64, ctx->n_cus, QS_LEAVES, QS_TILE_ROWS);
   if (nw == 2 || nw == 4 || nw == 8 || nw == 16) {
     const size_t lds = (size_t)V * 256 + (size_t)8 * nw * (QS_LEAVES * (F64 ? 8 : 4) + QS_TILE_ROWS);
     if (lds <= 160 * 1024) {
