@@ -246,6 +246,9 @@ size_t DecodedRequest::decode(const uint8_t *bytes, size_t len) {
   req.session = f.in.byte() ? keep(f.in.utf()) : nullptr;
   const int nf = f.i32();
   if (nf < 0) throw StatusError(MRK_ERR_PARSE, "ranking event: negative field count");
+  // a field is at least a name length, a tag and a payload byte: a count beyond the rest of the input is corrupt and must
+  // not size an allocation
+  if ((size_t)nf > (size_t)(f.in.end - f.in.p)) throw StatusError(MRK_ERR_PARSE, "ranking event: field count exceeds the input");
   fields.resize(nf);
   for (int i = 0; i < nf; ++i) read_field(f, fields[i], strs, lists, nums);
   const int ni = f.i32();

@@ -88,7 +88,7 @@ int vector_dim(const json::Value *reduce) {
     bool ok = false;
     for (auto o : one) ok = ok || s == o;
     if (ok) { d += 1; continue; }
-    if (s.rfind("vector", 0) == 0 && s.size() > 6 && std::all_of(s.begin() + 6, s.end(), ::isdigit)) { d += atoi(s.c_str() + 6); continue; }
+    if (s.rfind("vector", 0) == 0 && s.size() > 6 && s.size() <= 6 + 6 && std::all_of(s.begin() + 6, s.end(), ::isdigit)) { d += atoi(s.c_str() + 6); continue; }
     bad("reducer " + s + " is not supported");
   }
   return d;
@@ -101,6 +101,7 @@ static bool parse_duration_ms(const std::string &s, int64_t &out) {
   for (size_t i = 0; i + 1 < s.size(); ++i) {
     if (s[i] < '0' || s[i] > '9') return false;
     n = n * 10 + (s[i] - '0');
+    if (n > 100000000000LL) return false;  // (FiniteDuration is bounded too: ~292 years; 1e11 days is far outside)
   }
   switch (s.back()) {
     case 's': out = n * 1000; return true;

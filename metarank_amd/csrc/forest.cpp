@@ -40,6 +40,10 @@ int64_t Forest::n_categorical() const {
   return n;
 }
 
+// feature indices index the caller's matrix row; beyond this a model is corrupt, and index + 1 must not overflow
+constexpr int MAX_FEATURE_INDEX = 1 << 24;
+constexpr int64_t MAX_CATEGORY = 1 << 24;
+
 static int tree_depth(const Tree &t) {
   if (t.feat.empty()) return 0;
   // iterative DFS; children indices are validated by the callers
@@ -71,6 +75,7 @@ static void validate_tree(const Tree &t, int n_features_hint) {
     chk(t.left[i]);
     chk(t.right[i]);
     if (t.feat[i] < 0) throw std::runtime_error("negative split feature");
+    if (t.feat[i] >= MAX_FEATURE_INDEX) throw std::runtime_error("split feature index out of range");
     (void)n_features_hint;
   }
   // a TREE: every internal node but the root and every leaf hangs under exactly one parent.  (Shared children pass
@@ -179,7 +184,7 @@ Forest parse_lightgbm_text(const char *text, size_t len) {
         cat_boundaries = split_parse<int32_t>(need("cat_boundaries"), toi);
         cat_threshold = split_parse<uint32_t>(
             need("cat_threshold"), [](const std::string &s) { return (uint32_t)strtoul(s.c_str(), nullptr, 10); });
-        if ((int)cat_boundaries.size() != num_cat + 1) throw std::runtime_error("lightgbm: cat_boundaries length");
+        if (cat_boundaries.size() != (size_t)num_cat + 1) throw std::runtime_error("lightgbm: cat_boundaries length");
       }
       t.flags.resize(nn);
       t.cat_begin.assign(nn, 0);
@@ -195,6 +200,7 @@ Forest parse_lightgbm_text(const char *text, size_t len) {
         else if (mt == 2) fl |= NF_MISS_NAN;
         t.flags[i] = fl;
         if (fl & NF_CATEGORICAL) {
+          if (!(t.thr[i] >= 0.0 && t.thr[i] < (double)num_cat)) throw std::runtime_error("lightgbm: categorical threshold index out of range");
           int ci = (int)t.thr[i];
           if (ci < 0 || ci >= num_cat) throw std::runtime_error("lightgbm: categorical threshold index out of range");
           int b = cat_boundaries[ci], e = cat_boundaries[ci + 1];
@@ -243,7 +249,11 @@ Forest parse_lightgbm_text(const char *text, size_t len) {
   if (header.count("num_tree_per_iteration")) num_tree_per_iteration = atoi(header["num_tree_per_iteration"].c_str());
   if (num_class != 1 || num_tree_per_iteration != 1)
     throw std::runtime_error("lightgbm: only single-output models are supported (num_class=1)");
-  if (header.count("max_feature_idx")) f.n_features = atoi(header["max_feature_idx"].c_str()) + 1;
+  if (header.count("max_feature_idx")) {
+    const long mfi = strtol(header["max_feature_idx"].c_str(), nullptr, 10);
+    if (mfi < -1 || mfi >= MAX_FEATURE_INDEX) throw std::runtime_error("lightgbm: max_feature_idx out of range");
+    f.n_features = (int)mfi + 1;
+  }
   if (header.count("objective")) f.objective = header["objective"];
   f.average_output = header.count("average_output") > 0;
   for (auto &t : f.trees)
@@ -328,7 +338,11 @@ void add_xgb_tree(Forest &f, const XgbRawTree &r) {
       auto it = r.categories.find(u);
       if (it == r.categories.end()) throw std::runtime_error("xgboost: categorical node without categories");
       int64_t maxc = -1;
-      for (int64_t c : it->second) maxc = std::max<int64_t>(maxc, c);
+      for (int64_t c : it->second) {
+        if (c < 0) throw std::runtime_error("xgboost: negative category");
+        if (c >= MAX_CATEGORY) throw std::runtime_error("xgboost: category out of range");  // (f32 holds integers up to 2^24 exactly)
+        maxc = std::max<int64_t>(maxc, c);
+      }
       uint32_t words = (uint32_t)(maxc < 0 ? 0 : (maxc / 32 + 1));
       t.cat_begin[id] = (uint32_t)f.cat_bits.size();
       t.cat_words[id] = words;
@@ -464,7 +478,11 @@ Forest parse_xgboost(const uint8_t *bytes, size_t len) {
   const json::Value &learner = root.at("learner");
   const json::Value &lmp = learner.at("learner_model_param");
   f.base_score = (double)lmp.at("base_score").as_float();  // margin space for rank:* objectives (identity link)
-  if (const json::Value *nf = lmp.find("num_feature")) f.n_features = (int)nf->as_int();
+  if (const json::Value *nf = lmp.find("num_feature")) {
+    const int64_t v = nf->as_int();
+    if (v < 0 || v > MAX_FEATURE_INDEX) throw std::runtime_error("xgboost: num_feature out of range");
+    f.n_features = (int)v;
+  }
   if (const json::Value *nc = lmp.find("num_class"))
     if (nc->as_int() > 1) throw std::runtime_error("xgboost: multi-class models are not supported");
   if (const json::Value *obj = learner.find("objective"))
@@ -504,10 +522,11 @@ Forest parse_xgboost(const uint8_t *bytes, size_t len) {
       const auto &segs = jt.at("categories_segments").arr;
       const auto &sizes = jt.at("categories_sizes").arr;
       for (size_t k = 0; k < cn->arr.size(); ++k) {
-        const size_t b = (size_t)segs.at(k).as_int(), sz = (size_t)sizes.at(k).as_int();
-        if (!cats || b + sz > cats->arr.size()) throw std::runtime_error("xgboost: categories segment out of range");
+        const int64_t b = segs.at(k).as_int(), sz = sizes.at(k).as_int();
+        if (!cats || b < 0 || sz < 0 || (uint64_t)b > cats->arr.size() || (uint64_t)sz > cats->arr.size() - (uint64_t)b)
+          throw std::runtime_error("xgboost: categories segment out of range");
         std::vector<int64_t> &v = r.categories[(int)cn->arr[k].as_int()];
-        for (size_t j = 0; j < sz; ++j) v.push_back(cats->arr[b + j].as_int());
+        for (int64_t j = 0; j < sz; ++j) v.push_back(cats->arr[(size_t)(b + j)].as_int());
       }
     }
     add_xgb_tree(f, r);

@@ -343,6 +343,9 @@ class UbjParser {
         if (p_ < end_ && *p_ == '#') { ++p_; count = integer(next()); }
         if (elem_type && count < 0) fail("typed array without count");
         if (count >= 0) {
+          // an element takes at least a byte of input (typed arrays of zero-byte markers are not something a model holds):
+          // a declared count beyond the rest of the input is corrupt - and must not size an allocation
+          if ((uint64_t)count > (uint64_t)(end_ - p_)) fail("array count exceeds the input");
           v.arr.resize((size_t)count);
           for (int64_t k = 0; k < count; ++k) value(v.arr[(size_t)k], elem_type ? elem_type : next(), depth + 1);
         } else {

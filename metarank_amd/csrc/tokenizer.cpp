@@ -309,7 +309,12 @@ Tokenizer Tokenizer::from_json(const char *text, size_t len) {
     for (auto &kv : model.at("vocab").obj) t.vocab_.emplace(kv.first, (int32_t)kv.second.as_int());
     t.vocab_size_ = t.vocab_.size();
     if (const json::Value *p = model.find("continuing_subword_prefix")) if (!p->is_null()) t.prefix_ = p->as_string();
-    if (const json::Value *p = model.find("max_input_chars_per_word")) if (!p->is_null()) t.max_chars_ = (int)p->as_int();
+    if (const json::Value *p = model.find("max_input_chars_per_word"))
+      if (!p->is_null()) {
+        const int64_t v = p->as_int();
+        if (v < 0 || v > (1 << 20)) throw StatusError(MRK_ERR_PARSE, "tokenizer.json: max_input_chars_per_word out of range");
+        t.max_chars_ = (int)v;
+      }
     std::string unk = "[UNK]";
     if (const json::Value *p = model.find("unk_token")) if (!p->is_null()) unk = p->as_string();
     auto u = t.vocab_.find(unk);
@@ -375,7 +380,9 @@ Tokenizer Tokenizer::from_json(const char *text, size_t len) {
     // DJL: truncation=true -> LongestFirst at the JSON's max_length, else 512; padding=true -> BatchLongest
     if (const json::Value *tr = root.find("truncation"))
       if (!tr->is_null()) {
-        t.max_length_ = (int)tr->at("max_length").as_int();
+        const int64_t ml = tr->at("max_length").as_int();
+        if (ml < 0 || ml > (1 << 20)) throw StatusError(MRK_ERR_PARSE, "tokenizer.json: truncation.max_length out of range");
+        t.max_length_ = (int)ml;
         if (const json::Value *d = tr->find("direction")) if (!d->is_null() && d->as_string() != "Right") unsupported("left truncation");
       }
     auto pad = t.vocab_.find("[PAD]");
