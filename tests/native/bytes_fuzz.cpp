@@ -159,8 +159,15 @@ int main(int argc, char **argv) {
   for (int a = 2; a < argc; ++a) {
     const std::string arg = argv[a];
     const size_t colon = arg.find(':');
-    const std::string kind = arg.substr(0, colon), path = arg.substr(colon + 1);
+    std::string kind = arg.substr(0, colon);
+    const std::string path = arg.substr(colon + 1);
     const std::vector<uint8_t> seed = slurp(path);
+    if (kind.rfind("reject-", 0) == 0) {  // a crafted blob (one of the defects the mutation runs found): must end in an error
+      kind = kind.substr(7);
+      if (load(kind, seed)) { printf("crafted blob %s was ACCEPTED\n", arg.c_str()); return 1; }
+      printf("%s: rejected\n", arg.c_str());
+      continue;
+    }
     if (!load(kind, seed)) { printf("seed %s was rejected\n", arg.c_str()); return 1; }
     long ok = 0;
     for (int r = 0; r < rounds; ++r) {

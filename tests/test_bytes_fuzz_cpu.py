@@ -6,6 +6,7 @@ libmrk_hip.so.  No device."""
 import json
 import os
 import shutil
+import struct
 import subprocess
 
 from oracle import codec
@@ -41,8 +42,25 @@ def test_mutated_checkpoints_requests_and_feature_values_never_corrupt_memory(tm
     (tmp_path / "fv.bin").write_bytes(b"".join(codec.feature_value(kind, key, v, compat=(i % 3 == 0)) for i, (kind, key, v) in enumerate(values)))
     (tmp_path / "tok.json").write_text(synth.wordpiece_tokenizer_json(vocab_size=200, max_length=32))
     (tmp_path / "config.json").write_text(json.dumps(ranklens.ranklens_config()))
+    # crafted blobs for the defects the first mutation runs found: must be refused
+    tok = (tmp_path / "tok.json").read_text()
+    cfg = (tmp_path / "config.json").read_text()
+    crafted = {
+        # a ranking event that declares 2^31 - 1 fields and ends: the count sized an allocation (51 GB) before the input was read
+        "request:field_count": codec.utf("r") + struct.pack(">q", 0) + b"\x00\x00" + struct.pack(">i", 2**31 - 1),
+        "tok:max_length": tok.replace('"max_length": 32', '"max_length": -2147483648'),     # signed overflow in the truncation
+        "config:bucket": cfg.replace('"bucket": "24h"', '"bucket": "999999999999999999d"', 1),  # ... in the duration
+    }
+    assert crafted["tok:max_length"] != tok and crafted["config:bucket"] != cfg
+    extra = []
+    for name, blob in crafted.items():
+        kind, fname = name.split(":")
+        path = tmp_path / ("crafted_" + fname)
+        path.write_bytes(blob if isinstance(blob, (bytes, bytearray)) else blob.encode())
+        extra.append(f"reject-{kind}:{path}")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=2048", UBSAN_OPTIONS="print_stacktrace=1")
     out = subprocess.run([exe, "1500", f"ckpt:{tmp_path / 'enc.safetensors'}", f"ckpt:{tmp_path / 'enc.onnx'}", f"request:{tmp_path / 'req.bin'}",
-                          f"fv:{tmp_path / 'fv.bin'}", f"tok:{tmp_path / 'tok.json'}", f"config:{tmp_path / 'config.json'}"], capture_output=True, text=True, env=env, timeout=900)
+                          f"fv:{tmp_path / 'fv.bin'}", f"tok:{tmp_path / 'tok.json'}", f"config:{tmp_path / 'config.json'}"] + extra, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:] + out.stderr[-6000:])
     assert "survived 9000 mutants" in out.stdout, out.stdout
+    assert out.stdout.count(": rejected") == len(crafted), out.stdout

@@ -2,6 +2,8 @@
 (tests/native/forest_fuzz.cpp): a corrupt `LambdaMARTModel` ends in an error status, never in memory corruption.
 forest.cpp is host-only C++ - it is compiled here with g++ and the sanitizers, without the rest of the library."""
 import os
+import re
+import struct
 import subprocess
 
 import numpy as np
@@ -34,7 +36,31 @@ def test_mutated_model_blobs_never_corrupt_memory(tmp_path):
         path = tmp_path / fname
         path.write_bytes(blob if isinstance(blob, (bytes, bytearray)) else blob.encode())
         args.append(f"{kind}:{path}")
+    # the defects the first mutation runs found, as crafted blobs that must be refused (each was memory-unsafe or undefined
+    # behaviour before its fix)
+    xgb = seeds["xgb:xgb.json"].decode()
+    lgbm_text = lgbm.decode() if isinstance(lgbm, (bytes, bytearray)) else lgbm
+    crafted = {
+        "lgbm:num_cat_int_max": lgbm_text.replace("num_cat=3", "num_cat=2147483647", 1),                       # signed overflow in num_cat + 1
+        "lgbm:max_feature_idx": lgbm_text.replace("max_feature_idx=5", "max_feature_idx=2147483647"),          # ... in max_feature_idx + 1
+        "lgbm:cat_boundaries": lgbm_text.replace("cat_boundaries=0 1 2 3", "cat_boundaries=0 1 2 4294967295", 1),
+        "xgb:category_2_40": xgb.replace('"categories":[3,', '"categories":[1099511627776,', 1),           # OOB write: 64-bit index cut to 32 bits
+        "xgb:negative_segment": xgb.replace('"categories_segments":[0,', '"categories_segments":[-1,', 1),  # OOB read: b + sz wrapped
+        "xgb:huge_size": xgb.replace('"categories_sizes":[7,', '"categories_sizes":[9223372036854775807,', 1),
+        "xgb:num_feature": xgb.replace('"num_feature":"6"', '"num_feature":"4294967296"'),
+        # UBJSON: {"learner": [ <count = 2^31 - 1, no elements> : the count sized an allocation before the input was looked at
+        "xgb:ubj_count": b"{i\x07learner[#l" + struct.pack(">i", 2**31 - 1) + b"}",
+        "xgb:ubj_typed_count": b"{i\x07learner[$d#L" + struct.pack(">q", 2**40) + b"}",
+    }
+    for name, blob in crafted.items():
+        kind, fname = name.split(":")
+        data = blob if isinstance(blob, (bytes, bytearray)) else blob.encode()
+        assert data not in [v if isinstance(v, (bytes, bytearray)) else v.encode() for v in seeds.values()], name  # the pattern was found
+        path = tmp_path / ("crafted_" + fname)
+        path.write_bytes(data)
+        args.append(f"reject-{kind}:{path}")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=2048", UBSAN_OPTIONS="print_stacktrace=1")
     out = subprocess.run([exe, "2500"] + args, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:] + out.stderr[-6000:])
     assert "survived 17500 mutants" in out.stdout, out.stdout
+    assert out.stdout.count(": rejected") == len(crafted), out.stdout
