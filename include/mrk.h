@@ -123,7 +123,9 @@ int mrk_model_dim(mrk_ctx *ctx, const char *model_name);
 /* Host-only (no device, no context): what the library builds the first time a model of this config is ranked - the
  * assembly kernel specialised for the model's feature list (the reference fixes that list per model when the config is
  * loaded, M/FeatureMapping.scala:56-99; here it becomes compile-time constants of the kernel).  f64: scorer precision the
- * kernel bins for (1 LightGBM, 0 XGBoost).  what = 0: the HIP source handed to hiprtc; what = 1: the gfx950 code object.
+ * kernel bins for (1 LightGBM, 0 XGBoost).  what = 0: the HIP source handed to hiprtc; what = 1: the gfx950 code object -
+ * of all specialised kernels; `what | (k << 8)`, k = 1..4: of the one kernel the library would compile by itself (1 the
+ * workgroup-per-request kernel of full batches, 2 its op-split / sliced form, 3 its f64-matrix form, 4 the item-parallel kernel).
  * MRK_ERR_INVALID_ARG with *needed set (for what = 1: to an upper bound) when `out` is NULL or `cap` too small; *needed is
  * the exact size on success. */
 int mrk_config_specialize(const char *json, size_t len, const char *model_name, int f64, int what, uint8_t *out, size_t cap,

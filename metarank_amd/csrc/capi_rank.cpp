@@ -448,12 +448,15 @@ int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len) {
 
 int mrk_config_specialize(const char *json, size_t len, const char *model_name, int f64, int what, uint8_t *out, size_t cap, size_t *needed) {
   return guard([&] {
-    if (!json || !model_name || !needed || (what != 0 && what != 1)) throw StatusError(MRK_ERR_INVALID_ARG, "null argument / unknown `what`");
+    const int kernel = (what >> 8) - 1;  // what = (1 + kernel) << 8 | form: one kernel's translation unit; high byte 0: all kernels
+    what &= 0xff;
+    if (!json || !model_name || !needed || (what != 0 && what != 1) || kernel < JIT_ALL || kernel >= JIT_KERNELS)
+      throw StatusError(MRK_ERR_INVALID_ARG, "null argument / unknown `what`");
     Store st;
     std::unique_ptr<Registry> reg = load_config(json, len, st, /*upload=*/false);
     const Program *p = reg->program(model_name);
     if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
-    const std::string src = jit_source(*p, f64 != 0);
+    const std::string src = jit_source(*p, f64 != 0, kernel);
     std::vector<char> code;
     if (what == 1 && out) {  // sizing calls (out == NULL) do not compile
       std::string log;

@@ -54,7 +54,7 @@ uint64_t fnv1a(const std::string &s) {
 
 }  // namespace
 
-std::string jit_source(const Program &prog, bool f64) {
+std::string jit_source(const Program &prog, bool f64, int kernel) {
   std::string s;
   s.reserve(strlen(k_device_source) + 8192);
   s += k_device_source;
@@ -93,23 +93,31 @@ std::string jit_source(const Program &prog, bool f64) {
     const int w = switches().jit_waves >= 1 && switches().jit_waves <= 8 ? switches().jit_waves : 4;
     attr = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(w) + ", " + std::to_string(w) + ")))";
   }
-  s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
-       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
-       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
-  // the same for a handful of requests (mrk_rank): up to 512 lanes per workgroup, the item lanes in op_split copies that
-  // share the program's ops between them (rank_device.hpp op_owner)
-  s += "extern \"C\" __global__ void __launch_bounds__(512)" + attr + "\nmrk_jit_rank_cells_split"
-       "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
-       "  mrk::rank_fused_cells_body<" + std::string(f64 ? "true" : "false") + ", true>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
-  // the same workgroup-per-request kernel writing the row-major f64 matrix (models scored by the tree walk, explain)
-  if (f64)  // one copy per module: the matrix does not depend on the scorer's precision
+  // One kernel per translation unit when `kernel` names one (JIT_ALL: all of them - what tools/jit_inspect.py looks at): a
+  // specialised kernel is ~150 KB of straight-line code and takes the compiler 10 - 20 s, so a model's first rank compiles
+  // the ONE kernel its batch shape runs, not four.
+  const std::string b64 = f64 ? "true" : "false";
+  if (kernel == JIT_ALL || kernel == JIT_RANK)
+    s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
+         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
+         "  mrk::rank_fused_cells_body<" + b64 + ", false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
+  // the same for a handful of requests (mrk_rank) or few large ones: up to 512 lanes per workgroup, the item lanes in
+  // op_split copies that share the program's ops between them (rank_device.hpp op_owner), `slices` workgroups per request
+  if (kernel == JIT_ALL || kernel == JIT_SPLIT)
+    s += "extern \"C\" __global__ void __launch_bounds__(512)" + attr + "\nmrk_jit_rank_cells_split"
+         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
+         "  mrk::rank_fused_cells_body<" + b64 + ", true>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
+  // the same workgroup-per-request kernel writing the row-major f64 matrix (models scored by the tree walk, explain);
+  // the matrix does not depend on the scorer's precision
+  if ((kernel == JIT_ALL && f64) || kernel == JIT_MATRIX)
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_matrix"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, int mode) {\n"
          "  mrk::rank_fused_matrix_body<false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, mode);\n}\n";
   // the item-parallel form (requests too large for one workgroup: tables from a previous pre-pass launch, in HBM)
-  s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
-       "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
-       "  mrk::assemble_cells_body<" + std::string(f64 ? "true" : "false") + ">(st, mrk::JitProg{}, b, q, cells);\n}\n";
+  if (kernel == JIT_ALL || kernel == JIT_ITEMS)
+    s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
+         "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
+         "  mrk::assemble_cells_body<" + b64 + ">(st, mrk::JitProg{}, b, q, cells);\n}\n";
   return s;
 }
 
@@ -138,19 +146,22 @@ std::vector<char> jit_compile(const std::string &source, std::string &log) {
   return code;
 }
 
-struct JitKernels {
-  hipModule_t mod[2] = {nullptr, nullptr};   // [f64]: one module per scorer precision, built when first needed
-  hipFunction_t fn[2] = {nullptr, nullptr};        // mrk_jit_rank_cells
-  hipFunction_t fn_items[2] = {nullptr, nullptr};  // mrk_jit_assemble_cells
-  hipFunction_t fn_matrix = nullptr;               // mrk_jit_rank_matrix (module [1])
-  hipFunction_t fn_split[2] = {nullptr, nullptr};  // mrk_jit_rank_cells_split
-  bool failed[2] = {false, false};
+// one specialised kernel = one module, built when a batch first needs it
+struct JitSlot {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  bool failed = false;
   // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
-  std::thread worker[2];
-  std::atomic<int> state[2] = {{0}, {0}};    // 0 idle, 1 compiling, 2 code ready, 3 failed
-  std::vector<char> code[2];
-  std::string error[2];
+  std::thread worker;
+  std::atomic<int> state{0};    // 0 idle, 1 compiling, 2 code ready, 3 failed
+  std::vector<char> code;
+  std::string error;
 };
+struct JitKernels {
+  JitSlot slot[JIT_KERNELS][2];   // [kernel][f64] (the matrix kernel lives in [JIT_MATRIX][1])
+};
+
+const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells"};
 
 // 0 off; 1 on: the first rank of a model waits for the compile (a failure falls back to the generic kernel with a warning);
 // 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready
@@ -202,19 +213,20 @@ void write_file(const std::string &path, const std::vector<char> &data) {
 
 }  // namespace
 
-// Called WITHOUT the context's launch lock: the first rank of a model compiles for seconds, and other batches keep
-// launching meanwhile.  The program's own mutex serialises callers that want the same kernel.
-void *jit_rank_function(const Program &prog, bool f64) {
+// Called WITHOUT the context's launch lock: the first batch of a shape compiles for seconds, and other batches keep
+// launching meanwhile.  The program's own mutex serialises callers that want a kernel of the same program.
+static void *jit_function(const Program &prog, int kernel, bool f64) {
   const int mode = jit_mode();
   if (mode == 0) return nullptr;
   std::lock_guard<std::mutex> lk(prog.jit_mu);
   if (!prog.jit) prog.jit = new JitKernels();
   JitKernels *k = (JitKernels *)prog.jit;
-  const int v = f64 ? 1 : 0;
-  if (k->fn[v]) return (void *)k->fn[v];
-  if (k->failed[v] && mode != 2) return nullptr;
-  auto produce = [&prog, f64]() {  // host only: no device call (safe on any thread)
-    const std::string src = jit_source(prog, f64);
+  if (kernel == JIT_MATRIX) f64 = true;
+  JitSlot &sl = k->slot[kernel][f64 ? 1 : 0];
+  if (sl.fn) return (void *)sl.fn;
+  if (sl.failed && mode != 2) return nullptr;
+  auto produce = [&prog, f64, kernel]() {  // host only: no device call (safe on any thread)
+    const std::string src = jit_source(prog, f64, kernel);
     const std::string path = cache_path(src);
     std::vector<char> code = read_file(path);
     if (code.empty()) {
@@ -226,52 +238,58 @@ void *jit_rank_function(const Program &prog, bool f64) {
   };
   try {
     std::vector<char> code;
-    if (mode == 3 || k->state[v].load() != 0) {
-      int st = k->state[v].load();
-      if (st == 0) {  // first sight of this (program, precision): start the compile, keep ranking with the generic kernel
-        k->state[v].store(1);
-        k->worker[v] = std::thread([k, v, produce]() {
+    if (mode == 3 || sl.state.load() != 0) {
+      int st = sl.state.load();
+      if (st == 0) {  // first sight of this (program, kernel, precision): start the compile, keep ranking with the generic kernel
+        sl.state.store(1);
+        JitSlot *slot = &sl;
+        sl.worker = std::thread([slot, produce]() {
           try {
-            k->code[v] = produce();
-            k->state[v].store(2);
+            slot->code = produce();
+            slot->state.store(2);
           } catch (const std::exception &e) {
-            k->error[v] = e.what();
-            k->state[v].store(3);
+            slot->error = e.what();
+            slot->state.store(3);
           }
         });
         return nullptr;
       }
       if (st == 1) {
         if (mode != 2 && mode != 1) return nullptr;  // still compiling
-        k->worker[v].join();                         // a synchronous mode took over: wait for it
-        st = k->state[v].load();
+        sl.worker.join();                            // a synchronous mode took over: wait for it
+        st = sl.state.load();
       }
-      if (k->worker[v].joinable()) k->worker[v].join();
-      if (st == 3) throw StatusError(MRK_ERR_DEVICE, k->error[v]);
-      code.swap(k->code[v]);
+      if (sl.worker.joinable()) sl.worker.join();
+      if (st == 3) throw StatusError(MRK_ERR_DEVICE, sl.error);
+      code.swap(sl.code);
     } else {
       code = produce();
     }
-    MRK_HIP(hipModuleLoadData(&k->mod[v], code.data()));
-    MRK_HIP(hipModuleGetFunction(&k->fn[v], k->mod[v], "mrk_jit_rank_cells"));
-    MRK_HIP(hipModuleGetFunction(&k->fn_items[v], k->mod[v], "mrk_jit_assemble_cells"));
-    MRK_HIP(hipModuleGetFunction(&k->fn_split[v], k->mod[v], "mrk_jit_rank_cells_split"));
-    if (v == 1) MRK_HIP(hipModuleGetFunction(&k->fn_matrix, k->mod[v], "mrk_jit_rank_matrix"));
+    MRK_HIP(hipModuleLoadData(&sl.mod, code.data()));
+    MRK_HIP(hipModuleGetFunction(&sl.fn, sl.mod, JIT_KERNEL_NAME[kernel]));
   } catch (const std::exception &e) {
-    k->failed[v] = true;
+    sl.failed = true;
     if (mode == 2) throw;
-    fprintf(stderr, "[mrk] specialised assembly kernel for model '%s' unavailable, using the generic kernel: %s\n", prog.model.c_str(), e.what());
+    fprintf(stderr, "[mrk] specialised kernel %s for model '%s' unavailable, using the generic kernel: %s\n", JIT_KERNEL_NAME[kernel], prog.model.c_str(), e.what());
     return nullptr;
   }
-  return (void *)k->fn[v];
+  return (void *)sl.fn;
 }
+
+void *jit_rank_function(const Program &prog, bool f64) { return jit_function(prog, JIT_RANK, f64); }
+// the item-parallel kernel (nullptr under the same conditions)
+void *jit_items_function(const Program &prog, bool f64) { return jit_function(prog, JIT_ITEMS, f64); }
+// the op-split / sliced form of the fused kernel (small batches, few large requests)
+void *jit_split_function(const Program &prog, bool f64) { return jit_function(prog, JIT_SPLIT, f64); }
+// the f64-matrix form of the fused kernel
+void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_MATRIX, true); }
 
 #ifdef MRK_PHASE_CLOCKS
 // measurement builds: read-and-reset the phase clocks of the specialised kernel of `prog`
 extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *out64) {
   if (!prog || !prog->jit) return -1;
   JitKernels *k = (JitKernels *)prog->jit;
-  hipModule_t mod = k->mod[1] ? k->mod[1] : k->mod[0];
+  hipModule_t mod = k->slot[JIT_RANK][1].mod ? k->slot[JIT_RANK][1].mod : k->slot[JIT_RANK][0].mod;
   hipDeviceptr_t p = nullptr;
   size_t bytes = 0;
   if (!mod || hipModuleGetGlobal(&p, &bytes, mod, "mrk_phase_clocks") != hipSuccess || bytes < 64 * 8) return -2;
@@ -281,37 +299,14 @@ extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *o
 }
 #endif
 
-// the item-parallel kernel of the same module (nullptr under the same conditions as jit_rank_function)
-void *jit_items_function(const Program &prog, bool f64) {
-  if (!jit_rank_function(prog, f64)) return nullptr;
-  std::lock_guard<std::mutex> lk(prog.jit_mu);
-  JitKernels *k = (JitKernels *)prog.jit;
-  return k ? (void *)k->fn_items[f64 ? 1 : 0] : nullptr;
-}
-
-// the op-split form of the fused kernel (small batches)
-void *jit_split_function(const Program &prog, bool f64) {
-  if (!jit_rank_function(prog, f64)) return nullptr;
-  std::lock_guard<std::mutex> lk(prog.jit_mu);
-  JitKernels *k = (JitKernels *)prog.jit;
-  return k ? (void *)k->fn_split[f64 ? 1 : 0] : nullptr;
-}
-
-// the f64-matrix form of the fused kernel (it lives in the f64 module)
-void *jit_matrix_function(const Program &prog) {
-  if (!jit_rank_function(prog, true)) return nullptr;
-  std::lock_guard<std::mutex> lk(prog.jit_mu);
-  JitKernels *k = (JitKernels *)prog.jit;
-  return k ? (void *)k->fn_matrix : nullptr;
-}
-
 void jit_release(Program &prog) {
   if (!prog.jit) return;
   JitKernels *k = (JitKernels *)prog.jit;
-  for (std::thread &t : k->worker)
-    if (t.joinable()) t.join();  // the worker reads `prog`
-  for (hipModule_t m : k->mod)
-    if (m) (void)hipModuleUnload(m);
+  for (auto &per_kernel : k->slot)
+    for (JitSlot &sl : per_kernel) {
+      if (sl.worker.joinable()) sl.worker.join();  // the worker reads `prog`
+      if (sl.mod) (void)hipModuleUnload(sl.mod);
+    }
   delete k;
   prog.jit = nullptr;
 }

@@ -35,6 +35,16 @@ def test_source_carries_the_program_as_constants():
     assert rc == 0 and b"rank_fused_cells_body<false, false>" in src32
     # the normalised rate's weight travels as an exact hexadecimal literal (10.0)
     assert "0x1.4p+3" in text
+    # what the library compiles by itself is ONE kernel per translation unit (the kernel a batch shape needs, 10 - 20 s of
+    # compiler time each instead of 50 s for all four): what = form | (1 + kernel) << 8
+    names = ["mrk_jit_rank_cells(", "mrk_jit_rank_cells_split(", "mrk_jit_rank_matrix(", "mrk_jit_assemble_cells("]
+    flat = text.replace("\n", "")
+    assert all(n in flat for n in names)
+    for k, name in enumerate(names):
+        rc, one = specialize(cfg, 0 | ((k + 1) << 8))
+        one = one.decode().replace("\n", "")
+        assert rc == 0 and name in one and not any(o in one for o in names if o != name), name
+    assert specialize(cfg, 0 | (9 << 8))[0] == _native.ERR_INVALID_ARG
 
 
 def test_unknown_model_and_bad_arguments():
@@ -49,9 +59,11 @@ def test_unknown_model_and_bad_arguments():
 @pytest.mark.parametrize("which,f64", [("c2", 1), ("c3", 0)])
 def test_hiprtc_compiles_the_specialised_kernel_for_gfx950(which, f64):
     cfg = ranklens.c3_config() if which == "c3" else ranklens.ranklens_config()
-    rc, code = specialize(cfg, 1, f64=f64)
+    kernel = 1 if which == "c2" else 2  # c2: the kernel of full batches; c3: the sliced form its batches run
+    rc, code = specialize(cfg, 1 | (kernel << 8), f64=f64)
     assert rc == 0, _native.lib().mrk_last_error()
-    assert code[:4] == b"\x7fELF" and b"mrk_jit_rank_cells" in code and b"gfx950" in code
+    assert code[:4] == b"\x7fELF" and b"gfx950" in code
+    assert (b"mrk_jit_rank_cells_split" in code) == (kernel == 2) and b"mrk_jit_rank_cells" in code and b"mrk_jit_assemble_cells" not in code
 
 
 def test_compiles_when_torch_brought_its_own_rocm_libraries(tmp_path):
@@ -71,9 +83,9 @@ from workloads import ranklens
 lib = _native.lib()
 js = json.dumps(ranklens.ranklens_config()).encode()
 need = C.c_size_t(0)
-lib.mrk_config_specialize(js, len(js), b"xgboost", 1, 1, None, 0, C.byref(need))
+lib.mrk_config_specialize(js, len(js), b"xgboost", 1, 1 | (3 << 8), None, 0, C.byref(need))
 buf = (C.c_uint8 * need.value)()
-rc = lib.mrk_config_specialize(js, len(js), b"xgboost", 1, 1, buf, need.value, C.byref(need))
+rc = lib.mrk_config_specialize(js, len(js), b"xgboost", 1, 1 | (3 << 8), buf, need.value, C.byref(need))
 maps = open("/proc/%%d/maps" %% os.getpid()).read()
 print("RC", rc, bytes(buf[:4]) == b"\x7fELF", "torch/lib/libhiprtc" in maps)
 """ % repo
