@@ -57,6 +57,14 @@ def test_store_loaded_from_binary_ranks_like_typed_puts():
         ma = np.concatenate([a.matrix(ev) for ev in reqs])
         mb = np.concatenate([b.matrix(ev) for ev in reqs])
         assert ((ma == mb) | (np.isnan(ma) & np.isnan(mb))).all()
+        # ... and like the ORACLE given the same values through its typed puts: the binary-loaded device store against an
+        # implementation that shares nothing with it (not only HIP against HIP)
+        from backends import OracleBackend
+
+        o = OracleBackend(cfg, "xgboost")
+        ranklens.load_state(o, iter(state))
+        mo = np.concatenate([o.matrix(ev) for ev in reqs])
+        assert ((mb == mo) | (np.isnan(mb) & np.isnan(mo))).all()
         model = synth.synthetic_lgbm_model(n_trees=100, n_features=64, quantiles=ranklens.column_quantiles(ma))
         a.load_model(model, 0)
         b.load_model(model, 0)
@@ -105,10 +113,18 @@ def test_binary_requests_and_container_warmup():
         names = cfg["models"]["xgboost"]["features"]
         blob = synth.write_container(names, 0, inner, warmup=[codec.ranking_event(ev) for ev in reqs[:3]])
         booster = hip.M.HipBooster.from_container(blob, names, hip.ctx)
+        # the oracle with the same state and the container's inner model: what the binary path must reproduce
+        from backends import OracleBackend
+
+        oracle = OracleBackend(cfg, "xgboost")
+        ranklens.load_state(oracle, ranklens.generate_state(2000, 200))
+        oracle.load_model(inner, 0)
         for ev in reqs:
             _, s1, o1 = hip.ranker.rerank("xgboost", ev, booster)
             s2, o2 = hip.ranker.rerank_binary("xgboost", codec.ranking_event(ev), booster)
             assert np.array_equal(s1, s2) and o1.tolist() == o2.tolist()
+            _, s3, o3 = oracle.rerank(ev)
+            assert np.array_equal(s2, s3) and o2.tolist() == o3.tolist()
         assert hip.ranker.warmup("xgboost", booster) == 3
         with pytest.raises(hip.M.MrkError):
             hip.ranker.rerank_binary("xgboost", codec.ranking_event(reqs[0]), booster, capacity=10)  # more items than room
