@@ -64,3 +64,21 @@ def test_percentile_legacy():
     assert p([10, 20, 40, 15, 5]) == 15.0 and p([10, 20, 30]) == 20.0 and p([7.0]) == 7.0
     assert p([1, 2, 4, 8]) == 3.0 and p([1, 2]) == 1.5 and p([5, NAN, 1]) == 3.0
     assert math.isnan(p([NAN]))
+
+
+def test_percentile_legacy_is_the_r6_estimator():
+    """commons-math `Percentile.evaluate(50)` (LEGACY) is Hyndman-Fan type 6, pos = p (n + 1) - numpy's method 'weibull', an
+    implementation that shares nothing with the oracle: identical for odd n (the median is an element), within an ulp of the neighbours for
+    even n (numpy interpolates from the upper neighbour when the weight is >= 0.5, commons-math always from the lower:
+    `lower + d * (upper - lower)`, which is what the oracle and the device compute)."""
+    rng = np.random.default_rng(5)
+    for t in range(1500):
+        n = int(rng.integers(1, 80))
+        x = rng.normal(size=n) if t % 3 == 0 else rng.integers(0, 10, size=n).astype(float) if t % 3 == 1 else np.round(rng.normal(size=n) * 1e6) / 1e3
+        got = A.lib().orc_percentile50(np.ascontiguousarray(x).ctypes.data_as(C.c_void_p), n)
+        want = float(np.percentile(x, 50, method="weibull"))
+        if n % 2 == 1:
+            assert got == want, (n, got, want)
+        else:
+            lo, hi = np.sort(x)[n // 2 - 1], np.sort(x)[n // 2]
+            assert got == lo + 0.5 * (hi - lo) and abs(got - want) <= 2 * np.spacing(max(abs(lo), abs(hi))), (n, got, want)
