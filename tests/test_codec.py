@@ -18,6 +18,21 @@ def test_varnum_known_answers():  # util/VarNum.java = unsigned LEB128 (hand-com
     assert codec.f64(1.0) == b"\x3f\xf0" + b"\x00" * 6
 
 
+def test_varnum_is_protobuf_varint():
+    """util/VarNum.java's layout is the protobuf base-128 varint of the 64-bit two's complement; protobuf's own encoder
+    (an implementation that shares nothing with oracle/codec.py or csrc/codec.cpp) writes the same bytes."""
+    import random
+
+    from google.protobuf.internal.encoder import _VarintBytes
+
+    rnd = random.Random(1)
+    for _ in range(5000):
+        v = rnd.getrandbits(rnd.randint(1, 63)) * rnd.choice((1, 1, -1))
+        assert codec.var_long(v) == _VarintBytes(v & (2**64 - 1)), v
+        if -2**31 <= v < 2**31:
+            assert codec.var_int(v) == _VarintBytes(v & (2**32 - 1)), v
+
+
 def test_roundtrip_of_the_reference_test_values():  # T/fstore/redis/codec/impl/FeatureValueCodecTest.scala:27-53
     k, ts = "user=u1/foo", 1661345221008
     values = [("string", "foo"), ("counter", 1), ("numstats", (1.0, 2.0, {1: 1.0})), ("map", {"foo": ("string", "bar")}),
