@@ -125,6 +125,34 @@ def main():
     import metarank_amd as M
     from workloads import ranklens, synth
 
+    if os.environ.get("MRK_BENCH_DRY_DIST"):
+        # No device: walk the multi-process start-up as far as it goes without one (tests/test_dist_cpu.py launches this
+        # with 2 ranks on the CPU box) - the communicator id hand-over between the launcher's children, the argument checks of
+        # mrk_comm_init, and the library's own shard arithmetic for this workload's request.
+        import ctypes as C
+        from metarank_amd import _native as N
+        from metarank_amd.dist import exchange_unique_id_file
+
+        L = N.lib()
+
+        def make_id():
+            buf = (C.c_uint8 * 128)()
+            if L.mrk_comm_unique_id(buf) != N.MRK_OK:   # RCCL may refuse to draw an id on a host without a GPU
+                return bytes((7 * i + 1) & 0xff for i in range(128))
+            return bytes(buf)
+
+        comm_key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_dry"
+        uid = exchange_unique_id_file(rank, n_gpus, make_id, comm_key)
+        assert len(uid) == 128
+        rc = L.mrk_comm_init(None, uid, rank, n_gpus)   # no context: the call must get as far as its argument checks
+        assert rc == N.ERR_INVALID_ARG, rc
+        items = args.items or {"c2": 100, "c3": 1000, "c4": 100_000, "c4x": 100_000 * (args.clones + 1) // 2, "c5": 100}[wl]
+        lo, hi = C.c_int64(), C.c_int64()
+        assert L.mrk_shard_range(items, rank, n_gpus, C.byref(lo), C.byref(hi)) == N.MRK_OK
+        print(json.dumps({"dry": True, "rank": rank, "world": n_gpus, "uid_crc": sum(uid) & 0xffff, "items": items,
+                          "chunk": int(L.mrk_shard_chunk(items, n_gpus)), "lo": lo.value, "hi": hi.value}), flush=True)
+        return
+
     ctx = M.Context(local_rank)
     if use_dist:
         from metarank_amd.dist import exchange_unique_id_file

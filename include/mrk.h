@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MRK_ABI_VERSION 5
+#define MRK_ABI_VERSION 6
 
 typedef enum mrk_status {
   MRK_OK = 0,
@@ -258,7 +258,14 @@ int mrk_batch_prepare(mrk_ctx *ctx, const char *model_name, const mrk_request *r
 typedef struct mrk_item_ids {
   const uint8_t *bytes;     /* concatenated UTF-8 ids, no terminators                  */
   const uint32_t *offsets;  /* total_items + 1 byte offsets into `bytes`, ascending    */
+  size_t bytes_len;         /* size of `bytes`: offsets[total_items] must not exceed it.  Offsets come off the wire: a
+                               batch whose last offset passes bytes_len is refused (MRK_ERR_INVALID_ARG); an item whose
+                               offsets descend or pass bytes_len fails ITS request with MRK_ERR_INVALID_ARG (checked by
+                               the id-resolution kernel, and by the host wherever it reads an id itself)            */
 } mrk_item_ids;
+/* LIFETIME of ids->bytes / ids->offsets: pinned buffers (mrk_host_alloc) are read by the copy engine AFTER mrk_batch_load
+ * has returned - do not rewrite or free them before the next mrk_batch_sync / mrk_batch_host_outputs / mrk_batch_fetch of
+ * this batch.  Pageable memory is copied before mrk_batch_load returns and may be reused at once. */
 int mrk_batch_create(mrk_ctx *ctx, mrk_batch **out);
 int mrk_batch_load(mrk_batch *batch, const char *model_name, const mrk_request *reqs, int n_req, const mrk_item_ids *ids);
 int mrk_batch_enqueue_fetch(mrk_batch *batch);
@@ -277,6 +284,13 @@ int mrk_batch_run(mrk_batch *batch, mrk_model *model);
  * slices of all shards into the device score buffer (one all-gather of chunk * count f64; the buffer
  * has room for the padded tail) and then calls mrk_batch_sort on the rank(s) that need the order. */
 int mrk_batch_shard_chunk(mrk_batch *batch, int shard_count);
+/* The shard arithmetic by itself - host-only, no context, no device (a host lays out its buffers with it, the CPU tests
+ * of the N > 1 path check it): mrk_shard_chunk = ceil(total_items / shard_count) rounded up to whole MRK_SHARD_TILE-item
+ * scorer tiles (negative mrk_status on bad arguments); mrk_shard_range = the items [lo, hi) shard `shard_index` assembles
+ * and scores: [index * chunk, (index + 1) * chunk) clipped to total_items (trailing shards may be empty). */
+#define MRK_SHARD_TILE 128
+int64_t mrk_shard_chunk(int64_t total_items, int shard_count);
+int mrk_shard_range(int64_t total_items, int shard_index, int shard_count, int64_t *lo, int64_t *hi);
 int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int shard_count);
 int mrk_batch_sort(mrk_batch *batch);
 /* A prepared batch owns a HIP stream: batches of one context may be in flight together (mrk_batch_run is
@@ -316,7 +330,12 @@ int mrk_comm_barrier(mrk_ctx *ctx);
 /* Item-sharded rank of a batch over the communicator's ranks (every rank holds the same batch and a replica of the
  * store): this rank's slice is assembled and scored (mrk_batch_run_shard with the communicator's rank / world), ONE
  * in-place ncclAllGather of the score slices on the batch's stream, then the sort - every rank ends up with all scores
- * and the order.  Asynchronous like mrk_batch_run.  Without a communicator it is mrk_batch_run. */
+ * and the order.  Per-request status words are merged too (an item that fails its request - dim mismatch, an XGBoost inf -
+ * sits in ONE rank's slice: the words of all ranks are all-gathered and OR-ed before the sort, so every rank reports what
+ * the single-GPU path reports).  Asynchronous like mrk_batch_run.  Without a communicator it is mrk_batch_run.
+ * COLLECTIVE ORDER: all ranks must issue the collectives of a communicator (these calls, mrk_comm_max_f64, _barrier) in
+ * the same order; the library serialises them per context, so driving several batches from several host threads is safe
+ * only if every rank runs them in one agreed order. */
 int mrk_batch_run_sharded(mrk_batch *batch, mrk_model *model);
 /* the all-gather step alone: after mrk_batch_run_shard(batch, model, mrk_comm_rank, mrk_comm_world) on every rank */
 int mrk_batch_allgather_scores(mrk_batch *batch);

@@ -118,7 +118,7 @@ class mrk_request(C.Structure):
 
 
 class mrk_item_ids(C.Structure):
-    _fields_ = [("bytes", C.c_void_p), ("offsets", C.c_void_p)]
+    _fields_ = [("bytes", C.c_void_p), ("offsets", C.c_void_p), ("bytes_len", C.c_size_t)]
 
 
 # every symbol include/mrk.h declares: (restype, argtypes)
@@ -167,6 +167,8 @@ SIGNATURES = {
     "mrk_batch_run": (_I, [_V, _V]),
     "mrk_batch_shard_chunk": (_I, [_V, _I]),
     "mrk_batch_run_shard": (_I, [_V, _V, _I, _I]),
+    "mrk_shard_chunk": (C.c_int64, [C.c_int64, _I]),
+    "mrk_shard_range": (_I, [C.c_int64, _I, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mrk_batch_sort": (_I, [_V]),
     "mrk_batch_stream": (_V, [_V]),
     "mrk_batch_sync": (_I, [_V]),

@@ -15,6 +15,7 @@ namespace mrk {
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries);
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_sort(mrk_ctx *ctx, const BatchDev &b);
+void launch_status_or(hipStream_t stream, const int32_t *all, int world, int n_req, int32_t *status);
 void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode);
 void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx);
 size_t big_sort_padded(int n_items);
@@ -28,8 +29,8 @@ size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
-void launch_resolve_ids(hipStream_t stream, const IdTableDev &tab, const uint8_t *d_bytes, const uint32_t *d_offs, const ReqDev *d_reqs,
-                        int n_req, int total, int32_t *d_item_slot, uint32_t *d_item_req);  // resolve.hip
+void launch_resolve_ids(hipStream_t stream, const IdTableDev &tab, const uint8_t *d_bytes, const uint32_t *d_offs, uint32_t bytes_len, const ReqDev *d_reqs,
+                        int n_req, int total, int32_t *d_item_slot, uint32_t *d_item_req, int32_t *d_load_status);  // resolve.hip
 
 template <typename F>
 static int guard(F &&f) {
@@ -59,6 +60,7 @@ int status_to_code(int st, std::string &msg) {
   if (st & ST_DIM) { msg = "dim mismatch: item embedding is shorter than the query embedding"; return MRK_ERR_DIM_MISMATCH; }
   if (st & ST_ILLEGAL_ARG) { msg = "requirement failed: Duration is limited to +-(2^63-1)ns (ca. 292 years)"; return MRK_ERR_INVALID_ARG; }
   if (st & 32) { msg = "Input data contains `inf` or a value too large, while `missing` is not set to `inf`"; return MRK_ERR_INVALID_ARG; }
+  if (st & ST_BAD_IDS) { msg = "item id offsets descend or pass bytes_len (mrk_item_ids)"; return MRK_ERR_INVALID_ARG; }
   if (st & ST_NORM_TOO_MANY) { msg = "norm: position over more than 4096 candidates is not supported on the device"; return MRK_ERR_UNSUPPORTED; }
   if (st & ST_TOO_MANY) { msg = "diversity over more values than the device pre-pass supports: set `top`"; return MRK_ERR_UNSUPPORTED; }
   if (st & ST_TABLE_FULL) { msg = "internal: pre-pass hash table under-sized (store changed between prepare and run?)"; return MRK_ERR_DEVICE; }
@@ -77,13 +79,15 @@ struct mrk_batch {
   DevBuf d_in, d_prep_out, d_arena, d_matrix;
   hipStream_t stream = nullptr;   // batches made by mrk_batch_prepare / _create own a stream: several can be in flight on one device
   hipStream_t s() const { return stream ? stream : ctx->stream; }
-  DevBuf d_out;              // [scores: (T + shard padding) f64][order: T i32][status: n_req i32], fetched with ONE copy
+  DevBuf d_out;              // [scores: (T + shard padding) f64][order: T i32][status: n_req i32][load status: n_req i32], fetched with ONE copy
+                             // (load status: what the id-resolution kernel found at load time - ST_BAD_IDS; status is zeroed by every run)
   size_t out_order_off = 0, out_status_off = 0, out_bytes = 0;
   PinBuf h_out;
   bool fetch_enqueued = false;          // the download of d_out into h_out is on the stream behind the last run
   DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
   DevBuf d_sort_keys, d_sort_idx;       // scratch of the multi-workgroup sort
   DevBuf d_gather;                      // mrk_batch_gather_scores: the scores of every rank
+  DevBuf d_gather_status;               // item-sharded runs: the status words of every rank ([world][n_req]) before they are OR-ed
   std::vector<std::pair<int, int>> big; // (request, n_items) with n_items > SORT_MAX_ITEMS
   PinBuf h_in;
   HostBatch hb;              // host half of the last load (grow-only scratch)
@@ -206,11 +210,21 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   }
   MRK_HIP(hipMemcpyAsync(b.d_in.p, h, up_bytes, hipMemcpyHostToDevice, b.s()));
   uint8_t *d = b.d_in.as<uint8_t>();
+  // outputs in one allocation: one device-to-host copy per fetch (single-request latency)
+  const size_t score_slots = (size_t)T + 256 * QS_TILE_ROWS;  // room for the padded chunks of an item-sharded all-gather
+  b.out_order_off = align_up(score_slots * 8, 256);
+  b.out_status_off = align_up(b.out_order_off + std::max<size_t>(T, 1) * 4, 256);
+  b.out_bytes = b.out_status_off + 2 * std::max<size_t>(n_req, 1) * 4;
+  b.d_out.reserve(b.out_bytes);
+  int32_t *d_load_status = (int32_t *)(b.d_out.as<uint8_t>() + b.out_status_off) + std::max(n_req, 1);
+  MRK_HIP(hipMemsetAsync(d_load_status, 0, std::max<size_t>(n_req, 1) * 4, b.s()));
   if (hb.device_ids && T > 0) {
     // the ids as they arrived: [offsets][bytes] in one device buffer; pinned caller memory is read by the copy engine
     // directly, anything else goes through the batch's pinned staging buffer
     const size_t off_bytes = ((size_t)T + 1) * 4;
     const size_t id_bytes = ids->offsets[T];
+    if (id_bytes > ids->bytes_len || ids->bytes_len > 0xffffffffull)
+      throw StatusError(MRK_ERR_INVALID_ARG, "mrk_item_ids: the last offset passes bytes_len (or bytes_len >= 4 GiB)");
     const size_t o_bytes = align_up(off_bytes, 256);
     b.d_ids.reserve(o_bytes + std::max<size_t>(id_bytes, 1));
     const void *src_off = ids->offsets, *src_bytes = ids->bytes;
@@ -223,16 +237,10 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
     }
     MRK_HIP(hipMemcpyAsync(b.d_ids.p, src_off, off_bytes, hipMemcpyHostToDevice, b.s()));
     if (id_bytes) MRK_HIP(hipMemcpyAsync(b.d_ids.as<uint8_t>() + o_bytes, src_bytes, id_bytes, hipMemcpyHostToDevice, b.s()));
-    launch_resolve_ids(b.s(), store.tables[SC_ITEM].id_table_view(), b.d_ids.as<uint8_t>() + o_bytes, b.d_ids.as<uint32_t>(),
-                       (const ReqDev *)(d + o_reqs), n_req, T, (int32_t *)(d + o_slot), (uint32_t *)(d + o_ireq));
+    launch_resolve_ids(b.s(), store.tables[SC_ITEM].id_table_view(), b.d_ids.as<uint8_t>() + o_bytes, b.d_ids.as<uint32_t>(), (uint32_t)id_bytes,
+                       (const ReqDev *)(d + o_reqs), n_req, T, (int32_t *)(d + o_slot), (uint32_t *)(d + o_ireq), d_load_status);
   }
   b.d_arena.reserve(std::max<size_t>(hb.arena_entries, 1) * 8);
-  // outputs in one allocation: one device-to-host copy per fetch (single-request latency)
-  const size_t score_slots = (size_t)T + 256 * QS_TILE_ROWS;  // room for the padded chunks of an item-sharded all-gather
-  b.out_order_off = align_up(score_slots * 8, 256);
-  b.out_status_off = align_up(b.out_order_off + std::max<size_t>(T, 1) * 4, 256);
-  b.out_bytes = b.out_status_off + std::max<size_t>(n_req, 1) * 4;
-  b.d_out.reserve(b.out_bytes);
   b.d_matrix.reserve(std::max<size_t>((size_t)T * prog.dim, 1) * 8);
   BatchDev &v = b.view;
   v.reqs = (const ReqDev *)(d + o_reqs);
@@ -307,10 +315,8 @@ static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &
 }
 
 // items per shard of an item-sharded run: ceil(total / count) rounded up to whole scorer tiles
-static int shard_chunk(const mrk_batch &b, int count) {
-  const long long per = ((long long)b.total_items + count - 1) / count;
-  return (int)((per + QS_TILE_ROWS - 1) / QS_TILE_ROWS * QS_TILE_ROWS);
-}
+static_assert(MRK_SHARD_TILE == QS_TILE_ROWS, "a shard is a whole number of scorer tiles");
+static int shard_chunk(const mrk_batch &b, int count) { return (int)mrk_shard_chunk(b.total_items, count); }
 
 static void sort_batch(mrk_batch &b) {
   mrk_ctx *ctx = b.ctx;
@@ -400,7 +406,7 @@ static void enqueue_fetch(mrk_batch &b, bool scores, bool order) {
   } else {                   // else the used ranges
     if (scores && T) MRK_HIP(hipMemcpyAsync(h, d, T * 8, hipMemcpyDeviceToHost, b.s()));
     if (order && T) MRK_HIP(hipMemcpyAsync(h + b.out_order_off, d + b.out_order_off, T * 4, hipMemcpyDeviceToHost, b.s()));
-    if (b.n_req) MRK_HIP(hipMemcpyAsync(h + b.out_status_off, d + b.out_status_off, (size_t)b.n_req * 4, hipMemcpyDeviceToHost, b.s()));
+    MRK_HIP(hipMemcpyAsync(h + b.out_status_off, d + b.out_status_off, 2 * std::max<size_t>(b.n_req, 1) * 4, hipMemcpyDeviceToHost, b.s()));  // status + load status
   }
 }
 
@@ -421,7 +427,8 @@ static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *ma
   const uint8_t *h = b.h_out.as<uint8_t>();
   if (scores && T) memcpy(scores, h, T * 8);
   if (order && T) memcpy(order, h + b.out_order_off, T * 4);
-  if (b.n_req) memcpy(b.h_status.data(), h + b.out_status_off, (size_t)b.n_req * 4);
+  const int32_t *hs = (const int32_t *)(h + b.out_status_off), *hl = hs + std::max(b.n_req, 1);
+  for (int r = 0; r < b.n_req; ++r) b.h_status[(size_t)r] = hs[r] | hl[r];
   if (ctx->profile) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     drain_profile_events(ctx);
@@ -625,6 +632,10 @@ void rank_tickets(mrk_ctx *ctx, RankTicket **tk, int n) {
     StoreAccess access(ctx, program_mutates_store(prog));
     if (!ctx->rank_scratch) ctx->rank_scratch = new mrk_batch();  // grow-only: no hipMalloc / hipFree per request
     mrk_batch &b = *(mrk_batch *)ctx->rank_scratch;
+    if (b.ctx) {  // a previous call that failed before its fetch may have left an upload from h_in in flight
+      MRK_HIP(hipSetDevice(ctx->device));
+      MRK_HIP(hipStreamSynchronize(b.s()));
+    }
     std::vector<mrk_request> reqs(n);
     for (int i = 0; i < n; ++i) reqs[i] = *tk[i]->req;
     build_batch(ctx, prog, reqs.data(), n, nullptr, b);
@@ -828,10 +839,9 @@ int mrk_batch_run_shard(mrk_batch *batch, mrk_model *model, int shard_index, int
       throw StatusError(MRK_ERR_INVALID_ARG, "bad shard index / count (1..256 shards)");
     std::lock_guard<std::mutex> bl(batch->bmu);
     StoreAccess access(batch->ctx, false, false);
-    const int chunk = shard_chunk(*batch, shard_count);
-    const int lo = std::min<long long>((long long)chunk * shard_index, batch->total_items);
-    const int hi = std::min<long long>((long long)chunk * (shard_index + 1), batch->total_items);
-    run_batch(*batch, model, lo, hi, false);
+    int64_t lo = 0, hi = 0;
+    if (mrk_shard_range(batch->total_items, shard_index, shard_count, &lo, &hi) != MRK_OK) throw StatusError(MRK_ERR_INVALID_ARG, "bad shard");
+    run_batch(*batch, model, (int)lo, (int)hi, false);
   });
 }
 
@@ -844,6 +854,12 @@ int mrk_batch_allgather_scores(mrk_batch *batch) {
     MRK_HIP(hipSetDevice(ctx->device));
     // the score buffer has room for the padded chunks of up to 256 shards (build_batch)
     comm_allgather_f64_inplace(ctx, batch->view.scores, (size_t)shard_chunk(*batch, ctx->comm_world), batch->s());
+    // the status words too: an item that fails its request lies in ONE rank's slice, every rank must report it
+    if (batch->n_req > 0) {
+      batch->d_gather_status.reserve((size_t)ctx->comm_world * batch->n_req * 4);
+      comm_allgather_i32(ctx, batch->view.status, batch->d_gather_status.as<int32_t>(), (size_t)batch->n_req, batch->s());
+      launch_status_or(batch->s(), batch->d_gather_status.as<int32_t>(), ctx->comm_world, batch->n_req, batch->view.status);
+    }
     batch->fetch_enqueued = false;
   });
 }

@@ -10,6 +10,7 @@
 // has (bench.py: one TCP message to MASTER_ADDR:MASTER_PORT); every rank then calls mrk_comm_init.
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "runtime.hpp"
@@ -50,11 +51,20 @@ void comm_destroy(mrk_ctx *ctx) {
 // in-place all-gather of `chunk` f64 per rank inside `buf` (rank r's slice at buf + r * chunk), on `stream`
 void comm_allgather_f64_inplace(mrk_ctx *ctx, double *buf, size_t chunk, hipStream_t stream) {
   if (!ctx->comm) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_comm_init has not been called on this context");
+  std::lock_guard<std::mutex> cl(ctx->comm_mu);
   MRK_NCCL(ncclAllGather(buf + (size_t)ctx->comm_rank * chunk, buf, chunk, ncclFloat64, (ncclComm_t)ctx->comm, stream));
+}
+
+// all-gather of `count` i32 per rank (the per-request status words of an item-sharded run)
+void comm_allgather_i32(mrk_ctx *ctx, const int32_t *send, int32_t *recv, size_t count, hipStream_t stream) {
+  if (!ctx->comm) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_comm_init has not been called on this context");
+  std::lock_guard<std::mutex> cl(ctx->comm_mu);
+  MRK_NCCL(ncclAllGather(send, recv, count, ncclInt32, (ncclComm_t)ctx->comm, stream));
 }
 
 void comm_allgather_f64(mrk_ctx *ctx, const double *send, double *recv, size_t count, hipStream_t stream) {
   if (!ctx->comm) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_comm_init has not been called on this context");
+  std::lock_guard<std::mutex> cl(ctx->comm_mu);
   MRK_NCCL(ncclAllGather(send, recv, count, ncclFloat64, (ncclComm_t)ctx->comm, stream));
 }
 
@@ -91,6 +101,21 @@ int mrk_comm_init(mrk_ctx *ctx, const uint8_t *id, int rank, int world) {
   });
 }
 
+// Host-only shard arithmetic (no context, no device): what mrk_batch_shard_chunk / mrk_batch_run_shard use.
+int64_t mrk_shard_chunk(int64_t total_items, int shard_count) {
+  if (total_items < 0 || shard_count < 1) return MRK_ERR_INVALID_ARG;
+  const int64_t per = (total_items + shard_count - 1) / shard_count;
+  return (per + MRK_SHARD_TILE - 1) / MRK_SHARD_TILE * MRK_SHARD_TILE;
+}
+
+int mrk_shard_range(int64_t total_items, int shard_index, int shard_count, int64_t *lo, int64_t *hi) {
+  if (total_items < 0 || shard_count < 1 || shard_index < 0 || shard_index >= shard_count || !lo || !hi) return MRK_ERR_INVALID_ARG;
+  const int64_t chunk = mrk_shard_chunk(total_items, shard_count);
+  *lo = std::min(chunk * shard_index, total_items);
+  *hi = std::min(chunk * (shard_index + 1), total_items);
+  return MRK_OK;
+}
+
 int mrk_comm_rank(mrk_ctx *ctx) { return ctx ? ctx->comm_rank : MRK_ERR_INVALID_ARG; }
 int mrk_comm_world(mrk_ctx *ctx) { return ctx ? ctx->comm_world : MRK_ERR_INVALID_ARG; }
 
@@ -99,7 +124,7 @@ int mrk_comm_max_f64(mrk_ctx *ctx, double *value) {
   return guard([&] {
     if (!ctx || !value) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
     if (!ctx->comm) return;  // a world of one
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> cl(ctx->comm_mu);  // also the owner of d_comm
     MRK_HIP(hipSetDevice(ctx->device));
     MRK_HIP(hipMemcpyAsync(ctx->d_comm.p, value, 8, hipMemcpyHostToDevice, ctx->stream));
     MRK_NCCL(ncclAllReduce(ctx->d_comm.p, ctx->d_comm.p, 1, ncclFloat64, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));

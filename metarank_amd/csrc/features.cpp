@@ -839,6 +839,7 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
   auto id_of = [&](int r, int i) -> std::string_view {
     if (ids) {
       const uint32_t o0 = ids->offsets[begins[r] + i], o1 = ids->offsets[begins[r] + i + 1];
+      if (o1 < o0 || o1 > ids->bytes_len) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_item_ids: offsets descend or pass bytes_len");
       return std::string_view((const char *)ids->bytes + o0, o1 - o0);
     }
     const char *s = reqs[r].item_ids[i];

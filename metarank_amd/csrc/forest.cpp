@@ -415,7 +415,7 @@ Forest parse_xgboost_legacy(const uint8_t *bytes, size_t len) {
   if (booster != "gbtree") throw std::runtime_error("xgboost: only gbtree boosters are supported (found '" + booster.substr(0, 32) + "')");
   check_objective(f.objective);
   f.base_score = (double)base_score;  // identity-link objectives: ProbToMargin (applied to pre-1.0 files) is the identity
-  (void)major;
+  if (major > 3) throw std::runtime_error("xgboost: unknown serialisation (not JSON / UBJSON, and the legacy header carries major version " + std::to_string(major) + ")");
   const uint8_t *gp = in.p;
   in.skip(160);
   int32_t num_trees, gb_leaf_vec;
@@ -425,7 +425,9 @@ Forest parse_xgboost_legacy(const uint8_t *bytes, size_t len) {
   for (int t = 0; t < num_trees; ++t) {
     const uint8_t *tp = in.p;
     in.skip(148);
-    int32_t num_nodes, leaf_vec;
+    int32_t num_roots, num_nodes, leaf_vec;
+    memcpy(&num_roots, tp, 4);
+    if (num_roots != 1) throw std::runtime_error("xgboost legacy model: unknown serialisation (a tree with num_roots = " + std::to_string(num_roots) + ")");
     memcpy(&num_nodes, tp + 4, 4);
     memcpy(&leaf_vec, tp + 20, 4);
     if (num_nodes <= 0 || (uint64_t)num_nodes * 36 > (uint64_t)(in.end - in.p)) throw std::runtime_error("xgboost legacy model: bad node count");

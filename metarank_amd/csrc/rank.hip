@@ -499,6 +499,21 @@ void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mod
   MRK_HIP(hipGetLastError());
 }
 
+// item-sharded runs: status[r] |= OR over the ranks of all[rank][r]
+__global__ void status_or_kernel(const int32_t *__restrict__ all, int world, int n_req, int32_t *__restrict__ status) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_req) return;
+  int32_t v = status[r];
+  for (int w = 0; w < world; ++w) v |= all[(size_t)w * n_req + r];
+  status[r] = v;
+}
+
+void launch_status_or(hipStream_t stream, const int32_t *all, int world, int n_req, int32_t *status) {
+  if (n_req <= 0) return;
+  hipLaunchKernelGGL(status_or_kernel, dim3((n_req + 255) / 256), dim3(256), 0, stream, all, world, n_req, status);
+  MRK_HIP(hipGetLastError());
+}
+
 void launch_sort(mrk_ctx *ctx, const BatchDev &b) {
   if (b.n_req <= 0) return;
   ScopedKernelTimer timer(ctx, "sort");

@@ -16,8 +16,9 @@ namespace {
 constexpr int RESOLVE_THREADS = 256;
 
 __global__ void __launch_bounds__(RESOLVE_THREADS)
-resolve_ids_kernel(IdTableDev tab, const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ offs, const ReqDev *__restrict__ reqs,
-                   int n_req, int total, int32_t *__restrict__ item_slot, uint32_t *__restrict__ item_req) {
+resolve_ids_kernel(IdTableDev tab, const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ offs, uint32_t bytes_len,
+                   const ReqDev *__restrict__ reqs, int n_req, int total, int32_t *__restrict__ item_slot, uint32_t *__restrict__ item_req,
+                   int32_t *__restrict__ load_status) {
   const int i = blockIdx.x * RESOLVE_THREADS + threadIdx.x;
   if (i >= total) return;
   // the request of item i: the last request whose first item is <= i (requests without items share a start)
@@ -28,6 +29,11 @@ resolve_ids_kernel(IdTableDev tab, const uint8_t *__restrict__ bytes, const uint
   }
   item_req[i] = (uint32_t)lo;
   const uint32_t o0 = offs[i], o1 = offs[i + 1];
+  if (o1 < o0 || o1 > bytes_len) {  // offsets come off the wire: never read outside the uploaded bytes
+    atomicOr(&load_status[lo], ST_BAD_IDS);
+    item_slot[i] = -1;
+    return;
+  }
   const uint8_t *id = bytes + o0;
   const uint32_t len = o1 - o0;
   int32_t slot = -1;
@@ -49,11 +55,11 @@ resolve_ids_kernel(IdTableDev tab, const uint8_t *__restrict__ bytes, const uint
 
 }  // namespace
 
-void launch_resolve_ids(hipStream_t stream, const IdTableDev &tab, const uint8_t *d_bytes, const uint32_t *d_offs, const ReqDev *d_reqs,
-                        int n_req, int total, int32_t *d_item_slot, uint32_t *d_item_req) {
+void launch_resolve_ids(hipStream_t stream, const IdTableDev &tab, const uint8_t *d_bytes, const uint32_t *d_offs, uint32_t bytes_len,
+                        const ReqDev *d_reqs, int n_req, int total, int32_t *d_item_slot, uint32_t *d_item_req, int32_t *d_load_status) {
   if (total <= 0 || n_req <= 0) return;
   hipLaunchKernelGGL(resolve_ids_kernel, dim3((total + RESOLVE_THREADS - 1) / RESOLVE_THREADS), dim3(RESOLVE_THREADS), 0, stream, tab,
-                     d_bytes, d_offs, d_reqs, n_req, total, d_item_slot, d_item_req);
+                     d_bytes, d_offs, bytes_len, d_reqs, n_req, total, d_item_slot, d_item_req, d_load_status);
   MRK_HIP(hipGetLastError());
 }
 

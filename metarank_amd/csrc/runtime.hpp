@@ -154,6 +154,9 @@ struct mrk_ctx {
   void *comm = nullptr;
   int comm_rank = 0, comm_world = 1;
   mrk::DevBuf d_comm;                 // scratch of the host-value collectives
+  // EVERY collective on `comm` is issued under this lock (RCCL does not allow concurrent calls on one communicator).  The
+  // host must also issue collectives in the same order on every rank (mrk.h): the lock makes a mistake a wait, not a race.
+  std::mutex comm_mu;
   std::mutex rank_mu;                 // owner of rank_scratch (the leader of the batching front, or a caller with the front off)
   // batching front of mrk_rank: concurrent callers are combined into one device batch by whichever caller
   // finds no leader active (capi_rank.cpp)
@@ -200,6 +203,7 @@ void free_rank_state(mrk_ctx *ctx);
 void comm_destroy(mrk_ctx *ctx);
 void comm_allgather_f64_inplace(mrk_ctx *ctx, double *buf, size_t chunk, hipStream_t stream);
 void comm_allgather_f64(mrk_ctx *ctx, const double *send, double *recv, size_t count, hipStream_t stream);
+void comm_allgather_i32(mrk_ctx *ctx, const int32_t *send, int32_t *recv, size_t count, hipStream_t stream);
 // features.cpp: drops the encoder references mrk_config_bind_encoder took
 void unbind_encoders(mrk_ctx *ctx);
 

@@ -142,11 +142,11 @@ class RequestSet:
             C.memmove(pb, blob, len(blob))
             C.memmove(po, offs.ctypes.data, offs.nbytes)
             self._blob, self._offs = None, None
-            self.ids = N.mrk_item_ids(pb, po)
+            self.ids = N.mrk_item_ids(pb, po, len(blob))
         else:
             self._blob = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(1, dtype=np.uint8)
             self._offs = offs
-            self.ids = N.mrk_item_ids(self._blob.ctypes.data, offs.ctypes.data)
+            self.ids = N.mrk_item_ids(self._blob.ctypes.data, offs.ctypes.data, len(blob))
         self.id_bytes_total = len(blob)
 
     def requests_with_ids(self):

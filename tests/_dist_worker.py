@@ -39,9 +39,18 @@ def main():
     merged2 = all_gather_scores(torch.from_numpy(part), [shard_range(len(m), r, world)[1] - shard_range(len(m), r, world)[0] for r in range(world)])
     # (3) the same the way the library shards it (mrk_batch_run_shard): equal tile-aligned chunks, each rank
     #     fills its slice of one padded buffer, one in-place all-gather
-    chunk = padded_chunk(len(m), world)
+    #     - the chunk and this rank's range come from the LIBRARY (mrk_shard_chunk / mrk_shard_range, host-only entry points)
+    import ctypes as C
+
+    from metarank_amd import _native as N
+
+    L = N.lib()
+    chunk = int(L.mrk_shard_chunk(len(m), world))
+    assert chunk == padded_chunk(len(m), world)
+    c_lo, c_hi = C.c_int64(), C.c_int64()
+    assert L.mrk_shard_range(len(m), rank, world, C.byref(c_lo), C.byref(c_hi)) == N.MRK_OK
     buf = torch.zeros(chunk * world, dtype=torch.float64)
-    lo3, hi3 = min(rank * chunk, len(m)), min((rank + 1) * chunk, len(m))
+    lo3, hi3 = c_lo.value, c_hi.value
     buf[lo3:hi3] = torch.from_numpy(b.forest.predict(m[lo3:hi3]))
     all_gather_padded(buf, chunk)
     assert chunk % 128 == 0 and np.array_equal(buf[:len(m)].numpy(), b.forest.predict(m))

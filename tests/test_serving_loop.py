@@ -279,6 +279,14 @@ def test_rccl_code_path_with_a_world_of_one(oracle_c2):
         assert same(s0, s2) and (o0 == o2).all()
         assert b2.gather_scores() not in (None, 0)   # ncclAllGather into the batch's merge buffer (one rank: a copy)
         b2.sync()
+        assert (b2.status() == 0).all()
+        # per-request failures survive the merge: the status words of every rank are all-gathered and OR-ed before the
+        # sort (an item that fails its request lies in ONE rank's slice; here: the normalised rate's / by zero)
+        hip.put_periodic("global/ctr_click_norm", [0, 5])
+        b3 = hip.ranker.prepare("xgboost", reqs)
+        b3.run_sharded(hip.booster)
+        assert (b3.status() == -5).all()   # MRK_ERR_ARITHMETIC
+        b3.close()
         batch.close()
         b2.close()
     finally:
