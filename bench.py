@@ -367,6 +367,7 @@ def main():
     # kernel the truth lies between the two (DESIGN.md "Roofline accounting").  Only filled when the profiled launch had
     # this run's shape.
     traffic = traffic_raw = None
+    valu_issue = {}
     jit_on = os.environ.get("MRK_RANK_JIT", "1") not in ("0",)
     # the kernel behind `dominant` in the newest committed summary of this workload (names change with the batch shape:
     # mrk_jit_rank_cells / _split / mrk_jit_assemble_cells; qs_score_wave_kernel / qs_score_split_kernel)
@@ -385,6 +386,18 @@ def main():
                     traffic_raw = (d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
                     traffic = (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
                     break
+            # The bound these kernels actually run against (neither is bandwidth-bound): VALU issue.  A wavefront's
+            # vector instruction occupies its SIMD's VALU for 4 cycles, so a launch cannot take less than
+            # (VALU wavefront-instructions of the launch, SQ_INSTS_VALU of the committed PMC pass) x 4 cycles / 1 024 SIMDs /
+            # 2.4 GHz; frac = that floor / this run's measured launch time.
+            for kname in ("assemble", "score"):
+                for name, d in summary.items():
+                    if kname in kernels and name.startswith(prefixes[kname]) and "SQ_INSTS_VALU" in d:
+                        floor_ms = d["SQ_INSTS_VALU"]["mean"] * 4.0 / 1024.0 / 2.4e9 * 1e3
+                        valu_issue[kname] = {"kernel": name, "valu_wave_instructions": d["SQ_INSTS_VALU"]["mean"], "floor_ms": floor_ms,
+                                             "avg_launch_ms": kernels[kname]["avg_ms"], "frac": floor_ms / kernels[kname]["avg_ms"],
+                                             "pmc_summary": os.path.basename(files[0])}
+                        break
     except Exception:
         traffic = traffic_raw = None
     dur_s = kernels[dominant]["avg_ms"] * 1e-3
@@ -393,6 +406,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "traffic_kernel": pmc_kernel, "algorithmic_bytes_per_launch": alg[dominant],
                 "bytes_per_item": b_item, "items_per_launch": my_items, "model_bytes_per_launch": model_bytes,
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
+                # `frac` prices the SURVEY 8(d) bytes against HBM; when the item table fits the 256 MiB Infinity Cache none of
+                # those bytes come from HBM and `frac` is NOT a bandwidth statement - the instruction-issue bound below is
+                "cache_resident": int(n_catalogue) * ranker.item_stride() < 256 * 1024 * 1024,
+                "valu_issue": valu_issue or None,
                 "whole_path": {"achieved": alg_path / (ms_per_batch * 1e-3) / 1e9, "frac": alg_path / (ms_per_batch * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "ms_per_batch": ms_per_batch},
                 "note": "the forest scorer is VALU-issue bound, not HBM bound (SURVEY.md 8d): "
@@ -585,7 +602,7 @@ def main():
             multi = {"value": len(work) * args.items / mt_s, "unit": "items/s", "cores": n_thr, "seconds": mt_s}
         except Exception as e:  # the single-thread figure is the contract; this one is extra
             multi = {"error": str(e)}
-        cpu = {"value": n * args.items / cpu_s, "unit": "items/s", "cores": 1, "kind": "port", "all_cores": multi,
+        cpu = {"value": n * args.items / cpu_s, "unit": "items/s", "cores": 1, "kind": "port", "kind_in_words": "port (this repo's C++ oracle, oracle/; the reference's JVM + LightGBM/XGBoost natives cannot run on this image)", "all_cores": multi,
                "sample": f"{n} requests x {args.items} items of the same workload, assemble+score+sort, single thread",
                "host_cores": os.cpu_count(), "seconds": cpu_s,
                "split_s": {"assemble": parts[0], "score": parts[1], "sort": parts[2]}}

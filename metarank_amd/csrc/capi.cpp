@@ -34,8 +34,8 @@ static Switches read_switches() {
   else if (const char *x = getenv("XDG_CACHE_HOME")) s.jit_cache_dir = std::string(x) + "/mrk_jit";
   else if (const char *h = getenv("HOME")) s.jit_cache_dir = std::string(h) + "/.cache/mrk_jit";
   if (s.jit_cache_dir == "off") s.jit_cache_dir.clear();
-  const int sc = num("MRK_SORT_CHUNK", 1024);
-  s.sort_chunk = sc == 2048 || sc == 4096 ? sc : 1024;
+  s.big_sort_cap = num("MRK_BIG_SORT_CAP", 4096);
+  s.big_sort_tile = num("MRK_BIG_SORT_TILE", 0);
   s.qs_split = num("MRK_QS_SPLIT", -1);
   s.qs_kernel = num("MRK_QS_KERNEL", 1);
   s.qs_r = num("MRK_QS_R", 2);

@@ -17,8 +17,10 @@ void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
 void launch_sort(mrk_ctx *ctx, const BatchDev &b);
 void launch_status_or(hipStream_t stream, const int32_t *all, int world, int n_req, int32_t *status);
 void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode);
-void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx);
-size_t big_sort_padded(int n_items);
+void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int item_begin, int n, int *order, void *scratch);
+struct SortSrc { const double *vals; const unsigned long long *raw; long long stride; int negate; };  // sort_device.hpp
+void launch_big_sort(hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch);  // bigsort.hip
+size_t big_sort_scratch_bytes(int n);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
@@ -85,10 +87,12 @@ struct mrk_batch {
   PinBuf h_out;
   bool fetch_enqueued = false;          // the download of d_out into h_out is on the stream behind the last run
   DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
-  DevBuf d_sort_keys, d_sort_idx;       // scratch of the multi-workgroup sort
+  DevBuf d_sort;                        // scratch of the multi-workgroup sort (bigsort.hip)
+  DevBuf d_norm_order;                  // norm: position over a request of more than SORT_MAX_ITEMS candidates: its column's order
   DevBuf d_gather;                      // mrk_batch_gather_scores: the scores of every rank
   DevBuf d_gather_status;               // item-sharded runs: the status words of every rank ([world][n_req]) before they are OR-ed
-  std::vector<std::pair<int, int>> big; // (request, n_items) with n_items > SORT_MAX_ITEMS
+  struct BigReq { int r, n_items, item_begin; };
+  std::vector<BigReq> big;              // requests with n_items > SORT_MAX_ITEMS
   PinBuf h_in;
   HostBatch hb;              // host half of the last load (grow-only scratch)
   DevBuf d_ids;              // flat item ids of the batch: [offsets: (T + 1) u32][bytes]
@@ -265,16 +269,13 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.matrix_valid = false;
   b.fetch_enqueued = false;
   b.big.clear();
-  size_t big_p2 = 0;
+  size_t big_bytes = 0;
   for (int r = 0; r < n_req; ++r)
     if (hb.reqs[r].n_items > SORT_MAX_ITEMS) {
-      b.big.emplace_back(r, hb.reqs[r].n_items);
-      big_p2 = std::max(big_p2, big_sort_padded(hb.reqs[r].n_items));
+      b.big.push_back({r, hb.reqs[r].n_items, (int)hb.reqs[r].item_begin});
+      big_bytes = std::max(big_bytes, big_sort_scratch_bytes(hb.reqs[r].n_items));
     }
-  if (big_p2) {  // ping-pong buffers of the merge passes
-    b.d_sort_keys.reserve(2 * big_p2 * 8);
-    b.d_sort_idx.reserve(2 * big_p2 * 4);
-  }
+  if (big_bytes) b.d_sort.reserve(big_bytes);  // one scratch: the big requests of a batch are sorted one after the other on its stream
   // small requests: both phases in one workgroup, tables in LDS (<= 64 KB keeps two workgroups per CU)
   uint32_t vals = 1;
   while ((int)vals < hb.max_doubles) vals <<= 1;
@@ -310,7 +311,14 @@ static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &
     launch_assemble(ctx, st, pd, b.view);
   }
   for (const Program::NormCol &nc : b.prog->norm_cols)  // schema.norm.scale over the request's column (Normalize.scala:13-45)
-    if (!nc.cross || nc.cross->encoder) launch_normalize(ctx, b.view, pd.dim, nc.col, nc.mode);
+    if (!nc.cross || nc.cross->encoder) {
+      launch_normalize(ctx, b.view, pd.dim, nc.col, nc.mode);
+      if (nc.mode == NORM_POSITION)  // requests too large for one workgroup: ordered by the multi-workgroup sort
+        for (auto &br : b.big) {
+          b.d_norm_order.reserve((size_t)br.n_items * 4);
+          launch_normalize_big(ctx, b.view, pd.dim, nc.col, br.item_begin, br.n_items, b.d_norm_order.as<int>(), b.d_sort.p);
+        }
+    }
   b.matrix_valid = true;
 }
 
@@ -321,7 +329,12 @@ static int shard_chunk(const mrk_batch &b, int count) { return (int)mrk_shard_ch
 static void sort_batch(mrk_batch &b) {
   mrk_ctx *ctx = b.ctx;
   launch_sort(ctx, b.view);
-  for (auto &br : b.big) launch_big_sort(ctx, b.view, br.first, br.second, b.d_sort_keys.as<unsigned long long>(), b.d_sort_idx.as<int>());
+  if (b.big.empty()) return;
+  ScopedKernelTimer timer(ctx, "sort");
+  for (auto &br : b.big) {
+    const SortSrc src{b.view.scores + br.item_begin, nullptr, 1, 1};
+    launch_big_sort(ctx->launch, src, br.n_items, b.view.order + br.item_begin, b.d_sort.p);
+  }
 }
 
 // routes kernel launches (and their timers) to a batch's stream; holds ctx->mu for as long as it lives

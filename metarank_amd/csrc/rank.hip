@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "rank_device.hpp"
+#include "sort_device.hpp"
 #include "runtime.hpp"
 
 namespace mrk {
@@ -112,14 +113,7 @@ __global__ void override_cells_kernel(BatchDev b, QsDev q, uint16_t *cells) {
 }
 
 // ---------------------------------------------------------------- ordering
-// sortBy(-_.score): ascending java.lang.Double.compare on the negated score, stable.
-__device__ __forceinline__ unsigned long long sort_key(double score) {
-  double k = -score;
-  unsigned long long bits = (unsigned long long)__double_as_longlong(k);
-  if (k != k) bits = 0x7ff8000000000000ULL;  // Double.compare canonicalises NaN: above +Infinity
-  return (bits & 0x8000000000000000ULL) ? ~bits : (bits | 0x8000000000000000ULL);
-}
-
+// sortBy(-_.score): ascending java.lang.Double.compare on the negated score, stable (keys: sort_device.hpp).
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_COUNT_MAX = 256;  // requests up to this size are ordered by counting (sort_kernel)
 
@@ -180,16 +174,6 @@ sort_kernel(BatchDev b) {
 //   linear    (v - min) / (max - min) with min / max over the non-NaN values (scala Ordering.Double = Double.compare:
 //             -0.0 < +0.0); nothing changes when every value is NaN; max == min gives NaN (0 / 0) like the reference
 //   position  sortedIndex / size after a stable ascending sort of ALL values (NaN last); NaN values stay NaN
-__device__ __forceinline__ unsigned long long asc_key(double v) {  // monotone in java.lang.Double.compare order
-  unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-  if (v != v) bits = 0x7ff8000000000000ULL;
-  return (bits & 0x8000000000000000ULL) ? ~bits : (bits | 0x8000000000000000ULL);
-}
-__device__ __forceinline__ double asc_value(unsigned long long key) {
-  const unsigned long long bits = (key & 0x8000000000000000ULL) ? (key & 0x7fffffffffffffffULL) : ~key;
-  return __longlong_as_double((long long)bits);
-}
-
 __global__ void __launch_bounds__(SORT_THREADS)
 normalize_kernel(BatchDev b, int dim, int col, int mode) {
   __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
@@ -222,10 +206,7 @@ normalize_kernel(BatchDev b, int dim, int col, int mode) {
     }
     return;
   }
-  if (n > SORT_MAX_ITEMS) {
-    if (tid == 0) atomicOr(&b.status[r], ST_NORM_TOO_MANY);
-    return;
-  }
+  if (n > SORT_MAX_ITEMS) return;  // ordered by the multi-workgroup sort, applied by norm_position_apply_kernel (launch_normalize_big)
   int p2 = 1;
   while (p2 < n) p2 <<= 1;
   for (int i = tid; i < p2; i += SORT_THREADS) {
@@ -254,131 +235,9 @@ normalize_kernel(BatchDev b, int dim, int col, int mode) {
     if (s_key[s] != nan_key) colp[(size_t)s_idx[s] * dim] = __ddiv_rn((double)s, size);
 }
 
-// ---- requests with more than SORT_MAX_ITEMS candidates (C4: 100 000): merge sort.  Chunks of SORT_MAX_ITEMS
-// (key, index) pairs are sorted in LDS (bitonic), then log2(chunks) merge passes; in a pass every workgroup
-// produces SORT_MAX_ITEMS consecutive outputs of one pair of runs: merge-path binary searches find its input
-// ranges, the inputs go to LDS, every lane merges MERGE_TILE / 256 outputs.  (key, index) pairs are distinct, so the result
-// is the stable order.
-__device__ __forceinline__ bool pair_lt(unsigned long long ka, int ia, unsigned long long kb, int ib) {
-  return ka < kb || (ka == kb && ia < ib);
-}
-
-constexpr int MERGE_TILE = 1024;  // outputs of one workgroup of a merge pass
-
-template <int CHUNK>
-__global__ void __launch_bounds__(SORT_THREADS)
-msort_chunk_kernel(BatchDev b, int r, unsigned long long *keys, int *idx) {
-  __shared__ unsigned long long s_key[CHUNK];
-  __shared__ int s_idx[CHUNK];
-  const ReqDev rq = b.reqs[r];
-  const int base = blockIdx.x * CHUNK;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < CHUNK; i += SORT_THREADS) {
-    const int g = base + i;
-    s_key[i] = g < rq.n_items ? sort_key(b.scores[rq.item_begin + g]) : ~0ull;  // padding sorts last
-    s_idx[i] = g < rq.n_items ? g : 0x7fffffff;
-  }
-  __syncthreads();
-  for (int k = 2; k <= CHUNK; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int p = tid; p < CHUNK / 2; p += SORT_THREADS) {  // one compare-exchange per lane (see sort_kernel)
-        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
-        const unsigned long long ka = s_key[i], kb = s_key[ixj];
-        const int ia = s_idx[i], ib = s_idx[ixj];
-        const bool up = (i & k) == 0;
-        if (pair_lt(kb, ib, ka, ia) == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = tid; i < CHUNK; i += SORT_THREADS) { keys[base + i] = s_key[i]; idx[base + i] = s_idx[i]; }
-}
-
-// number of elements taken from run A among the first `diag` outputs of merge(A, B); A, B sorted, pairs distinct
-template <typename KeyP, typename IdxP>
-__device__ __forceinline__ int merge_path(KeyP ka, IdxP ia, int na, KeyP kb, IdxP ib, int nb, int diag) {
-  int lo = max(0, diag - nb), hi = min(diag, na);
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;  // take mid from A, diag - mid from B
-    // A[mid] must come after B[diag - mid - 1] to stop taking from A
-    if (pair_lt(ka[mid], ia[mid], kb[diag - mid - 1], ib[diag - mid - 1])) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-
-// the same split found by the whole workgroup: SORT_THREADS candidates per round instead of one, so a split
-// over runs of 100 000 elements in global memory takes 3 rounds of loads instead of 17 dependent ones
-__device__ __forceinline__ int merge_path_block(const unsigned long long *ka, const int *ia, int na, const unsigned long long *kb,
-                                                const int *ib, int nb, int diag) {
-  int lo = max(0, diag - nb), hi = min(diag, na);  // the answer is the first mid in [lo, hi] whose test is false (hi: false)
-  while (lo < hi) {
-    const int step = (hi - lo + SORT_THREADS - 1) / SORT_THREADS;
-    const int mid = lo + (int)threadIdx.x * step;
-    const bool p = mid < hi && pair_lt(ka[mid], ia[mid], kb[diag - mid - 1], ib[diag - mid - 1]);  // monotone: true ... true false ... false
-    const int cnt = __syncthreads_count(p);
-    if (cnt == 0) { hi = lo; break; }
-    const int last_true = lo + (cnt - 1) * step;
-    hi = min(hi, lo + cnt * step);
-    lo = last_true + 1;
-  }
-  return lo;
-}
-
-// TILE outputs per workgroup: a pass over 100 000 candidates is 25 workgroups at TILE = 4096 (a tenth of the chip),
-// 98 at 1024
-template <int TILE>
-__global__ void __launch_bounds__(SORT_THREADS)
-msort_merge_kernel(const unsigned long long *__restrict__ src_k, const int *__restrict__ src_i, unsigned long long *__restrict__ dst_k,
-                   int *__restrict__ dst_i, int n_pad, int run, int *__restrict__ order, const ReqDev *__restrict__ rq, int n_items) {
-  int *order_out = order ? order + rq->item_begin : nullptr;  // last pass: the request's slice of the batch order
-  constexpr int PER_THREAD = TILE / SORT_THREADS;
-  __shared__ unsigned long long s_key[TILE];
-  __shared__ int s_idx[TILE];
-  const int tid = threadIdx.x;
-  const int out0 = blockIdx.x * TILE;
-  const int pair0 = (out0 / (2 * run)) * (2 * run);
-  const int na = min(run, n_pad - pair0);
-  const int nb = max(0, min(run, n_pad - pair0 - run));
-  const unsigned long long *ak = src_k + pair0, *bk = src_k + pair0 + run;
-  const int *ai = src_i + pair0, *bi = src_i + pair0 + run;
-  const int d0 = out0 - pair0;
-  const int a0 = merge_path_block(ak, ai, na, bk, bi, nb, d0);
-  const int a1 = merge_path_block(ak, ai, na, bk, bi, nb, min(d0 + TILE, na + nb));
-  const int b0 = d0 - a0, b1 = min(d0 + TILE, na + nb) - a1;
-  const int la = a1 - a0, lb = b1 - b0;  // la + lb outputs (TILE: run and n_pad are multiples of it)
-  for (int i = tid; i < la; i += SORT_THREADS) { s_key[i] = ak[a0 + i]; s_idx[i] = ai[a0 + i]; }
-  for (int i = tid; i < lb; i += SORT_THREADS) { s_key[la + i] = bk[b0 + i]; s_idx[la + i] = bi[b0 + i]; }
-  __syncthreads();
-  const int d = tid * PER_THREAD;  // la + lb == TILE
-  int x = merge_path(s_key, s_idx, la, s_key + la, s_idx + la, lb, d);
-  int y = d - x;
-#pragma unroll
-  for (int o = 0; o < PER_THREAD; ++o) {
-    bool take_a;
-    if (x >= la) take_a = false;
-    else if (y >= lb) take_a = true;
-    else take_a = pair_lt(s_key[x], s_idx[x], s_key[la + y], s_idx[la + y]);
-    const int p = take_a ? x : la + y;
-    if (order_out) {  // the last pass writes the request's order itself (padding sorts last: the first n_items are real)
-      if (out0 + d + o < n_items) order_out[out0 + d + o] = s_idx[p];
-    } else {
-      dst_k[out0 + d + o] = s_key[p];
-      dst_i[out0 + d + o] = s_idx[p];
-    }
-    x += take_a ? 1 : 0;
-    y += take_a ? 0 : 1;
-  }
-}
-
-__global__ void __launch_bounds__(SORT_THREADS)
-bigsort_store_kernel(BatchDev b, int r, const int *idx) {
-  const ReqDev rq = b.reqs[r];
-  const int i = blockIdx.x * SORT_THREADS + threadIdx.x;
-  if (i < rq.n_items) b.order[rq.item_begin + i] = idx[i];
-}
-
 }  // namespace
+
+void launch_big_sort(hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch);  // bigsort.hip
 
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries) {
   if (b.n_req <= 0 || prog.n_prep <= 0) return;
@@ -491,6 +350,26 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
   }
 }
 
+// norm: position of a request of more than SORT_MAX_ITEMS candidates: `order` = the candidates in stable ascending order
+// of the column (bigsort.hip); the one at sorted place s gets s / size, NaN values stay NaN (Normalize.scala:25-40)
+__global__ void __launch_bounds__(SORT_THREADS)
+norm_position_apply_kernel(const int *__restrict__ order, int n, double *colp, int dim) {
+  const int s = blockIdx.x * SORT_THREADS + threadIdx.x;
+  if (s >= n) return;
+  double *p = colp + (size_t)order[s] * dim;
+  const double v = *p;
+  if (v == v) *p = __ddiv_rn((double)s, (double)n);
+}
+
+void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int item_begin, int n, int *order, void *scratch) {
+  ScopedKernelTimer timer(ctx, "normalize");
+  double *colp = b.matrix + (size_t)item_begin * dim + col;
+  const SortSrc src{colp, nullptr, dim, 0};
+  launch_big_sort(ctx->launch, src, n, order, scratch);
+  hipLaunchKernelGGL(norm_position_apply_kernel, dim3((n + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), 0, ctx->launch, order, n, colp, dim);
+  MRK_HIP(hipGetLastError());
+}
+
 // Normalize.scale over matrix column `col` of every request of the batch (after assembly and overrides)
 void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode) {
   if (b.n_req <= 0 || mode == NORM_NOOP) return;
@@ -518,35 +397,6 @@ void launch_sort(mrk_ctx *ctx, const BatchDev &b) {
   if (b.n_req <= 0) return;
   ScopedKernelTimer timer(ctx, "sort");
   hipLaunchKernelGGL(sort_kernel, dim3(b.n_req), dim3(SORT_THREADS), 0, ctx->launch, b);
-  MRK_HIP(hipGetLastError());
-}
-
-// one request with n_items > SORT_MAX_ITEMS; keys / idx hold 2 x n_pad elements (ping-pong), n_pad = n_items rounded
-// up to whole chunks (big_sort_padded)
-size_t big_sort_padded(int n_items) { return ((size_t)n_items + SORT_MAX_ITEMS - 1) / SORT_MAX_ITEMS * SORT_MAX_ITEMS; }
-
-void launch_big_sort(mrk_ctx *ctx, const BatchDev &b, int r, int n_items, unsigned long long *keys, int *idx) {
-  const int n_pad = (int)big_sort_padded(n_items);
-  // chunks sorted in LDS: smaller chunks = more workgroups in the first launch and shallower compare-exchange networks,
-  // but more merge passes.  Measured on 100 000 candidates (MRK_SORT_CHUNK): see DESIGN.md
-  const int chunk = switches().sort_chunk;
-  ScopedKernelTimer timer(ctx, "sort");
-  const dim3 blk(SORT_THREADS);
-  unsigned long long *k0 = keys, *k1 = keys + n_pad;
-  int *i0 = idx, *i1 = idx + n_pad;
-  if (chunk == 4096) hipLaunchKernelGGL(msort_chunk_kernel<4096>, dim3(n_pad / 4096), blk, 0, ctx->launch, b, r, k0, i0);
-  else if (chunk == 2048) hipLaunchKernelGGL(msort_chunk_kernel<2048>, dim3(n_pad / 2048), blk, 0, ctx->launch, b, r, k0, i0);
-  else hipLaunchKernelGGL(msort_chunk_kernel<1024>, dim3(n_pad / 1024), blk, 0, ctx->launch, b, r, k0, i0);
-  bool stored = false;
-  for (int run = chunk; run < n_pad; run <<= 1) {
-    const bool last = run * 2 >= n_pad;
-    hipLaunchKernelGGL(msort_merge_kernel<MERGE_TILE>, dim3(n_pad / MERGE_TILE), blk, 0, ctx->launch, k0, i0, k1, i1, n_pad, run,
-                       last ? b.order : (int *)nullptr, b.reqs + r, n_items);
-    stored = last;
-    std::swap(k0, k1);
-    std::swap(i0, i1);
-  }
-  if (!stored) hipLaunchKernelGGL(bigsort_store_kernel, dim3((n_items + SORT_THREADS - 1) / SORT_THREADS), blk, 0, ctx->launch, b, r, i0);
   MRK_HIP(hipGetLastError());
 }
 

@@ -108,7 +108,8 @@ struct Switches {
   int jit_waves = 0;           // MRK_JIT_WAVES
   bool jit_record_regs = true; // MRK_JIT_REGS=0: the specialised kernel reads the candidate's record cell by cell instead of keeping it in registers
   std::string jit_cache_dir;   // MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else ~/.cache/mrk_jit; "" / "off": none
-  int sort_chunk = 1024;       // MRK_SORT_CHUNK
+  int big_sort_cap = 4096;     // MRK_BIG_SORT_CAP: pairs a bucket of the multi-workgroup sort orders in LDS (smaller: tests reach the global-memory path)
+  int big_sort_tile = 0;       // MRK_BIG_SORT_TILE: candidates per workgroup of its classify / scatter passes (0: n / 512, at least 1 024)
   int qs_split = -1;           // MRK_QS_SPLIT
   int qs_kernel = 1;           // MRK_QS_KERNEL
   int qs_r = 2;                // MRK_QS_R

@@ -292,3 +292,47 @@ def test_rccl_code_path_with_a_world_of_one(oracle_c2):
     finally:
         hip.close()
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_item_id_offsets_from_the_wire_are_checked(oracle_c2):
+    """mrk_item_ids.offsets is untrusted input: a last offset past bytes_len refuses the whole load; an item whose
+    offsets descend (or pass bytes_len) fails ITS request with MRK_ERR_INVALID_ARG, the other requests rank as usual -
+    and nothing reads outside the uploaded bytes."""
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
+        reqs = ranklens.generate_requests(4, 50, N_ITEMS, N_SESS, seed=75)
+        blob = synth.synthetic_lgbm_model(n_trees=40, n_features=24, seed=2)
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        rs = M.RequestSet(reqs, pinned=False)
+        batch = hip.ranker.new_batch()
+        good = rs._offs.copy()
+        # (1) the last offset passes bytes_len
+        rs._offs[-1] = good[-1] + 1000
+        with pytest.raises(M.MrkError) as ei:
+            batch.load("xgboost", rs)
+        assert ei.value.status == -1
+        # (2) descending offsets inside request 2, and a huge one inside request 3 (the last offset itself is fine)
+        rs._offs[:] = good
+        rs._offs[2 * 50 + 7] = good[2 * 50 + 7 + 1] + 5      # > its successor: item 2*50+7 has o1 < o0
+        rs._offs[3 * 50 + 10] = 0xfffffff0                    # far past bytes_len
+        batch.load("xgboost", rs)
+        batch.run(hip.booster)
+        scores, order, status = batch.host_outputs()
+        assert status.tolist() == [0, 0, -1, -1]
+        for r in (0, 1):
+            _, es, eo = oracle_c2.rerank(reqs[r])
+            lo, hi = batch.offsets[r], batch.offsets[r + 1]
+            assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist()
+        # (3) and the batch recovers with good offsets
+        rs._offs[:] = good
+        batch.load("xgboost", rs)
+        batch.run(hip.booster)
+        _, _, status = batch.host_outputs()
+        assert (status == 0).all()
+        batch.close()
+        rs.close()
+    finally:
+        hip.close()
