@@ -24,6 +24,7 @@ static Switches read_switches() {
   s.fused_slices = std::max(0, num("MRK_FUSED_SLICES", 0));
   s.prepass_lds = flag("MRK_PREPASS_LDS", true);
   s.rank_combine = flag("MRK_RANK_COMBINE", true);
+  s.rank_one = flag("MRK_RANK_ONE", true);
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
   s.table_load_pct = std::max(10, std::min(90, num("MRK_TABLE_LOAD_PCT", 75)));
   s.host_threads = std::max(0, std::min(256, num("MRK_HOST_THREADS", 0)));

@@ -30,6 +30,10 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap);
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
+QsForestDev qs_forest_view(const mrk_model *m);  // score_qs.hip
+size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64);
+void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
+                     int threads, int op_split, const QsDev &q, const QsForestDev &f, const OneOut &out, bool f64, void *jit_fn);
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
 void launch_resolve_ids(hipStream_t stream, const IdTableDev &tab, const uint8_t *d_bytes, const uint32_t *d_offs, uint32_t bytes_len, const ReqDev *d_reqs,
                         int n_req, int total, int32_t *d_item_slot, uint32_t *d_item_req, int32_t *d_load_status);  // resolve.hip
@@ -86,6 +90,7 @@ struct mrk_batch {
   size_t out_order_off = 0, out_status_off = 0, out_bytes = 0;
   PinBuf h_out;
   bool fetch_enqueued = false;          // the download of d_out into h_out is on the stream behind the last run
+  bool direct_out = false;              // the last run was the one-launch kernel: scores / order / status were written into h_out by the device
   DevBuf d_cells;            // the scorer's binned tile (bit-vector models), grow-only
   DevBuf d_sort;                        // scratch of the multi-workgroup sort (bigsort.hip)
   DevBuf d_norm_order;                  // norm: position over a request of more than SORT_MAX_ITEMS candidates: its column's order
@@ -345,8 +350,18 @@ struct LaunchOn {
   ~LaunchOn() { ctx->launch = ctx->stream; }
 };
 
+// A handful of small requests (mrk_rank and its batching front): everything in ONE launch, results straight into the
+// batch's pinned buffer (rank_device.hpp rank_one_body).  Only for callers that read the results through h_out.
+static bool rank_one_applies(const mrk_batch &b, const mrk_model *model, bool cells) {
+  const Switches &sw = switches();
+  if (!sw.rank_one || !cells || !b.fused_ok || b.n_req < 1 || b.n_req > 16 || b.hb.max_items > QS_TILE_ROWS || b.view.n_overrides > 0) return false;
+  if (b.fused_slices != 1 || b.fused_threads > 512) return false;
+  const QsDev q = qs_device_view(model);
+  return rank_one_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, q.thr_cap, q.n_views, model->forest.backend == Backend::LightGBM) <= 96 * 1024;
+}
+
 // enqueue the pipeline on the batch's stream for batch items [lo, hi); the caller holds the store (StoreAccess)
-static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort) {
+static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort, bool direct = false) {
   mrk_ctx *ctx = b.ctx;
   MRK_HIP(hipSetDevice(ctx->device));
   check_model_fits(model, *b.prog);
@@ -362,16 +377,32 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort)
   const bool f64 = model && model->forest.backend == Backend::LightGBM;
   // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
   // (the specialised matrix kernel has no op-split form: a split batch of a matrix-scored model runs the interpreting kernel)
+  const bool one = direct && sort && lo == 0 && hi == b.total_items && rank_one_applies(b, model, cells);
   void *jit_fn = !cells ? (b.fused_ok && model && b.fused_split == 1 && b.fused_slices == 1 ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too
+                        : one ? jit_one_function(*b.prog, f64)
                         : !b.fused_ok ? jit_items_function(*b.prog, f64)
                         : b.fused_split > 1 || b.fused_slices > 1 ? jit_split_function(*b.prog, f64) : jit_rank_function(*b.prog, f64);
   LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
+  b.fetch_enqueued = false;
+  b.direct_out = false;
+  if (one) {
+    b.h_out.reserve(b.out_bytes);
+    uint8_t *h = b.h_out.as<uint8_t>();
+    const OneOut out{(double *)h, (int32_t *)(h + b.out_order_off), (int32_t *)(h + b.out_status_off),
+                     (const int32_t *)(b.d_out.as<uint8_t>() + b.out_status_off) + std::max(b.n_req, 1), std::max(b.n_req, 1)};
+    b.view.item_lo = 0;
+    b.view.item_hi = b.total_items;
+    launch_rank_one(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, qs_device_view(model), qs_forest_view(model), out, f64, jit_fn);
+    b.matrix_valid = false;
+    b.direct_out = true;
+    b.ran = true;
+    return;
+  }
   MRK_HIP(hipMemsetAsync(b.view.status, 0, std::max<size_t>(b.n_req, 1) * 4, b.s()));
   b.view.item_lo = lo;
   b.view.item_hi = hi;
-  b.fetch_enqueued = false;
   if (cells) {
     // hot path: the assembled values go straight into the scorer's binned tile; no f64 matrix
     const QsDev q = qs_device_view(model);
@@ -410,6 +441,7 @@ static void run_batch(mrk_batch &b, mrk_model *model) { run_batch(b, model, 0, b
 // scores + order + status -> the batch's pinned result buffer, one copy (a copy into pageable caller memory is staged by
 // the runtime anyway, and three small copies cost three round trips); asynchronous
 static void enqueue_fetch(mrk_batch &b, bool scores, bool order) {
+  if (b.direct_out) return;  // the device wrote h_out itself
   const size_t T = (size_t)b.total_items;
   b.h_out.reserve(b.out_bytes);
   uint8_t *h = b.h_out.as<uint8_t>();
@@ -653,7 +685,7 @@ void rank_tickets(mrk_ctx *ctx, RankTicket **tk, int n) {
     for (int i = 0; i < n; ++i) reqs[i] = *tk[i]->req;
     build_batch(ctx, prog, reqs.data(), n, nullptr, b);
     b.want_matrix = tk[0]->matrix != nullptr;
-    run_batch(b, tk[0]->model);
+    run_batch(b, tk[0]->model, 0, b.total_items, true, /*direct=*/true);
     if (n == 1) {
       fetch_batch(b, tk[0]->scores, tk[0]->order, tk[0]->matrix);
     } else {

@@ -118,6 +118,13 @@ std::string jit_source(const Program &prog, bool f64, int kernel) {
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
          "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
          "  mrk::assemble_cells_body<" + b64 + ">(st, mrk::JitProg{}, b, q, cells);\n}\n";
+  // pre-pass + assembly + forest + ordering of a small request in one launch (rank_device.hpp rank_one_body)
+  if (kernel == JIT_ALL || kernel == JIT_ONE)
+    // (a request's workgroup is 8 wavefronts = 2 per SIMD and a handful of them run at a time: nothing to gain from the
+    //  128-register cap of the batch kernels)
+    s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_one"
+         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, mrk::QsForestDev f, int mode, mrk::OneOut out) {\n"
+         "  mrk::rank_one_body<" + b64 + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, mode, out);\n}\n";
   return s;
 }
 
@@ -161,7 +168,7 @@ struct JitKernels {
   JitSlot slot[JIT_KERNELS][2];   // [kernel][f64] (the matrix kernel lives in [JIT_MATRIX][1])
 };
 
-const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells"};
+const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one"};
 
 // 0 off; 1 on: the first rank of a model waits for the compile (a failure falls back to the generic kernel with a warning);
 // 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready
@@ -283,6 +290,8 @@ void *jit_items_function(const Program &prog, bool f64) { return jit_function(pr
 void *jit_split_function(const Program &prog, bool f64) { return jit_function(prog, JIT_SPLIT, f64); }
 // the f64-matrix form of the fused kernel
 void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_MATRIX, true); }
+// the one-launch kernel of small requests
+void *jit_one_function(const Program &prog, bool f64) { return jit_function(prog, JIT_ONE, f64); }
 
 #ifdef MRK_PHASE_CLOCKS
 // measurement builds: read-and-reset the phase clocks of the specialised kernel of `prog`

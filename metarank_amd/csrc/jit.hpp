@@ -8,7 +8,7 @@ namespace mrk {
 struct Program;
 
 // the specialised kernels of a program; each is compiled (and cached on disk) by itself when a batch first needs it
-enum { JIT_RANK = 0, JIT_SPLIT = 1, JIT_MATRIX = 2, JIT_ITEMS = 3, JIT_KERNELS = 4, JIT_ALL = -1 };
+enum { JIT_RANK = 0, JIT_SPLIT = 1, JIT_MATRIX = 2, JIT_ITEMS = 3, JIT_ONE = 4, JIT_KERNELS = 5, JIT_ALL = -1 };
 // the translation unit hiprtc compiles for this model's program: the shared device code + the program as constants +
 // the kernel `kernel` (JIT_ALL: every kernel - inspection tools)
 std::string jit_source(const Program &prog, bool f64, int kernel = JIT_ALL);
@@ -23,6 +23,8 @@ void *jit_items_function(const Program &prog, bool f64);
 void *jit_split_function(const Program &prog, bool f64);
 // the fused kernel writing the row-major f64 matrix (mrk_jit_rank_matrix), same conditions
 void *jit_matrix_function(const Program &prog);
+// pre-pass + assembly + forest + ordering of a small request in one launch (mrk_jit_rank_one), same conditions
+void *jit_one_function(const Program &prog, bool f64);
 void jit_release(Program &prog);
 
 }  // namespace mrk

@@ -107,4 +107,131 @@ __device__ __forceinline__ bool qs_bin_column(double x, const QsFeature ft, cons
   return ok;
 }
 
+// ---------------------------------------------------------------------------------- scoring (shared by score_qs.hip and
+// the one-launch rank kernel of rank_device.hpp)
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+struct QsForestDev {   // the bit-vector image of a forest (forest.hpp "qs"): what a scoring kernel reads
+  const uint32_t *nodes;       // per tree QS_TREE_WORDS dwords; one all-zero tree after the last
+  const uint8_t *leaves;       // per tree QS_LEAVES values (f64 | f32), position order
+  const QsCatNode *cat_nodes;
+  const uint32_t *cat_bits;
+  int32_t n_trees;
+  int32_t n_views;
+  double base;                 // XGBoost base margin
+};
+
+// categorical nodes of one tree (rare path): the cell is the category id, tested against the node's bitset
+template <bool F64>
+__device__ __forceinline__ uint32_t qs_cat_pair(const QsCatNode &cn, uint32_t cc, const uint32_t *__restrict__ cat_bits) {
+  const bool dl = (cn.view_dl >> 16) != 0;
+  uint32_t removed = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t cat = (cc >> (16 * h)) & 0xffffu;
+    const uint32_t w = cat >> 5;
+    bool in = false;
+    if (cat < QS_CAT_BEYOND && w < cn.bits_words) in = (cat_bits[cn.bits_begin + w] >> (cat & 31)) & 1u;
+    bool right;
+    if constexpr (F64) right = !in;  // LightGBM: member -> left; NaN / negative / unknown -> right
+    else right = cat == QS_CAT_NAN ? !dl : in;  // XGBoost: member -> right; invalid / unknown -> left
+    if (right) removed |= cn.mm & (0xffffu << (16 * h));
+  }
+  return removed;
+}
+
+struct QsNodeRegs {
+  uint32_t kk[QS_SLOTS], mv[QS_SLOTS];  // kk[QS_SLOTS-1] = categorical word
+};
+
+__device__ __forceinline__ void qs_load_nodes(QsNodeRegs &r, const uint32_t *__restrict__ nd) {
+#pragma unroll
+  for (int s = 0; s < QS_SLOTS; ++s) {
+    r.kk[s] = nd[s];
+    r.mv[s] = nd[QS_SLOTS + s];
+  }
+}
+
+// the same through the constant address space: uniform loads from it are always scalar loads, whatever else the kernel
+// writes (the forest image is read-only for every kernel)
+typedef const __attribute__((address_space(4))) uint32_t *QsNodesK;
+__device__ __forceinline__ void qs_load_nodes_k(QsNodeRegs &r, QsNodesK nd) {
+#pragma unroll
+  for (int s = 0; s < QS_SLOTS; ++s) {
+    r.kk[s] = nd[s];
+    r.mv[s] = nd[QS_SLOTS + s];
+  }
+}
+
+// One 128-row tile scored by the `nw` wavefronts of the calling workgroup (nw * 64 lanes, all of them call): the same
+// arithmetic as qs_score_split_kernel - per chunk of 8 * nw trees every wavefront writes the exit-leaf indices of its
+// trees to LDS, then row `tid` (tid < 128) adds the chunk's leaf values in tree order.  The tile's slab (V x 256 B)
+// must start at LDS byte 0 (`ds_read_addtid_b32` addresses it through M0); s_leaf: 8 * nw trees x QS_LEAVES values,
+// s_idx: 8 * nw x 128 B.  Returns the score of row threadIdx.x (meaningful for threadIdx.x < 128).
+template <bool F64>
+__device__ __forceinline__ double qs_score_tile_split(const uint8_t *smem, uint8_t *s_leaf, uint8_t *s_idx, const QsForestDev &f, int nw) {
+  constexpr int LS = F64 ? 8 : 4;
+  constexpr int TREE_LEAF_BYTES = QS_LEAVES * LS;
+  const int CH = 8 * nw;
+  const int tid = threadIdx.x, lane = tid & 63, nthr = nw * 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double acc64 = 0.0;
+  float acc32 = (float)f.base;
+  for (int c0 = 0; c0 < f.n_trees; c0 += CH) {
+    const int nt = min(CH, f.n_trees - c0);
+    __syncthreads();  // slab complete / previous chunk consumed
+    {
+      const uint4 *src = (const uint4 *)(f.leaves + (size_t)c0 * TREE_LEAF_BYTES);
+      uint4 *dst = (uint4 *)s_leaf;
+      for (int i = tid; i < nt * (TREE_LEAF_BYTES / 16); i += nthr) dst[i] = src[i];
+    }
+    for (int tt = wave; tt < nt; tt += nw) {
+      const QsNodesK nd = (QsNodesK)(unsigned long long)(f.nodes + (size_t)(c0 + tt) * QS_TREE_WORDS);
+      QsNodeRegs r;
+      qs_load_nodes_k(r, nd);
+      uint32_t c[QS_SLOTS - 1], mm[QS_SLOTS - 1];
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; ++s)
+        asm volatile("s_lshr_b32 m0, %2, 16\n\ts_pack_ll_b32_b16 %1, %2, %2\n\tds_read_addtid_b32 %0"
+                     : "=v"(c[s]), "=s"(mm[s]) : "s"(r.mv[s]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads above are invisible to the compiler
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; ++s)
+        c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, r.kk[s]) - __builtin_bit_cast(short2v, c[s]));
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; ++s)
+        c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, c[s]) >> 15);
+      uint32_t acc_a = 0, acc_b = 0;
+#pragma unroll
+      for (int s = 0; s < QS_SLOTS - 1; s += 2) {
+        asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_a) : "v"(c[s]), "s"(mm[s]));
+        if (s + 1 < QS_SLOTS - 1) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_b) : "v"(c[s + 1]), "s"(mm[s + 1]));
+      }
+      uint32_t accn = acc_a | acc_b;
+      const uint32_t catw = __builtin_amdgcn_readfirstlane(r.kk[QS_SLOTS - 1]);
+      if (catw >> 24) {
+        const QsCatNode *cn = f.cat_nodes + (catw & 0xffffffu);
+        for (uint32_t j = 0; j < (catw >> 24); ++j) {
+          const QsCatNode cnode = cn[j];
+          accn |= qs_cat_pair<F64>(cnode, *(const uint32_t *)(smem + ((cnode.view_dl & 0xffffu) << 8) + lane * 4), f.cat_bits);
+        }
+      }
+      const uint32_t inv = ~accn;
+      const uint32_t pair = (uint32_t)__builtin_ctz(inv) | ((uint32_t)__builtin_ctz(inv >> 16) << 8);
+      *(uint16_t *)(s_idx + tt * QS_TILE_ROWS + lane * 2) = (uint16_t)pair;  // rows 2 * lane, 2 * lane + 1
+    }
+    __syncthreads();
+    if (tid < QS_TILE_ROWS) {  // row `tid`: the chunk's leaves, in tree order
+      for (int tt = 0; tt < nt; ++tt) {
+        const uint32_t li = s_idx[tt * QS_TILE_ROWS + tid];
+        if constexpr (F64) acc64 += *(const double *)(s_leaf + tt * TREE_LEAF_BYTES + li * 8);
+        else acc32 += *(const float *)(s_leaf + tt * TREE_LEAF_BYTES + li * 4);
+      }
+    }
+  }
+  return F64 ? acc64 : (double)acc32;
+}
+
 }  // namespace mrk

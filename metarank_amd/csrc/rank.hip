@@ -89,6 +89,13 @@ rank_fused_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_e
   rank_fused_cells_body<F64, true>(st, prog, b, tab_entries, vals_cap, q, cells, mode);
 }
 
+// pre-pass + assembly + forest + ordering of a small request in ONE launch (rank_device.hpp rank_one_body)
+template <bool F64>
+__global__ void __launch_bounds__(512)
+rank_one_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, QsDev q, QsForestDev f, int mode, OneOut out) {
+  rank_one_body<F64>(st, prog, b, tab_entries, vals_cap, q, f, mode, out);
+}
+
 __global__ void override_kernel(BatchDev b, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n_overrides) return;
@@ -368,6 +375,43 @@ void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int
   launch_big_sort(ctx->launch, src, n, order, scratch);
   hipLaunchKernelGGL(norm_position_apply_kernel, dim3((n + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), 0, ctx->launch, order, n, colp, dim);
   MRK_HIP(hipGetLastError());
+}
+
+// LDS of the one-launch kernel: [slab][status word][max(assembly regions, scoring regions)]
+size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64) {
+  const size_t nw = (size_t)threads / 64;
+  const size_t scoring = 8 * nw * (QS_LEAVES * (f64 ? 8 : 4) + QS_TILE_ROWS) + QS_TILE_ROWS * 8;
+  return (size_t)n_views * QS_TILE_ROWS * 2 + 16 + std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap), scoring);
+}
+
+// One workgroup per request (requests of <= QS_TILE_ROWS candidates, `threads` = item lanes x op split, <= 512);
+// jit_fn: the specialised mrk_jit_rank_one of this program, or nullptr = the interpreting kernel.
+void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
+                     int threads, int op_split, const QsDev &q, const QsForestDev &f, const OneOut &out, bool f64, void *jit_fn) {
+  if (b.n_req <= 0) return;
+  int mode = op_split > 1 ? op_split : 1;
+  const size_t lds = rank_one_lds_bytes(tab_entries, vals_cap, threads, q.thr_cap, f.n_views, f64);
+  ScopedKernelTimer timer(ctx, "rank_one");
+  if (jit_fn) {
+    StoreDev a_st = st;
+    BatchDev a_b = b;
+    QsDev a_q = q;
+    QsForestDev a_f = f;
+    OneOut a_out = out;
+    int a_vals = vals_cap;
+    void *args[] = {&a_st, &a_b, &tab_entries, &a_vals, &a_q, &a_f, &mode, &a_out};
+    MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
+  } else {
+    static thread_local bool configured = false;
+    if (!configured) {
+      MRK_HIP(hipFuncSetAttribute((const void *)rank_one_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MRK_HIP(hipFuncSetAttribute((const void *)rank_one_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      configured = true;
+    }
+    if (f64) hipLaunchKernelGGL(rank_one_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, mode, out);
+    else hipLaunchKernelGGL(rank_one_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, mode, out);
+    MRK_HIP(hipGetLastError());
+  }
 }
 
 // Normalize.scale over matrix column `col` of every request of the batch (after assembly and overrides)

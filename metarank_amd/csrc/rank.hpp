@@ -120,6 +120,38 @@ struct BatchDev {
 };
 
 constexpr int PREP_MAX_VALUES = 4096;  // diversity numeric: values sorted in LDS
+// where the one-launch kernel (rank_device.hpp rank_one_body) leaves a batch's results: the host-visible (pinned) buffer
+struct OneOut {
+  double *scores;        // [total_items], request order
+  int32_t *order;        // [total_items], request-local indices in response order
+  int32_t *status;       // [n_req] status words of this run, [n_req_pad .. n_req_pad + n_req) what the id resolution found at load time
+  const int32_t *load_status;   // device copy of the latter (nullptr: zeros)
+  int32_t n_req_pad;     // max(n_req, 1)
+};
+
+// ---- the serving queue (rank_device.hpp rank_serve_body, capi_rank.cpp mrk_serve_*): one persistent workgroup per slot.
+// ServeCtl lives in pinned host memory: the host writes `seq` / `stop` and the request header, the device `ack` /
+// `exited`.  No word is written from both sides.
+struct ServeCtl {
+  uint32_t seq;       // host: number of the request in the slot's input block (published last, after the block and this header)
+  uint32_t stop;      // host: 1 = leave at the next poll
+  uint32_t ack;       // device: last request whose results are in the slot's output block
+  uint32_t exited;    // device: the launch id of the workgroup that has left (idle for `idle_ticks`, or told to stop)
+  // the request's header
+  uint32_t in_bytes;  // bytes of the input block
+  uint32_t o_reqs, o_consts, o_irf, o_prep, o_slot, o_ireq;   // where the arrays of BatchDev start inside it
+  uint32_t total_items, tab_entries, vals_cap, mode;
+  uint32_t pad[17];   // 128 B
+};
+struct ServeSlotDev {
+  ServeCtl *ctl;             // pinned
+  const uint8_t *in_host;    // pinned input block (the host side's packing of one request: build_batch's layout)
+  uint8_t *in_dev;           // its device copy, made by the workgroup itself
+  OneOut out;                // pinned output block
+  uint32_t launch_id, last_seq;
+  unsigned long long idle_ticks;   // wall_clock64 ticks (100 MHz) without a request after which the workgroup leaves
+};
+
 constexpr int SORT_MAX_ITEMS = 4096;   // per-request LDS sort
 
 }  // namespace mrk

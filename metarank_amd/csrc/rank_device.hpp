@@ -8,6 +8,7 @@
 
 #include "qs_device.hpp"
 #include "rank.hpp"
+#include "sort_device.hpp"
 
 #ifdef MRK_PHASE_CLOCKS
 // measurement builds only (MRK_DEFINES=MRK_PHASE_CLOCKS): core-clock cycles thread 0 of every workgroup spends per phase
@@ -1330,12 +1331,14 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 //     in its own LDS) and assembles one slice of the candidates.  A batch of few large requests - 384 requests x 1 000
 //     candidates is 1.5 workgroups per CU, each looping four times over its lanes - fills the chip this way: the
 //     pre-pass is paid `slices` times, the dependent chain of a workgroup shrinks by the same factor.
+// lds_skip: bytes at the start of the dynamic LDS that belong to the caller (the one-launch kernel keeps the scorer's slab there).
 template <bool SPLIT, typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
-                                                int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink) {
+                                                int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink, uint32_t lds_skip = 0) {
   const int op_split = SPLIT ? ((mode & 255) > 1 ? (mode & 255) : 1) : 1;
   const int slices = SPLIT ? ((mode >> 8) > 1 ? (mode >> 8) : 1) : 1;   // (the plain kernel keeps its registers for the ops)
-  extern __shared__ __align__(16) uint8_t smem[];
+  extern __shared__ __align__(16) uint8_t smem_base[];
+  uint8_t *smem = smem_base + lds_skip;
   unsigned long long *s_tab = (unsigned long long *)smem;
   double *s_vals = (double *)(smem + (size_t)tab_entries * 8);
   PrepOut *s_po = (PrepOut *)(smem + (size_t)tab_entries * 8 + (size_t)vals_cap * 8);
@@ -1406,6 +1409,135 @@ __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const 
   rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, q.thr_cap, mode, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
     return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
   });
+}
+
+// ---- ONE launch for a handful of small requests (mrk_rank, the serving queue): pre-pass + assembly + forest + ordering in
+// the request's workgroup.  The binned tile never leaves LDS: the assembly writes the request's cells into the slab the
+// scorer reads (LDS byte 0 on: `ds_read_addtid_b32` addresses it through M0), the workgroup's wavefronts split the trees
+// (qs_score_tile_split: the additions of qs_score_split_kernel, in tree order), the rows' owners order the scores by
+// counting (sort_kernel's rule) and write scores / order / status where the host reads them - pinned memory - so the
+// whole of Ranker.rerank (ml/Ranker.scala:27-83) is one dispatch and no copy.  Requests of <= QS_TILE_ROWS candidates.
+// Dynamic LDS: [slab: slab_bytes = V x 256][the request's status word, 16 B][the regions of rank_fused_body | afterwards:
+// leaf values, exit-leaf indices, sort keys of the scoring phase].  The status word lives in LDS too (the batch view the
+// assembly sees has its `status` pointer bent there): no global atomic, nothing to wait for before it is copied out.
+template <bool F64, typename Prog>
+__device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
+                                              const QsDev &q, const QsForestDev &f, int mode, const OneOut &out) {
+  extern __shared__ __align__(16) uint8_t smem_base[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int r = blockIdx.x;
+  const ReqDev rq = b.reqs[r];
+  const uint32_t slab_bytes = (uint32_t)f.n_views * (QS_TILE_ROWS * 2);
+  for (uint32_t i = tid; i < slab_bytes / 4 + 4; i += nthr) ((uint32_t *)smem_base)[i] = 0u;  // rows past the request's last candidate; the status word
+  int32_t *s_status = (int32_t *)(smem_base + slab_bytes);
+  BatchDev bl = b;
+  bl.status = s_status - r;   // &bl.status[r] is the LDS word
+  __syncthreads();
+  rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, q.thr_cap, mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
+    return CellSink<F64>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active};
+  }, slab_bytes + 16);
+  // (qs_score_tile_split starts with a barrier: the slab is complete, the assembly's LDS regions are free)
+  constexpr int TREE_LEAF_BYTES = QS_LEAVES * (F64 ? 8 : 4);
+  const int nw = nthr >> 6;
+  uint8_t *s_leaf = smem_base + slab_bytes + 16;
+  uint8_t *s_idx = s_leaf + 8 * nw * TREE_LEAF_BYTES;
+  unsigned long long *s_key = (unsigned long long *)(s_idx + 8 * nw * QS_TILE_ROWS);
+  const double score = qs_score_tile_split<F64>(smem_base, s_leaf, s_idx, f, nw);
+  const int n = rq.n_items;
+  if (tid < n) {
+    out.scores[rq.item_begin + tid] = score;
+    s_key[tid] = sort_key(score);
+  }
+  __syncthreads();
+  if (tid < n) {  // the place of candidate `tid`: the pairs (key, index) that precede its own
+    const unsigned long long mine = s_key[tid];
+    int before = 0;
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long kj = s_key[j];
+      before += (kj < mine || (kj == mine && j < tid)) ? 1 : 0;
+    }
+    out.order[rq.item_begin + before] = tid;
+  }
+  if (tid == 0) {
+    out.status[r] = *s_status;
+    out.status[out.n_req_pad + r] = out.load_status ? out.load_status[r] : 0;
+  }
+}
+
+// ---- the persistent form of the same: ONE workgroup that stays on its CU and serves the requests the host publishes in
+// its slot (main/command/Serve.scala:130-150 + api/routes/RankApi.scala:25-41: the process that answers POST /rank - here
+// the request path contains no HIP call at all).  Per request: lane 0 polls `seq` in pinned memory; the workgroup copies
+// the request's input block from pinned memory into its device scratch (one coalesced pass over PCIe; the assembly reads
+// its inputs many times), drops its CU's cached lines of that scratch, runs rank_one_body - which writes scores / order /
+// status into the slot's pinned output block - and acknowledges.  A workgroup that has seen no request for `idle_ticks`
+// announces `exited` and leaves (a persistent kernel must never outlive its use: hipFree and friends wait for it); the host
+// relaunches it with the next request.  If a request slips in between the announcement and the exit it is still served
+// (device: store exited, fence, read seq; host: store seq, fence, read exited - one side sees the other).
+template <bool F64, typename Prog>
+__device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &s) {
+  extern __shared__ __align__(16) uint8_t smem_base[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t slab_bytes = (uint32_t)f.n_views * (QS_TILE_ROWS * 2);
+  volatile uint32_t *s_word = (volatile uint32_t *)(smem_base + slab_bytes + 8);   // [0] seq | STOP, [1] leave after this request
+  uint32_t last = s.last_seq;
+  unsigned long long idle_since = wall_clock64();
+  for (;;) {
+    if (tid == 0) {
+      uint32_t seq = last, leave = 0, stop = 0;
+      for (;;) {
+        seq = __hip_atomic_load(&s.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (seq != last) break;
+        const bool told = __hip_atomic_load(&s.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        if (told || wall_clock64() - idle_since > s.idle_ticks) {
+          __hip_atomic_store(&s.ctl->exited, s.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __threadfence_system();
+          seq = __hip_atomic_load(&s.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (seq != last) leave = 1;   // a request slipped in: serve it, then leave
+          else stop = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      s_word[0] = stop ? 0xffffffffu : seq;
+      s_word[1] = leave;
+    }
+    __syncthreads();
+    const uint32_t seq = s_word[0], leave = s_word[1];
+    if (seq == 0xffffffffu) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // the header and the block were written before `seq`
+    const ServeCtl *ctl = s.ctl;
+    const uint32_t in_bytes = ctl->in_bytes;
+    {
+      const uint4 *src = (const uint4 *)s.in_host;
+      uint4 *dst = (uint4 *)s.in_dev;
+      for (uint32_t i = tid; i < (in_bytes + 15) / 16; i += nthr) dst[i] = src[i];
+    }
+    BatchDev b = {};
+    b.reqs = (const ReqDev *)(s.in_dev + ctl->o_reqs);
+    b.n_req = 1;
+    b.total_items = (int32_t)ctl->total_items;
+    b.item_lo = 0;
+    b.item_hi = b.total_items;
+    b.item_slot = (const int32_t *)(s.in_dev + ctl->o_slot);
+    b.item_req = (const uint32_t *)(s.in_dev + ctl->o_ireq);
+    b.consts = (const double *)(s.in_dev + ctl->o_consts);
+    b.irf = (const int32_t *)(s.in_dev + ctl->o_irf);
+    b.prep_out = (PrepOut *)(s.in_dev + ctl->o_prep);
+    const uint32_t tab_entries = ctl->tab_entries, vals_cap = ctl->vals_cap, mode = ctl->mode;
+    // the copy must have reached L2 and this CU must not serve the previous request's lines of the scratch from its
+    // vector or scalar cache
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    rank_one_body<F64>(st, prog, b, tab_entries, (int)vals_cap, q, f, (int)mode, s.out);
+    __threadfence_system();   // every lane's results are in host memory before the acknowledgement
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&s.ctl->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (leave) return;
+    last = seq;
+    idle_since = wall_clock64();
+  }
 }
 
 }  // namespace

@@ -101,6 +101,7 @@ struct Switches {
   int fused_slices = 0;        // MRK_FUSED_SLICES=n: workgroups per request of the fused kernel (0: by batch shape; 1: off)
   int fused_split = 0;         // MRK_FUSED_SPLIT=1|2|4: op split of the fused kernel's workgroups (0: 4 / 2 for batches of <= 16 requests)
   bool rank_combine = true;    // MRK_RANK_COMBINE=0: no batching front in mrk_rank
+  bool rank_one = true;        // MRK_RANK_ONE=0: mrk_rank's small batches take the three-launch path instead of the one-launch kernel
   int combine_max = 256;       // MRK_RANK_COMBINE_MAX
   int table_load_pct = 75;     // MRK_TABLE_LOAD_PCT
   int host_threads = 0;        // MRK_HOST_THREADS (0: min(8, hardware threads))

@@ -31,8 +31,6 @@ QsDev qs_device_view(const mrk_model *m);
 
 namespace {
 
-typedef short short2v __attribute__((ext_vector_type(2)));
-
 constexpr int QS_WAVES = 4;  // wavefronts per workgroup (they share the staged leaf values)
 
 // ---------------------------------------------------------------------------------- binning
@@ -76,25 +74,6 @@ qs_bin_kernel(const double *__restrict__ X, int rows, int cols, QsDev q, uint16_
 }
 
 // ---------------------------------------------------------------------------------- scoring
-
-// categorical nodes of one tree (rare path): the cell is the category id, tested against the node's bitset
-template <bool F64>
-__device__ __forceinline__ uint32_t qs_cat_pair(const QsCatNode &cn, uint32_t cc, const uint32_t *__restrict__ cat_bits) {
-  const bool dl = (cn.view_dl >> 16) != 0;
-  uint32_t removed = 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t cat = (cc >> (16 * h)) & 0xffffu;
-    const uint32_t w = cat >> 5;
-    bool in = false;
-    if (cat < QS_CAT_BEYOND && w < cn.bits_words) in = (cat_bits[cn.bits_begin + w] >> (cat & 31)) & 1u;
-    bool right;
-    if constexpr (F64) right = !in;  // LightGBM: member -> left; NaN / negative / unknown -> right
-    else right = cat == QS_CAT_NAN ? !dl : in;  // XGBoost: member -> right; invalid / unknown -> left
-    if (right) removed |= cn.mm & (0xffffu << (16 * h));
-  }
-  return removed;
-}
 
 // Generic kernel: QS_WAVES wavefronts per workgroup share LDS-staged leaf chunks; R = 2, 4 or 8 rows per lane.
 template <bool F64, int R>
@@ -216,18 +195,6 @@ qs_score_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restrict__ 
 // so the scalar-load latency of the next tree hides behind D and behind the other waves of the SIMD.
 // No LDS leaf chunks and no barriers: a workgroup's LDS footprint is its V x 256 B slab, so occupancy is
 // 160 KB / (V x 256 B) waves per CU at wave granularity.
-struct QsNodeRegs {
-  uint32_t kk[QS_SLOTS], mv[QS_SLOTS];  // kk[QS_SLOTS-1] = categorical word
-};
-
-__device__ __forceinline__ void qs_load_nodes(QsNodeRegs &r, const uint32_t *__restrict__ nd) {
-#pragma unroll
-  for (int s = 0; s < QS_SLOTS; ++s) {
-    r.kk[s] = nd[s];
-    r.mv[s] = nd[QS_SLOTS + s];
-  }
-}
-
 template <bool F64>
 __global__ void __launch_bounds__(64)
 qs_score_wave_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restrict__ leaves,
@@ -543,6 +510,18 @@ QsDev qs_device_view(const mrk_model *m) {
     if (f.view_begin != f.view_end && f.thr_len <= QS_LDS_THR) longest = std::max<uint32_t>(longest, f.thr_len);
   q.thr_cap = (longest + QS_STAGE_CHUNK - 1) / QS_STAGE_CHUNK * QS_STAGE_CHUNK;
   return q;
+}
+
+QsForestDev qs_forest_view(const mrk_model *m) {
+  QsForestDev f;
+  f.nodes = m->d_qs_nodes.as<uint32_t>();
+  f.leaves = m->d_qs_leaves.as<uint8_t>();
+  f.cat_nodes = m->d_qs_catnodes.as<QsCatNode>();
+  f.cat_bits = m->d_qs_cat.as<uint32_t>();
+  f.n_trees = m->qs.n_trees;
+  f.n_views = (int32_t)m->qs.views.size();
+  f.base = m->forest.base_score;
+  return f;
 }
 
 // Returns false when the model has no bit-vector image (trees with more than 16 leaves, ...): the
