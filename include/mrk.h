@@ -131,6 +131,19 @@ int mrk_model_dim(mrk_ctx *ctx, const char *model_name);
 int mrk_config_specialize(const char *json, size_t len, const char *model_name, int f64, int what, uint8_t *out, size_t cap,
                           size_t *needed);
 
+/* Host-only: writes into directory `dir` the gfx950 code object of every specialised kernel in `kernel_mask` (bit k: 0 the
+ * workgroup-per-request kernel, 1 its op-split / sliced form, 2 the f64-matrix form, 3 the item-parallel kernel, 4 the
+ * one-launch kernel of mrk_rank, 5 the persistent workgroup of the serving queue) for this config's model - what a
+ * deployment ships next to libmrk_hip.so (directory `jit_cache`) so that no process ever compiles: the library looks
+ * there, then in the user's cache ($MRK_JIT_CACHE_DIR, ~/.cache/mrk_jit), and only then compiles - in the BACKGROUND,
+ * ranking with the kernel that interprets the program meanwhile (MRK_RANK_JIT: 0 never specialise, 1 wait for the compiler,
+ * require, async, auto = this default).  out_compiled (nullable): how many were not there yet. */
+int mrk_config_precompile(const char *json, size_t len, const char *model_name, int f64, unsigned kernel_mask, const char *dir,
+                          int *out_compiled);
+/* Serve.maybeWarmup for the kernels: waits until the background compiles of this model's kernels that are under way have
+ * finished (the next launch uses them).  A host calls it before it opens its port; nothing on the request path waits. */
+int mrk_config_warmup(mrk_ctx *ctx, const char *model_name);
+
 /* ------------------------- feature store (KVStore[Key, FeatureValue] mirror) */
 
 /* `key` is Key.encode (M/model/Key.scala:9): "<ScopeCodec.encode(scope)>/<feature name>", e.g.
@@ -312,6 +325,24 @@ int mrk_batch_fetch(mrk_batch *batch, double *out_scores, int32_t *out_order, do
  * exception for that request maps to (e.g. MRK_ERR_ARITHMETIC); results of failed requests are undefined */
 int mrk_batch_status(mrk_batch *batch, int32_t *out_status);
 void mrk_batch_free(mrk_batch *batch);
+
+/* ---- the serving queue ---------------------------------------------------------------------------
+ * Replaces the request loop around Ranker.rerank - main/command/Serve.scala:130-150 (warm-up, then the port opens) and
+ * api/routes/RankApi.scala:25-41 (one rerank per request thread).  mrk_serve_start compiles what the model needs (the
+ * warm-up: no request ever waits for a compiler) and prepares n_slots slots, each served by a PERSISTENT workgroup on
+ * the device that polls its slot in pinned memory.  mrk_serve_rank is then the whole request path, callable from any
+ * number of host threads: the request is resolved on the calling thread and written into a free slot; the workgroup
+ * assembles, scores and orders it and writes scores / order / status back into pinned memory - no launch, no copy
+ * command, no HIP call.  Results and errors are exactly mrk_rank's.  Requests the one-workgroup path does not take
+ * (more than 128 candidates, per-item field overrides, a model with a request-normalised column, all slots busy) go
+ * through mrk_rank transparently.  A workgroup that has seen no request for a while (2 ms; MRK_SERVE_IDLE_US) leaves
+ * its CU and is relaunched by the next request; store flushes stop the workgroups for their duration.
+ * mrk_serve_stats: out3 = {requests through the queue, requests through mrk_rank, workgroup launches}. */
+typedef struct mrk_server mrk_server;
+int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int n_slots, mrk_server **out);
+int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, int32_t *out_order);
+int mrk_serve_stats(mrk_server *srv, int64_t *out3);
+void mrk_serve_stop(mrk_server *srv);
 
 /* ------------------------------------------------ multi-GPU (RCCL over xGMI) */
 

@@ -5,5 +5,5 @@ thin host-side mirror of the reference's interfaces used by tests and benchmarks
 """
 from ._native import MrkError, build, lib, reload_switches  # noqa: F401
 from .booster import LIGHTGBM, XGBOOST, Context, HipBooster, default_context  # noqa: F401
-from .ranker import Batch, HipRanker  # noqa: F401,E402
+from .ranker import Batch, HipRanker, Server  # noqa: F401,E402
 from .request import Request, RequestSet  # noqa: F401,E402

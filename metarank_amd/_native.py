@@ -138,6 +138,8 @@ SIGNATURES = {
     "mrk_config_load_json": (_I, [_V, _S, C.c_size_t]),
     "mrk_model_dim": (_I, [_V, _S]),
     "mrk_config_specialize": (_I, [_S, C.c_size_t, _S, _I, _I, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mrk_config_precompile": (_I, [_S, C.c_size_t, _S, _I, C.c_uint, _S, C.POINTER(C.c_int)]),
+    "mrk_config_warmup": (_I, [_V, _S]),
     "mrk_store_put_double": (_I, [_V, _S, C.c_double]),
     "mrk_store_put_bool": (_I, [_V, _S, _I]),
     "mrk_store_put_string": (_I, [_V, _S, _S]),
@@ -176,6 +178,10 @@ SIGNATURES = {
     "mrk_batch_fetch": (_I, [_V, _P, _P, _P]),
     "mrk_batch_status": (_I, [_V, _P]),
     "mrk_batch_free": (None, [_V]),
+    "mrk_serve_start": (_I, [_V, _V, _S, _I, C.POINTER(_V)]),
+    "mrk_serve_rank": (_I, [_V, C.POINTER(mrk_request), _P, _P]),
+    "mrk_serve_stats": (_I, [_V, _P]),
+    "mrk_serve_stop": (None, [_V]),
     "mrk_comm_unique_id": (_I, [_P]),
     "mrk_comm_init": (_I, [_V, _P, _I, _I]),
     "mrk_comm_rank": (_I, [_V]),

@@ -25,10 +25,12 @@ static Switches read_switches() {
   s.prepass_lds = flag("MRK_PREPASS_LDS", true);
   s.rank_combine = flag("MRK_RANK_COMBINE", true);
   s.rank_one = flag("MRK_RANK_ONE", true);
+  s.rank_serve = flag("MRK_RANK_SERVE", true);
+  s.serve_idle_us = std::max(1, num("MRK_SERVE_IDLE_US", 2000));
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
   s.table_load_pct = std::max(10, std::min(90, num("MRK_TABLE_LOAD_PCT", 75)));
   s.host_threads = std::max(0, std::min(256, num("MRK_HOST_THREADS", 0)));
-  if (const char *e = getenv("MRK_RANK_JIT")) s.jit_mode = !strcmp(e, "require") ? 2 : !strcmp(e, "async") ? 3 : atoi(e) != 0 ? 1 : 0;
+  if (const char *e = getenv("MRK_RANK_JIT")) s.jit_mode = !strcmp(e, "require") ? 2 : !strcmp(e, "async") ? 3 : !strcmp(e, "auto") ? 4 : atoi(e) != 0 ? 1 : 0;
   s.jit_waves = num("MRK_JIT_WAVES", 0);
   s.jit_record_regs = flag("MRK_JIT_REGS", true);
   if (const char *d = getenv("MRK_JIT_CACHE_DIR")) s.jit_cache_dir = d;

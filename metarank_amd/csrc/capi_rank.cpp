@@ -1,4 +1,8 @@
 // Feature store + rank entry points of the C ABI (include/mrk.h).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 
 #include <cstdlib>
@@ -32,6 +36,8 @@ int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 QsForestDev qs_forest_view(const mrk_model *m);  // score_qs.hip
 size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64);
+void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
+                       int threads, size_t lds, bool f64, void *jit_fn);
 void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                      int threads, int op_split, const QsDev &q, const QsForestDev &f, const OneOut &out, bool f64, void *jit_fn);
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
@@ -133,6 +139,8 @@ void free_rank_state(mrk_ctx *ctx) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+static void quiesce_servers(mrk_ctx *ctx);
+
 // Access to the feature store for the duration of a call.  Readers (resolving a batch, launching kernels that gather from
 // the device tables) share it; whatever is dirty is flushed first, exclusively.  `exclusive`: the call mutates host-side
 // store state itself (lazily tokenised cross-encoder texts).
@@ -159,6 +167,7 @@ struct StoreAccess {
   }
   void do_flush() {
     MRK_HIP(hipSetDevice(ctx->device));
+    quiesce_servers(ctx);  // persistent workgroups hold the device views they were launched with: they leave, and come back with the next request
     ctx->store->flush(ctx->stream);
   }
 };
@@ -519,6 +528,33 @@ int mrk_config_specialize(const char *json, size_t len, const char *model_name, 
     *needed = what == 1 && !out ? (size_t)1 << 22 : n;  // code objects: an upper bound for the sizing call
     if (cap < n || !out) throw StatusError(MRK_ERR_INVALID_ARG, "output buffer too small (see *needed)");
     memcpy(out, data, n);
+  });
+}
+
+static const Program &program_of(mrk_ctx *ctx, const char *model_name);
+
+int mrk_config_precompile(const char *json, size_t len, const char *model_name, int f64, unsigned kernel_mask, const char *dir, int *out_compiled) {
+  return guard([&] {
+    if (out_compiled) *out_compiled = 0;
+    if (!json || !model_name || !dir) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    Store st;
+    std::unique_ptr<Registry> reg = load_config(json, len, st, /*upload=*/false);
+    const Program *p = reg->program(model_name);
+    if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
+    const int n = jit_precompile(*p, f64 != 0, kernel_mask, dir);
+    if (out_compiled) *out_compiled = n;
+  });
+}
+
+int mrk_config_warmup(mrk_ctx *ctx, const char *model_name) {
+  return guard([&] {
+    if (!ctx || !model_name) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    const Program *p;
+    {
+      std::shared_lock<std::shared_mutex> sl(ctx->store_mu);
+      p = &program_of(ctx, model_name);
+    }
+    jit_wait(*p);
   });
 }
 
@@ -1037,6 +1073,263 @@ int mrk_batch_status(mrk_batch *batch, int32_t *out_status) {
       out_status[r] = status_to_code(batch->h_status[r], msg);
     }
   });
+}
+
+// ---------------------------------------------------------------- the serving queue
+// main/command/Serve.scala:130-150 (warm-up, then the port opens) and api/routes/RankApi.scala:25-41 (one rerank per
+// request thread): mrk_serve_start compiles what the model needs and prepares `n_slots` slots, each a persistent workgroup
+// (rank_device.hpp rank_serve_body) with its request / result blocks in pinned memory; mrk_serve_rank is then the whole
+// request path: resolve the request on the calling thread, write it into a free slot, publish, spin on the acknowledgement -
+// no HIP call, no launch, no copy command.  Whatever the one-workgroup path does not cover (more than 128 candidates,
+// per-item overrides, tables beyond the slot's LDS, explain) goes through mrk_rank.
+}  // extern "C"
+
+namespace {
+
+struct ServeSlot {
+  hipStream_t stream = nullptr;
+  void *pinned = nullptr;       // [ServeCtl 128 B][output block][input block], coherent host memory
+  ServeCtl *ctl = nullptr;
+  uint8_t *h_out = nullptr, *h_in = nullptr;
+  DevBuf d_in;
+  HostBatch hb;
+  uint32_t seq = 0, launch_id = 0;
+  bool running = false;         // a workgroup was launched and has not been seen to leave (owner: whoever holds the slot + the store shared, or the store exclusively)
+};
+
+constexpr size_t SERVE_OUT_BYTES = 2048;          // scores 128 x 8 | order 128 x 4 | status 2 x 4
+constexpr size_t SERVE_IN_CAP = 64 * 1024;
+constexpr int SERVE_THREADS = 512;                // 128 item lanes x op split 4; 8 wavefronts split the trees
+constexpr size_t SERVE_LDS = 128 * 1024;
+
+}  // namespace
+
+struct mrk_server {
+  mrk_ctx *ctx = nullptr;
+  mrk_model *model = nullptr;
+  std::string model_name;
+  const Program *prog = nullptr;
+  bool f64 = true;
+  void *jit_fn = nullptr;
+  uint64_t idle_ticks = 0;
+  std::vector<std::unique_ptr<ServeSlot>> slots;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<int> free_slots;  // a stack: the most recently used slot is the one whose workgroup is still resident
+  bool closing = false;
+  std::atomic<uint64_t> n_queue{0}, n_fallback{0}, n_launches{0};
+};
+
+namespace {
+
+void stop_slot(ServeSlot &sl) {  // the caller owns the slot and no request is in flight in it
+  if (!sl.running) return;
+  __atomic_store_n(&sl.ctl->stop, 1u, __ATOMIC_SEQ_CST);
+  (void)hipStreamSynchronize(sl.stream);
+  __atomic_store_n(&sl.ctl->stop, 0u, __ATOMIC_SEQ_CST);
+  sl.running = false;
+}
+
+void launch_slot(mrk_server &srv, ServeSlot &sl) {  // the caller holds the store (shared): the device views are current
+  mrk_ctx *ctx = srv.ctx;
+  sl.launch_id += 1;
+  ServeSlotDev d;
+  d.ctl = sl.ctl;
+  d.in_host = sl.h_in;
+  d.in_dev = sl.d_in.as<uint8_t>();
+  d.out = OneOut{(double *)sl.h_out, (int32_t *)(sl.h_out + 1024), (int32_t *)(sl.h_out + 1536), nullptr, 1};
+  d.launch_id = sl.launch_id;
+  d.last_seq = sl.seq - 1;  // the request just published is the first thing the workgroup sees
+  d.idle_ticks = srv.idle_ticks;
+  launch_rank_serve(sl.stream, ctx->store->device_view(), srv.prog->device_view(), qs_device_view(srv.model), qs_forest_view(srv.model), d,
+                    SERVE_THREADS, SERVE_LDS, srv.f64, srv.jit_fn);
+  sl.running = true;
+  srv.n_launches.fetch_add(1);
+}
+
+// true: ranked through the queue (status = the request's device status word); false: not a request the queue takes
+bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int32_t *out_order, int &status) {
+  mrk_ctx *ctx = srv.ctx;
+  if (!switches().rank_serve || req->n_items > QS_TILE_ROWS) return false;
+  int si = -1;
+  {
+    std::lock_guard<std::mutex> lk(srv.mu);
+    if (srv.closing || srv.free_slots.empty()) return false;  // every slot busy: the batching front of mrk_rank combines the overflow
+    si = srv.free_slots.back();
+    srv.free_slots.pop_back();
+  }
+  struct Release {
+    mrk_server &s;
+    int i;
+    ~Release() {
+      { std::lock_guard<std::mutex> lk(s.mu); s.free_slots.push_back(i); }
+      s.cv.notify_one();
+    }
+  } release{srv, si};
+  ServeSlot &sl = *srv.slots[(size_t)si];
+  const Program &prog = locked_program(ctx, srv.model_name.c_str());
+  if (&prog != srv.prog || program_mutates_store(prog) || prog.normalises()) return false;
+  StoreAccess access(ctx);
+  MRK_HIP(hipSetDevice(ctx->device));
+  check_model_fits(srv.model, prog);
+  HostBatch &hb = sl.hb;
+  resolve_requests(prog, *ctx->store, req, 1, nullptr, hb);
+  const int T = hb.total_items;
+  uint32_t vals = 1;
+  while ((int)vals < hb.max_doubles) vals <<= 1;
+  const uint32_t entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
+  const QsDev q = qs_device_view(srv.model);
+  if (!hb.overrides.empty() || (int)prog.prep.size() > fused_max_prep() || hb.max_req_entries > (1u << 20) ||
+      rank_one_lds_bytes(entries, (int)vals, SERVE_THREADS, q.thr_cap, q.n_views, srv.f64) > SERVE_LDS)
+    return false;
+  // the request's input block: build_batch's arrays, 16-byte aligned
+  size_t off = 0;
+  auto place = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return o; };
+  const size_t o_reqs = place(hb.reqs.size() * sizeof(ReqDev)), o_consts = place(hb.consts.size() * 8), o_irf = place(hb.irf.size() * 4);
+  const size_t o_prep = place(hb.prep_out.size() * sizeof(PrepOut)), o_slot = place((size_t)T * 4), o_ireq = place((size_t)T * 4);
+  if (off > SERVE_IN_CAP) return false;
+  auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) memcpy(sl.h_in + o, src, bytes); };
+  put(o_reqs, hb.reqs.data(), hb.reqs.size() * sizeof(ReqDev));
+  put(o_consts, hb.consts.data(), hb.consts.size() * 8);
+  put(o_irf, hb.irf.data(), hb.irf.size() * 4);
+  put(o_prep, hb.prep_out.data(), hb.prep_out.size() * sizeof(PrepOut));
+  put(o_slot, hb.item_slot.data(), (size_t)T * 4);
+  put(o_ireq, hb.item_req.data(), (size_t)T * 4);
+  ServeCtl &ctl = *sl.ctl;
+  ctl.in_bytes = (uint32_t)std::max<size_t>(off, 16);
+  ctl.o_reqs = (uint32_t)o_reqs; ctl.o_consts = (uint32_t)o_consts; ctl.o_irf = (uint32_t)o_irf;
+  ctl.o_prep = (uint32_t)o_prep; ctl.o_slot = (uint32_t)o_slot; ctl.o_ireq = (uint32_t)o_ireq;
+  ctl.total_items = (uint32_t)T; ctl.tab_entries = entries; ctl.vals_cap = vals; ctl.mode = 4;
+  const uint32_t seq = ++sl.seq;
+  if (seq == 0xffffffffu) sl.seq = 0;  // (never: 4 G requests through one slot)
+  __atomic_store_n(&ctl.seq, seq, __ATOMIC_SEQ_CST);  // publishes the block and the header
+  auto gone = [&] { return __atomic_load_n(&ctl.exited, __ATOMIC_SEQ_CST) == sl.launch_id; };
+  auto acked = [&] { return __atomic_load_n(&ctl.ack, __ATOMIC_ACQUIRE) == seq; };
+  if (!sl.running) launch_slot(srv, sl);
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(5);
+  for (uint32_t spin = 1; !acked(); ++spin) {
+    if ((spin & 31u) == 0u) {
+      if (gone()) {  // the workgroup left (idle / told to stop) - possibly after serving this request
+        MRK_HIP(hipStreamSynchronize(sl.stream));
+        sl.running = false;
+        if (acked()) break;
+        launch_slot(srv, sl);
+      } else if ((spin & 0xffffu) == 0u && std::chrono::steady_clock::now() > deadline) {
+        throw StatusError(MRK_ERR_DEVICE, "the serving workgroup did not answer within 5 s");
+      }
+    }
+    __builtin_ia32_pause();
+  }
+  if (out_scores && T) memcpy(out_scores, sl.h_out, (size_t)T * 8);
+  if (out_order && T) memcpy(out_order, sl.h_out + 1024, (size_t)T * 4);
+  const int32_t *hs = (const int32_t *)(sl.h_out + 1536);
+  status = hs[0] | hs[1];
+  srv.n_queue.fetch_add(1);
+  return true;
+}
+
+}  // namespace
+
+namespace mrk {
+static void quiesce_servers(mrk_ctx *ctx) {  // the caller holds the store exclusively: no request is in flight in any slot
+  std::lock_guard<std::mutex> lk(ctx->servers_mu);
+  for (void *p : ctx->servers) {
+    mrk_server *srv = (mrk_server *)p;
+    for (auto &sl : srv->slots)
+      if (sl->running) __atomic_store_n(&sl->ctl->stop, 1u, __ATOMIC_SEQ_CST);
+    for (auto &sl : srv->slots) stop_slot(*sl);
+  }
+}
+}  // namespace mrk
+
+extern "C" {
+
+int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int n_slots, mrk_server **out) {
+  return guard([&] {
+    if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!ctx || !model || !model_name || n_slots < 1 || n_slots > 64) throw StatusError(MRK_ERR_INVALID_ARG, "bad arguments (1..64 slots)");
+    if (model->ctx != ctx) throw StatusError(MRK_ERR_INVALID_ARG, "model belongs to another context");
+    const Program &prog = locked_program(ctx, model_name);
+    if (!model->qs.ok) throw StatusError(MRK_ERR_UNSUPPORTED, "the serving queue scores with the bit-vector scorer (trees of <= 16 leaves); use mrk_rank for this model");
+    check_model_fits(model, prog);
+    MRK_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<mrk_server> srv(new mrk_server());
+    srv->ctx = ctx;
+    srv->model = model;
+    srv->model_name = model_name;
+    srv->prog = &prog;
+    srv->f64 = model->forest.backend == Backend::LightGBM;
+    srv->idle_ticks = (uint64_t)std::max(1, switches().serve_idle_us) * 100ull;  // wall_clock64: 100 MHz
+    srv->jit_fn = jit_serve_function(prog, srv->f64);  // warm-up: the compile happens here, not under the first request
+    for (int i = 0; i < n_slots; ++i) {
+      std::unique_ptr<ServeSlot> sl(new ServeSlot());
+      MRK_HIP(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
+      MRK_HIP(hipHostMalloc(&sl->pinned, 128 + SERVE_OUT_BYTES + SERVE_IN_CAP, hipHostMallocCoherent | hipHostMallocMapped));
+      memset(sl->pinned, 0, 128 + SERVE_OUT_BYTES + SERVE_IN_CAP);
+      static_assert(sizeof(ServeCtl) == 128, "ServeCtl is one 128-byte line");
+      sl->ctl = (ServeCtl *)sl->pinned;
+      sl->h_out = (uint8_t *)sl->pinned + 128;
+      sl->h_in = sl->h_out + SERVE_OUT_BYTES;
+      sl->d_in.reserve(SERVE_IN_CAP);
+      srv->slots.push_back(std::move(sl));
+      srv->free_slots.push_back(n_slots - 1 - i);  // slot 0 on top
+    }
+    mrk_model_retain(model);
+    ctx_retain(ctx);
+    {
+      std::lock_guard<std::mutex> lk(ctx->servers_mu);
+      ctx->servers.push_back(srv.get());
+    }
+    *out = srv.release();
+  });
+}
+
+int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, int32_t *out_order) {
+  if (!srv || !req) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
+  bool done = false;
+  int status = 0;
+  const int rc = guard([&] { done = serve_fast(*srv, req, out_scores, out_order, status); });
+  if (rc != MRK_OK) return rc;
+  if (!done) {
+    srv->n_fallback.fetch_add(1);
+    return mrk_rank(srv->ctx, srv->model, srv->model_name.c_str(), req, out_scores, out_order, nullptr);
+  }
+  std::string msg;
+  const int code = status_to_code(status, msg);
+  if (code != MRK_OK) set_last_error(msg);
+  return code;
+}
+
+int mrk_serve_stats(mrk_server *srv, int64_t *out3) {
+  if (!srv || !out3) return MRK_ERR_INVALID_ARG;
+  out3[0] = (int64_t)srv->n_queue.load();
+  out3[1] = (int64_t)srv->n_fallback.load();
+  out3[2] = (int64_t)srv->n_launches.load();
+  return MRK_OK;
+}
+
+void mrk_serve_stop(mrk_server *srv) {
+  if (!srv) return;
+  mrk_ctx *ctx = srv->ctx;
+  {
+    std::unique_lock<std::mutex> lk(srv->mu);
+    srv->closing = true;
+    srv->cv.wait(lk, [&] { return srv->free_slots.size() == srv->slots.size(); });  // requests in flight finish first
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->servers_mu);
+    ctx->servers.erase(std::remove(ctx->servers.begin(), ctx->servers.end(), (void *)srv), ctx->servers.end());
+  }
+  (void)hipSetDevice(ctx->device);
+  for (auto &sl : srv->slots) {
+    stop_slot(*sl);
+    if (sl->stream) (void)hipStreamDestroy(sl->stream);
+    if (sl->pinned) (void)hipHostFree(sl->pinned);
+  }
+  mrk_model_free(srv->model);
+  delete srv;
+  ctx_release(ctx);
 }
 
 void mrk_batch_free(mrk_batch *batch) {

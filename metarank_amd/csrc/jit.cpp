@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -125,6 +127,11 @@ std::string jit_source(const Program &prog, bool f64, int kernel) {
     s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_one"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, mrk::QsForestDev f, int mode, mrk::OneOut out) {\n"
          "  mrk::rank_one_body<" + b64 + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, mode, out);\n}\n";
+  // ... and its persistent form (rank_device.hpp rank_serve_body)
+  if (kernel == JIT_ALL || kernel == JIT_SERVE)
+    s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_serve"
+         "(mrk::StoreDev st, mrk::QsDev q, mrk::QsForestDev f, mrk::ServeSlotDev slot) {\n"
+         "  mrk::rank_serve_body<" + b64 + ">(st, mrk::JitProg{}, q, f, slot);\n}\n";
   return s;
 }
 
@@ -168,10 +175,14 @@ struct JitKernels {
   JitSlot slot[JIT_KERNELS][2];   // [kernel][f64] (the matrix kernel lives in [JIT_MATRIX][1])
 };
 
-const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one"};
+const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve"};
 
 // 0 off; 1 on: the first rank of a model waits for the compile (a failure falls back to the generic kernel with a warning);
-// 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready
+// 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready;
+// 4 auto (the default): a code object found on disk - the user's cache, or the directory shipped next to the library
+// (built for the stock Ranklens program by __graft_entry__.build()) - is loaded at once, anything else compiles in the
+// background while the generic kernel ranks: no request ever waits for the compiler (Serve.scala:130-150: warm-up happens
+// before the port opens, never under a request)
 int jit_mode() { return switches().jit_mode; }
 
 namespace {
@@ -191,6 +202,28 @@ std::string cache_path(const std::string &src) {
 #endif
   snprintf(name, sizeof name, "/%016llx-%zu-rtc%d.%d-gfx950%s.co", (unsigned long long)fnv1a(src), src.size(), major, minor, flavour);
   return d + name;
+}
+
+// <directory of libmrk_hip.so>/jit_cache: code objects built ahead of time (read-only; same file names as the user's cache)
+std::string shipped_path(const std::string &src) {
+  static const std::string dir = [] {
+    Dl_info info;
+    if (!dladdr((const void *)&jit_mode, &info) || !info.dli_fname) return std::string();
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_cache";
+  }();
+  if (dir.empty()) return "";
+  int major = 0, minor = 0;
+  (void)hiprtcVersion(&major, &minor);
+  char name[96];
+#ifdef MRK_PHASE_CLOCKS
+  const char *flavour = "-clk";
+#else
+  const char *flavour = "";
+#endif
+  snprintf(name, sizeof name, "/%016llx-%zu-rtc%d.%d-gfx950%s.co", (unsigned long long)fnv1a(src), src.size(), major, minor, flavour);
+  return dir + name;
 }
 
 std::vector<char> read_file(const std::string &path) {
@@ -222,8 +255,8 @@ void write_file(const std::string &path, const std::vector<char> &data) {
 
 // Called WITHOUT the context's launch lock: the first batch of a shape compiles for seconds, and other batches keep
 // launching meanwhile.  The program's own mutex serialises callers that want a kernel of the same program.
-static void *jit_function(const Program &prog, int kernel, bool f64) {
-  const int mode = jit_mode();
+static void *jit_function(const Program &prog, int kernel, bool f64, bool wait = false) {
+  const int mode = wait && jit_mode() >= 3 ? 1 : jit_mode();  // wait: a warm-up call - the one place that may wait for the compiler
   if (mode == 0) return nullptr;
   std::lock_guard<std::mutex> lk(prog.jit_mu);
   if (!prog.jit) prog.jit = new JitKernels();
@@ -232,10 +265,17 @@ static void *jit_function(const Program &prog, int kernel, bool f64) {
   JitSlot &sl = k->slot[kernel][f64 ? 1 : 0];
   if (sl.fn) return (void *)sl.fn;
   if (sl.failed && mode != 2) return nullptr;
+  auto cached = [&prog, f64, kernel]() {   // the code object, if a previous process (or the build) left it on disk
+    const std::string src = jit_source(prog, f64, kernel);
+    std::vector<char> code = read_file(cache_path(src));
+    if (code.empty()) code = read_file(shipped_path(src));
+    return code;
+  };
   auto produce = [&prog, f64, kernel]() {  // host only: no device call (safe on any thread)
     const std::string src = jit_source(prog, f64, kernel);
     const std::string path = cache_path(src);
     std::vector<char> code = read_file(path);
+    if (code.empty()) code = read_file(shipped_path(src));
     if (code.empty()) {
       std::string log;
       code = jit_compile(src, log);
@@ -245,7 +285,10 @@ static void *jit_function(const Program &prog, int kernel, bool f64) {
   };
   try {
     std::vector<char> code;
-    if (mode == 3 || sl.state.load() != 0) {
+    if (mode == 4 && sl.state.load() == 0) code = cached();
+    if (!code.empty()) {
+      // on disk: loaded below, at once
+    } else if (mode == 3 || mode == 4 || sl.state.load() != 0) {
       int st = sl.state.load();
       if (st == 0) {  // first sight of this (program, kernel, precision): start the compile, keep ranking with the generic kernel
         sl.state.store(1);
@@ -283,6 +326,30 @@ static void *jit_function(const Program &prog, int kernel, bool f64) {
   return (void *)sl.fn;
 }
 
+// host only: make sure `dir` holds the code object of every kernel in `kernel_mask` (bit k = kernel k) for this program;
+// returns how many had to be compiled
+int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const std::string &dir) {
+  int compiled = 0;
+  for (int k = 0; k < JIT_KERNELS; ++k) {
+    if (!(kernel_mask & (1u << k))) continue;
+    const bool kf64 = k == JIT_MATRIX ? true : f64;
+    const std::string src = jit_source(prog, kf64, k);
+    const std::string user = cache_path(src);
+    const std::string name = user.empty() ? shipped_path(src) : user;
+    if (name.empty()) throw StatusError(MRK_ERR_INVALID_ARG, "no cache file name");
+    const std::string path = dir + name.substr(name.rfind('/'));
+    if (!read_file(path).empty()) continue;
+    std::vector<char> code = read_file(user);
+    if (code.empty()) {
+      std::string log;
+      code = jit_compile(src, log);
+      ++compiled;
+    }
+    write_file(path, code);
+  }
+  return compiled;
+}
+
 void *jit_rank_function(const Program &prog, bool f64) { return jit_function(prog, JIT_RANK, f64); }
 // the item-parallel kernel (nullptr under the same conditions)
 void *jit_items_function(const Program &prog, bool f64) { return jit_function(prog, JIT_ITEMS, f64); }
@@ -292,6 +359,17 @@ void *jit_split_function(const Program &prog, bool f64) { return jit_function(pr
 void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_MATRIX, true); }
 // the one-launch kernel of small requests
 void *jit_one_function(const Program &prog, bool f64) { return jit_function(prog, JIT_ONE, f64); }
+void *jit_serve_function(const Program &prog, bool f64) { return jit_function(prog, JIT_SERVE, f64, /*wait=*/true); }  // mrk_serve_start IS the warm-up
+
+// waits for the background compiles of `prog` that are under way (a warm-up / measurement aid; the next launch loads them)
+void jit_wait(const Program &prog) {
+  std::lock_guard<std::mutex> lk(prog.jit_mu);
+  if (!prog.jit) return;
+  JitKernels *k = (JitKernels *)prog.jit;
+  for (auto &per_kernel : k->slot)
+    for (JitSlot &sl : per_kernel)
+      if (sl.state.load() == 1 && sl.worker.joinable()) sl.worker.join();
+}
 
 #ifdef MRK_PHASE_CLOCKS
 // measurement builds: read-and-reset the phase clocks of the specialised kernel of `prog`

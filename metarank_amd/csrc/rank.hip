@@ -96,6 +96,13 @@ rank_one_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, 
   rank_one_body<F64>(st, prog, b, tab_entries, vals_cap, q, f, mode, out);
 }
 
+// the persistent form: one workgroup serves the requests published in its slot (rank_device.hpp rank_serve_body)
+template <bool F64>
+__global__ void __launch_bounds__(512)
+rank_serve_kernel(StoreDev st, ProgramDev prog, QsDev q, QsForestDev f, ServeSlotDev slot) {
+  rank_serve_body<F64>(st, prog, q, f, slot);
+}
+
 __global__ void override_kernel(BatchDev b, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n_overrides) return;
@@ -412,6 +419,28 @@ void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
     else hipLaunchKernelGGL(rank_one_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, mode, out);
     MRK_HIP(hipGetLastError());
   }
+}
+
+// one persistent workgroup of `threads` lanes with `lds` bytes of dynamic LDS on `stream` (capi_rank.cpp mrk_serve_*)
+void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
+                       int threads, size_t lds, bool f64, void *jit_fn) {
+  if (jit_fn) {
+    StoreDev a_st = st;
+    QsDev a_q = q;
+    QsForestDev a_f = f;
+    ServeSlotDev a_s = slot;
+    void *args[] = {&a_st, &a_q, &a_f, &a_s};
+    MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, 1, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, args, nullptr));
+    return;
+  }
+  static std::once_flag once;
+  std::call_once(once, [] {
+    MRK_HIP(hipFuncSetAttribute((const void *)rank_serve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MRK_HIP(hipFuncSetAttribute((const void *)rank_serve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  });
+  if (f64) hipLaunchKernelGGL(rank_serve_kernel<true>, dim3(1), dim3(threads), lds, stream, st, prog, q, f, slot);
+  else hipLaunchKernelGGL(rank_serve_kernel<false>, dim3(1), dim3(threads), lds, stream, st, prog, q, f, slot);
+  MRK_HIP(hipGetLastError());
 }
 
 // Normalize.scale over matrix column `col` of every request of the batch (after assembly and overrides)

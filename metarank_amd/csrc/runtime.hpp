@@ -101,11 +101,13 @@ struct Switches {
   int fused_slices = 0;        // MRK_FUSED_SLICES=n: workgroups per request of the fused kernel (0: by batch shape; 1: off)
   int fused_split = 0;         // MRK_FUSED_SPLIT=1|2|4: op split of the fused kernel's workgroups (0: 4 / 2 for batches of <= 16 requests)
   bool rank_combine = true;    // MRK_RANK_COMBINE=0: no batching front in mrk_rank
+  bool rank_serve = true;      // MRK_RANK_SERVE=0: mrk_serve_rank never takes the persistent-workgroup queue (everything through mrk_rank)
+  int serve_idle_us = 2000;    // MRK_SERVE_IDLE_US: a serving workgroup without a request for this long leaves its CU (relaunched by the next request)
   bool rank_one = true;        // MRK_RANK_ONE=0: mrk_rank's small batches take the three-launch path instead of the one-launch kernel
   int combine_max = 256;       // MRK_RANK_COMBINE_MAX
   int table_load_pct = 75;     // MRK_TABLE_LOAD_PCT
   int host_threads = 0;        // MRK_HOST_THREADS (0: min(8, hardware threads))
-  int jit_mode = 1;            // MRK_RANK_JIT: 0 off, 1 on, 2 require, 3 async
+  int jit_mode = 4;            // MRK_RANK_JIT: 0 off, 1 on (wait for the compiler), 2 require, 3 async, 4 auto (default: disk cache at once, else async)
   int jit_waves = 0;           // MRK_JIT_WAVES
   bool jit_record_regs = true; // MRK_JIT_REGS=0: the specialised kernel reads the candidate's record cell by cell instead of keeping it in registers
   std::string jit_cache_dir;   // MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else ~/.cache/mrk_jit; "" / "off": none
@@ -159,6 +161,8 @@ struct mrk_ctx {
   // EVERY collective on `comm` is issued under this lock (RCCL does not allow concurrent calls on one communicator).  The
   // host must also issue collectives in the same order on every rank (mrk.h): the lock makes a mistake a wait, not a race.
   std::mutex comm_mu;
+  std::mutex servers_mu;              // the serving queues of this context (capi_rank.cpp mrk_serve_*): a store flush stops their workgroups
+  std::vector<void *> servers;        // mrk_server*
   std::mutex rank_mu;                 // owner of rank_scratch (the leader of the batching front, or a caller with the front off)
   // batching front of mrk_rank: concurrent callers are combined into one device batch by whichever caller
   // finds no leader active (capi_rank.cpp)

@@ -259,6 +259,14 @@ class HipRanker:
         """mrk_config_bind_encoder: the bi-encoder `feature` embeds its rankingField text on the device from now on"""
         N.check(N.lib().mrk_config_bind_encoder(self.ctx.handle, feature.encode(), encoder.handle))
 
+    def serve(self, model_name: str, booster: HipBooster, n_slots: int = 4) -> "Server":
+        """mrk_serve_start: the serving queue (persistent workgroups polling slots in pinned memory)"""
+        return Server(self, model_name, booster, n_slots)
+
+    def warmup_kernels(self, model_name: str):
+        """mrk_config_warmup: waits for the background compiles of this model's specialised kernels that are under way"""
+        N.check(N.lib().mrk_config_warmup(self.ctx.handle, model_name.encode()))
+
     def prepare(self, model_name: str, events) -> Batch:
         return Batch(self, model_name, events)
 
@@ -270,3 +278,37 @@ class HipRanker:
         if self._own_ctx:
             self.ctx.close()
             self._own_ctx = False
+
+
+class Server:
+    """mrk_serve_*: Ranker.rerank through the serving queue - no launch, no copy command on the request path."""
+
+    def __init__(self, ranker: HipRanker, model_name: str, booster: HipBooster, n_slots: int = 4):
+        self.ranker = ranker
+        self._h = C.c_void_p()
+        N.check(N.lib().mrk_serve_start(ranker.ctx.handle, booster.handle, model_name.encode(), n_slots, C.byref(self._h)))
+
+    def rerank(self, event):
+        """-> (scores, order) like HipRanker.rerank"""
+        req = event if isinstance(event, Request) else Request(event)
+        n = req.n_items
+        scores = np.empty(n, dtype=np.float64)
+        order = np.empty(n, dtype=np.int32)
+        N.check(N.lib().mrk_serve_rank(self._h, C.byref(req.c), scores.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p)))
+        return scores, order
+
+    def stats(self) -> dict:
+        out = (C.c_int64 * 3)()
+        N.check(N.lib().mrk_serve_stats(self._h, out))
+        return {"queue": out[0], "fallback": out[1], "launches": out[2]}
+
+    def close(self):
+        if self._h:
+            N.lib().mrk_serve_stop(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -112,3 +112,103 @@ def test_one_launch_reports_an_xgboost_inf_like_the_batch_path():
             restore_env(saved)
     finally:
         hip.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", ["1", "0"])
+def test_serving_queue_equals_mrk_rank(jit):
+    """mrk_serve_rank (persistent workgroups polling slots in pinned memory) gives mrk_rank's bytes and errors: requests
+    the queue takes, requests it hands to mrk_rank (129 candidates), many host threads over few slots, store puts
+    between requests (the workgroups are stopped for the flush and come back), idle workgroups that left."""
+    import time
+
+    saved = with_env({"MRK_RANK_JIT": jit, "MRK_SERVE_IDLE_US": "300"})
+    cfg = ranklens.ranklens_config()
+    orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+    srv = None
+    try:
+        for b in (orc, hip):
+            ranklens.load_state(b, ranklens.generate_state(N_ITEMS, N_SESS))
+        reqs = requests()
+        q = ranklens.column_quantiles(np.concatenate([orc.matrix(ev) for ev in reqs[:6]]))
+        blob = synth.synthetic_lgbm_model(n_trees=500, n_features=24, quantiles=q, cat_features=[7], cat_prob=0.05, missing="per_feature")
+        orc.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        srv = hip.ranker.serve("xgboost", hip.booster, n_slots=3)
+        expected = [orc.rerank(ev) for ev in reqs]
+        for rep in range(3):
+            for k, ev in enumerate(reqs):
+                s, o = srv.rerank(ev)
+                assert same(s, expected[k][1]) and o.tolist() == expected[k][2].tolist(), (rep, k)
+            time.sleep(0.01)   # longer than the idle time: the workgroups leave and are relaunched
+        st = srv.stats()
+        assert st["fallback"] == 3 and st["queue"] == 3 * (len(reqs) - 1) and st["launches"] >= 3, st   # the 129-candidate request
+        with ThreadPoolExecutor(8) as ex:
+            res = list(ex.map(srv.rerank, reqs * 6))
+        for k, (s, o) in enumerate(res):
+            e = expected[k % len(reqs)]
+            assert same(s, e[1]) and o.tolist() == e[2].tolist(), k
+        # a put between requests: visible to the next request through the queue
+        it = reqs[0]["items"][0]["id"]
+        for b in (orc, hip):
+            b.put_double(f"item={it}/popularity", 987654.0)
+            b.put_periodic(f"item={it}/ctr_click", [50, 60])
+        _, es, eo = orc.rerank(reqs[0])
+        s, o = srv.rerank(reqs[0])
+        assert same(s, es) and o.tolist() == eo.tolist()
+        # and a request the reference throws on
+        for b in (orc, hip):
+            b.put_periodic("global/ctr_click_norm", [0, 5])
+        with pytest.raises(M.MrkError) as ei:
+            srv.rerank(reqs[1])
+        assert ei.value.status == -5
+    finally:
+        if srv is not None:
+            srv.close()
+        restore_env(saved)
+        hip.close()
+
+
+@pytest.mark.gpu
+def test_default_jit_mode_never_waits_for_the_compiler():
+    """MRK_RANK_JIT=auto (the library's default): (a) the stock Ranklens program's kernels are shipped next to the library
+    (metarank_amd/jit_cache, built by __graft_entry__.build()): the first mrk_rank of a fresh context takes milliseconds and
+    already runs them; (b) a program nobody has compiled is ranked by the interpreting kernel at once while its kernel
+    compiles in the background - same bytes before and after the swap."""
+    import tempfile
+    import time
+
+    saved = with_env({"MRK_RANK_JIT": "auto", "MRK_JIT_CACHE_DIR": tempfile.mkdtemp(prefix="mrk_jit_test_")})   # an empty user cache
+    try:
+        shipped = os.path.join(os.path.dirname(M.__file__), "jit_cache")
+        assert os.path.isdir(shipped) and len([f for f in os.listdir(shipped) if f.endswith(".co")]) >= 6, "run __graft_entry__.build()"
+        for variant in ("stock", "new"):
+            cfg = ranklens.ranklens_config()
+            if variant == "new":   # one feature less: a program no cache has seen
+                cfg["features"] = [f for f in cfg["features"] if f["name"] != "runtime"]
+                cfg["models"]["xgboost"]["features"] = [f for f in cfg["models"]["xgboost"]["features"] if f != "runtime"]
+            orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+            try:
+                for b in (orc, hip):
+                    ranklens.load_state(b, ranklens.generate_state(N_ITEMS, N_SESS))
+                reqs = ranklens.generate_requests(4, 100, N_ITEMS, N_SESS, seed=86)
+                dim = hip.dim
+                blob = synth.synthetic_lgbm_model(n_trees=300, n_features=dim, quantiles=ranklens.column_quantiles(np.concatenate([orc.matrix(ev) for ev in reqs])))
+                orc.load_model(blob, 0)
+                hip.load_model(blob, 0)
+                hip.ranker.flush()
+                t0 = time.perf_counter()
+                _, s, o = hip.ranker.rerank("xgboost", reqs[0], hip.booster)
+                first_ms = (time.perf_counter() - t0) * 1e3
+                _, es, eo = orc.rerank(reqs[0])
+                assert same(s, es) and o.tolist() == eo.tolist()
+                assert first_ms < 50.0, (variant, first_ms)   # a hiprtc compile of this kernel takes seconds
+                hip.ranker.warmup_kernels("xgboost")            # the background compile (variant "new") is done after this
+                for ev in reqs:
+                    _, s, o = hip.ranker.rerank("xgboost", ev, hip.booster)
+                    _, es, eo = orc.rerank(ev)
+                    assert same(s, es) and o.tolist() == eo.tolist(), variant
+            finally:
+                hip.close()
+    finally:
+        restore_env(saved)
