@@ -33,6 +33,7 @@ static Switches read_switches() {
   if (const char *e = getenv("MRK_RANK_JIT")) s.jit_mode = !strcmp(e, "require") ? 2 : !strcmp(e, "async") ? 3 : !strcmp(e, "auto") ? 4 : atoi(e) != 0 ? 1 : 0;
   s.jit_waves = num("MRK_JIT_WAVES", 0);
   s.jit_record_regs = flag("MRK_JIT_REGS", true);
+  s.jit_shipped = flag("MRK_JIT_SHIPPED", true);
   if (const char *d = getenv("MRK_JIT_CACHE_DIR")) s.jit_cache_dir = d;
   else if (const char *x = getenv("XDG_CACHE_HOME")) s.jit_cache_dir = std::string(x) + "/mrk_jit";
   else if (const char *h = getenv("HOME")) s.jit_cache_dir = std::string(h) + "/.cache/mrk_jit";

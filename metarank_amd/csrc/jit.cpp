@@ -213,7 +213,7 @@ std::string shipped_path(const std::string &src) {
     const size_t k = p.rfind('/');
     return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_cache";
   }();
-  if (dir.empty()) return "";
+  if (dir.empty() || !switches().jit_shipped) return "";
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
   char name[96];

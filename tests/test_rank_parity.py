@@ -523,8 +523,9 @@ def test_background_specialisation_swaps_in_without_changing_results(oracle_c2, 
     import os
     import time
 
-    saved = {k: os.environ.get(k) for k in ("MRK_RANK_JIT", "MRK_JIT_CACHE_DIR")}
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_JIT", "MRK_JIT_CACHE_DIR", "MRK_JIT_SHIPPED")}
     os.environ["MRK_RANK_JIT"], os.environ["MRK_JIT_CACHE_DIR"] = "async", str(tmp_path)
+    os.environ["MRK_JIT_SHIPPED"] = "0"   # (the stock program's kernels ship next to the library: this test wants the compile)
     M.reload_switches()
     hip = HipBackend(ranklens.ranklens_config(), "xgboost")
     try:
