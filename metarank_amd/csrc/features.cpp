@@ -761,7 +761,7 @@ static uint32_t table_capacity(uint64_t tokens, uint64_t pct) {
   // request): a 16-bit fixed-point reciprocal rounded UP, so the capacity never falls below the exact quotient
   const uint64_t inv = (100ull * 65536ull + pct - 1) / pct;  // pct is a per-process constant: hoisted by the compiler's inliner
   const uint64_t cap = (tokens < (1ull << 40) ? (tokens * inv) >> 16 : tokens * 100 / pct) + 2;
-  return (uint32_t)((cap + 1) & ~1ull);
+  return (uint32_t)std::max<uint64_t>((cap + 1) & ~1ull, 8);  // >= one probe window (rank_device.hpp PROBE_W): a window never laps its table
 }
 
 // Host threads of one resolve_requests call: MRK_HOST_THREADS, else min(8, hardware threads).  The per-request work

@@ -60,6 +60,10 @@ __device__ __forceinline__ uint32_t qs_bin_search(P T, uint32_t len, double x) {
   return pos;
 }
 
+// (Measured and rejected, round 3: a three-level 8-ary search over the staged table - 17 independent LDS reads in 3 trips
+// instead of 8 dependent ones - made the c2 assembly kernel 40 % SLOWER (0.284 -> 0.406 ms, gpurun_out r03_j): after the
+// first level the lanes' ranges start at multiples of 256 B, i.e. in the same LDS bank, and the LDS pipe - shared by the 16
+// wavefronts of a CU - is the resource this kernel is short of, not the round trips of one wavefront.)
 // every view of the column: (view index, cell) -> emit
 template <bool F64, typename Emit>
 __device__ __forceinline__ void qs_emit_views(double x, uint32_t pos, const QsFeature ft, const QsView *__restrict__ views, Emit emit) {

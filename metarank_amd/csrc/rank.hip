@@ -325,7 +325,8 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
   if (b.n_req <= 0) return;
   int mode = (op_split > 1 ? op_split : 1) | ((slices > 1 ? slices : 1) << 8);  // rank_device.hpp rank_fused_body
   const unsigned grid = (unsigned)b.n_req * (unsigned)(slices > 1 ? slices : 1);
-  const size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u);
+  size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u);
+  if (switches().fused_lds_min > 0) lds = std::max(lds, (size_t)switches().fused_lds_min);  // experiments: cap the kernel's residency (co-residency with the scorer)
   {
     ScopedKernelTimer timer(ctx, "assemble");
     static thread_local bool configured = false;

@@ -93,74 +93,80 @@ __device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t cap) { retur
 // false) - ride along on selects.  A per-lane `while` costs ~25 scalar exec-mask instructions per probe.
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-// A probe is a dependent trip to LDS, and a wave-uniform loop runs as long as its slowest lane: measured (phase clocks,
-// profiles/r02_f) a token lookup cost ~5 k cycles - a third of the assembly phase went into these loops.  So both
-// primitives first read the next PROBE_W entries of the probe sequence TOGETHER (independent reads, one wait); the
-// loop behind it only runs for the rare lane whose key lies deeper.
-constexpr int PROBE_W = 4;
+// A probe is a dependent trip to LDS, and a wave-uniform loop runs as long as its SLOWEST lane.  Most lookups of the
+// assembly phase are misses (a candidate's token that the session profile does not hold), a miss ends at the first empty
+// entry, and at the 75 % load the tables are sized for a miss walks 8.5 entries on average - the longest walk among 64
+// lanes is 20 - 30.  Round 2 read 4 entries together and then walked the rest ONE entry per trip: 20 dependent LDS round
+// trips per lookup (phase clocks, profiles/r02_g: ~10 k cycles per lookup of a diversity / interacted_with column).  Both
+// primitives now take every trip PROBE_W entries wide: independent reads, one wait, the whole window examined in registers.
+constexpr int PROBE_W = 8;
 
 __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   // tab / cap may differ between lanes (item-parallel kernel: lanes of several requests in one wavefront)
   uint32_t idx = tok_home(tok, cap);
   const unsigned long long fresh = (unsigned long long)tok | (1ull << 32);
-  // look before the first atomic: entries that hold OTHER keys can be skipped for good (a key, once set, never changes)
-  unsigned long long e[PROBE_W];
-  uint32_t pos[PROBE_W];
-  {
-    uint32_t ix = idx;
+  bool open = want;          // still looking for tok's entry
+  bool full = false;
+  uint32_t walked = 0;       // entries known to hold other keys
+  while (wave_any(open)) {
+    // a window of the probe sequence: entries that hold OTHER keys can be skipped for good (a key, once set, never changes)
+    unsigned long long e[PROBE_W];
+    uint32_t pos[PROBE_W];
+    {
+      uint32_t ix = idx;
 #pragma unroll
-    for (int k = 0; k < PROBE_W; ++k) {
-      pos[k] = ix;
-      e[k] = tab[ix];  // every lane reads: ix stays inside its table
-      ix = ix + 1 == cap ? 0 : ix + 1;
+      for (int k = 0; k < PROBE_W; ++k) {
+        pos[k] = ix;
+        e[k] = tab[ix];  // every lane reads: ix stays inside its table
+        ix = ix + 1 == cap ? 0 : ix + 1;
+      }
     }
-  }
-  uint32_t skipped = PROBE_W;     // entries known to hold other keys
-  bool at_key = false;
+    uint32_t stop = PROBE_W;  // the FIRST entry of the window that holds tok or is empty
+    bool at_key = false;
 #pragma unroll
-  for (int k = PROBE_W - 1; k >= 0; --k) {  // the FIRST entry that holds tok or was empty wins
-    const uint32_t key = (uint32_t)e[k];
-    if (key == tok || key == 0u) { skipped = (uint32_t)k; at_key = key == tok; }
-  }
-  if (skipped < (uint32_t)PROBE_W) idx = pos[skipped];
-  else idx = pos[PROBE_W - 1] + 1 == cap ? 0 : pos[PROBE_W - 1] + 1;
-  if (want && at_key) atomicAdd(&tab[idx], 1ull << 32);  // the key is there already: one atomic, no compare-and-swap
-  bool open = want && !at_key && skipped < cap, full = want && !at_key && skipped >= cap;
-  for (uint32_t probe = skipped + 1; wave_any(open); ++probe) {
-    unsigned long long prev = ~0ull;  // riding lanes: a foreign key
-    if (open) prev = atomicCAS(&tab[idx], 0ull, fresh);  // empty -> {tok, 1}
-    const bool same = open && (uint32_t)prev == tok;
-    if (same) atomicAdd(&tab[idx], 1ull << 32);
-    open = open && prev != 0ull && !same;
-    full = full || (open && probe >= cap);  // every entry holds another key
-    open = open && probe < cap;
-    idx = idx + 1 == cap ? 0 : idx + 1;
+    for (int k = PROBE_W - 1; k >= 0; --k) {
+      const uint32_t key = (uint32_t)e[k];
+      if (key == tok || key == 0u) { stop = (uint32_t)k; at_key = key == tok; }
+    }
+    const bool here = open && stop < (uint32_t)PROBE_W && walked + stop < cap;
+    const uint32_t at = pos[stop < (uint32_t)PROBE_W ? stop : 0];
+    if (here && at_key) atomicAdd(&tab[at], 1ull << 32);  // the key is there already: one atomic, no compare-and-swap
+    unsigned long long prev = ~0ull;
+    if (here && !at_key) prev = atomicCAS(&tab[at], 0ull, fresh);  // empty -> {tok, 1}
+    const bool took = here && !at_key && prev == 0ull;
+    const bool same = here && !at_key && (uint32_t)prev == tok;    // another lane put tok there in the meantime
+    if (same) atomicAdd(&tab[at], 1ull << 32);
+    const bool done = here && (at_key || took || same);
+    // not done: either the whole window holds other keys (walk on behind it), or the empty entry went to another key
+    // (walk on behind that entry)
+    const uint32_t adv = here ? stop + 1 : (uint32_t)PROBE_W;
+    walked += adv;
+    idx = idx + adv;
+    idx = idx >= cap ? idx - cap : idx;
+    full = full || (open && !done && walked >= cap);  // every entry holds another key
+    open = open && !done && walked < cap;
   }
   return !full;
 }
 
 __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   uint32_t idx = tok_home(tok, cap);
-  unsigned long long e[PROBE_W];
-#pragma unroll
-  for (int k = 0; k < PROBE_W; ++k) {
-    e[k] = tab[idx];  // every lane reads: idx stays inside its table
-    idx = idx + 1 == cap ? 0 : idx + 1;
-  }
   uint32_t res = 0;
   bool open = want;
+  for (uint32_t walked = 0;; walked += PROBE_W) {  // the first window unconditionally: one trip serves most lanes
+    unsigned long long e[PROBE_W];
 #pragma unroll
-  for (int k = 0; k < PROBE_W; ++k) {
-    const uint32_t key = (uint32_t)e[k];
-    res = open && key == tok ? (uint32_t)(e[k] >> 32) : res;
-    open = open && key != tok && key != 0u && (uint32_t)(k + 1) < cap;  // keys are token ids >= 1: key 0 = empty entry
-  }
-  for (uint32_t probe = PROBE_W + 1; wave_any(open); ++probe) {  // rare: PROBE_W entries in a row hold other keys
-    const unsigned long long cur = tab[idx];
-    const uint32_t key = (uint32_t)cur;
-    res = open && key == tok ? (uint32_t)(cur >> 32) : res;
-    open = open && key != tok && key != 0u && probe < cap;
-    idx = idx + 1 == cap ? 0 : idx + 1;
+    for (int k = 0; k < PROBE_W; ++k) {
+      e[k] = tab[idx];  // every lane reads: idx stays inside its table
+      idx = idx + 1 == cap ? 0 : idx + 1;
+    }
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      const uint32_t key = (uint32_t)e[k];
+      res = open && key == tok ? (uint32_t)(e[k] >> 32) : res;
+      open = open && key != tok && key != 0u && walked + (uint32_t)(k + 1) < cap;  // keys are token ids >= 1: key 0 = empty entry
+    }
+    if (!wave_any(open)) break;
   }
   return res;
 }
@@ -607,7 +613,7 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
   // registers (constant address space: s_load).
   mutable QsFeature ft_cur = {}, ft_next = {};   // feats[next_col], feats[next_col + 1]
   mutable int next_col = -1;                     // the column whose table has been requested
-  mutable bool landed = false;                   // ... and is known to be in its buffer
+  mutable uint32_t newer = 0;                    // cell stores this wavefront issued AFTER that request (vmcnt retires in order)
 
   __device__ __forceinline__ bool staged(const QsFeature &ft) const { return ft.thr_len <= q.thr_cap && ft.view_begin != ft.view_end; }
   __device__ __forceinline__ QsFeature feature(int col) const {
@@ -638,11 +644,19 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     ft_cur = feature(col);
     ft_next = feature(col + 1);
     next_col = col;
-    landed = false;
+    newer = 0;
     request(ft_cur, col);
   }
+  // The requested table is in its buffer.  vmcnt counts loads, stores and LDS-DMA alike and retires them IN ORDER: once at
+  // most `newer` operations are outstanding, everything issued before the last `newer` - the request among it - is
+  // complete.  Waiting for vmcnt(0) instead (round 2) made every column wait for the previous column's cell stores as
+  // well: a store's round trip per matrix column on the critical path of the workgroup.  (Loads the ops issue between two
+  // columns only make this wait stricter, never too weak.)
   __device__ __forceinline__ void wait_landed() const {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the compiler does not track LDS-DMA
+    if (newer == 1u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (newer == 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (newer == 3u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not track LDS-DMA
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -658,12 +672,12 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     }
     if (col != next_col) restart(col);  // a column out of order
     const QsFeature ft = ft_cur;
-    if (!landed) wait_landed();  // the item's first column only: later tables are waited for at the end of the previous put
+    wait_landed();   // this column's table (requested one column ago, before that column's cell stores)
     ft_cur = ft_next;
-    request(ft_cur, col + 1);
+    request(ft_cur, col + 1);   // into the other buffer: the search that used it is over
     ft_next = feature(col + 2);
     next_col = col + 1;
-    landed = false;
+    newer = 0;
     bool ok;
     const double x = qs_prep<F64>(v, ok);
     // XGBoost's DMatrix rejects the whole row for an inf in ANY column, split on or not - every scorer path does the same
@@ -671,11 +685,7 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
     const uint32_t pos = staged(ft) ? qs_bin_search<F64>(thr_lds + (size_t)(col & 1) * q.thr_cap, ft.thr_len, x)
                                     : qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
-    // vmcnt counts loads and stores alike, in order: waiting for the next table AFTER this column's cell stores would
-    // wait for the stores' round trip at every column (measured: 3 k cycles).  Here the table requested a whole search
-    // ago has landed long since, and the only stores in flight are the previous column's.
-    wait_landed();
-    landed = true;
+    newer = ft.view_end - ft.view_begin;   // one store per view below (at least one lane of the wavefront has an item)
     uint16_t *d = dst;
     const bool act = active;
     qs_emit_views<F64>(x, pos, ft, q.views, [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; });

@@ -15,6 +15,8 @@ from workloads import ranklens, synth
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n_req, n_items = (3840, 100) if wl == "c2" else (384, 1000)
+if len(sys.argv) > 2:
+    n_req = int(sys.argv[2])   # few requests: every workgroup alone on its CU - the cycles are the critical path itself
 ctx = M.Context(0)
 cfg = ranklens.c3_config() if wl == "c3" else ranklens.ranklens_config()
 ranker = M.HipRanker(cfg, ctx)
