@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--batches-per-step", type=int, default=None,
                     help="device batches one step runs (default: c2 / c3 96, c4 128, c5 8: a step is about 50 ms of device work)")
     ap.add_argument("--e2e-seconds", type=float, default=1.5, help="timed length of the end-to-end serving loop (0 = skip)")
-    ap.add_argument("--e2e-batches", type=int, default=3, help="batches in flight per host thread in the end-to-end loop")
+    ap.add_argument("--e2e-batches", type=int, default=4, help="batches in flight per host thread in the end-to-end loop")
     ap.add_argument("--e2e-threads", type=int, default=1,
                     help="host threads driving the end-to-end loop (each its own batches).  One keeps up with the device (0.28 ms of host "
                          "work per device batch); through Python more threads only add GIL hand-overs (measured: 683 / 592 / 636 M items/s "
@@ -345,7 +345,7 @@ def main():
             batch.run(booster)
         batch.sync()
     kernels = {}
-    for k in ("prepass", "assemble", "override", "bin", "score", "sort"):
+    for k in ("prepass", "assemble", "override", "bin", "score", "sort", "rank_fused"):
         ms, n = ctx.profile_get(k)
         if n:
             kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / prof_steps}
@@ -364,7 +364,7 @@ def main():
     b_item = 8 * dim + 48 + 4 + 8 + (384 * 4 if wl == "c5" else 0)
     model_bytes = int(info["n_nodes"]) * 16 + int(info["n_leaves"]) * (8 if args.backend == "lightgbm" else 4)
     alg_path = my_items * b_item + model_bytes      # the whole fused path (8d)
-    alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass")}
+    alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass", "rank_fused")}
     alg["sort"] = total_items * (8 + 4)
     alg["override"] = 0
     # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE, KB per launch,
@@ -378,7 +378,7 @@ def main():
     jit_on = os.environ.get("MRK_RANK_JIT", "1") not in ("0",)
     # the kernel behind `dominant` in the newest committed summary of this workload (names change with the batch shape:
     # mrk_jit_rank_cells / _split / mrk_jit_assemble_cells; qs_score_wave_kernel / qs_score_split_kernel)
-    prefixes = {"score": ("qs_score",), "assemble": ("mrk_jit_rank_cells", "mrk_jit_assemble_cells") if jit_on else ("rank_fused_cells", "assemble_cells")}
+    prefixes = {"rank_fused": ("mrk_jit_rank_fused_score", "rank_fused_score"), "score": ("qs_score",), "assemble": ("mrk_jit_rank_cells", "mrk_jit_assemble_cells") if jit_on else ("rank_fused_cells", "assemble_cells")}
     pmc_kernel = None
     try:
         import glob
@@ -397,7 +397,7 @@ def main():
             # vector instruction occupies its SIMD's VALU for 4 cycles, so a launch cannot take less than
             # (VALU wavefront-instructions of the launch, SQ_INSTS_VALU of the committed PMC pass) x 4 cycles / 1 024 SIMDs /
             # 2.4 GHz; frac = that floor / this run's measured launch time.
-            for kname in ("assemble", "score"):
+            for kname in ("assemble", "score", "rank_fused"):
                 for name, d in summary.items():
                     if kname in kernels and name.startswith(prefixes[kname]) and "SQ_INSTS_VALU" in d:
                         floor_ms = d["SQ_INSTS_VALU"]["mean"] * 4.0 / 1024.0 / 2.4e9 * 1e3
@@ -419,9 +419,11 @@ def main():
                 "valu_issue": valu_issue or None,
                 "whole_path": {"achieved": alg_path / (ms_per_batch * 1e-3) / 1e9, "frac": alg_path / (ms_per_batch * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "ms_per_batch": ms_per_batch},
-                "note": "the forest scorer is VALU-issue bound, not HBM bound (SURVEY.md 8d): "
-                        f"{my_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G item-trees/s "
-                        f"in {kernels['score']['avg_ms']:.3f} ms"}
+                "note": ("the forest scorer is VALU-issue bound, not HBM bound (SURVEY.md 8d): "
+                         f"{my_items * info['n_trees'] / max(kernels['score']['avg_ms'] * 1e-3, 1e-12) / 1e9:.1f} G item-trees/s "
+                         f"in {kernels['score']['avg_ms']:.3f} ms") if "score" in kernels else
+                        "rank_fused = pre-pass + assembly + forest + ordering of a request in its own workgroup, ONE launch per batch "
+                        "(MRK_RANK_FUSED_SCORE=0: the three-launch path with per-kernel times)"}
 
     # ---- end to end: FRESH requests every device batch (host part + upload of the id bytes + device-side id resolution
     #      + run + download into pinned memory), several batches in flight, one host thread

@@ -25,6 +25,7 @@ static Switches read_switches() {
   s.prepass_lds = flag("MRK_PREPASS_LDS", true);
   s.rank_combine = flag("MRK_RANK_COMBINE", true);
   s.rank_one = flag("MRK_RANK_ONE", true);
+  s.rank_fused_score = flag("MRK_RANK_FUSED_SCORE", false);
   s.rank_serve = flag("MRK_RANK_SERVE", true);
   s.serve_idle_us = std::max(1, num("MRK_SERVE_IDLE_US", 2000));
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));

@@ -18,7 +18,7 @@ namespace mrk {
 
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries);
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
-void launch_sort(mrk_ctx *ctx, const BatchDev &b);
+void launch_sort(mrk_ctx *ctx, const BatchDev &b, int max_items);
 void launch_status_or(hipStream_t stream, const int32_t *all, int world, int n_req, int32_t *status);
 void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode);
 void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int item_begin, int n, int *order, void *scratch);
@@ -36,6 +36,9 @@ int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 QsForestDev qs_forest_view(const mrk_model *m);  // score_qs.hip
 size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64);
+size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64);
+void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
+                             int threads, const QsDev &q, const QsForestDev &f, uint16_t *cells, bool f64, void *jit_fn);
 void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
                        int threads, size_t lds, bool f64, void *jit_fn);
 void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
@@ -342,7 +345,7 @@ static int shard_chunk(const mrk_batch &b, int count) { return (int)mrk_shard_ch
 
 static void sort_batch(mrk_batch &b) {
   mrk_ctx *ctx = b.ctx;
-  launch_sort(ctx, b.view);
+  launch_sort(ctx, b.view, b.hb.max_items);
   if (b.big.empty()) return;
   ScopedKernelTimer timer(ctx, "sort");
   for (auto &br : b.big) {
@@ -387,8 +390,14 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
   // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
   // (the specialised matrix kernel has no op-split form: a split batch of a matrix-scored model runs the interpreting kernel)
   const bool one = direct && sort && lo == 0 && hi == b.total_items && rank_one_applies(b, model, cells);
+  // full batches of small requests: assembly + forest + ordering in the request's workgroup (one launch, phases of different
+  // kinds side by side on every CU)
+  const bool fused_score = !one && sort && lo == 0 && hi == b.total_items && cells && sw.rank_fused_score && b.fused_ok && b.fused_split == 1 &&
+                           b.fused_slices == 1 && b.hb.max_items <= QS_TILE_ROWS && b.view.n_overrides == 0 && b.big.empty() && b.fused_threads <= 256 &&
+                           rank_fused_score_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, qs_device_view(model).thr_cap, qs_device_view(model).n_views, f64) <= 64 * 1024;
   void *jit_fn = !cells ? (b.fused_ok && model && b.fused_split == 1 && b.fused_slices == 1 ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too
                         : one ? jit_one_function(*b.prog, f64)
+                        : fused_score ? jit_fused_score_function(*b.prog, f64)
                         : !b.fused_ok ? jit_items_function(*b.prog, f64)
                         : b.fused_split > 1 || b.fused_slices > 1 ? jit_split_function(*b.prog, f64) : jit_rank_function(*b.prog, f64);
   LaunchOn on(ctx, b.s());
@@ -412,6 +421,14 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
   MRK_HIP(hipMemsetAsync(b.view.status, 0, std::max<size_t>(b.n_req, 1) * 4, b.s()));
   b.view.item_lo = lo;
   b.view.item_hi = hi;
+  if (fused_score) {
+    const QsDev q = qs_device_view(model);
+    b.d_cells.reserve(std::max<size_t>((size_t)b.n_req * q.n_views * QS_TILE_ROWS * 2, 16));   // one tile per request
+    launch_rank_fused_score(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, q, qs_forest_view(model), b.d_cells.as<uint16_t>(), f64, jit_fn);
+    b.matrix_valid = false;
+    b.ran = true;
+    return;
+  }
   if (cells) {
     // hot path: the assembled values go straight into the scorer's binned tile; no f64 matrix
     const QsDev q = qs_device_view(model);

@@ -127,6 +127,11 @@ std::string jit_source(const Program &prog, bool f64, int kernel) {
     s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_one"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, mrk::QsForestDev f, int mode, mrk::OneOut out) {\n"
          "  mrk::rank_one_body<" + b64 + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, mode, out);\n}\n";
+  // full batches of small requests: assembly + forest + ordering in the request's workgroup (rank_fused_score_body)
+  if (kernel == JIT_ALL || kernel == JIT_FUSED_SCORE)
+    s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_fused_score"
+         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, mrk::QsForestDev f, uint16_t *cells) {\n"
+         "  mrk::rank_fused_score_body<" + b64 + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, cells);\n}\n";
   // ... and its persistent form (rank_device.hpp rank_serve_body)
   if (kernel == JIT_ALL || kernel == JIT_SERVE)
     s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_serve"
@@ -175,7 +180,7 @@ struct JitKernels {
   JitSlot slot[JIT_KERNELS][2];   // [kernel][f64] (the matrix kernel lives in [JIT_MATRIX][1])
 };
 
-const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve"};
+const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve", "mrk_jit_rank_fused_score"};
 
 // 0 off; 1 on: the first rank of a model waits for the compile (a failure falls back to the generic kernel with a warning);
 // 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready;
@@ -359,6 +364,7 @@ void *jit_split_function(const Program &prog, bool f64) { return jit_function(pr
 void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_MATRIX, true); }
 // the one-launch kernel of small requests
 void *jit_one_function(const Program &prog, bool f64) { return jit_function(prog, JIT_ONE, f64); }
+void *jit_fused_score_function(const Program &prog, bool f64) { return jit_function(prog, JIT_FUSED_SCORE, f64); }
 void *jit_serve_function(const Program &prog, bool f64) { return jit_function(prog, JIT_SERVE, f64, /*wait=*/true); }  // mrk_serve_start IS the warm-up
 
 // waits for the background compiles of `prog` that are under way (a warm-up / measurement aid; the next launch loads them)

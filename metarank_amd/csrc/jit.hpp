@@ -8,7 +8,7 @@ namespace mrk {
 struct Program;
 
 // the specialised kernels of a program; each is compiled (and cached on disk) by itself when a batch first needs it
-enum { JIT_RANK = 0, JIT_SPLIT = 1, JIT_MATRIX = 2, JIT_ITEMS = 3, JIT_ONE = 4, JIT_SERVE = 5, JIT_KERNELS = 6, JIT_ALL = -1 };
+enum { JIT_RANK = 0, JIT_SPLIT = 1, JIT_MATRIX = 2, JIT_ITEMS = 3, JIT_ONE = 4, JIT_SERVE = 5, JIT_FUSED_SCORE = 6, JIT_KERNELS = 7, JIT_ALL = -1 };
 // the translation unit hiprtc compiles for this model's program: the shared device code + the program as constants +
 // the kernel `kernel` (JIT_ALL: every kernel - inspection tools)
 std::string jit_source(const Program &prog, bool f64, int kernel = JIT_ALL);
@@ -27,6 +27,8 @@ void *jit_matrix_function(const Program &prog);
 void *jit_one_function(const Program &prog, bool f64);
 // the persistent workgroup of the serving queue (mrk_jit_rank_serve), same conditions
 void *jit_serve_function(const Program &prog, bool f64);
+// full batches of small requests: assembly + forest + ordering in one launch (mrk_jit_rank_fused_score)
+void *jit_fused_score_function(const Program &prog, bool f64);
 int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const std::string &dir);
 void jit_wait(const Program &prog);
 void jit_release(Program &prog);

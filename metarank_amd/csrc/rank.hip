@@ -96,6 +96,13 @@ rank_one_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, 
   rank_one_body<F64>(st, prog, b, tab_entries, vals_cap, q, f, mode, out);
 }
 
+// full batches of small requests: assembly, forest and ordering in the request's workgroup (rank_device.hpp rank_fused_score_body)
+template <bool F64>
+__global__ void __launch_bounds__(256)
+rank_fused_score_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_entries, int vals_cap, QsDev q, QsForestDev f, uint16_t *cells) {
+  rank_fused_score_body<F64>(st, prog, b, tab_entries, vals_cap, q, f, cells);
+}
+
 // the persistent form: one workgroup serves the requests published in its slot (rank_device.hpp rank_serve_body)
 template <bool F64>
 __global__ void __launch_bounds__(512)
@@ -131,10 +138,16 @@ __global__ void override_cells_kernel(BatchDev b, QsDev q, uint16_t *cells) {
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_COUNT_MAX = 256;  // requests up to this size are ordered by counting (sort_kernel)
 
+// Dynamic LDS: the keys (8 B) - and for requests of more than SORT_COUNT_MAX candidates the indices (4 B) - of the batch's
+// LARGEST request rounded up to a power of two (`cap` entries), not of the largest request the kernel can order: with the
+// 48 KB a 4 096-candidate request needs, the workgroups of a batch of 100-candidate requests could not be placed next to
+// another batch's assembly workgroups (which fill a CU's LDS) and the kernel took as long as that assembly did
+// (gpurun_out r03_r: 24 us alone, 250 - 290 us in the serving loop - on the critical path of every batch's download).
 __global__ void __launch_bounds__(SORT_THREADS)
-sort_kernel(BatchDev b) {
-  __shared__ unsigned long long s_key[SORT_MAX_ITEMS];
-  __shared__ int s_idx[SORT_MAX_ITEMS];
+sort_kernel(BatchDev b, int cap) {
+  extern __shared__ __align__(16) unsigned long long sort_smem[];
+  unsigned long long *s_key = sort_smem;
+  int *s_idx = (int *)(sort_smem + cap);
   const int r = blockIdx.x;
   const int tid = threadIdx.x;
   const ReqDev rq = b.reqs[r];
@@ -422,6 +435,38 @@ void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
   }
 }
 
+size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64) {
+  const size_t nw = (size_t)threads / 64;
+  const size_t scoring = (size_t)n_views * QS_TILE_ROWS * 2 + 16 + 8 * nw * (QS_LEAVES * (f64 ? 8 : 4) + QS_TILE_ROWS) + QS_TILE_ROWS * 8;
+  return std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap), scoring);
+}
+
+// One workgroup per request of a full batch (requests of <= QS_TILE_ROWS candidates, 128 or 64 lanes); `cells`: one tile per request.
+void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
+                             int threads, const QsDev &q, const QsForestDev &f, uint16_t *cells, bool f64, void *jit_fn) {
+  if (b.n_req <= 0) return;
+  const size_t lds = rank_fused_score_lds_bytes(tab_entries, vals_cap, threads, q.thr_cap, f.n_views, f64);
+  ScopedKernelTimer timer(ctx, "rank_fused");
+  if (jit_fn) {
+    StoreDev a_st = st;
+    BatchDev a_b = b;
+    QsDev a_q = q;
+    QsForestDev a_f = f;
+    int a_vals = vals_cap;
+    void *args[] = {&a_st, &a_b, &tab_entries, &a_vals, &a_q, &a_f, &cells};
+    MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
+    return;
+  }
+  static std::once_flag once;
+  std::call_once(once, [] {
+    MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_score_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  });
+  if (f64) hipLaunchKernelGGL(rank_fused_score_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, cells);
+  else hipLaunchKernelGGL(rank_fused_score_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, cells);
+  MRK_HIP(hipGetLastError());
+}
+
 // one persistent workgroup of `threads` lanes with `lds` bytes of dynamic LDS on `stream` (capi_rank.cpp mrk_serve_*)
 void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
                        int threads, size_t lds, bool f64, void *jit_fn) {
@@ -467,10 +512,14 @@ void launch_status_or(hipStream_t stream, const int32_t *all, int world, int n_r
   MRK_HIP(hipGetLastError());
 }
 
-void launch_sort(mrk_ctx *ctx, const BatchDev &b) {
+// max_items: the batch's largest request (requests of more than SORT_MAX_ITEMS are ordered by bigsort.hip)
+void launch_sort(mrk_ctx *ctx, const BatchDev &b, int max_items) {
   if (b.n_req <= 0) return;
+  int cap = 64;
+  while (cap < std::min(max_items, SORT_MAX_ITEMS)) cap <<= 1;
+  const size_t lds = cap <= SORT_COUNT_MAX ? (size_t)cap * 8 : (size_t)cap * 12;
   ScopedKernelTimer timer(ctx, "sort");
-  hipLaunchKernelGGL(sort_kernel, dim3(b.n_req), dim3(SORT_THREADS), 0, ctx->launch, b);
+  hipLaunchKernelGGL(sort_kernel, dim3(b.n_req), dim3(SORT_THREADS), lds, ctx->launch, b, cap);
   MRK_HIP(hipGetLastError());
 }
 

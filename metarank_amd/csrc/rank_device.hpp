@@ -1474,6 +1474,60 @@ __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &pr
   }
 }
 
+// ---- the same idea for FULL batches of small requests (c2: 3 840 requests x 100 candidates): the request's workgroup
+// assembles its binned tile (one 128-row tile per request, in global memory: the assembly's LDS is full of tables), then
+// pulls the tile back into LDS - over the tables it no longer needs -, scores it with its own wavefronts and orders the
+// scores.  One launch instead of three, and - the point - every CU holds workgroups in BOTH kinds of phase at any time:
+// the assembly waits on memory (55 % of a wavefront's life, profiles/r03_i), the forest is pure instruction issue; as two
+// kernels they met on a CU only by accident of two streams (the assembly kernel's workgroups take the whole LDS).
+// Dynamic LDS: max(rank_fused_body's regions, [slab V x 256][16][leaf values, exit-leaf indices of 8 x nw trees][128 sort keys]).
+template <bool F64, typename Prog>
+__device__ __forceinline__ void rank_fused_score_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
+                                                      const QsDev &q, const QsForestDev &f, uint16_t *cells) {
+  extern __shared__ __align__(16) uint8_t smem_base[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int r = blockIdx.x;
+  const ReqDev rq = b.reqs[r];
+  const uint32_t slab_bytes = (uint32_t)f.n_views * (QS_TILE_ROWS * 2);
+  uint16_t *tile = cells + (size_t)r * f.n_views * QS_TILE_ROWS;
+  // rows past the request's last candidate (their cells only have to be harmless)
+  for (uint32_t i = tid; i < (uint32_t)f.n_views * QS_TILE_ROWS; i += nthr)
+    if ((int)(i % QS_TILE_ROWS) >= rq.n_items) tile[i] = 0;
+  rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, q.thr_cap, 1, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
+    return CellSink<F64>{q, tile + (gi - rq.item_begin), &b.status[rr], s_thr, active};
+  });
+  // the tile has reached L2 (this CU's L1 holds none of its lines: nothing has read them), every table is dead
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const uint4 *src = (const uint4 *)tile;
+    uint4 *dst = (uint4 *)smem_base;
+    for (uint32_t i = tid; i < slab_bytes / 16; i += nthr) dst[i] = src[i];
+  }
+  constexpr int TREE_LEAF_BYTES = QS_LEAVES * (F64 ? 8 : 4);
+  const int nw = nthr >> 6;
+  uint8_t *s_leaf = smem_base + slab_bytes + 16;
+  uint8_t *s_idx = s_leaf + 8 * nw * TREE_LEAF_BYTES;
+  unsigned long long *s_key = (unsigned long long *)(s_idx + 8 * nw * QS_TILE_ROWS);
+  const double score = qs_score_tile_split<F64>(smem_base, s_leaf, s_idx, f, nw);   // (starts with a barrier: the slab is complete)
+  const int n = rq.n_items;
+  if (tid < n) {
+    b.scores[rq.item_begin + tid] = score;
+    s_key[tid] = sort_key(score);
+  }
+  __syncthreads();
+  if (tid < n) {
+    const unsigned long long mine = s_key[tid];
+    int before = 0;
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long kj = s_key[j];
+      before += (kj < mine || (kj == mine && j < tid)) ? 1 : 0;
+    }
+    b.order[rq.item_begin + before] = tid;
+  }
+}
+
 // ---- the persistent form of the same: ONE workgroup that stays on its CU and serves the requests the host publishes in
 // its slot (main/command/Serve.scala:130-150 + api/routes/RankApi.scala:25-41: the process that answers POST /rank - here
 // the request path contains no HIP call at all).  Per request: lane 0 polls `seq` in pinned memory; the workgroup copies
