@@ -8,10 +8,10 @@
 //      splitter: NB buckets of about 1 024 pairs each.  Because the INDEX is part of a pair, a request whose scores are
 //      all equal (NoopModel: every score 0.0) splits as evenly as any other.
 //   2. classify: every pair finds its bucket by a binary search over the splitters (in LDS), bucket numbers are kept
-//      (u16), bucket sizes are counted in LDS and added to the global totals; the last workgroup to finish turns the
-//      totals into bucket starts.
-//   3. scatter: a workgroup counts its tile's pairs per bucket again, reserves its share of every bucket it feeds with
-//      ONE returning atomic per (workgroup, bucket) and writes its pairs there (order inside a bucket: arbitrary).
+//      (u16), a workgroup's counts per bucket go to its row of a [workgroups][buckets] table; one lane per bucket then
+//      walks its column (counts -> offsets) and the last workgroup of that launch turns the totals into bucket starts.
+//   3. scatter: a workgroup's share of bucket b starts at base[b] + table[w][b]; it writes its pairs there (order inside a
+//      bucket: arbitrary).  No global atomics anywhere.
 //   4. one workgroup per bucket sorts its pairs in LDS (counting for <= 256, a bitonic network up to 4 096) and writes
 //      the request's order.  A bucket that outgrew LDS - with 8-fold oversampling the chance is ~1e-7 per bucket - is
 //      sorted in place in global memory by the same workgroup (slow, correct; MRK_BIG_SORT_CAP shrinks the LDS limit so
@@ -50,20 +50,85 @@ __device__ __forceinline__ int sample_pos(int i, int n, int samples) {
   return (int)(lo + (long long)(h % (uint32_t)(hi - lo)));
 }
 
-// bitonic network over p2 (key, index) pairs in LDS, one compare-exchange per lane and step
-__device__ __forceinline__ void lds_bitonic(unsigned long long *s_key, int *s_idx, int p2) {
+// Bitonic network over nthr x E (key, index) pairs held IN REGISTERS, E per lane, blocked (lane t holds pairs t E ... t E +
+// E - 1).  A step of stride j is a register move when j < E, a wavefront shuffle when the partner lane lies in the same
+// wavefront (j / E < 64), and a trip through LDS - two barriers - only when it does not.  Round 3's first version kept the
+// pairs in LDS and went there for every one of the 55 steps of a 1 024-pair sort: 8-byte keys at stride 2 j are an 8-way
+// bank conflict for small j, and a step cost 0.8 us (46 us per bucket; the local sort was 45 % of a 4 M-candidate order).
+template <int E>
+__device__ __forceinline__ void bitonic_regs(unsigned long long (&k)[E], int (&x)[E], unsigned long long *s_key, int *s_idx) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  for (int k = 2; k <= p2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int p = tid; p < p2 / 2; p += nthr) {
-        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
-        const unsigned long long ka = s_key[i], kb = s_key[ixj];
-        const int ia = s_idx[i], ib = s_idx[ixj];
-        const bool up = (i & k) == 0;
-        if (pair_lt(kb, ib, ka, ia) == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
+  const int total = nthr * E;
+  auto cmpex_keep = [](unsigned long long &ka, int &ia, unsigned long long kb, int ib, bool keep_min) {
+    const bool b_lt = pair_lt(kb, ib, ka, ia);
+    if (b_lt == keep_min) { ka = kb; ia = ib; }   // keep_min: take the other when it is smaller; else take it when it is larger
+  };
+  for (int size = 2; size <= total; size <<= 1) {
+    // strides that cross wavefronts
+    for (int j = size >> 1; j >= 64 * E; j >>= 1) {
+      const int pt = tid ^ (j / E);
+#pragma unroll
+      for (int c = 0; c < E; ++c) { s_key[c * nthr + tid] = k[c]; s_idx[c * nthr + tid] = x[c]; }
+      __syncthreads();
+      const bool lower = (tid & (j / E)) == 0;
+#pragma unroll
+      for (int c = 0; c < E; ++c) {
+        const bool up = ((tid * E + c) & size) == 0;
+        cmpex_keep(k[c], x[c], s_key[c * nthr + pt], s_idx[c * nthr + pt], lower == up);
       }
       __syncthreads();
     }
+    // strides inside a wavefront: shuffles
+    for (int j = min(size >> 1, 32 * E); j >= E; j >>= 1) {
+      const int m = j / E;
+      const bool lower = (tid & m) == 0;
+#pragma unroll
+      for (int c = 0; c < E; ++c) {
+        const unsigned lo = (unsigned)k[c], hi = (unsigned)(k[c] >> 32);
+        const unsigned olo = (unsigned)__shfl_xor((int)lo, m, 64), ohi = (unsigned)__shfl_xor((int)hi, m, 64);
+        const int oi = __shfl_xor(x[c], m, 64);
+        const bool up = ((tid * E + c) & size) == 0;
+        cmpex_keep(k[c], x[c], ((unsigned long long)ohi << 32) | olo, oi, lower == up);
+      }
+    }
+    // strides inside a lane: registers (compile-time indices)
+#pragma unroll
+    for (int jj = E >> 1; jj > 0; jj >>= 1) {
+      if (jj < size) {
+#pragma unroll
+        for (int c = 0; c < E; ++c) {
+          if ((c & jj) == 0) {
+            const bool up = ((tid * E + c) & size) == 0;
+            const bool b_lt = pair_lt(k[c | jj], x[c | jj], k[c], x[c]);
+            if (b_lt == up) {
+              const unsigned long long tk = k[c]; k[c] = k[c | jj]; k[c | jj] = tk;
+              const int tx = x[c]; x[c] = x[c | jj]; x[c | jj] = tx;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// sorts m <= nthr x E pairs of (gk, gi)[0, m) and hands pair number p, in order, to emit(p, key, index)
+template <int E, typename Load, typename Emit>
+__device__ __forceinline__ void sort_block(int m, unsigned long long *s_key, int *s_idx, Load load, Emit emit) {
+  const int tid = threadIdx.x;
+  unsigned long long k[E];
+  int x[E];
+#pragma unroll
+  for (int c = 0; c < E; ++c) {
+    const int i = tid * E + c;
+    k[c] = ~0ull;         // padding sorts last (no pair has key ~0 AND index INT_MAX)
+    x[c] = 0x7fffffff;
+    if (i < m) load(i, k[c], x[c]);
+  }
+  bitonic_regs<E>(k, x, s_key, s_idx);
+#pragma unroll
+  for (int c = 0; c < E; ++c) {
+    const int i = tid * E + c;
+    if (i < m) emit(i, k[c], x[c]);
   }
 }
 
@@ -72,19 +137,20 @@ __global__ void __launch_bounds__(1024)
 ss_sample_sort_kernel(SortSrc src, int n, int samples, int nb, unsigned long long *__restrict__ spl_k, int *__restrict__ spl_i) {
   __shared__ unsigned long long s_key[BS_ONE_WG];
   __shared__ int s_idx[BS_ONE_WG];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < samples; i += 1024) {  // samples is a power of two
+  auto load = [&](int i, unsigned long long &k, int &x) {
     const int p = sample_pos(i, n, samples);
-    s_key[i] = src_key(src, p);
-    s_idx[i] = p;
-  }
-  __syncthreads();
-  lds_bitonic(s_key, s_idx, samples);
-  for (int j = tid; j < nb - 1; j += 1024) {
-    const int e = (j + 1) * BS_OVERSAMPLE - 1;
-    spl_k[j] = s_key[e];
-    spl_i[j] = s_idx[e];
-  }
+    k = src_key(src, p);
+    x = p;
+  };
+  auto emit = [&](int i, unsigned long long k, int x) {  // every BS_OVERSAMPLE-th pair is a splitter
+    if ((i + 1) % BS_OVERSAMPLE == 0 && (i + 1) / BS_OVERSAMPLE <= nb - 1) {
+      spl_k[(i + 1) / BS_OVERSAMPLE - 1] = k;
+      spl_i[(i + 1) / BS_OVERSAMPLE - 1] = x;
+    }
+  };
+  if (samples <= 1024) sort_block<1>(samples, s_key, s_idx, load, emit);
+  else if (samples <= 2048) sort_block<2>(samples, s_key, s_idx, load, emit);
+  else sort_block<4>(samples, s_key, s_idx, load, emit);
 }
 
 // step 1 for larger samples: draw ...
@@ -108,16 +174,16 @@ ss_pick_splitters_kernel(const unsigned long long *__restrict__ smp_k, const int
 }
 
 // step 2.  Dynamic LDS: [nb u64 splitter keys][nb i32 splitter indices][nb u32 counters] (LDS_SPL), else the counters only.
+// A workgroup leaves its tile's counts per bucket in ITS row of `table` ([n_wg][nb], coalesced) - no global atomics: 512
+// workgroups x 4 096 buckets were 1.8 M device-scope atomics per pass, twice (round 3's first version: 250 us of a 4 M order).
 template <bool LDS_SPL>
 __global__ void __launch_bounds__(BS_THREADS)
 ss_classify_kernel(SortSrc src, int n, int tile, int nb, const unsigned long long *__restrict__ spl_k, const int *__restrict__ spl_i,
-                   uint16_t *__restrict__ bucket, uint32_t *totals, uint32_t *ticket, uint32_t *__restrict__ base, uint32_t *__restrict__ cursor) {
+                   uint16_t *__restrict__ bucket, uint32_t *__restrict__ table) {
   extern __shared__ unsigned long long bs_smem[];
   unsigned long long *s_k = bs_smem;
   int *s_i = (int *)(s_k + (LDS_SPL ? nb : 0));
   uint32_t *s_hist = (uint32_t *)(s_i + (LDS_SPL ? nb : 0));
-  __shared__ uint32_t s_part[BS_THREADS];
-  __shared__ int s_last;
   const int tid = threadIdx.x;
   if (LDS_SPL)
     for (int j = tid; j < nb - 1; j += BS_THREADS) { s_k[j] = spl_k[j]; s_i[j] = spl_i[j]; }
@@ -137,25 +203,41 @@ ss_classify_kernel(SortSrc src, int n, int tile, int nb, const unsigned long lon
     atomicAdd(&s_hist[b], 1u);
   }
   __syncthreads();
-  for (int j = tid; j < nb; j += BS_THREADS) {
-    const uint32_t c = s_hist[j];
-    if (c) atomicAdd(&totals[j], c);
+  uint32_t *row = table + (size_t)blockIdx.x * nb;
+  for (int j = tid; j < nb; j += BS_THREADS) row[j] = s_hist[j];
+}
+
+// step 2b: one lane per bucket walks its column of the table - table[w][b] becomes the number of bucket-b pairs of the
+// workgroups before w -, then the last workgroup to finish turns the bucket totals into bucket starts.
+__global__ void __launch_bounds__(BS_THREADS)
+ss_offsets_kernel(uint32_t *__restrict__ table, int n_wg, int nb, int n, uint32_t *totals, uint32_t *ticket, uint32_t *__restrict__ base) {
+  __shared__ uint32_t s_part[BS_THREADS];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x * BS_THREADS + tid;
+  if (b < nb) {
+    uint32_t run = 0;
+    int w = 0;
+    for (; w + 8 <= n_wg; w += 8) {  // the loads of eight rows in flight together
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(w + u) * nb + b];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { table[(size_t)(w + u) * nb + b] = run; run += v[u]; }
+    }
+    for (; w < n_wg; ++w) { const uint32_t v = table[(size_t)w * nb + b]; table[(size_t)w * nb + b] = run; run += v; }
+    totals[b] = run;
   }
-  // the last workgroup to get here turns the totals into bucket starts
   __threadfence();
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
-  const int per = nb / BS_THREADS > 0 ? nb / BS_THREADS : 1;  // nb: a power of two >= 8
+  const int per = (nb + BS_THREADS - 1) / BS_THREADS;
   uint32_t sum = 0;
   for (int q = 0; q < per; ++q) {
     const int j = tid * per + q;
-    if (j < nb) {
-      const uint32_t c = atomicAdd(&totals[j], 0u);  // a returning atomic reads what the other workgroups' atomics left
-      s_hist[j] = c;
-      sum += c;
-    }
+    if (j < nb) sum += atomicAdd(&totals[j], 0u);  // written by other workgroups of this launch: a returning atomic reads the coherent value
   }
   s_part[tid] = sum;
   __syncthreads();
@@ -169,32 +251,26 @@ ss_classify_kernel(SortSrc src, int n, int tile, int nb, const unsigned long lon
     const int j = tid * per + q;
     if (j < nb) {
       base[j] = run;
-      cursor[j] = run;
-      run += s_hist[j];
+      run += atomicAdd(&totals[j], 0u);
     }
   }
   if (tid == 0) base[nb] = (uint32_t)n;
 }
 
-// step 3.  Dynamic LDS: nb u32.
+// step 3.  Dynamic LDS: nb u32.  A workgroup's share of bucket b starts at base[b] + table[w][b]; inside it the order is
+// arbitrary (LDS atomics).
 __global__ void __launch_bounds__(BS_THREADS)
-ss_scatter_kernel(SortSrc src, int n, int tile, int nb, const uint16_t *__restrict__ bucket, uint32_t *cursor,
-                  unsigned long long *__restrict__ keys, int *__restrict__ idx) {
+ss_scatter_kernel(SortSrc src, int n, int tile, int nb, const uint16_t *__restrict__ bucket, const uint32_t *__restrict__ table,
+                  const uint32_t *__restrict__ base, unsigned long long *__restrict__ keys, int *__restrict__ idx) {
   extern __shared__ unsigned long long bs_smem[];
-  uint32_t *s_cnt = (uint32_t *)bs_smem;
+  uint32_t *s_off = (uint32_t *)bs_smem;
   const int tid = threadIdx.x;
-  for (int j = tid; j < nb; j += BS_THREADS) s_cnt[j] = 0u;
+  const uint32_t *row = table + (size_t)blockIdx.x * nb;
+  for (int j = tid; j < nb; j += BS_THREADS) s_off[j] = base[j] + row[j];
   __syncthreads();
   const int lo = blockIdx.x * tile, hi = min(lo + tile, n);
-  for (int i = lo + tid; i < hi; i += BS_THREADS) atomicAdd(&s_cnt[bucket[i]], 1u);
-  __syncthreads();
-  for (int j = tid; j < nb; j += BS_THREADS) {
-    const uint32_t c = s_cnt[j];
-    s_cnt[j] = c ? atomicAdd(&cursor[j], c) : 0u;  // this workgroup's share of bucket j starts here
-  }
-  __syncthreads();
   for (int i = lo + tid; i < hi; i += BS_THREADS) {
-    const uint32_t pos = atomicAdd(&s_cnt[bucket[i]], 1u);
+    const uint32_t pos = atomicAdd(&s_off[bucket[i]], 1u);
     keys[pos] = src_key(src, i);
     idx[pos] = i;
   }
@@ -209,27 +285,13 @@ ss_local_sort_kernel(const uint32_t *__restrict__ base, unsigned long long *keys
   const int lo = (int)base[blockIdx.x], m = (int)base[blockIdx.x + 1] - lo;
   if (m <= 0) return;
   if (m <= lds_cap) {
-    if (m <= BS_THREADS) {  // every lane counts the pairs below its own (rank.hip sort_kernel)
-      if (tid < m) { s_key[tid] = keys[lo + tid]; s_idx[tid] = idx[lo + tid]; }
-      __syncthreads();
-      if (tid < m) {
-        const unsigned long long mk = s_key[tid];
-        const int mi = s_idx[tid];
-        int before = 0;
-        for (int j = 0; j < m; ++j) before += pair_lt(s_key[j], s_idx[j], mk, mi) ? 1 : 0;
-        out_order[lo + before] = mi;
-      }
-      return;
-    }
-    int p2 = 512;
-    while (p2 < m) p2 <<= 1;
-    for (int i = tid; i < p2; i += BS_THREADS) {
-      s_key[i] = i < m ? keys[lo + i] : ~0ull;  // padding sorts last (no pair has key ~0 AND index INT_MAX)
-      s_idx[i] = i < m ? idx[lo + i] : 0x7fffffff;
-    }
-    __syncthreads();
-    lds_bitonic(s_key, s_idx, p2);
-    for (int i = tid; i < m; i += BS_THREADS) out_order[lo + i] = s_idx[i];
+    auto load = [&](int i, unsigned long long &k, int &x) { k = keys[lo + i]; x = idx[lo + i]; };
+    auto emit = [&](int i, unsigned long long, int x) { out_order[lo + i] = x; };
+    if (m <= BS_THREADS) sort_block<1>(m, s_key, s_idx, load, emit);
+    else if (m <= 2 * BS_THREADS) sort_block<2>(m, s_key, s_idx, load, emit);
+    else if (m <= 4 * BS_THREADS) sort_block<4>(m, s_key, s_idx, load, emit);
+    else if (m <= 8 * BS_THREADS) sort_block<8>(m, s_key, s_idx, load, emit);
+    else sort_block<16>(m, s_key, s_idx, load, emit);
     return;
   }
   // A bucket that does not fit LDS: an all-ascending bitonic network in place in global memory.  Every comparator puts
@@ -270,7 +332,7 @@ struct Level {
   unsigned long long *keys = nullptr, *spl_k = nullptr, *smp_k = nullptr;
   int *idx = nullptr, *spl_i = nullptr, *smp_i = nullptr, *smp_order = nullptr;
   uint16_t *bucket = nullptr;
-  uint32_t *totals = nullptr, *ticket = nullptr, *base = nullptr, *cursor = nullptr;
+  uint32_t *totals = nullptr, *ticket = nullptr, *base = nullptr, *table = nullptr;
 };
 
 int pow2_ceil(long long v) {
@@ -302,7 +364,7 @@ size_t plan_levels(int n, uint8_t *scratch, std::vector<Level> &out) {
     lv.totals = (uint32_t *)take((size_t)lv.nb * 4 + 16);  // [totals][ticket]: zeroed together
     lv.ticket = lv.totals ? lv.totals + lv.nb : nullptr;
     lv.base = (uint32_t *)take((size_t)(lv.nb + 1) * 4);
-    lv.cursor = (uint32_t *)take((size_t)lv.nb * 4);
+    lv.table = (uint32_t *)take((size_t)lv.n_wg * lv.nb * 4);
     lv.spl_k = (unsigned long long *)take((size_t)lv.nb * 8);
     lv.spl_i = (int *)take((size_t)lv.nb * 4);
     if (lv.samples > BS_ONE_WG) {
@@ -318,7 +380,7 @@ size_t plan_levels(int n, uint8_t *scratch, std::vector<Level> &out) {
 
 void sort_level(hipStream_t s, const std::vector<Level> &lv, size_t k, const SortSrc &src, int *out_order, int lds_cap) {
   const Level &L = lv[k];
-  MRK_HIP(hipMemsetAsync(L.totals, 0, (size_t)L.nb * 4 + 16, s));
+  MRK_HIP(hipMemsetAsync(L.ticket, 0, 16, s));
   if (L.samples <= BS_ONE_WG) {
     hipLaunchKernelGGL(ss_sample_sort_kernel, dim3(1), dim3(1024), 0, s, src, L.n, L.samples, L.nb, L.spl_k, L.spl_i);
   } else {
@@ -333,11 +395,12 @@ void sort_level(hipStream_t s, const std::vector<Level> &lv, size_t k, const Sor
   std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)ss_classify_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS_SPLITTERS * 16)); });
   if (L.nb <= BS_LDS_SPLITTERS)
     hipLaunchKernelGGL(ss_classify_kernel<true>, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 16, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
-                       L.bucket, L.totals, L.ticket, L.base, L.cursor);
+                       L.bucket, L.table);
   else
     hipLaunchKernelGGL(ss_classify_kernel<false>, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 4, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
-                       L.bucket, L.totals, L.ticket, L.base, L.cursor);
-  hipLaunchKernelGGL(ss_scatter_kernel, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 4, s, src, L.n, L.tile, L.nb, L.bucket, L.cursor, L.keys,
+                       L.bucket, L.table);
+  hipLaunchKernelGGL(ss_offsets_kernel, dim3((L.nb + BS_THREADS - 1) / BS_THREADS), dim3(BS_THREADS), 0, s, L.table, L.n_wg, L.nb, L.n, L.totals, L.ticket, L.base);
+  hipLaunchKernelGGL(ss_scatter_kernel, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 4, s, src, L.n, L.tile, L.nb, L.bucket, L.table, L.base, L.keys,
                      L.idx);
   hipLaunchKernelGGL(ss_local_sort_kernel, dim3(L.nb), dim3(BS_THREADS), 0, s, L.base, L.keys, L.idx, out_order, lds_cap);
   MRK_HIP(hipGetLastError());
