@@ -416,6 +416,15 @@ typedef struct mrk_encoder_info {
  * the residual stream, LayerNorm statistics, softmax and every accumulation are f32. */
 int mrk_encoder_load(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len,
                      int heads, mrk_encoder **out);
+/* The same with the arithmetic chosen by the caller.  MRK_ENCODER_FP16 (what mrk_encoder_load uses): fp16 operands on the
+ * matrix cores, f32 accumulation - pooled cosines within 3e-3 of an fp32 run of the graph.  MRK_ENCODER_F32: every product on
+ * f32 operands with f32 accumulation, exact erf / exp - the arithmetic of the reference's fp32 ONNX session (onnxruntime on
+ * the CPU, OnnxSession.scala:42-56); cosines within 1e-5 of transformers' fp32 output (the reference's own tests accept 1e-3,
+ * OnnxBiencoderTest.scala:23-25).  About 20x slower than the fp16 path: a parity instrument and the mode for a host that
+ * must reproduce the JVM's numbers. */
+enum { MRK_ENCODER_FP16 = 0, MRK_ENCODER_F32 = 1 };
+int mrk_encoder_load_ex(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
+                        int precision, mrk_encoder **out);
 int mrk_encoder_get_info(mrk_encoder *enc, mrk_encoder_info *info);
 /* Host-only view of what mrk_encoder_load reads from a model file: writes a JSON object
  * {"heads": h, "tensors": {name: {"shape": [...], "sum": s, "abs_sum": a}}} (BertModel state_dict names, Linear weights

@@ -199,6 +199,7 @@ SIGNATURES = {
     "mrk_tokenizer_encode_batch": (_I, [_V, C.POINTER(_S), C.POINTER(_S), _I, _P, _P, _P, _I, C.POINTER(C.c_int)]),
     "mrk_tokenizer_free": (None, [_V]),
     "mrk_encoder_load": (_I, [_V, _P, C.c_size_t, _P, C.c_size_t, _I, C.POINTER(_V)]),
+    "mrk_encoder_load_ex": (_I, [_V, _P, C.c_size_t, _P, C.c_size_t, _I, _I, C.POINTER(_V)]),
     "mrk_checkpoint_describe": (_I, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mrk_encoder_get_info": (_I, [_V, C.POINTER(mrk_encoder_info)]),
     "mrk_encoder_embed": (_I, [_V, C.POINTER(_S), _I, _P]),

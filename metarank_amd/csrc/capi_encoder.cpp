@@ -52,7 +52,7 @@ uint16_t to_half(float f) {
 }
 
 // Validates the checkpoint against the BertModel layout, converts and uploads it (one device allocation).
-void build_encoder(mrk_encoder &e, const Checkpoint &ck) {
+void build_encoder(mrk_encoder &e, const Checkpoint &ck, bool f32) {
   auto get = [&](const std::string &name) -> const HostTensor & {
     auto it = ck.tensors.find(name);
     if (it == ck.tensors.end()) throw StatusError(MRK_ERR_PARSE, "encoder weights: tensor " + name + " is missing (BERT-family graphs only)");
@@ -133,6 +133,34 @@ void build_encoder(mrk_encoder &e, const Checkpoint &ck) {
     d.layers.push_back(LayerDev{hb + o.wqkv, hb + o.wo, hb + o.w1, hb + o.w2, fb + o.bqkv, fb + o.bo, fb + o.b1, fb + o.b2,
                                 fb + o.g1, fb + o.be1, fb + o.g2, fb + o.be2});
   if (sh.classifier) { d.pool_w = hb + o_pw; d.pool_b = fb + o_pb; d.cls_w = fb + o_cw; d.cls_b = fb + o_cb; }
+  if (f32) {  // the same matrices at the same offsets (in elements), as f32
+    std::vector<float> ms(hs.size(), 0.f);
+    auto put_m = [&](const HostTensor &t, size_t off) { std::copy(t.data.begin(), t.data.end(), ms.begin() + off); };
+    put_m(word, o_word);
+    put_m(get("embeddings.position_embeddings.weight"), o_pos);
+    put_m(get("embeddings.token_type_embeddings.weight"), o_type);
+    for (int l = 0; l < sh.layers; ++l) {
+      const std::string p = "encoder.layer." + std::to_string(l) + ".";
+      size_t at = lo[l].wqkv;
+      for (const char *nm : {"query", "key", "value"}) {
+        const HostTensor &w = get(p + "attention.self." + nm + ".weight");
+        put_m(w, at);
+        at += w.data.size();
+      }
+      put_m(get(p + "attention.output.dense.weight"), lo[l].wo);
+      put_m(get(p + "intermediate.dense.weight"), lo[l].w1);
+      put_m(get(p + "output.dense.weight"), lo[l].w2);
+    }
+    if (sh.classifier) put_m(get("pooler.dense.weight"), o_pw);
+    e.weights32.reserve(ms.size() * 4);
+    MRK_HIP(hipMemcpy(e.weights32.p, ms.data(), ms.size() * 4, hipMemcpyHostToDevice));
+    e.device_bytes += (int64_t)(ms.size() * 4);
+    const float *mb = e.weights32.as<float>();
+    d.f32 = true;
+    d.word32 = mb + o_word; d.pos32 = mb + o_pos; d.type32 = mb + o_type;
+    for (auto &o : lo) d.layers32.push_back(LayerDev32{mb + o.wqkv, mb + o.wo, mb + o.w1, mb + o.w2});
+    if (sh.classifier) d.pool_w32 = mb + o_pw;
+  }
 }
 
 constexpr size_t GRAPH_MAX_TOKENS = 8192, GRAPH_MAX_CACHED = 256;
@@ -224,7 +252,7 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
   // Opt-in (MRK_ENCODER_GRAPH=1): measured 0.230 vs 0.240 ms for a 9-token query -- the forward pass of a small batch
   // is bound by the dependent-kernel chain, not by launch overhead -- and rocprofv3's kernel tracing crashes inside
   // the HIP runtime when a captured graph is launched.
-  const bool use_graphs = switches().encoder_graph;
+  const bool use_graphs = switches().encoder_graph && !e.dev.f32;
   if (use_graphs && M <= GRAPH_MAX_TOKENS) {
     // (a packed batch's launch geometry depends on its token count and its longest sequence)
     const std::tuple<int, int, int> key(n, packed ? -(int)M : seq, mode * 4096 + (packed ? max_len : 0));
@@ -364,14 +392,20 @@ void mrk_tokenizer_free(mrk_tokenizer *tok) { delete tok; }
 
 int mrk_encoder_load(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
                      mrk_encoder **out) {
+  return mrk_encoder_load_ex(ctx, weights, len, tokenizer_json, tok_len, heads, MRK_ENCODER_FP16, out);
+}
+
+int mrk_encoder_load_ex(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
+                        int precision, mrk_encoder **out) {
   return guard([&] {
     need(ctx && weights && tokenizer_json && out, "mrk_encoder_load: null argument");
+    need(precision == MRK_ENCODER_FP16 || precision == MRK_ENCODER_F32, "mrk_encoder_load_ex: unknown precision");
     std::unique_ptr<mrk_encoder> e(new mrk_encoder);
     e->tok = Tokenizer::from_json(tokenizer_json, tok_len);
     Checkpoint ck = read_checkpoint(weights, len);
     if (heads > 0) ck.heads = heads;
     MRK_HIP(hipSetDevice(ctx->device));
-    build_encoder(*e, ck);
+    build_encoder(*e, ck, precision == MRK_ENCODER_F32);
     MRK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->ctx = ctx;
     ctx_retain(ctx);

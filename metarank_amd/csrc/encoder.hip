@@ -58,8 +58,9 @@ __device__ __forceinline__ void layer_norm_row(float (&v)[LN_MAX_PER_LANE], int 
 // word + position + token-type embeddings, then LayerNorm: one wavefront per token
 // (pos_ids != nullptr: the tokens are PACKED - sequences back to back without padding - and pos_ids[t] is the token's
 // position inside its sequence; else the batch is padded to `seq` tokens per row)
+template <typename T>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *ids, const int32_t *types, const int32_t *pos_ids, int M, int seq, int H, int vocab, int type_vocab,
-                                                       const _Float16 *word, const _Float16 *pos, const _Float16 *type, const float *g, const float *b,
+                                                       const T *word, const T *pos, const T *type, const float *g, const float *b,
                                                        float eps, float *x, _Float16 *xh) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -455,7 +456,8 @@ __global__ void meanpool_kernel(const float *x, const int32_t *mask, const int32
 }
 
 // BertPooler (dense + tanh on the [CLS] row) and the 1-logit classifier: one workgroup per sequence
-__global__ __launch_bounds__(256) void classify_kernel(const float *x, const int32_t *cu, int seq, int H, const _Float16 *pw, const float *pb, const float *cw,
+template <typename T>
+__global__ __launch_bounds__(256) void classify_kernel(const float *x, const int32_t *cu, int seq, int H, const T *pw, const float *pb, const float *cw,
                                                        const float *cb, float *out) {
   extern __shared__ float sm[];  // H inputs | 4 partials
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const float *x, const int
   float part = 0.f;
   for (int o = tid; o < H; o += 256) {
     float acc = 0.f;
-    const _Float16 *w = pw + (size_t)o * H;
+    const T *w = pw + (size_t)o * H;
     for (int c = 0; c < H; ++c) acc += (float)w[c] * sm[c];
     part += tanhf(acc + pb[o]) * cw[o];
   }
@@ -488,15 +490,113 @@ void launch_gemm(const uint16_t *A, const uint16_t *W, const float *bias, const 
   else hipLaunchKernelGGL((gemm_kernel<1, 1, EPI>), grid_of(64, 64), dim3(256), 0, s, (const _Float16 *)A, (const _Float16 *)W, bias, res, out, M, N, K);
 }
 
+// ---- precision f32 (mrk_encoder_load_ex(MRK_ENCODER_F32)): the arithmetic of the reference's fp32 ONNX session - f32
+// operands, f32 accumulation, libm erf / exp.  Plain tiled kernels: this path exists to REPRODUCE numbers (cosines within
+// 1e-5 of transformers' fp32 output where the fp16 path is within 3e-3), not to be fast.
+enum { EPI32_NONE = 0, EPI32_GELU = 1, EPI32_RES = 2 };
+
+// C[M, N] = A[M, K] W[N, K]^T + bias (+ GELU | + res): 64 x 64 tiles, 4 x 4 outputs per lane, k in ascending order
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+                                                       const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
+  constexpr int T = 64, KB = 16;
+  __shared__ float As[KB][T + 4], Ws[KB][T + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    for (int e = tid; e < T * KB; e += 256) {
+      const int r = e / KB, k = e % KB;
+      const int m = m0 + r < M ? m0 + r : M - 1;
+      As[k][r] = A[(size_t)m * K + k0 + k];
+      Ws[k][r] = W[(size_t)(n0 + r) * K + k0 + k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Ws[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nn = n0 + tx * 4 + j;
+      float v = acc[i][j] + bias[nn];
+      if (EPI == EPI32_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+      if (EPI == EPI32_RES) v += res[(size_t)m * N + nn];
+      out[(size_t)m * N + nn] = v;
+    }
+  }
+}
+
+template <int EPI>
+void launch_gemm_f32(const float *A, const float *W, const float *bias, const float *res, float *out, int M, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+}
+
+// one wavefront per (query row, head, sequence): scores over the sequence's live keys, softmax, weighted sum of V.
+// Dynamic LDS: 4 wavefronts x seq floats (the probabilities).  Same conventions as attention_kernel (padded | packed).
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ qkv, const int32_t *__restrict__ mask, const int32_t *__restrict__ cu,
+                                                            int seq_pad, int H, int DH, float scale, float *__restrict__ ctx) {
+  extern __shared__ float att_p[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, head = blockIdx.y, qi = blockIdx.x * 4 + wave;
+  const size_t row = (size_t)3 * H;
+  const size_t first = cu ? (size_t)cu[b] : (size_t)b * seq_pad;
+  const int seq = cu ? cu[b + 1] - cu[b] : seq_pad;
+  if (qi >= seq) return;
+  const float *base = qkv + first * row + head * DH;
+  const int32_t *mrow = mask ? mask + first : nullptr;
+  float *p = att_p + (size_t)wave * seq_pad;
+  const float *q = base + (size_t)qi * row;
+  float mx = -FLT_MAX;
+  for (int j = lane; j < seq; j += 64) {
+    const bool live = mrow == nullptr || mrow[j] != 0;
+    float s = 0.f;
+    const float *k = base + (size_t)j * row + H;
+    for (int d = 0; d < DH; ++d) s = __fmaf_rn(q[d], k[d], s);
+    s = live ? s * scale : -FLT_MAX;
+    p[j] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int j = lane; j < seq; j += 64) {
+    const float e = p[j] == -FLT_MAX ? 0.f : expf(p[j] - mx);
+    p[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < DH) {
+    float o = 0.f;
+    const float *v = base + 2 * H + lane;
+    for (int j = 0; j < seq; ++j) o = __fmaf_rn(p[j], v[(size_t)j * row], o);
+    ctx[(first + qi) * H + head * DH + lane] = o / sum;
+  }
+}
+
 }  // namespace
 
 void encoder_reserve(const EncoderDev &enc, EncoderScratch &sc, int n, int seq) {
   const size_t M = (size_t)n * seq, H = enc.shape.hidden, I = enc.shape.inter;
+  const size_t w = enc.f32 ? 4 : 2;  // bytes per activation between the products
   sc.x.reserve(M * H * 4);
   sc.xh.reserve(M * H * 2);
-  sc.qkv.reserve(M * 3 * H * 2);
-  sc.ctx.reserve(M * H * 2);
-  sc.mid.reserve(M * I * 2);
+  sc.qkv.reserve(M * 3 * H * w);
+  sc.ctx.reserve(M * H * w);
+  sc.mid.reserve(M * I * w);
   sc.y.reserve(M * H * 4);
 }
 
@@ -513,9 +613,28 @@ static void forward_impl(const EncoderDev &enc, EncoderScratch &sc, int n, int s
   float *x = sc.x.as<float>(), *y = sc.y.as<float>();
   uint16_t *xh = sc.xh.as<uint16_t>(), *qkv = sc.qkv.as<uint16_t>(), *ctx = sc.ctx.as<uint16_t>(), *mid = sc.mid.as<uint16_t>();
   const int row_blocks = (M + 3) / 4;
-  hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids, types, pos_ids, M, seq, H, sh.vocab, sh.type_vocab, (const _Float16 *)enc.word,
-                     (const _Float16 *)enc.pos, (const _Float16 *)enc.type, enc.embg, enc.embb, sh.eps, x, (_Float16 *)xh);
   const float scale = 1.0f / sqrtf((float)DH);
+  if (enc.f32) {  // precision f32 (mrk_encoder_load_ex): the fp32 graph's arithmetic; qkv / ctx / mid hold f32 here
+    float *qf = sc.qkv.as<float>(), *cf = sc.ctx.as<float>(), *mf = sc.mid.as<float>();
+    hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(row_blocks), dim3(256), 0, s, ids, types, pos_ids, M, seq, H, sh.vocab, sh.type_vocab, enc.word32, enc.pos32,
+                       enc.type32, enc.embg, enc.embb, sh.eps, x, (_Float16 *)xh);
+    for (size_t l = 0; l < enc.layers.size(); ++l) {
+      const LayerDev &L = enc.layers[l];
+      const LayerDev32 &W = enc.layers32[l];
+      launch_gemm_f32<EPI32_NONE>(x, W.wqkv, L.bqkv, nullptr, qf, M, 3 * H, H, s);
+      hipLaunchKernelGGL(attention_f32_kernel, dim3((seq + 3) / 4, sh.heads, n), dim3(256), (size_t)4 * seq * sizeof(float), s, (const float *)qf, mask, cu, seq, H,
+                         DH, scale, cf);
+      launch_gemm_f32<EPI32_RES>(cf, W.wo, L.bo, x, y, M, H, H, s);
+      hipLaunchKernelGGL(ln_kernel, dim3(row_blocks), dim3(256), 0, s, (const float *)y, M, H, L.ln1g, L.ln1b, sh.eps, x, (_Float16 *)xh);
+      launch_gemm_f32<EPI32_GELU>(x, W.w1, L.b1, nullptr, mf, M, I, H, s);
+      launch_gemm_f32<EPI32_RES>(mf, W.w2, L.b2, x, y, M, H, I, s);
+      hipLaunchKernelGGL(ln_kernel, dim3(row_blocks), dim3(256), 0, s, (const float *)y, M, H, L.ln2g, L.ln2b, sh.eps, x, (_Float16 *)xh);
+    }
+    MRK_HIP(hipGetLastError());
+    return;
+  }
+  hipLaunchKernelGGL(embed_ln_kernel<_Float16>, dim3(row_blocks), dim3(256), 0, s, ids, types, pos_ids, M, seq, H, sh.vocab, sh.type_vocab, (const _Float16 *)enc.word,
+                     (const _Float16 *)enc.pos, (const _Float16 *)enc.type, enc.embg, enc.embb, sh.eps, x, (_Float16 *)xh);
   for (const LayerDev &L : enc.layers) {
     launch_gemm<EPI_F16>(xh, L.wqkv, L.bqkv, nullptr, qkv, M, 3 * H, H, s);
     dim3 ag((seq + 31) / 32, (sh.heads + ATT_HEADS - 1) / ATT_HEADS, n);  // packed: seq = the longest sequence
@@ -545,8 +664,12 @@ void encoder_classify(const EncoderDev &enc, EncoderScratch &sc, int n, int seq,
   if (n <= 0) return;
   const int H = enc.shape.hidden;
   const int32_t *cu = M_packed > 0 ? sc.ids.as<int32_t>() + 3 * (size_t)M_packed : nullptr;
-  hipLaunchKernelGGL(classify_kernel, dim3(n), dim3(256), (H + 4) * sizeof(float), s, (const float *)sc.x.as<float>(), cu, seq, H,
-                     (const _Float16 *)enc.pool_w, enc.pool_b, enc.cls_w, enc.cls_b, d_out);
+  if (enc.f32)
+    hipLaunchKernelGGL(classify_kernel<float>, dim3(n), dim3(256), (H + 4) * sizeof(float), s, (const float *)sc.x.as<float>(), cu, seq, H, enc.pool_w32, enc.pool_b,
+                       enc.cls_w, enc.cls_b, d_out);
+  else
+    hipLaunchKernelGGL(classify_kernel<_Float16>, dim3(n), dim3(256), (H + 4) * sizeof(float), s, (const float *)sc.x.as<float>(), cu, seq, H,
+                       (const _Float16 *)enc.pool_w, enc.pool_b, enc.cls_w, enc.cls_b, d_out);
   MRK_HIP(hipGetLastError());
 }
 

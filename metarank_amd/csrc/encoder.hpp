@@ -41,6 +41,12 @@ struct LayerDev {
   const float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 
+// the f32 copies of the matrices an encoder loaded with precision f32 keeps (mrk_encoder_load_ex): every product then runs
+// on f32 operands with f32 accumulation - the arithmetic of the reference's fp32 ONNX graph, for parity work
+struct LayerDev32 {
+  const float *wqkv, *wo, *w1, *w2;              // f32 [out, in]
+};
+
 struct EncoderDev {
   EncoderShape shape;
   const uint16_t *word, *pos, *type;             // fp16 embedding tables
@@ -48,6 +54,9 @@ struct EncoderDev {
   std::vector<LayerDev> layers;
   const uint16_t *pool_w = nullptr;              // fp16 [H, H]
   const float *pool_b = nullptr, *cls_w = nullptr, *cls_b = nullptr;
+  bool f32 = false;                              // precision f32: the fields below are set and the forward pass uses them
+  const float *word32 = nullptr, *pos32 = nullptr, *type32 = nullptr, *pool_w32 = nullptr;
+  std::vector<LayerDev32> layers32;
 };
 
 // activations of one forward call (grow-only, owned by the encoder handle)
@@ -85,6 +94,7 @@ struct mrk_encoder {
   mrk::Tokenizer tok;
   mrk::EncoderDev dev;
   mrk::DevBuf weights;     // one allocation: fp16 matrices then f32 vectors
+  mrk::DevBuf weights32;   // precision f32: the matrices once more, as f32
   mrk::EncoderScratch scratch;
   mrk::PinBuf h_ids, h_out;  // pinned staging of one call
   hipStream_t stream = nullptr;

@@ -359,3 +359,108 @@ def test_cross_encoder_column(minilm):
                 np.testing.assert_allclose(logits, want, rtol=0, atol=ATOL_MODEL)
         finally:
             hip.close()
+
+
+# ---- precision f32 (mrk_encoder_load_ex(MRK_ENCODER_F32)): the fp32 ONNX session's arithmetic --------------------------
+ATOL_F32_HIDDEN, ATOL_F32_COS = 2e-4, 1e-5   # vs transformers / numpy fp32: what is left is f32 summation order and exp / erf
+
+
+def test_f32_mode_reproduces_the_fp32_graph():
+    """Tiny fixtures (transformers fp32 outputs, ONNX and safetensors readers) and all-MiniLM-L6-v2's architecture: hidden
+    states within 2e-4, pooled cosines within 1e-5 of the fp32 graph - the reference's own encoder tests accept 1e-3
+    (OnnxBiencoderTest.scala:23-25); the fp16 path is within 3e-3 (ATOL_COS above)."""
+    g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
+    for fname in ("encoder_tiny.onnx", "encoder_tiny.safetensors"):
+        enc = HipEncoder(open(os.path.join(GOLDEN, fname), "rb").read(), TOK_TINY, f32=True)
+        h = enc.hidden_ids(g["ids"], g["type_ids"], g["mask"])
+        live = g["mask"].astype(bool)
+        np.testing.assert_allclose(h[live], g["hidden"][live], rtol=0, atol=ATOL_F32_HIDDEN)   # transformers fp32
+        pooled = enc.embed_ids(g["ids"], g["type_ids"], g["mask"])
+        np.testing.assert_array_equal(pooled, bert.avgpool(h, g["mask"]))
+        assert np.abs(_cos(pooled, g["pooled"]) - 1.0).max() < ATOL_F32_COS
+        enc.close()
+    enc = HipEncoder(open(os.path.join(GOLDEN, "cross_tiny.onnx"), "rb").read(), TOK_TINY, f32=True)
+    np.testing.assert_allclose(enc.score_ids(g["pair_ids"], g["pair_type_ids"], g["pair_mask"]), g["logits"], rtol=0, atol=ATOL_F32_HIDDEN)
+    enc.close()
+    w = synth.synthetic_bert(**MINILM, classifier=True)
+    tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
+    enc = HipEncoder(synth.bert_safetensors(w, 12), tj, f32=True)
+    try:
+        for n, seq in ((1, 9), (5, 47), (3, 200), (70, 64)):
+            rng = np.random.default_rng(n * 1000 + seq)
+            ids = rng.integers(5, 2000, size=(n, seq)); types = np.zeros_like(ids)
+            lens = rng.integers(1, seq + 1, size=n); lens[0] = seq
+            mask = (np.arange(seq)[None, :] < lens[:, None]).astype(np.int32)
+            types[:, seq // 2:] = 1
+            fp32 = bert.last_hidden_state(w, ids, types, mask, heads=12)
+            h = enc.hidden_ids(ids, types, mask)
+            live = mask.astype(bool)
+            np.testing.assert_allclose(h[live], fp32[live], rtol=0, atol=ATOL_F32_HIDDEN)
+            pooled = enc.embed_ids(ids, types, mask)     # packed layout: the same rows
+            assert np.abs(_cos(pooled, bert.avgpool(fp32, mask)) - 1.0).max() < ATOL_F32_COS
+            np.testing.assert_allclose(pooled, bert.avgpool(fp32, mask), rtol=0, atol=ATOL_F32_HIDDEN)
+            logits = enc.score_ids(ids, types, mask)
+            np.testing.assert_allclose(logits, bert.cross_logits(w, ids, types, mask, heads=12), rtol=0, atol=5e-4)
+    finally:
+        enc.close()
+
+
+def test_c5_against_the_fp32_embedding_not_against_itself():
+    """BASELINE config 5 with the oracle fed an INDEPENDENT embedding - numpy's fp32 run of the graph - instead of the device's
+    own: with the encoder in f32 mode the device's cosine column is within 1e-6 of the oracle's, and every score the
+    500-tree forest produces is the oracle's except where a cosine sits within that distance of a split threshold; the same
+    comparison for the default fp16 mode is reported (how many of the scores move by more than 1e-5 at 3e-3 cosine error)."""
+    w = synth.synthetic_bert(**MINILM, classifier=False)
+    tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
+    blob_w = synth.bert_safetensors(w, 12)
+    tok = HipTokenizer(tj)
+    cfg = ranklens.c5_config()
+    queries = synth.synthetic_queries(24, seed=13)
+    ids, types, mask = tok.encode_batch(queries)
+    fp32_emb = bert.embed(w, ids, types, mask, heads=12)
+    reqs = ranklens.generate_requests(24, 100, N_ITEMS, N_SESS, seed=53)
+    text_reqs, emb_reqs = [], []
+    for k, ev in enumerate(reqs):
+        t, e = dict(ev), dict(ev)
+        t["fields"] = [{"name": "query", "value": queries[k]}]
+        e["fields"] = [{"name": "__embedding:title_match", "value": [float(x) for x in fp32_emb[k]]}]
+        text_reqs.append(t); emb_reqs.append(e)
+    orc = OracleBackend(cfg, "xgboost")
+    ranklens.load_state(orc, ranklens.generate_state(N_ITEMS, N_SESS))
+    ranklens.load_state(orc, ranklens.c5_embeddings(N_ITEMS))
+    mats = [orc.matrix(ev) for ev in emb_reqs]
+    model = synth.synthetic_lgbm_model(n_trees=500, n_features=25, quantiles=ranklens.column_quantiles(np.concatenate(mats)), missing="per_feature")
+    orc.load_model(model, 0)
+    want = [orc.rerank(ev) for ev in emb_reqs]
+    report = {}
+    for mode in ("f32", "fp16"):
+        enc = HipEncoder(blob_w, tj, f32=(mode == "f32"))
+        hip = HipBackend(cfg, "xgboost")
+        try:
+            ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
+            ranklens.load_state(hip, ranklens.c5_embeddings(N_ITEMS))
+            hip.ranker.bind_encoder("title_match", enc)
+            hip.load_model(model, 0)
+            batch = hip.ranker.prepare("xgboost", text_reqs)
+            batch.run(hip.booster)
+            scores, order, mat = batch.fetch(matrix=True)
+            assert (batch.status() == 0).all()
+            cos_err, moved, total, reordered = 0.0, 0, 0, 0
+            for r in range(len(reqs)):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                a, b = mat[lo:hi], mats[r]
+                other = [c for c in range(25) if c != 24]
+                assert bool(((a[:, other] == b[:, other]) | (np.isnan(a[:, other]) & np.isnan(b[:, other]))).all()), (mode, r)
+                ok = np.isfinite(b[:, 24])
+                cos_err = max(cos_err, float(np.abs(a[ok, 24] - b[ok, 24]).max()))
+                moved += int((np.abs(scores[lo:hi] - want[r][1]) > 1e-5).sum())
+                total += hi - lo
+                reordered += int(order[lo:hi].tolist() != want[r][2].tolist())
+            report[mode] = {"cosine_err": cos_err, "scores_moved": moved, "of": total, "requests_reordered": reordered}
+            batch.close()
+        finally:
+            hip.close()
+            enc.close()
+    print("\nC5 against the fp32 embedding:", report)
+    assert report["f32"]["cosine_err"] < 1e-5 and report["f32"]["scores_moved"] <= report["f32"]["of"] // 200, report
+    assert report["fp16"]["cosine_err"] < ATOL_COS, report
