@@ -35,6 +35,8 @@ static Switches read_switches() {
   s.jit_waves = num("MRK_JIT_WAVES", 0);
   s.jit_record_regs = flag("MRK_JIT_REGS", true);
   s.jit_shipped = flag("MRK_JIT_SHIPPED", true);
+  if (const char *d = getenv("MRK_JIT_DEFINES")) s.jit_defines = d; else s.jit_defines.clear();
+  s.thr_stage = flag("MRK_THR_STAGE", true);
   s.fused_lds_min = std::max(0, num("MRK_FUSED_LDS_MIN", 0));
   if (const char *d = getenv("MRK_JIT_CACHE_DIR")) s.jit_cache_dir = d;
   else if (const char *x = getenv("XDG_CACHE_HOME")) s.jit_cache_dir = std::string(x) + "/mrk_jit";

@@ -59,6 +59,16 @@ uint64_t fnv1a(const std::string &s) {
 std::string jit_source(const Program &prog, bool f64, int kernel) {
   std::string s;
   s.reserve(strlen(k_device_source) + 8192);
+  // experiments: MRK_JIT_DEFINES="A=1 B=2" - macros the device code reads (MRK_PROBE_W, MRK_PRE_GROUP_BUDGET); part of the text, so of the cache key
+  for (size_t at = 0; at < switches().jit_defines.size();) {
+    size_t end = switches().jit_defines.find(' ', at);
+    if (end == std::string::npos) end = switches().jit_defines.size();
+    std::string d = switches().jit_defines.substr(at, end - at);
+    at = end + 1;
+    if (d.empty()) continue;
+    const size_t eq = d.find('=');
+    s += "#define " + (eq == std::string::npos ? d : d.substr(0, eq) + " " + d.substr(eq + 1)) + "\n";
+  }
   s += k_device_source;
   s += "\nnamespace mrk {\nnamespace {\n";
   // tables as function-local constexpr arrays: a namespace-scope / static-member constexpr array is emitted as an

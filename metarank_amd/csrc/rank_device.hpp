@@ -97,9 +97,15 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 // assembly phase are misses (a candidate's token that the session profile does not hold), a miss ends at the first empty
 // entry, and at the 75 % load the tables are sized for a miss walks 8.5 entries on average - the longest walk among 64
 // lanes is 20 - 30.  Round 2 read 4 entries together and then walked the rest ONE entry per trip: 20 dependent LDS round
-// trips per lookup (phase clocks, profiles/r02_g: ~10 k cycles per lookup of a diversity / interacted_with column).  Both
-// primitives now take every trip PROBE_W entries wide: independent reads, one wait, the whole window examined in registers.
-constexpr int PROBE_W = 8;
+// trips per lookup.  Both primitives now take EVERY trip PROBE_W entries wide: independent reads, one wait, the whole window
+// examined in registers.  Width measured same-box on c2 / c3 (gpurun_out r03_za; MRK_JIT_DEFINES="MRK_PROBE_W=n" compiles the
+// specialised kernels with another width): 2 -> 0.269 / 0.415 ms, 3 -> 0.270 / 0.416, **4 -> 0.265 / 0.412**, 6 -> 0.276 / 0.420,
+// 8 -> 0.288 / 0.423 (a window costs three VALU per entry for the wrap-around and two for the compare, and its registers are
+// live next to the candidate's record); round 2's 4-then-1 loop: 0.282 / 0.431.
+#ifndef MRK_PROBE_W
+#define MRK_PROBE_W 4
+#endif
+constexpr int PROBE_W = MRK_PROBE_W;
 
 __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   // tab / cap may differ between lanes (item-parallel kernel: lanes of several requests in one wavefront)
@@ -802,7 +808,10 @@ __device__ __forceinline__ constexpr int op_pre_weight(const Op &op) {
     default: return 0;
   }
 }
-constexpr int PRE_GROUP_BUDGET = 72;  // registers of fetched-ahead state per group (c2's 19 ops: 2 groups)
+#ifndef MRK_PRE_GROUP_BUDGET
+#define MRK_PRE_GROUP_BUDGET 72
+#endif
+constexpr int PRE_GROUP_BUDGET = MRK_PRE_GROUP_BUDGET;  // registers of fetched-ahead state per group (c2's 19 ops: 2 groups)
 // end of the group of ops that starts at `lo` (in_regs: the candidate's record is held in registers, so a primary cell
 // that lives in it costs nothing more)
 template <typename Prog, bool IN_REGS>

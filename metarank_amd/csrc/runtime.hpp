@@ -111,6 +111,8 @@ struct Switches {
   int jit_mode = 4;            // MRK_RANK_JIT: 0 off, 1 on (wait for the compiler), 2 require, 3 async, 4 auto (default: disk cache at once, else async)
   int jit_waves = 0;           // MRK_JIT_WAVES
   int fused_lds_min = 0;       // MRK_FUSED_LDS_MIN: least dynamic LDS the fused assembly kernel asks for (experiments: fewer resident workgroups)
+  std::string jit_defines;     // MRK_JIT_DEFINES: macros prepended to the specialised kernels' source (experiments)
+  bool thr_stage = true;       // MRK_THR_STAGE=0: the assembly kernels search threshold tables in global memory instead of staging them in LDS (experiments)
   bool jit_shipped = true;     // MRK_JIT_SHIPPED=0: ignore the code objects shipped next to the library (tests of the compile paths)
   bool jit_record_regs = true; // MRK_JIT_REGS=0: the specialised kernel reads the candidate's record cell by cell instead of keeping it in registers
   std::string jit_cache_dir;   // MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else ~/.cache/mrk_jit; "" / "off": none

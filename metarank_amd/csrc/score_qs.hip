@@ -508,7 +508,7 @@ QsDev qs_device_view(const mrk_model *m) {
   uint32_t longest = 1;
   for (const QsFeature &f : m->qs.feats)
     if (f.view_begin != f.view_end && f.thr_len <= QS_LDS_THR) longest = std::max<uint32_t>(longest, f.thr_len);
-  q.thr_cap = (longest + QS_STAGE_CHUNK - 1) / QS_STAGE_CHUNK * QS_STAGE_CHUNK;
+  q.thr_cap = switches().thr_stage ? (longest + QS_STAGE_CHUNK - 1) / QS_STAGE_CHUNK * QS_STAGE_CHUNK : 0u;
   return q;
 }
 
