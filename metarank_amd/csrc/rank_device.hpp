@@ -86,7 +86,9 @@ __device__ __forceinline__ int scoped_slot(const ReqDev &rq, int scope, int item
 // with linear probing; the capacity is any number > the number of tokens inserted (not a power of two:
 // the tables of a request live in LDS and their size sets the occupancy), the home slot is the
 // multiply-high range reduction of a multiplicative hash.
-__device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t cap) { return __umulhi(tok * 2654435761u, cap); }
+// (homes lie in [0, cap - PROBE_W]: the first window of a probe sequence - the one most lookups end in - never wraps, so its
+// entries are read at constant offsets from ONE address; later windows wrap around `cap`.  The host sizes every table >= 8.)
+__device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t span) { return __umulhi(tok * 2654435761u, span); }
 
 // Both primitives are written for the wavefront, not for the lane: the probe loop runs while ANY active lane is
 // still looking (one scalar branch per round), lanes that are done - or that never wanted anything (`want`
@@ -109,16 +111,23 @@ constexpr int PROBE_W = MRK_PROBE_W;
 
 __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   // tab / cap may differ between lanes (item-parallel kernel: lanes of several requests in one wavefront)
-  uint32_t idx = tok_home(tok, cap);
+  uint32_t idx = tok_home(tok, cap - (uint32_t)(PROBE_W - 1));
   const unsigned long long fresh = (unsigned long long)tok | (1ull << 32);
   bool open = want;          // still looking for tok's entry
   bool full = false;
   uint32_t walked = 0;       // entries known to hold other keys
+  bool first = true;         // (uniform) the window at the home entry: no wrap-around
   while (wave_any(open)) {
     // a window of the probe sequence: entries that hold OTHER keys can be skipped for good (a key, once set, never changes)
     unsigned long long e[PROBE_W];
     uint32_t pos[PROBE_W];
-    {
+    if (first) {
+#pragma unroll
+      for (int k = 0; k < PROBE_W; ++k) {
+        pos[k] = idx + (uint32_t)k;
+        e[k] = tab[idx + (uint32_t)k];
+      }
+    } else {
       uint32_t ix = idx;
 #pragma unroll
       for (int k = 0; k < PROBE_W; ++k) {
@@ -127,6 +136,7 @@ __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap,
         ix = ix + 1 == cap ? 0 : ix + 1;
       }
     }
+    first = false;
     uint32_t stop = PROBE_W;  // the FIRST entry of the window that holds tok or is empty
     bool at_key = false;
 #pragma unroll
@@ -156,10 +166,23 @@ __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap,
 }
 
 __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
-  uint32_t idx = tok_home(tok, cap);
+  uint32_t idx = tok_home(tok, cap - (uint32_t)(PROBE_W - 1));
   uint32_t res = 0;
   bool open = want;
-  for (uint32_t walked = 0;; walked += PROBE_W) {  // the first window unconditionally: one trip serves most lanes
+  {  // the window at the home entry, unconditionally: one trip, no wrap-around, serves most lanes
+    unsigned long long e[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) e[k] = tab[idx + (uint32_t)k];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      const uint32_t key = (uint32_t)e[k];
+      res = open && key == tok ? (uint32_t)(e[k] >> 32) : res;
+      open = open && key != tok && key != 0u;  // keys are token ids >= 1: key 0 = empty entry
+    }
+    idx += (uint32_t)PROBE_W;
+    idx = idx >= cap ? idx - cap : idx;
+  }
+  for (uint32_t walked = PROBE_W; wave_any(open); walked += PROBE_W) {
     unsigned long long e[PROBE_W];
 #pragma unroll
     for (int k = 0; k < PROBE_W; ++k) {
@@ -170,9 +193,8 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
     for (int k = 0; k < PROBE_W; ++k) {
       const uint32_t key = (uint32_t)e[k];
       res = open && key == tok ? (uint32_t)(e[k] >> 32) : res;
-      open = open && key != tok && key != 0u && walked + (uint32_t)(k + 1) < cap;  // keys are token ids >= 1: key 0 = empty entry
+      open = open && key != tok && key != 0u && walked + (uint32_t)(k + 1) < cap;
     }
-    if (!wave_any(open)) break;
   }
   return res;
 }
