@@ -201,7 +201,10 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
 
 // The tokens of a list are fetched TOK_BATCH at a time (independent loads in flight together) before the
 // probes start: one trip to memory per batch instead of one per token.
-constexpr int TOK_BATCH = 8;
+#ifndef MRK_TOK_BATCH
+#define MRK_TOK_BATCH 8
+#endif
+constexpr int TOK_BATCH = MRK_TOK_BATCH;
 
 // every token of toks[0, len) -> table (pre-pass); len = 0 for lanes without a list.  Returns the
 // number of tokens this lane could not insert (table full).
@@ -801,7 +804,10 @@ __device__ __forceinline__ constexpr bool op_primary_in_item(const Op &op) {
   return op.scope == SC_ITEM;
 }
 
-constexpr int IW_BATCH = 4, IW_TOK = 4;   // interacted_with: fields handled together, tokens per field fetched ahead
+#ifndef MRK_IW_TOK
+#define MRK_IW_TOK 4
+#endif
+constexpr int IW_BATCH = 4, IW_TOK = MRK_IW_TOK;   // interacted_with: fields handled together, tokens per field fetched ahead
 constexpr int RATE_BATCH = 4;             // rate: periods fetched together
 constexpr int PRE_TOK = IW_BATCH * IW_TOK;
 constexpr int PRE_F64 = 8;
