@@ -166,10 +166,11 @@ __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap,
 }
 
 __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
+  if (!wave_any(want)) return 0u;  // (a diversity column of string LISTS asks for no single-string lookup at all)
   uint32_t idx = tok_home(tok, cap - (uint32_t)(PROBE_W - 1));
   uint32_t res = 0;
   bool open = want;
-  {  // the window at the home entry, unconditionally: one trip, no wrap-around, serves most lanes
+  {  // the window at the home entry: one trip, no wrap-around, serves most lanes
     unsigned long long e[PROBE_W];
 #pragma unroll
     for (int k = 0; k < PROBE_W; ++k) e[k] = tab[idx + (uint32_t)k];
