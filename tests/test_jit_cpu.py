@@ -37,7 +37,8 @@ def test_source_carries_the_program_as_constants():
     assert "0x1.4p+3" in text
     # what the library compiles by itself is ONE kernel per translation unit (the kernel a batch shape needs, 10 - 20 s of
     # compiler time each instead of 50 s for all four): what = form | (1 + kernel) << 8
-    names = ["mrk_jit_rank_cells(", "mrk_jit_rank_cells_split(", "mrk_jit_rank_matrix(", "mrk_jit_assemble_cells("]
+    names = ["mrk_jit_rank_cells(", "mrk_jit_rank_cells_split(", "mrk_jit_rank_matrix(", "mrk_jit_assemble_cells(", "mrk_jit_rank_one(",
+             "mrk_jit_rank_serve(", "mrk_jit_rank_fused_score("]
     flat = text.replace("\n", "")
     assert all(n in flat for n in names)
     for k, name in enumerate(names):
@@ -92,3 +93,28 @@ print("RC", rc, bytes(buf[:4]) == b"\x7fELF", "torch/lib/libhiprtc" in maps)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, MRK_JIT_CACHE_DIR=str(tmp_path)))
     assert "RC 0 True" in out.stdout, out.stdout + out.stderr
+
+
+def test_precompile_writes_the_code_objects_a_deployment_ships(tmp_path):
+    """mrk_config_precompile (host-only): one gfx950 code object per kernel of the mask into a directory - what
+    __graft_entry__.build() puts next to the library for the stock Ranklens program (metarank_amd/jit_cache) so that a process
+    serving that model never compiles.  A small program here (one feature: seconds per kernel); a second call finds the files."""
+    import os
+
+    from backends import single_feature_config
+
+    lib = _native.lib()
+    cfg = single_feature_config({"name": "popularity", "type": "number", "scope": "item", "source": "item.popularity"})
+    js = json.dumps({"features": cfg["features"], "models": cfg["models"]}).encode()
+    model = list(cfg["models"])[0].encode()
+    n = C.c_int(-1)
+    mask = (1 << 0) | (1 << 4)   # the full-batch kernel and mrk_rank's one-launch kernel
+    assert lib.mrk_config_precompile(js, len(js), model, 1, mask, str(tmp_path).encode(), C.byref(n)) == 0, lib.mrk_last_error()
+    files = sorted(os.listdir(tmp_path))
+    assert n.value == 2 and len(files) == 2 and all(f.endswith("-gfx950.co") for f in files)
+    for f in files:
+        blob = open(os.path.join(tmp_path, f), "rb").read()
+        assert blob[:4] == b"\x7fELF" and (b"mrk_jit_rank_cells" in blob or b"mrk_jit_rank_one" in blob)
+    assert lib.mrk_config_precompile(js, len(js), model, 1, mask, str(tmp_path).encode(), C.byref(n)) == 0 and n.value == 0
+    assert lib.mrk_config_precompile(js, len(js), b"nope", 1, mask, str(tmp_path).encode(), C.byref(n)) == _native.ERR_NOT_FOUND
+    assert lib.mrk_config_precompile(None, 0, model, 1, mask, str(tmp_path).encode(), None) == _native.ERR_INVALID_ARG
