@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <stdexcept>
 
@@ -729,6 +730,10 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
     pf.feats[ft].thr_len = (uint16_t)v.size();
     pf.feats[ft].zero_bin = (uint16_t)(std::lower_bound(v.begin(), v.end(), 0.0) - v.begin());  // #{t < 0.0}: LightGBM only
     pf.thr.insert(pf.thr.end(), v.begin(), v.end());
+    // +inf up to the next multiple of the staging chunk: the assembly kernels stage a table in whole chunks and search the
+    // staged copy in a FIXED number of steps (qs_device.hpp qs_bin_search_staged) - an entry past the table compares as
+    // "not below" for every value
+    while (pf.thr.size() % QS_STAGE_CHUNK) pf.thr.push_back(std::numeric_limits<double>::infinity());
   }
   {
     int id = 0, cur = -1;

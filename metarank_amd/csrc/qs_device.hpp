@@ -60,6 +60,27 @@ __device__ __forceinline__ uint32_t qs_bin_search(P T, uint32_t len, double x) {
   return pos;
 }
 
+// The same lower bound over a table STAGED IN LDS: the staged copy is a whole number of 128-entry chunks, +inf past the table's
+// end (forest.cpp pads the tables), at most 256 entries - so the search is 7 or 8 steps with COMPILE-TIME strides: a step is one
+// ds_read_b64 at an immediate offset from the running address, one compare, one conditional add; no loop, no scalar
+// arithmetic (the run-time loop cost ~6 VALU + 4 SALU per step, 24 columns x 8 steps per candidate).
+template <bool F64>
+__device__ __forceinline__ uint32_t qs_bin_search_staged(qs_lds_double *T, uint32_t len, double x) {
+  if (len == 0u) return 0u;
+  auto below = [&](double t) { return F64 ? (t < x) : (t <= x); };
+  uint32_t pos = 0;
+  if (len > 128u) pos = below(T[127]) ? 128u : 0u;   // (uniform)
+  qs_lds_double *p = T + pos;
+#pragma unroll
+  for (int h = 64; h >= 1; h >>= 1) {
+    const bool b = below(p[h - 1]);
+    p += b ? h : 0;
+  }
+  pos = (uint32_t)(p - T);
+  pos += below(p[0]) ? 1u : 0u;
+  return pos;
+}
+
 // (Measured and rejected, round 3: a three-level 8-ary search over the staged table - 17 independent LDS reads in 3 trips
 // instead of 8 dependent ones - made the c2 assembly kernel 40 % SLOWER (0.284 -> 0.406 ms, gpurun_out r03_j): after the
 // first level the lanes' ranges start at multiples of 256 B, i.e. in the same LDS bank, and the LDS pipe - shared by the 16

@@ -715,7 +715,7 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     // XGBoost's DMatrix rejects the whole row for an inf in ANY column, split on or not - every scorer path does the same
     if (!ok && active) atomicOr(status, ST_XGB_INF);
     if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
-    const uint32_t pos = staged(ft) ? qs_bin_search<F64>(thr_lds + (size_t)(col & 1) * q.thr_cap, ft.thr_len, x)
+    const uint32_t pos = staged(ft) ? qs_bin_search_staged<F64>(thr_lds + (size_t)(col & 1) * q.thr_cap, ft.thr_len, x)
                                     : qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
     newer = ft.view_end - ft.view_begin;   // one store per view below (at least one lane of the wavefront has an item)
     uint16_t *d = dst;
