@@ -1135,6 +1135,8 @@ struct mrk_server {
   std::vector<int> free_slots;  // a stack: the most recently used slot is the one whose workgroup is still resident
   bool closing = false;
   std::atomic<uint64_t> n_queue{0}, n_fallback{0}, n_launches{0};
+  std::atomic<uint64_t> dev_ticks[3] = {{0}, {0}, {0}};   // device-side 100 MHz ticks: input copy, ranking, result write-back
+  std::atomic<uint64_t> host_ns[3] = {{0}, {0}, {0}};     // host-side ns: resolve + pack, publish -> acknowledgement, copy-out
 };
 
 namespace {
@@ -1186,6 +1188,7 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   ServeSlot &sl = *srv.slots[(size_t)si];
   const Program &prog = locked_program(ctx, srv.model_name.c_str());
   if (&prog != srv.prog || program_mutates_store(prog) || prog.normalises()) return false;
+  const auto h0 = std::chrono::steady_clock::now();
   StoreAccess access(ctx);
   MRK_HIP(hipSetDevice(ctx->device));
   check_model_fits(srv.model, prog);
@@ -1219,6 +1222,7 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   ctl.total_items = (uint32_t)T; ctl.tab_entries = entries; ctl.vals_cap = vals; ctl.mode = 4;
   const uint32_t seq = ++sl.seq;
   if (seq == 0xffffffffu) sl.seq = 0;  // (never: 4 G requests through one slot)
+  const auto h1 = std::chrono::steady_clock::now();
   __atomic_store_n(&ctl.seq, seq, __ATOMIC_SEQ_CST);  // publishes the block and the header
   auto gone = [&] { return __atomic_load_n(&ctl.exited, __ATOMIC_SEQ_CST) == sl.launch_id; };
   auto acked = [&] { return __atomic_load_n(&ctl.ack, __ATOMIC_ACQUIRE) == seq; };
@@ -1237,10 +1241,17 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
     }
     __builtin_ia32_pause();
   }
+  const auto h2 = std::chrono::steady_clock::now();
   if (out_scores && T) memcpy(out_scores, sl.h_out, (size_t)T * 8);
   if (out_order && T) memcpy(out_order, sl.h_out + 1024, (size_t)T * 4);
   const int32_t *hs = (const int32_t *)(sl.h_out + 1536);
   status = hs[0] | hs[1];
+  const unsigned long long *clk = (const unsigned long long *)(hs + 16);
+  for (int k = 0; k < 3; ++k) srv.dev_ticks[k].fetch_add(clk[k]);
+  const auto h3 = std::chrono::steady_clock::now();
+  srv.host_ns[0].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(h1 - h0).count());
+  srv.host_ns[1].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(h2 - h1).count());
+  srv.host_ns[2].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(h3 - h2).count());
   srv.n_queue.fetch_add(1);
   return true;
 }
@@ -1318,11 +1329,15 @@ int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, 
   return code;
 }
 
-int mrk_serve_stats(mrk_server *srv, int64_t *out3) {
-  if (!srv || !out3) return MRK_ERR_INVALID_ARG;
-  out3[0] = (int64_t)srv->n_queue.load();
-  out3[1] = (int64_t)srv->n_fallback.load();
-  out3[2] = (int64_t)srv->n_launches.load();
+int mrk_serve_stats(mrk_server *srv, int64_t *out9) {
+  if (!srv || !out9) return MRK_ERR_INVALID_ARG;
+  out9[0] = (int64_t)srv->n_queue.load();
+  out9[1] = (int64_t)srv->n_fallback.load();
+  out9[2] = (int64_t)srv->n_launches.load();
+  for (int k = 0; k < 3; ++k) {
+    out9[3 + k] = (int64_t)srv->host_ns[k].load();
+    out9[6 + k] = (int64_t)(srv->dev_ticks[k].load() * 10);   // 100 MHz ticks -> ns
+  }
   return MRK_OK;
 }
 

@@ -1606,6 +1606,7 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
     __syncthreads();
     const uint32_t seq = s_word[0], leave = s_word[1];
     if (seq == 0xffffffffu) return;
+    const unsigned long long t_seen = wall_clock64();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // the header and the block were written before `seq`
     const ServeCtl *ctl = s.ctl;
     const uint32_t in_bytes = ctl->in_bytes;
@@ -1632,10 +1633,21 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t_in = wall_clock64();
     rank_one_body<F64>(st, prog, b, tab_entries, (int)vals_cap, q, f, (int)mode, s.out);
+    const unsigned long long t_ranked = wall_clock64();
     __threadfence_system();   // every lane's results are in host memory before the acknowledgement
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&s.ctl->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+      // where the request's time went on the device, in 100 MHz ticks (mrk_serve_stats): input copy + cache drops, ranking,
+      // result writes reaching host memory
+      unsigned long long *clk = (unsigned long long *)(s.out.status + 16);
+      clk[0] = t_in - t_seen;
+      clk[1] = t_ranked - t_in;
+      clk[2] = wall_clock64() - t_ranked;
+      __threadfence_system();
+      __hip_atomic_store(&s.ctl->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (leave) return;
     last = seq;
     idle_since = wall_clock64();

@@ -298,9 +298,12 @@ class Server:
         return scores, order
 
     def stats(self) -> dict:
-        out = (C.c_int64 * 3)()
+        out = (C.c_int64 * 9)()
         N.check(N.lib().mrk_serve_stats(self._h, out))
-        return {"queue": out[0], "fallback": out[1], "launches": out[2]}
+        n = max(out[0], 1)
+        return {"queue": out[0], "fallback": out[1], "launches": out[2],
+                "us_per_request": {"host_resolve_pack": out[3] / n / 1e3, "host_publish_to_ack": out[4] / n / 1e3, "host_copy_out": out[5] / n / 1e3,
+                                   "device_input": out[6] / n / 1e3, "device_rank": out[7] / n / 1e3, "device_write_back": out[8] / n / 1e3}}
 
     def close(self):
         if self._h:

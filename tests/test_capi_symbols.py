@@ -33,6 +33,16 @@ def test_abi_version_and_error_paths_without_gpu():
     assert b"null model" in L.mrk_last_error()
     L.mrk_model_free(None)
     L.mrk_shutdown(None)
+    # round 3's entry points: argument checks come before any device work
+    import ctypes as C
+    out = C.c_void_p()
+    assert L.mrk_serve_start(None, None, b"m", 2, C.byref(out)) == _native.ERR_INVALID_ARG and not out.value
+    assert L.mrk_serve_rank(None, None, None, None) == _native.ERR_INVALID_ARG
+    assert L.mrk_serve_stats(None, None) == _native.ERR_INVALID_ARG
+    L.mrk_serve_stop(None)
+    assert L.mrk_encoder_load_ex(None, None, 0, None, 0, 0, 1, C.byref(out)) == _native.ERR_INVALID_ARG
+    assert L.mrk_config_warmup(None, b"m") == _native.ERR_INVALID_ARG
+    assert L.mrk_shard_chunk(1000, 8) == 128 and L.mrk_shard_chunk(1025, 8) == 256
 
 
 def test_no_product_file_references_the_oracle():
