@@ -170,6 +170,11 @@ def main():
             ctx.comm_barrier()
         finally:
             sys.stdout.flush()
+            try:   # RCCL printed through C stdio: its buffer must be emptied while descriptor 1 still points at stderr
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
     cfg = ranklens.c3_config() if wl == "c3" else ranklens.c5_config() if wl == "c5" else ranklens.ranklens_config()
