@@ -1115,10 +1115,40 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
           else if (mode == 1 && c.tag == TAG_STRING_LIST) { tokens += (uint32_t)(c.bits >> 32); ++taken; }
           else if (mode == 2 && c.tag == TAG_DOUBLE) { ++doubles; ++taken; }
         }
-        wk.max_doubles = std::max(wk.max_doubles, doubles);
-        if (doubles > PREP_MAX_VALUES)
-          throw StatusError(MRK_ERR_UNSUPPORTED, "diversity feature '" + f.name + "' over more than " + std::to_string(PREP_MAX_VALUES) + " values: set `top`");
         PrepOut &po = hb.prep_out[(size_t)r * prog.prep.size() + ho.prep_base];
+        if (doubles > PREP_MAX_VALUES) {
+          // More values than the device pre-pass sorts in LDS (`top` above 4 096 over that many present candidates): the host
+          // holds the same values in its mirror (this path runs with host-resolved slots) and takes the median itself -
+          // commons-math Percentile(50), LEGACY estimation, NaN removed (DiversityFeature.scala:113-126), the arithmetic of
+          // rank_device.hpp median_of - and hands it over as a finished pre-pass result.
+          std::vector<double> vals;
+          vals.reserve((size_t)doubles);
+          int took = 0;
+          for (int i = 0; i < rq.n_items && took < f.div_top; ++i) {
+            HostCell c = host_cell(store, SC_ITEM, hb.item_slot[begin + i], pe.item_col);
+            if (c.tag != TAG_DOUBLE) continue;
+            double v;
+            memcpy(&v, &c.bits, 8);
+            ++took;
+            if (v == v) vals.push_back(v);
+          }
+          std::sort(vals.begin(), vals.end(), [](double a, double b) { return a < b || (a == b && std::signbit(a) && !std::signbit(b)); });  // Arrays.sort: -0.0 before +0.0
+          double med = std::numeric_limits<double>::quiet_NaN();
+          const size_t m = vals.size();
+          if (m == 1) med = vals[0];
+          else if (m > 1) {
+            const double pos = 0.5 * (double)(m + 1), fpos = std::floor(pos), dif = pos - fpos;
+            const size_t ipos = (size_t)fpos;
+            if (pos < 1.0) med = vals[0];
+            else if (pos >= (double)m) med = vals[m - 1];
+            else med = vals[ipos - 1] + dif * (vals[ipos] - vals[ipos - 1]);
+          }
+          po.mode = DIV_DOUBLE;
+          po.scalar = med;
+          po.preset = 1;
+          doubles = 0;
+        }
+        wk.max_doubles = std::max(wk.max_doubles, doubles);
         const uint32_t cap = table_capacity(tokens, load_pct);
         po.tab_off = (uint32_t)arena;
         po.tab_cap = cap;

@@ -62,7 +62,7 @@ struct PrepOut {
   uint32_t tab_cap;    // capacity in entries (> number of tokens the host counted for it)
   double scalar;       // diversity: median (DOUBLE) or sum of counts (STRING)
   int32_t mode;        // DivMode
-  int32_t pad;
+  int32_t preset;      // 1: mode / scalar were computed by the host (a numeric diversity over more values than the pre-pass sorts in LDS): the pre-pass leaves the entry alone
 };
 
 struct ReqDev {

@@ -447,11 +447,11 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
   MRK_PHASE(sc.clk, sc.acc[1]);
   // ---- diversity (DiversityFeature.scala:72-103), PREP_GROUP entries at a time
   for (int e0 = 0; e0 < n_prep;) {
-    if (prog.prep[e0].kind != PREP_DIVERSITY) { ++e0; continue; }
+    if (prog.prep[e0].kind != PREP_DIVERSITY || po_out[e0].preset) { ++e0; continue; }  // (preset: the host took this entry's median)
     int ent[PREP_GROUP];
     int n = 0, e1 = e0;
     for (; e1 < n_prep && n < PREP_GROUP; ++e1) {
-      if (prog.prep[e1].kind != PREP_DIVERSITY) continue;
+      if (prog.prep[e1].kind != PREP_DIVERSITY || po_out[e1].preset) continue;
 #pragma unroll
       for (int u = 0; u < PREP_GROUP; ++u) if (u == n) ent[u] = e1;
       ++n;

@@ -149,3 +149,31 @@ def test_norm_position_over_a_request_larger_than_one_workgroup_sorts():
         batch.close()
     finally:
         hip.close()
+
+
+@pytest.mark.gpu
+def test_numeric_diversity_over_more_values_than_the_pre_pass_sorts():
+    """`diversity` with `top` above 4 096 over a request with that many present numeric values: round 2 answered
+    MRK_ERR_UNSUPPORTED; now the host - which holds the same values in its mirror - takes the median (commons-math LEGACY
+    percentile, DiversityFeature.scala:113-126) and hands it to the device as a finished pre-pass result."""
+    from backends import single_feature_config
+
+    cfg = single_feature_config({"name": "div_pop", "type": "diversity", "source": "item.popularity", "top": 100000})
+    orc, hip = OracleBackend(cfg, list(cfg["models"])[0]), HipBackend(cfg, list(cfg["models"])[0])
+    try:
+        rng = np.random.default_rng(3)
+        n = 6000
+        vals = rng.normal(size=n).round(3)
+        for b in (orc, hip):
+            for i in range(n):
+                if i % 17 != 5:   # some candidates have no state: NaN in the column, not part of the median
+                    b.put_double(f"item=i{i}/div_pop", float(vals[i]) if i % 101 else 0.0)
+        items = [{"id": f"i{i}"} for i in range(n)]
+        big = {"id": "big", "timestamp": ranklens.TS, "user": None, "session": None, "fields": [], "items": items}
+        small = {"id": "small", "timestamp": ranklens.TS, "user": None, "session": None, "fields": [], "items": items[:50]}
+        for ev in (big, small, dict(big, id="5000", items=items[:5000])):
+            a, b = hip.matrix(ev), orc.matrix(ev)
+            assert a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all()), ev["id"]
+            assert np.isnan(b).any() and np.isfinite(b).any()
+    finally:
+        hip.close()
