@@ -123,6 +123,72 @@ static void parse_window(const json::Value &o, FeatureDef &f) {
       for (auto &v : p->arr) f.periods.push_back((int32_t)v.as_int());
 }
 
+// Iteration order of a scala.collection.immutable.Map[String, _] of more than 4 entries (Scala 2.13, build.sbt:6) - what
+// `for ((fieldName, feature) <- fields)` in InteractedWithFeature.scala:56-65,152-162 walks, i.e. the order of the feature's
+// columns.  Up to 4 entries a Map keeps insertion order (Map1..Map4); beyond, `toMap` builds a HashMap: a compressed
+// hash-array-mapped prefix tree over improve(key.hashCode), 5 bits per level from the LOW end, whose iterator yields a
+// node's own entries by ascending 5-bit index first and then its sub-nodes by ascending index, depth first
+// (immutable/HashMap.scala, ChampCommon.scala `ChampBaseIterator`; hashing: collection/Hashing.scala `improve`).  The
+// structure is canonical - it does not depend on insertion order - except for keys whose 32-bit hashes are EQUAL, which
+// share a collision node in insertion order.  Known answer: Map(a,b,c,d,e) iterates e, a, b, c, d.
+static uint32_t java_string_hash(const std::string &utf8) {   // String.hashCode over UTF-16 code units
+  uint32_t h = 0;
+  for (size_t i = 0; i < utf8.size();) {
+    const unsigned char c = (unsigned char)utf8[i];
+    uint32_t cp;
+    int n;
+    if (c < 0x80) { cp = c; n = 1; }
+    else if ((c >> 5) == 6) { cp = c & 31; n = 2; }
+    else if ((c >> 4) == 14) { cp = c & 15; n = 3; }
+    else { cp = c & 7; n = 4; }
+    for (int k = 1; k < n && i + k < utf8.size(); ++k) cp = (cp << 6) | ((unsigned char)utf8[i + k] & 63);
+    i += n;
+    if (cp >= 0x10000) {
+      cp -= 0x10000;
+      h = 31 * h + (0xD800 + (cp >> 10));
+      h = 31 * h + (0xDC00 + (cp & 0x3ff));
+    } else {
+      h = 31 * h + cp;
+    }
+  }
+  return h;
+}
+
+static uint32_t scala_improve(uint32_t hcode) {
+  uint32_t h = hcode + ~(hcode << 9);
+  h ^= h >> 14;
+  h += h << 4;
+  return h ^ (h >> 10);
+}
+
+static void champ_order(const std::vector<std::pair<uint32_t, int>> &node, int shift, std::vector<int> &out) {
+  if (shift >= 32) {   // equal hashes: a collision node, insertion order
+    for (auto &e : node) out.push_back(e.second);
+    return;
+  }
+  std::vector<std::pair<uint32_t, int>> at[32];
+  for (auto &e : node) at[(e.first >> shift) & 31].push_back(e);
+  for (int m = 0; m < 32; ++m)
+    if (at[m].size() == 1) out.push_back(at[m][0].second);
+  for (int m = 0; m < 32; ++m)
+    if (at[m].size() > 1) champ_order(at[m], shift + 5, out);
+}
+
+}  // namespace
+
+std::vector<std::string> scala_map_key_order(const std::vector<std::string> &keys) {
+  if (keys.size() <= 4) return keys;
+  std::vector<std::pair<uint32_t, int>> root;
+  for (size_t i = 0; i < keys.size(); ++i) root.emplace_back(scala_improve(java_string_hash(keys[i])), (int)i);
+  std::vector<int> order;
+  champ_order(root, 0, order);
+  std::vector<std::string> out;
+  for (int i : order) out.push_back(keys[(size_t)i]);
+  return out;
+}
+
+namespace {
+
 std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
   std::unique_ptr<FeatureDef> f(new FeatureDef());
   const std::string type = o.at("type").as_string();
@@ -209,7 +275,8 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
       f->values.push_back(fn.field);
     }
     // the reference keeps the fields in a Scala immutable Map: insertion order up to 4 entries, hash
-    // order beyond (InteractedWithFeature.scala:56-65,152-162) — the host must pass that order
+    // order beyond (InteractedWithFeature.scala:56-65,152-162): computed here (scala_map_key_order); a host that
+    // knows better - another Scala version - passes the order it sees as "field_order"
     if (const json::Value *ord = o.find("field_order")) {
       std::vector<std::string> order;
       for (auto &v : ord->arr) order.push_back(v.as_string());
@@ -218,8 +285,8 @@ std::unique_ptr<FeatureDef> parse_feature(const json::Value &o) {
       std::sort(b2.begin(), b2.end());
       if (a != b2) bad("feature '" + nm + "': field_order must be a permutation of the fields");
       f->values = order;
-    } else if (f->values.size() > 4) {
-      throw StatusError(MRK_ERR_UNSUPPORTED, "feature '" + nm + "': more than 4 fields need an explicit \"field_order\" (the JVM's Map iteration order)");
+    } else {
+      f->values = scala_map_key_order(f->values);
     }
     f->dim = (int)f->values.size();
   } else if (type == "diversity") {

@@ -97,6 +97,8 @@ struct Registry {
 // uploads the programs
 // (`upload` false: host-side only, for mrk_config_specialize)
 std::unique_ptr<Registry> load_config(const char *json, size_t len, Store &store, bool upload = true);
+// iteration order of a Scala 2.13 immutable Map with these String keys inserted in this order (interacted_with's columns)
+std::vector<std::string> scala_map_key_order(const std::vector<std::string> &keys);
 
 // ---- host half of a batch -------------------------------------------------------------------
 struct HostBatch {

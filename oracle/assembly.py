@@ -24,6 +24,82 @@ NORMS = {"noop": 0, "linear": 1, "position": 2}
 INT_MAX = 2147483647
 
 
+class _ChampNode:
+    """one node of scala.collection.immutable.HashMap's prefix tree (Scala 2.13 immutable/HashMap.scala
+    BitmapIndexedMapNode): entries and sub-nodes by 5-bit index of the improved hash at this depth"""
+
+    def __init__(self):
+        self.entries = {}   # index -> (key, hash)
+        self.children = {}  # index -> _ChampNode | list (collision node: equal hashes, insertion order)
+
+
+def _scala_improve(h: int) -> int:   # collection/Hashing.scala `improve`, Int arithmetic
+    m = 0xFFFFFFFF
+    h = (h + (~(h << 9) & m)) & m
+    h ^= h >> 14
+    h = (h + (h << 4)) & m
+    return h ^ (h >> 10)
+
+
+def _java_hash(s: str) -> int:   # String.hashCode: UTF-16 code units
+    h = 0
+    b = s.encode("utf-16-be")
+    for i in range(0, len(b), 2):
+        h = (31 * h + ((b[i] << 8) | b[i + 1])) & 0xFFFFFFFF
+    return h
+
+
+def scala_map_key_order(keys):
+    """Iteration order of `keys.map(k -> ...).toMap` (InteractedWithFeature.scala:56-65): insertion order up to 4 entries
+    (Map1..Map4), a HashMap beyond - built here by inserting the keys one by one the way BitmapIndexedMapNode.updated
+    does, then walked like ChampBaseIterator: a node's entries by index, then its sub-nodes by index."""
+    if len(keys) <= 4:
+        return list(keys)
+    root = _ChampNode()
+
+    def insert(node, key, h, shift):
+        idx = (h >> shift) & 31
+        if idx in node.children:
+            child = node.children[idx]
+            if isinstance(child, list):
+                child.append(key)
+            else:
+                insert(child, key, h, shift + 5)
+        elif idx in node.entries:
+            other, oh = node.entries.pop(idx)
+            node.children[idx] = merge(other, oh, key, h, shift + 5)
+        else:
+            node.entries[idx] = (key, h)
+
+    def merge(k0, h0, k1, h1, shift):
+        if shift >= 32:
+            return [k0, k1]
+        n = _ChampNode()
+        i0, i1 = (h0 >> shift) & 31, (h1 >> shift) & 31
+        if i0 != i1:
+            n.entries[i0] = (k0, h0)
+            n.entries[i1] = (k1, h1)
+        else:
+            n.children[i0] = merge(k0, h0, k1, h1, shift + 5)
+        return n
+
+    for k in keys:
+        insert(root, k, _scala_improve(_java_hash(k)), 0)
+    out = []
+
+    def walk(node):
+        if isinstance(node, list):
+            out.extend(node)
+            return
+        for idx in sorted(node.entries):
+            out.append(node.entries[idx][0])
+        for idx in sorted(node.children):
+            walk(node.children[idx])
+
+    walk(root)
+    return out
+
+
 def parse_field_name(s: str):
     m = re.fullmatch(r"interaction:([a-zA-Z0-9_]+)\.([a-zA-Z0-9_]+)", s)
     if m:
@@ -113,7 +189,10 @@ def feature_desc(fc: dict) -> dict:
     elif t == "interacted_with":
         d["kind"] = "interacted_with"; scope()
         fields = fc["field"] if isinstance(fc["field"], list) else [fc["field"]]
-        d["strs"] = [parse_field_name(f)[1] for f in fields]
+        d["strs"] = scala_map_key_order([parse_field_name(f)[1] for f in fields])
+        if fc.get("field_order"):   # a host that sees another order says so
+            assert sorted(fc["field_order"]) == sorted(d["strs"])
+            d["strs"] = list(fc["field_order"])
         d["dim"] = len(d["strs"])
     elif t == "diversity":
         d["kind"] = "diversity"; src("source"); d["div_top"] = int(fc.get("top", 20))

@@ -191,6 +191,17 @@ def test_interacted_with_list_fields_and_repeats(mk):
     eq(b.matrix(ranking_event(["p1"], session=None)), [[0.0]])
 
 
+def test_interacted_with_five_fields_come_in_scala_map_order(mk):
+    """more than 4 fields: `fields` is a HashMap and the columns follow ITS iteration order (InteractedWithFeature.scala:56-65,
+    152-162) - for the keys a..e that is e, a, b, c, d (what a Scala 2.13 REPL prints for Map("a"->1,...,"e"->5);
+    tests/test_map_order_cpu.py).  Field k of the interacted item holds k + 1 equal tokens: the count is (k + 1)^2."""
+    b = mk(single_feature_config(dict(IW, field=[f"item.{c}" for c in "abcde"])))
+    for k, c in enumerate("abcde"):
+        b.put_string_list(f"item=p1/seen_{c}", ["t"] * (k + 1))
+    b.put_bounded_list("session=s1/seen_interactions", ["p1"])
+    eq(b.matrix(ranking_event(["p1", "p2"])), [[25.0, 1.0, 4.0, 9.0, 16.0], [0.0] * 5])
+
+
 # ---- T/feature/DiversityFeatureTest.scala:16-101 ------------------------------------------------------------------
 def test_diversity_numbers(mk):
     b = mk(single_feature_config({"name": "divnum", "type": "diversity", "source": "item.price", "top": 2147483647}))
