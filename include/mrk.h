@@ -293,7 +293,9 @@ int mrk_batch_run(mrk_batch *batch, mrk_model *model);
  * JVM thread): shard `shard_index` of `shard_count` assembles and scores batch items
  * [index * chunk, (index + 1) * chunk) only, chunk = mrk_batch_shard_chunk() (total / count rounded up to a
  * whole number of 128-item scorer tiles), and does NOT sort.  Request-level reductions (diversity,
- * interacted_with) are computed from the whole request on every shard.  The caller merges the score
+ * interacted_with) are computed from the whole request on every shard; a model with a request-normalised column
+ * (bi- / cross-encoder `norm`) has its whole matrix assembled and normalised on every shard - only the forest is
+ * shared out.  The caller merges the score
  * slices of all shards into the device score buffer (one all-gather of chunk * count f64; the buffer
  * has room for the padded tail) and then calls mrk_batch_sort on the rank(s) that need the order. */
 int mrk_batch_shard_chunk(mrk_batch *batch, int shard_count);

@@ -382,9 +382,11 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
   // MRK_RANK_CELLS=0 / MRK_SCORER=walk keep the f64 matrix between assembly and scoring (A/B measurements)
   // a column normalised across the request (bi- / cross-encoder `norm`) needs every raw value of the request before
   // any of them can be binned: such models go through the f64 matrix
+  // A SHARD of such a model assembles and normalises the whole batch - every rank holds the whole store, and the
+  // normalised column (one cosine per candidate) is the cheap part of that model - and scores its own slice: the forest
+  // is what the ranks share out.  (Exchanging the raw column instead would put a collective between assembly and scoring.)
   const bool normalises = b.prog->normalises();
-  if (normalises && (lo != 0 || hi != b.total_items))
-    throw StatusError(MRK_ERR_UNSUPPORTED, "item-sharded runs of a model with a normalised (norm: linear | position) column are not supported");
+  const bool whole_matrix = normalises && (lo != 0 || hi != b.total_items);
   const bool cells = sw.rank_cells && !sw.scorer_walk && model && model->qs.ok && !b.want_matrix && rows > 0 && !normalises;
   const bool f64 = model && model->forest.backend == Backend::LightGBM;
   // the kernel specialised for this model (hiprtc, ~7 s the first time): compiled before the launch lock is taken
@@ -419,8 +421,8 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
     return;
   }
   MRK_HIP(hipMemsetAsync(b.view.status, 0, std::max<size_t>(b.n_req, 1) * 4, b.s()));
-  b.view.item_lo = lo;
-  b.view.item_hi = hi;
+  b.view.item_lo = whole_matrix ? 0 : lo;
+  b.view.item_hi = whole_matrix ? b.total_items : hi;
   if (fused_score) {
     const QsDev q = qs_device_view(model);
     b.d_cells.reserve(std::max<size_t>((size_t)b.n_req * q.n_views * QS_TILE_ROWS * 2, 16));   // one tile per request
@@ -448,7 +450,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
     launch_score_qs_cells(ctx, model, b.d_cells.as<uint16_t>() + (size_t)(lo / QS_TILE_ROWS) * (tile_bytes / 2), rows, b.view.scores + lo);
   } else {
     assemble_matrix(b, st, pd, jit_fn);
-    b.matrix_valid = lo == 0 && hi == b.total_items;
+    b.matrix_valid = whole_matrix || (lo == 0 && hi == b.total_items);
     if (model && rows > 0) {
       launch_score_batch(ctx, model, b.view.matrix + (size_t)lo * pd.dim, rows, pd.dim, b.view.scores + lo, b.view.status, b.view.item_req + lo);
     } else if (rows > 0) {

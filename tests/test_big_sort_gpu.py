@@ -146,6 +146,17 @@ def test_norm_position_over_a_request_larger_than_one_workgroup_sorts():
             a, b = mat[lo:hi], mats[r]
             assert a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all()), r
             assert np.array_equal(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), r
+        # item-sharded 3 ways (round 2: MRK_ERR_UNSUPPORTED for a model with a normalised column): a shard normalises the
+        # whole request's column and scores its slice - the bytes of the unsharded run
+        b2 = hip.ranker.prepare("xgboost", reqs)
+        for rank in range(3):
+            b2.run_shard(hip.booster, rank, 3)
+        b2.sort()
+        s2, o2, m2 = b2.fetch(matrix=True)
+        assert (b2.status() == 0).all()
+        assert np.array_equal(s2, scores) and np.array_equal(o2, order)
+        assert bool(((m2 == mat) | (np.isnan(m2) & np.isnan(mat))).all())
+        b2.close()
         batch.close()
     finally:
         hip.close()
