@@ -362,6 +362,277 @@ __device__ double median_of(double *s_vals, int n_raw, int *s_misc) {
   return __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
 }
 
+#ifdef MRK_PREPASS_WAVES
+// ===== EXPERIMENT (compiled only with -DMRK_PREPASS_WAVES / MRK_JIT_DEFINES="MRK_PREPASS_WAVES=1"; written at the end of round 3
+// when the GPU budget was spent: it has been compiled, not yet run - tools/gpu/r04_first.sh runs the parity suite over it
+// and the A/B).  The sections of a request's pre-pass on DIFFERENT wavefronts of its workgroup.
+// Measured on the stock kernel (tools/phase_clocks.py c2 32): the interacted_with histograms are 37 k cycles of a request's
+// 225 k, the diversity sections 28 k + 37 k + 8 k, one after the other - and in both only ONE wavefront has work (50
+// interacted items, the first `top` = 20 candidates) while the other waits at the section's barriers.  Here wavefront 0
+// runs the whole diversity section with wave-local scans (ballots instead of LDS totals + two barriers per scan; lanes
+// of one wavefront talk through LDS in program order) while the other wavefronts build the interacted_with tables; one
+// barrier at the end.  Tables of different entries are disjoint, the histograms do not depend on insertion order: same
+// results.  Taken when every diversity entry looks at no more than 64 candidates' values (`top` <= 64: the default is 20);
+// otherwise the workgroup-wide code below runs.
+
+// keeps the compiler from moving this wavefront's LDS accesses across (the LDS unit executes them in order anyway)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive prefix sum of a 0/1 flag over the wavefront + total
+__device__ __forceinline__ int wave_scan_flag(bool flag, int &total) {
+  const unsigned long long ball = __ballot(flag);
+  total = __popcll(ball);
+  return __popcll(ball & ((1ull << (threadIdx.x & 63)) - 1ull));
+}
+
+// median_of for n_raw <= 64 values, one wavefront (the rank-sort branch: one value per lane)
+__device__ __forceinline__ double wave_median_of(double *s_vals, int n_raw) {
+  const int lane = threadIdx.x & 63;
+  if (n_raw == 1) return s_vals[0];
+  const bool mine = lane < n_raw;
+  const double v = mine ? s_vals[lane] : 0.0;
+  const bool isn = v != v;
+  const int n_nan = __popcll(__ballot(mine && isn));
+  int rank = 0;
+  if (mine && !isn)
+    for (int j = 0; j < n_raw; ++j) {
+      const double w = s_vals[j];
+      rank += (w < v || (w == v && j < lane)) ? 1 : 0;
+    }
+  wave_lds_sync();
+  if (mine && !isn) s_vals[rank] = v;
+  wave_lds_sync();
+  const int m = n_raw - n_nan;
+  if (m <= 0) return d_nan();
+  const double pos = 0.5 * (double)(m + 1);
+  const double fpos = floor(pos);
+  const int ipos = (int)fpos;
+  const double dif = pos - fpos;
+  if (pos < 1.0) return s_vals[0];
+  if (pos >= (double)m) return s_vals[m - 1];
+  const double lower = s_vals[ipos - 1], upper = s_vals[ipos];
+  return __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
+}
+
+// (a function of the program alone: in a specialised kernel the other pre-pass is not even compiled)
+template <typename Prog>
+__device__ __forceinline__ bool prepass_waves_ok(const Prog &prog) {
+  bool ok = true;
+  for (int e = 0; e < prog.n_prep; ++e)
+    if (prog.prep[e].kind == PREP_DIVERSITY && prog.prep[e].top > 64) ok = false;
+  return ok;
+}
+
+// the interacted_with section of prepass_request, run by lanes `lane_id` of `n_lanes` (nothing in it synchronises)
+template <typename Prog>
+__device__ __forceinline__ void prepass_interacted_with(const StoreDev &st, const Prog &prog, const BatchDev &b, int r, const ReqDev &rq,
+                                                        unsigned long long *tab_base, uint32_t tab_sub, PrepOut *po_out, int lane_id, int n_lanes) {
+  const int n_prep = prog.n_prep;
+  for (int e0 = 0; e0 < n_prep;) {
+    const PrepEntry pe0 = prog.prep[e0];
+    if (pe0.kind != PREP_IW_FIELD) { ++e0; continue; }
+    int n = 1;  // consecutive entries on the same bounded list
+    while (n < PREP_GROUP && e0 + n < n_prep) {
+      const PrepEntry q = prog.prep[e0 + n];
+      if (q.kind != PREP_IW_FIELD || q.list_scope != pe0.list_scope || q.list_col.tag != pe0.list_col.tag || q.list_col.val != pe0.list_col.val) break;
+      ++n;
+    }
+    ColRef col[PREP_GROUP];
+    unsigned long long *tab[PREP_GROUP];
+    uint32_t cap[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      const int e = e0 + (u < n ? u : 0);
+      col[u] = prog.prep[e].item_col;
+      tab[u] = tab_base + (po_out[e].tab_off - tab_sub);
+      cap[u] = po_out[e].tab_cap;
+    }
+    const int vslot = pe0.list_scope == SC_SESSION ? rq.session_slot : rq.user_slot;
+    const Cell lc = load_cell(record(st, pe0.list_scope, vslot), pe0.list_col);
+    if (lc.tag != TAG_MISSING) {
+      const uint32_t off = lc.lo(), len = lc.hi();
+      for (uint32_t k = (uint32_t)lane_id; k < len; k += (uint32_t)n_lanes) {
+        const uint8_t *irec = record(st, SC_ITEM, (int)st.slot_pool[off + k]);
+        Cell ic[PREP_GROUP];
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {  // the field cells of all entries: independent loads
+          ic[u].tag = TAG_MISSING;
+          ic[u].bits = 0;
+          if (u < n) ic[u] = load_cell(irec, col[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          if (u < n) {  // uniform
+            const bool list = ic[u].tag == TAG_STRING_LIST;
+            if (table_add_list(list_tokens(st, irec, ic[u].lo()), tab[u], cap[u], list ? ic[u].hi() : 0u)) atomicOr(&b.status[r], ST_TABLE_FULL);
+          }
+        }
+      }
+    }
+    e0 += n;
+  }
+
+
+}
+
+// the diversity section of prepass_request, run by ONE wavefront (all 64 lanes)
+template <typename Prog>
+__device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const Prog &prog, const BatchDev &b, int r, const ReqDev &rq,
+                                                       unsigned long long *tab_base, uint32_t tab_sub, PrepOut *po_out, const PrepScratch &sc) {
+  const int lane = threadIdx.x & 63;
+  const int n_prep = prog.n_prep;
+  int *s_first = sc.first();
+  int *s_tokens = sc.tokens();
+  for (int e0 = 0; e0 < n_prep;) {
+    if (prog.prep[e0].kind != PREP_DIVERSITY || po_out[e0].preset) { ++e0; continue; }
+    int ent[PREP_GROUP];
+    int n = 0, e1 = e0;
+    for (; e1 < n_prep && n < PREP_GROUP; ++e1) {
+      if (prog.prep[e1].kind != PREP_DIVERSITY || po_out[e1].preset) continue;
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) if (u == n) ent[u] = e1;
+      ++n;
+    }
+    ColRef col[PREP_GROUP];
+    unsigned long long *tab[PREP_GROUP];
+    uint32_t cap[PREP_GROUP];
+    int top[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      if (u >= n) ent[u] = e0;
+      col[u] = prog.prep[ent[u]].item_col;
+      top[u] = prog.prep[ent[u]].top;
+      tab[u] = tab_base + (po_out[ent[u]].tab_off - tab_sub);
+      cap[u] = po_out[ent[u]].tab_cap;
+    }
+    // (a) first candidate with state, per entry; the cells of the first 64 candidates stay in registers for (b) and (c)
+    const uint8_t *keep_rec = nullptr;
+    Cell keep[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) { keep[u].tag = TAG_MISSING; keep[u].bits = 0; }
+    for (int base = 0; base < rq.n_items; base += 64) {
+      const int i = base + lane;
+      if (i < rq.n_items) {
+        const uint8_t *irec = record(st, SC_ITEM, b.item_slot[rq.item_begin + i]);
+        Cell c[PREP_GROUP];
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          c[u].tag = TAG_MISSING;
+          c[u].bits = 0;
+          if (u < n) c[u] = load_cell(irec, col[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          if (u < n && c[u].tag != TAG_MISSING) atomicMin(&s_first[ent[u]], (i << 8) | (int)c[u].tag);
+          if (base == 0) keep[u] = c[u];
+        }
+        if (base == 0) keep_rec = irec;
+      }
+      wave_lds_sync();
+      bool all = true;
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) all = all && (u >= n || s_first[ent[u]] != 0x7fffffff);
+      wave_lds_sync();
+      if (all) break;
+    }
+    int mode[PREP_GROUP];
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      const int first = u < n ? s_first[ent[u]] : 0x7fffffff;
+      const int htag = first != 0x7fffffff ? (first & 255) : (int)TAG_MISSING;
+      mode[u] = (htag == TAG_STRING || htag == TAG_STRING_LIST) ? DIV_STRING : (htag == TAG_DOUBLE ? DIV_DOUBLE : DIV_EMPTY);
+    }
+    // (b) string entries: the first `top` candidates of that type, in request order
+    bool any_string = false;
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) any_string = any_string || (u < n && mode[u] == DIV_STRING);
+    if (lane < PREP_GROUP) s_tokens[lane] = 0;
+    wave_lds_sync();
+    if (any_string) {
+      int running[PREP_GROUP];
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u) running[u] = 0;
+      for (int base = 0; base < rq.n_items; base += 64) {
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) more = more || (u < n && mode[u] == DIV_STRING && running[u] < top[u]);
+        if (!more) break;
+        const int i = base + lane;
+        Cell c[PREP_GROUP];
+        bool cand[PREP_GROUP];
+        const uint8_t *irec = base == 0 ? keep_rec : (i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr);
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          c[u].tag = TAG_MISSING;
+          c[u].bits = 0;
+          if (u < n && mode[u] == DIV_STRING) c[u] = base == 0 ? keep[u] : load_cell(irec, col[u]);
+          cand[u] = c[u].tag == TAG_STRING || c[u].tag == TAG_STRING_LIST;
+        }
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          int total = 0;
+          const int excl = wave_scan_flag(u < n && cand[u], total);
+          if (u < n && mode[u] == DIV_STRING) {  // uniform
+            const bool take = cand[u] && running[u] + excl < top[u];
+            const bool one = take && c[u].tag == TAG_STRING;
+            const uint32_t tlen = take && !one ? c[u].hi() : 0u;
+            uint32_t failed = table_add(tab[u], cap[u], c[u].lo(), one) ? 0u : 1u;
+            failed += table_add_list(list_tokens(st, irec, c[u].lo()), tab[u], cap[u], tlen);
+            if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
+            if (take) atomicAdd(&s_tokens[u], one ? 1 : (int)tlen);
+          }
+          running[u] += total;
+        }
+      }
+      wave_lds_sync();
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < PREP_GROUP; ++u)
+        if (u < n && mode[u] != DIV_DOUBLE) {
+          po_out[ent[u]].mode = mode[u];
+          po_out[ent[u]].scalar = mode[u] == DIV_STRING ? (double)s_tokens[u] : 0.0;
+        }
+    }
+    wave_lds_sync();   // (the next group zeroes s_tokens)
+    // (c) numeric entries: the first `top` (<= 64) present values in request order, then their median
+#pragma unroll
+    for (int u = 0; u < PREP_GROUP; ++u) {
+      if (u >= n || mode[u] != DIV_DOUBLE) continue;
+      int running = 0;
+      for (int base = 0; base < rq.n_items && running < top[u]; base += 64) {
+        const int i = base + lane;
+        Cell c;
+        c.tag = TAG_MISSING;
+        c.bits = 0;
+        if (base == 0) c = keep[u];
+        else if (i < rq.n_items) c = load_cell(record(st, SC_ITEM, b.item_slot[rq.item_begin + i]), col[u]);
+        const bool cand = c.tag == TAG_DOUBLE;
+        int total;
+        const int rank = running + wave_scan_flag(cand, total);
+        if (cand && rank < top[u]) {
+          if (rank < sc.vals_cap) sc.vals[rank] = c.f64();
+          else atomicOr(&b.status[r], ST_TOO_MANY);
+        }
+        running += total;
+      }
+      wave_lds_sync();
+      const double scalar = wave_median_of(sc.vals, min(min(running, top[u]), min(sc.vals_cap, 64)));
+      if (lane == 0) {
+        po_out[ent[u]].mode = DIV_DOUBLE;
+        po_out[ent[u]].scalar = scalar;
+      }
+      wave_lds_sync();
+    }
+    e0 = e1;
+  }
+}
+#endif  // MRK_PREPASS_WAVES
+
 // The pre-pass of request r, run by one whole workgroup.  Tables live at tab_base + (po.tab_off - tab_sub)
 // (HBM arena: tab_sub = 0; LDS: tab_sub = the request's first arena entry); mode / scalar go to po_out[e].
 // The entries are not processed one by one: every global load is a trip to the Infinity Cache, so the loads
@@ -395,6 +666,17 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
   }
   __syncthreads();
   MRK_PHASE(sc.clk, sc.acc[0]);
+#ifdef MRK_PREPASS_WAVES
+  if (prepass_waves_ok(prog)) {   // (uniform) the sections side by side on different wavefronts
+    const bool lone = nthr <= 64;   // a one-wavefront workgroup runs both, one after the other
+    const int wave = tid >> 6;
+    if (lone || wave != 0) prepass_interacted_with(st, prog, b, r, rq, tab_base, tab_sub, po_out, lone ? tid : tid - 64, lone ? nthr : nthr - 64);
+    if (wave == 0) prepass_diversity_wave(st, prog, b, r, rq, tab_base, tab_sub, po_out, sc);
+    __syncthreads();
+    MRK_PHASE(sc.clk, sc.acc[1]);
+    return;
+  }
+#endif
 
   // Per-group state lives in registers indexed at COMPILE time (every loop over the group is fully unrolled
   // and predicated on u < n): a run-time index into a register array costs a select chain per access.
