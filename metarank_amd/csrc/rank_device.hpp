@@ -200,6 +200,63 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
   return res;
 }
 
+#ifdef MRK_GET_PAIR
+// ===== EXPERIMENT (-DMRK_GET_PAIR / MRK_JIT_DEFINES="MRK_GET_PAIR=1"; compiled, not yet run on a device) =====
+// TWO lookups whose home windows travel together: a lookup is one dependent trip to LDS (the window is read, waited for,
+// examined), and the lookups of a candidate's tokens do not depend on each other - the per-item phase spends 30 k cycles
+// of a request's 113 k in `profile`'s lookups and 10 k in each string-diversity column, one trip after the other.  Both
+// home windows are requested before the first wait; the (rare) later windows of either are walked as before.
+__device__ __forceinline__ uint32_t table_get_rest(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool open, uint32_t idx, uint32_t res) {
+  for (uint32_t walked = PROBE_W; wave_any(open); walked += PROBE_W) {
+    unsigned long long e[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      e[k] = tab[idx];
+      idx = idx + 1 == cap ? 0 : idx + 1;
+    }
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      const uint32_t key = (uint32_t)e[k];
+      res = open && key == tok ? (uint32_t)(e[k] >> 32) : res;
+      open = open && key != tok && key != 0u && walked + (uint32_t)(k + 1) < cap;
+    }
+  }
+  return res;
+}
+
+__device__ __forceinline__ void table_get2(const unsigned long long *tab, uint32_t cap, uint32_t tok0, bool want0, uint32_t tok1, bool want1,
+                                           uint32_t &res0, uint32_t &res1) {
+  res0 = 0u;
+  res1 = 0u;
+  if (!wave_any(want0 || want1)) return;
+  uint32_t idx0 = tok_home(tok0, cap - (uint32_t)(PROBE_W - 1)), idx1 = tok_home(tok1, cap - (uint32_t)(PROBE_W - 1));
+  bool open0 = want0, open1 = want1;
+  unsigned long long e0[PROBE_W], e1[PROBE_W];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) e0[k] = tab[idx0 + (uint32_t)k];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) e1[k] = tab[idx1 + (uint32_t)k];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t key = (uint32_t)e0[k];
+    res0 = open0 && key == tok0 ? (uint32_t)(e0[k] >> 32) : res0;
+    open0 = open0 && key != tok0 && key != 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t key = (uint32_t)e1[k];
+    res1 = open1 && key == tok1 ? (uint32_t)(e1[k] >> 32) : res1;
+    open1 = open1 && key != tok1 && key != 0u;
+  }
+  idx0 += (uint32_t)PROBE_W;
+  idx0 = idx0 >= cap ? idx0 - cap : idx0;
+  idx1 += (uint32_t)PROBE_W;
+  idx1 = idx1 >= cap ? idx1 - cap : idx1;
+  res0 = table_get_rest(tab, cap, tok0, open0, idx0, res0);
+  res1 = table_get_rest(tab, cap, tok1, open1, idx1, res1);
+}
+#endif  // MRK_GET_PAIR
+
 // The tokens of a list are fetched TOK_BATCH at a time (independent loads in flight together) before the
 // probes start: one trip to memory per batch instead of one per token.
 #ifndef MRK_TOK_BATCH
@@ -232,11 +289,23 @@ __device__ __forceinline__ double table_sum_list(const uint32_t *toks, const uns
     uint32_t tk[TOK_BATCH];
 #pragma unroll
     for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? toks[j0 + t] : 0u;
+#ifdef MRK_GET_PAIR
+    static_assert(TOK_BATCH % 2 == 0, "pairs");
+#pragma unroll
+    for (int t = 0; t < TOK_BATCH; t += 2) {
+      if (!wave_any(j0 + t < len)) break;
+      uint32_t g0, g1;
+      table_get2(tab, cap, tk[t], j0 + t < len, tk[t + 1], j0 + t + 1 < len, g0, g1);
+      cnt = cnt + (double)g0;
+      cnt = cnt + (double)g1;
+    }
+#else
 #pragma unroll
     for (int t = 0; t < TOK_BATCH; ++t) {
       if (!wave_any(j0 + t < len)) break;
       cnt = cnt + (double)table_get(tab, cap, tk[t], j0 + t < len);  // riding lanes add 0.0
     }
+#endif
   }
   return cnt;
 }
@@ -1472,11 +1541,23 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
             const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
             const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
             double cnt = 0.0;
+#ifdef MRK_GET_PAIR
+            static_assert(IW_TOK % 2 == 0, "pairs");
+#pragma unroll
+            for (int t = 0; t < IW_TOK; t += 2) {
+              if (!wave_any((uint32_t)t < len)) break;
+              uint32_t g0, g1;
+              table_get2(tab, po.tab_cap, tk[u][t], (uint32_t)t < len, tk[u][t + 1], (uint32_t)(t + 1) < len, g0, g1);
+              cnt = cnt + (double)g0;
+              cnt = cnt + (double)g1;
+            }
+#else
 #pragma unroll
             for (int t = 0; t < IW_TOK; ++t) {
               if (!wave_any((uint32_t)t < len)) break;
               cnt = cnt + (double)table_get(tab, po.tab_cap, tk[u][t], (uint32_t)t < len);
             }
+#endif
             if (wave_any(len > (uint32_t)IW_TOK))  // the rest of longer lists, in list order
               cnt = table_sum_list(list_tokens(st, irec, fc[u].lo()) + IW_TOK, tab, po.tab_cap, len > (uint32_t)IW_TOK ? len - IW_TOK : 0u, cnt);
             sink.put(dst + f0 + u, cnt);
@@ -1499,11 +1580,22 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
           // the list's first TOK_BATCH tokens were fetched ahead; longer lists continue from memory, in list order
           const uint32_t len = list ? c.hi() : 0u;
           double wl = 0.0;
+#ifdef MRK_GET_PAIR
+#pragma unroll
+          for (int t = 0; t < TOK_BATCH; t += 2) {
+            if (!wave_any((uint32_t)t < len)) break;
+            uint32_t g0, g1;
+            table_get2(tab, po.tab_cap, pre.tok[t], (uint32_t)t < len, pre.tok[t + 1], (uint32_t)(t + 1) < len, g0, g1);
+            wl = wl + (double)g0;
+            wl = wl + (double)g1;
+          }
+#else
 #pragma unroll
           for (int t = 0; t < TOK_BATCH; ++t) {
             if (!wave_any((uint32_t)t < len)) break;
             wl = wl + (double)table_get(tab, po.tab_cap, pre.tok[t], (uint32_t)t < len);
           }
+#endif
           if (wave_any(len > (uint32_t)TOK_BATCH))
             wl = table_sum_list(list_tokens(st, irec, c.lo()) + TOK_BATCH, tab, po.tab_cap, len > (uint32_t)TOK_BATCH ? len - TOK_BATCH : 0u, wl);
           if (one || list) v = (one ? w1 : wl) / po.scalar;

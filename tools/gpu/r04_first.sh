@@ -1,15 +1,16 @@
-# Round 4, first GPU call: the gated experiments written at the end of round 3 (tools/r04_prep.sh builds ab/base and ab/e1 on
-# the CPU side first).  (1) the parity suites over the e1 build - wave-per-section pre-pass, generic AND specialised kernels;
-# (2) same-box A/B base vs e1: c2, c3 and the single-request latency.   gpurun --timeout 900 -- 'bash tools/gpu/r04_first.sh'
+# Round 4, first GPU call: the gated experiments written at the end of round 3 (tools/r04_prep.sh builds ab/<variant> on
+# the CPU side first).  (1) the parity suites over the e14 build (both experiments; generic AND specialised kernels);
+# (2) same-box A/B of every variant against base: c2, c3 and the single-request latency.   gpurun --timeout 900 -- 'bash tools/gpu/r04_first.sh'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_first
 mkdir -p $O
-MRK_LIB=$PWD/ab/e1/libmrk_hip.so MRK_JIT_DEFINES="MRK_PREPASS_WAVES=1" timeout 400 python -m pytest tests/test_known_answers.py tests/test_rank_parity.py \
-  tests/test_rank_one_gpu.py tests/test_big_sort_gpu.py tests/test_serving_loop.py -m gpu -x -q -p no:cacheprovider > $O/pytest_e1.log 2>&1
-echo "e1 parity rc=$?" | tee -a $O/pytest_e1.log
-grep -E "passed|failed|error" $O/pytest_e1.log | tail -3
-for rep in 1 2; do for v in base e1; do for w in c2 c3; do
-  D=""; [ $v = e1 ] && D="MRK_PREPASS_WAVES=1"
+# e14 holds both experiments: one parity run covers them (a failure is narrowed down with e1 / e4 afterwards)
+MRK_LIB=$PWD/ab/e14/libmrk_hip.so MRK_JIT_DEFINES="$(cat ab/e14/jit_defines)" timeout 400 python -m pytest tests/test_known_answers.py tests/test_rank_parity.py \
+  tests/test_rank_one_gpu.py tests/test_big_sort_gpu.py tests/test_serving_loop.py -m gpu -x -q -p no:cacheprovider > $O/pytest_e14.log 2>&1
+echo "e14 parity rc=$?" | tee -a $O/pytest_e14.log
+grep -E "passed|failed|error" $O/pytest_e14.log | tail -3
+for rep in 1 2; do for v in ${VARIANTS:-base e1 e4 e4w2 e14}; do for w in c2 c3; do
+  D="$(cat ab/$v/jit_defines)"
   MRK_JIT_DEFINES="$D" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --cpu-sample 0 \
     --latency-requests $([ $w = c2 ] && echo 300 || echo 0) --e2e-seconds 0 > $O/${v}_${w}_$rep.json 2> $O/${v}_${w}_$rep.log || tail -3 $O/${v}_${w}_$rep.log
   python - $v $w $rep $O/${v}_${w}_$rep.json <<'PY'

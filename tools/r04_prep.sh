@@ -1,11 +1,25 @@
 #!/bin/bash
 # CPU-side preparation of the same-box A/B of the gated experiments (tools/gpu/r04_first.sh): one build of the library +
-# the stock program's kernels per variant under ab/<name>/ (git-ignored; travels with gpurun).  Variants:
-#   base  the default build
-#   e1    -DMRK_PREPASS_WAVES: the pre-pass sections on different wavefronts (rank_device.hpp)
+# the stock program's kernels per variant under ab/<name>/ (git-ignored; travels with gpurun), the variant's JIT defines in
+# ab/<name>/jit_defines.  ~5 min per variant on this container.  Variants (rank_device.hpp):
+#   base   the default build
+#   e1     MRK_PREPASS_WAVES: the pre-pass sections on different wavefronts
+#   e4     MRK_GET_PAIR: two lookups' home windows per LDS trip in the per-item phase
+#   e4w2   the same with 2-entry windows (the registers of one 4-entry window)
+#   e14    e1 + e4
 set -e
 cd "$(dirname "$0")/.."
-tools/ab_build.sh base
-MRK_DEFINES="MRK_PREPASS_WAVES" MRK_JIT_DEFINES="MRK_PREPASS_WAVES=1" tools/ab_build.sh e1
+variant() {  # name, defines...
+  local name=$1; shift
+  local aot="" jit=""
+  for d in "$@"; do aot="$aot $d"; jit="$jit $d"; done
+  MRK_DEFINES="${aot# }" MRK_JIT_DEFINES="${jit# }" tools/ab_build.sh $name
+  echo "${jit# }" > ab/$name/jit_defines
+}
+variant base
+variant e1 MRK_PREPASS_WAVES=1
+variant e4 MRK_GET_PAIR=1
+variant e4w2 MRK_GET_PAIR=1 MRK_PROBE_W=2
+variant e14 MRK_PREPASS_WAVES=1 MRK_GET_PAIR=1
 python -c "from metarank_amd import _native; _native.build()" > /dev/null 2>&1   # the in-tree library: back to the default build
 ls ab/*/
