@@ -1114,6 +1114,7 @@ struct ServeSlot {
   HostBatch hb;
   uint32_t seq = 0, launch_id = 0;
   bool running = false;         // a workgroup was launched and has not been seen to leave (owner: whoever holds the slot + the store shared, or the store exclusively)
+  bool dead = false;            // its workgroup did not answer in time: never handed out again (a late answer would land in the next request's buffers)
 };
 
 constexpr size_t SERVE_OUT_BYTES = 2048;          // scores 128 x 8 | order 128 x 4 | status 2 x 4
@@ -1135,6 +1136,7 @@ struct mrk_server {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<int> free_slots;  // a stack: the most recently used slot is the one whose workgroup is still resident
+  size_t dead_slots = 0;
   bool closing = false;
   std::atomic<uint64_t> n_queue{0}, n_fallback{0}, n_launches{0};
   std::atomic<uint64_t> dev_ticks[3] = {{0}, {0}, {0}};   // device-side 100 MHz ticks: input copy, ranking, result write-back
@@ -1144,7 +1146,7 @@ struct mrk_server {
 namespace {
 
 void stop_slot(ServeSlot &sl) {  // the caller owns the slot and no request is in flight in it
-  if (!sl.running) return;
+  if (!sl.running || sl.dead) return;  // (a retired slot's stream is not waited for: its workgroup may never leave)
   __atomic_store_n(&sl.ctl->stop, 1u, __ATOMIC_SEQ_CST);
   (void)hipStreamSynchronize(sl.stream);
   __atomic_store_n(&sl.ctl->stop, 0u, __ATOMIC_SEQ_CST);
@@ -1182,8 +1184,13 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   struct Release {
     mrk_server &s;
     int i;
+    bool dead = false;
     ~Release() {
-      { std::lock_guard<std::mutex> lk(s.mu); s.free_slots.push_back(i); }
+      {
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (dead) s.dead_slots += 1;
+        else s.free_slots.push_back(i);
+      }
       s.cv.notify_one();
     }
   } release{srv, si};
@@ -1238,7 +1245,10 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
         if (acked()) break;
         launch_slot(srv, sl);
       } else if ((spin & 0xffffu) == 0u && std::chrono::steady_clock::now() > deadline) {
-        throw StatusError(MRK_ERR_DEVICE, "the serving workgroup did not answer within 5 s");
+        __atomic_store_n(&ctl.stop, 1u, __ATOMIC_SEQ_CST);  // should it still be alive: leave
+        sl.dead = true;
+        release.dead = true;
+        throw StatusError(MRK_ERR_DEVICE, "the serving workgroup did not answer within 5 s (the slot is retired)");
       }
     }
     __builtin_ia32_pause();
@@ -1266,7 +1276,7 @@ static void quiesce_servers(mrk_ctx *ctx) {  // the caller holds the store exclu
   for (void *p : ctx->servers) {
     mrk_server *srv = (mrk_server *)p;
     for (auto &sl : srv->slots)
-      if (sl->running) __atomic_store_n(&sl->ctl->stop, 1u, __ATOMIC_SEQ_CST);
+      if (sl->running && !sl->dead) __atomic_store_n(&sl->ctl->stop, 1u, __ATOMIC_SEQ_CST);
     for (auto &sl : srv->slots) stop_slot(*sl);
   }
 }
@@ -1349,7 +1359,7 @@ void mrk_serve_stop(mrk_server *srv) {
   {
     std::unique_lock<std::mutex> lk(srv->mu);
     srv->closing = true;
-    srv->cv.wait(lk, [&] { return srv->free_slots.size() == srv->slots.size(); });  // requests in flight finish first
+    srv->cv.wait(lk, [&] { return srv->free_slots.size() + srv->dead_slots == srv->slots.size(); });  // requests in flight finish first
   }
   {
     std::lock_guard<std::mutex> lk(ctx->servers_mu);
@@ -1358,6 +1368,7 @@ void mrk_serve_stop(mrk_server *srv) {
   (void)hipSetDevice(ctx->device);
   for (auto &sl : srv->slots) {
     stop_slot(*sl);
+    if (sl->dead) continue;  // its workgroup may still be polling the slot's pinned block: leaked on purpose
     if (sl->stream) (void)hipStreamDestroy(sl->stream);
     if (sl->pinned) (void)hipHostFree(sl->pinned);
   }

@@ -23,3 +23,12 @@ except Exception as e:
     print(sys.argv[1], sys.argv[2], 'FAILED', e)
 PY
 done; done; done 2>&1 | tee $O/ab.txt
+# the out-of-cache gather (4 M candidates over an 8 M-item table): the lookups of MRK_GET_PAIR are in its kernel too
+for v in base e4 e4w2; do
+  D="$(cat ab/$v/jit_defines)"
+  MRK_JIT_DEFINES="$D" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload c4x --steps 5 --warmup 1 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0 \
+    > $O/${v}_c4x.json 2> $O/${v}_c4x.log || tail -3 $O/${v}_c4x.log
+  python -c "
+import json,sys
+d=json.load(open('$O/${v}_c4x.json')); print('$v'.ljust(6),'c4x',round(d['value']/1e6,1),'M items/s',{k: round(x['avg_ms']*x['launches_per_batch'],3) for k,x in d['kernels'].items()})" 2>&1 | tail -1
+done 2>&1 | tee -a $O/ab.txt
