@@ -32,3 +32,9 @@ for v in base e4 e4w2; do
 import json,sys
 d=json.load(open('$O/${v}_c4x.json')); print('$v'.ljust(6),'c4x',round(d['value']/1e6,1),'M items/s',{k: round(x['avg_ms']*x['launches_per_batch'],3) for k,x in d['kernels'].items()})" 2>&1 | tail -1
 done 2>&1 | tee -a $O/ab.txt
+
+# where an unloaded request's cycles go, default pre-pass vs sections on different wavefronts (32 requests: a workgroup per CU)
+for v in pc_base pc_e1; do
+  MRK_JIT_DEFINES="$(cat ab/$v/jit_defines)" MRK_LIB=$PWD/ab/$v/libmrk_hip.so MRK_RANK_JIT=1 MRK_FUSED_SPLIT=1 timeout 200 python tools/phase_clocks.py c2 32 > $O/phase_$v.txt 2>&1
+  echo "== $v"; head -9 $O/phase_$v.txt
+done

@@ -7,6 +7,7 @@
 #   e4     MRK_GET_PAIR: two lookups' home windows per LDS trip in the per-item phase
 #   e4w2   the same with 2-entry windows (the registers of one 4-entry window)
 #   e14    e1 + e4
+#   pc_*   base / e1 with MRK_PHASE_CLOCKS (clock64() stamps at the phase boundaries)
 set -e
 cd "$(dirname "$0")/.."
 variant() {  # name, defines...
@@ -21,5 +22,9 @@ variant e1 MRK_PREPASS_WAVES=1
 variant e4 MRK_GET_PAIR=1
 variant e4w2 MRK_GET_PAIR=1 MRK_PROBE_W=2
 variant e14 MRK_PREPASS_WAVES=1 MRK_GET_PAIR=1
+if [ "$1" != "nopc" ]; then   # measurement builds: tools/phase_clocks.py (cycles per phase of an unloaded request)
+  variant pc_base MRK_PHASE_CLOCKS=1
+  variant pc_e1 MRK_PHASE_CLOCKS=1 MRK_PREPASS_WAVES=1
+fi
 python -c "from metarank_amd import _native; _native.build()" > /dev/null 2>&1   # the in-tree library: back to the default build
 ls ab/*/
