@@ -165,6 +165,55 @@ __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap,
   return !full;
 }
 
+#ifdef MRK_LEAN_GET
+// ===== EXPERIMENT (-DMRK_LEAN_GET; compiled, not yet run on a device) =====
+// The same lookup with the bookkeeping per WINDOW instead of per entry.  The default examines every entry with
+// `hit = open && key == tok; open = open && key != tok && key != 0` - 4 VALU + 3 SALU (64-bit lane masks) per entry.  In an
+// insert-only table with linear probing no empty entry ever precedes a key on its probe sequence (the key went into the
+// FIRST empty entry of that sequence, and entries are never emptied), and a key occurs once: the count is simply that of
+// whichever entry holds the key, and the walk ends when the window held the key or an empty entry - decided once per
+// window from `res != 0` (counts are >= 1) and the minimum of the window's keys.  A lane that only rides along looks for
+// key 0: an empty entry's count is 0.
+__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok_in, bool want) {
+  if (!wave_any(want)) return 0u;
+  const uint32_t tok = want ? tok_in : 0u;
+  uint32_t idx = tok_home(tok, cap - (uint32_t)(PROBE_W - 1));
+  uint32_t res = 0u, lo = 0xffffffffu;
+  {
+    unsigned long long e[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) e[k] = tab[idx + (uint32_t)k];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      const uint32_t key = (uint32_t)e[k];
+      res = key == tok ? (uint32_t)(e[k] >> 32) : res;
+      lo = min(lo, key);
+    }
+    idx += (uint32_t)PROBE_W;
+    idx = idx >= cap ? idx - cap : idx;
+  }
+  bool open = want && res == 0u && lo != 0u;
+  for (uint32_t walked = PROBE_W; wave_any(open); walked += PROBE_W) {   // (a wrapped walk may look at the first entries twice: harmless)
+    unsigned long long e[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      e[k] = tab[idx];
+      idx = idx + 1 == cap ? 0 : idx + 1;
+    }
+    uint32_t r2 = 0u;
+    lo = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      const uint32_t key = (uint32_t)e[k];
+      r2 = key == tok ? (uint32_t)(e[k] >> 32) : r2;
+      lo = min(lo, key);
+    }
+    res = open ? r2 : res;
+    open = open && r2 == 0u && lo != 0u && walked + (uint32_t)PROBE_W < cap;
+  }
+  return res;
+}
+#else
 __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   if (!wave_any(want)) return 0u;  // (a diversity column of string LISTS asks for no single-string lookup at all)
   uint32_t idx = tok_home(tok, cap - (uint32_t)(PROBE_W - 1));
@@ -199,6 +248,7 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
   }
   return res;
 }
+#endif  // MRK_LEAN_GET
 
 #ifdef MRK_GET_PAIR
 // ===== EXPERIMENT (-DMRK_GET_PAIR / MRK_JIT_DEFINES="MRK_GET_PAIR=1"; compiled, not yet run on a device) =====
@@ -206,6 +256,61 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
 // examined), and the lookups of a candidate's tokens do not depend on each other - the per-item phase spends 30 k cycles
 // of a request's 113 k in `profile`'s lookups and 10 k in each string-diversity column, one trip after the other.  Both
 // home windows are requested before the first wait; the (rare) later windows of either are walked as before.
+#ifdef MRK_LEAN_GET   // (both experiments: the pair of lookups with the per-window bookkeeping of the lean lookup)
+__device__ __forceinline__ uint32_t table_get_rest(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool open, uint32_t idx, uint32_t res) {
+  for (uint32_t walked = PROBE_W; wave_any(open); walked += PROBE_W) {
+    unsigned long long e[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      e[k] = tab[idx];
+      idx = idx + 1 == cap ? 0 : idx + 1;
+    }
+    uint32_t r2 = 0u, lo = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      const uint32_t key = (uint32_t)e[k];
+      r2 = key == tok ? (uint32_t)(e[k] >> 32) : r2;
+      lo = min(lo, key);
+    }
+    res = open ? r2 : res;
+    open = open && r2 == 0u && lo != 0u && walked + (uint32_t)PROBE_W < cap;
+  }
+  return res;
+}
+
+__device__ __forceinline__ void table_get2(const unsigned long long *tab, uint32_t cap, uint32_t tok0_in, bool want0, uint32_t tok1_in, bool want1,
+                                           uint32_t &res0, uint32_t &res1) {
+  res0 = 0u;
+  res1 = 0u;
+  if (!wave_any(want0 || want1)) return;
+  const uint32_t tok0 = want0 ? tok0_in : 0u, tok1 = want1 ? tok1_in : 0u;
+  uint32_t idx0 = tok_home(tok0, cap - (uint32_t)(PROBE_W - 1)), idx1 = tok_home(tok1, cap - (uint32_t)(PROBE_W - 1));
+  unsigned long long e0[PROBE_W], e1[PROBE_W];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) e0[k] = tab[idx0 + (uint32_t)k];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) e1[k] = tab[idx1 + (uint32_t)k];
+  uint32_t lo0 = 0xffffffffu, lo1 = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t key = (uint32_t)e0[k];
+    res0 = key == tok0 ? (uint32_t)(e0[k] >> 32) : res0;
+    lo0 = min(lo0, key);
+  }
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t key = (uint32_t)e1[k];
+    res1 = key == tok1 ? (uint32_t)(e1[k] >> 32) : res1;
+    lo1 = min(lo1, key);
+  }
+  idx0 += (uint32_t)PROBE_W;
+  idx0 = idx0 >= cap ? idx0 - cap : idx0;
+  idx1 += (uint32_t)PROBE_W;
+  idx1 = idx1 >= cap ? idx1 - cap : idx1;
+  res0 = table_get_rest(tab, cap, tok0, want0 && res0 == 0u && lo0 != 0u, idx0, res0);
+  res1 = table_get_rest(tab, cap, tok1, want1 && res1 == 0u && lo1 != 0u, idx1, res1);
+}
+#else
 __device__ __forceinline__ uint32_t table_get_rest(const unsigned long long *tab, uint32_t cap, uint32_t tok, bool open, uint32_t idx, uint32_t res) {
   for (uint32_t walked = PROBE_W; wave_any(open); walked += PROBE_W) {
     unsigned long long e[PROBE_W];
@@ -255,6 +360,7 @@ __device__ __forceinline__ void table_get2(const unsigned long long *tab, uint32
   res0 = table_get_rest(tab, cap, tok0, open0, idx0, res0);
   res1 = table_get_rest(tab, cap, tok1, open1, idx1, res1);
 }
+#endif  // MRK_LEAN_GET
 #endif  // MRK_GET_PAIR
 
 // The tokens of a list are fetched TOK_BATCH at a time (independent loads in flight together) before the

@@ -1,15 +1,15 @@
 # Round 4, first GPU call: the gated experiments written at the end of round 3 (tools/r04_prep.sh builds ab/<variant> on
-# the CPU side first).  (1) the parity suites over the e14 build (both experiments; generic AND specialised kernels);
+# the CPU side first).  (1) the parity suites over the e145 build (all experiments; generic AND specialised kernels);
 # (2) same-box A/B of every variant against base: c2, c3 and the single-request latency.   gpurun --timeout 900 -- 'bash tools/gpu/r04_first.sh'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_first
 mkdir -p $O
-# e14 holds both experiments: one parity run covers them (a failure is narrowed down with e1 / e4 afterwards)
-MRK_LIB=$PWD/ab/e14/libmrk_hip.so MRK_JIT_DEFINES="$(cat ab/e14/jit_defines)" timeout 400 python -m pytest tests/test_known_answers.py tests/test_rank_parity.py \
-  tests/test_rank_one_gpu.py tests/test_big_sort_gpu.py tests/test_serving_loop.py -m gpu -x -q -p no:cacheprovider > $O/pytest_e14.log 2>&1
-echo "e14 parity rc=$?" | tee -a $O/pytest_e14.log
-grep -E "passed|failed|error" $O/pytest_e14.log | tail -3
-for rep in 1 2; do for v in ${VARIANTS:-base e1 e4 e4w2 e14}; do for w in c2 c3; do
+# e145 holds every experiment: one parity run covers them (a failure is narrowed down with e1 / e4 afterwards)
+MRK_LIB=$PWD/ab/e145/libmrk_hip.so MRK_JIT_DEFINES="$(cat ab/e145/jit_defines)" timeout 400 python -m pytest tests/test_known_answers.py tests/test_rank_parity.py \
+  tests/test_rank_one_gpu.py tests/test_big_sort_gpu.py tests/test_serving_loop.py -m gpu -x -q -p no:cacheprovider > $O/pytest_e145.log 2>&1
+echo "e145 parity rc=$?" | tee -a $O/pytest_e145.log
+grep -E "passed|failed|error" $O/pytest_e145.log | tail -3
+for rep in 1 2; do for v in ${VARIANTS:-base e1 e4 e4w2 e5 e45 e145}; do for w in c2 c3; do
   D="$(cat ab/$v/jit_defines)"
   MRK_JIT_DEFINES="$D" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --cpu-sample 0 \
     --latency-requests $([ $w = c2 ] && echo 300 || echo 0) --e2e-seconds 0 > $O/${v}_${w}_$rep.json 2> $O/${v}_${w}_$rep.log || tail -3 $O/${v}_${w}_$rep.log
@@ -24,7 +24,7 @@ except Exception as e:
 PY
 done; done; done 2>&1 | tee $O/ab.txt
 # the out-of-cache gather (4 M candidates over an 8 M-item table): the lookups of MRK_GET_PAIR are in its kernel too
-for v in base e4 e4w2; do
+for v in base e4 e5 e45; do
   D="$(cat ab/$v/jit_defines)"
   MRK_JIT_DEFINES="$D" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload c4x --steps 5 --warmup 1 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0 \
     > $O/${v}_c4x.json 2> $O/${v}_c4x.log || tail -3 $O/${v}_c4x.log

@@ -6,7 +6,8 @@
 #   e1     MRK_PREPASS_WAVES: the pre-pass sections on different wavefronts
 #   e4     MRK_GET_PAIR: two lookups' home windows per LDS trip in the per-item phase
 #   e4w2   the same with 2-entry windows (the registers of one 4-entry window)
-#   e14    e1 + e4
+#   e5     MRK_LEAN_GET: the lookup's bookkeeping per window instead of per entry (-8 % static instructions)
+#   e45    e4 + e5;  e145: all three (the build the parity suites run over)
 #   pc_*   base / e1 with MRK_PHASE_CLOCKS (clock64() stamps at the phase boundaries)
 set -e
 cd "$(dirname "$0")/.."
@@ -21,7 +22,9 @@ variant base
 variant e1 MRK_PREPASS_WAVES=1
 variant e4 MRK_GET_PAIR=1
 variant e4w2 MRK_GET_PAIR=1 MRK_PROBE_W=2
-variant e14 MRK_PREPASS_WAVES=1 MRK_GET_PAIR=1
+variant e5 MRK_LEAN_GET=1
+variant e45 MRK_GET_PAIR=1 MRK_LEAN_GET=1
+variant e145 MRK_PREPASS_WAVES=1 MRK_GET_PAIR=1 MRK_LEAN_GET=1
 if [ "$1" != "nopc" ]; then   # measurement builds: tools/phase_clocks.py (cycles per phase of an unloaded request)
   variant pc_base MRK_PHASE_CLOCKS=1
   variant pc_e1 MRK_PHASE_CLOCKS=1 MRK_PREPASS_WAVES=1
