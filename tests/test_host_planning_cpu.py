@@ -80,3 +80,49 @@ def test_a_config_with_six_fields_loads_in_that_order(exe):
     fields = ["genres", "actors", "tags", "director", "writer", "year"]
     assert native(exe, fields, config=True) == scala_map_key_order(fields) != fields
     assert native(exe, fields[:4], config=True) == fields[:4]
+
+
+# ---- the host-side median of a numeric diversity over more values than the device pre-pass sorts (same harness) --------
+def _preset(tmp_path, values, top):
+    import numpy as np
+
+    from metarank_amd import _native
+
+    _native.build()
+    exe = str(tmp_path / "preset_test")
+    lib_dir = os.path.dirname(_native.LIB_PATH)
+    csrc = os.path.join(REPO, "metarank_amd", "csrc")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(REPO, "tests", "native", "preset_test.cpp"),
+                               os.path.join(csrc, "store.cpp"), os.path.join(csrc, "features.cpp"), "-I" + csrc, "-I" + os.path.join(REPO, "include"),
+                               "-L" + lib_dir, "-lmrk_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    path = str(tmp_path / f"vals_{len(values)}_{top}.txt")
+    with open(path, "w") as f:
+        for i, v in enumerate(values):
+            f.write(f"i{i} {'-' if v is None else ('nan' if v != v else repr(float(v)))}\n")
+    out = subprocess.run([exe, path, str(top)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    w = out.stdout.split()
+    return int(w[1]), int(w[3]), float(w[5]), int(w[7])
+
+
+def test_host_median_of_a_numeric_diversity_beyond_the_device_limit(tmp_path):
+    """DiversityFeature.scala:113-126: commons-math Percentile(50), LEGACY estimation (R-6, numpy's 'weibull'), NaN removed,
+    over the first `top` candidates that have a value; up to 4 096 values the device sorts them itself (no preset)."""
+    import numpy as np
+
+    rng = np.random.default_rng(11)
+    n = 6001
+    vals = [None if i % 17 == 5 else (float("nan") if i % 101 == 7 else float(np.round(rng.normal() * 50, 3))) for i in range(n)]
+    vals[100], vals[200] = 0.0, -0.0
+    present = [v for v in vals if v is not None]
+    for top in (100000, 5000, 4097):
+        taken = np.array(present[:top])
+        exp = float(np.percentile(taken[~np.isnan(taken)], 50, method="weibull"))
+        preset, mode, scalar, _ = _preset(tmp_path, vals, top)
+        assert (preset, mode) == (1, 2) and scalar == exp, (top, scalar, exp)   # DIV_DOUBLE = 2
+    preset, _, _, max_doubles = _preset(tmp_path, vals, 4096)
+    assert preset == 0 and max_doubles == 4096          # the device's own median: nothing preset
+    preset, _, _, max_doubles = _preset(tmp_path, vals[:3000], 100000)
+    assert preset == 0 and max_doubles == len([v for v in vals[:3000] if v is not None])

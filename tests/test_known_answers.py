@@ -194,7 +194,7 @@ def test_interacted_with_list_fields_and_repeats(mk):
 def test_interacted_with_five_fields_come_in_scala_map_order(mk):
     """more than 4 fields: `fields` is a HashMap and the columns follow ITS iteration order (InteractedWithFeature.scala:56-65,
     152-162) - for the keys a..e that is e, a, b, c, d (what a Scala 2.13 REPL prints for Map("a"->1,...,"e"->5);
-    tests/test_map_order_cpu.py).  Field k of the interacted item holds k + 1 equal tokens: the count is (k + 1)^2."""
+    tests/test_host_planning_cpu.py).  Field k of the interacted item holds k + 1 equal tokens: the count is (k + 1)^2."""
     b = mk(single_feature_config(dict(IW, field=[f"item.{c}" for c in "abcde"])))
     for k, c in enumerate("abcde"):
         b.put_string_list(f"item=p1/seen_{c}", ["t"] * (k + 1))

@@ -98,7 +98,7 @@ int main(int argc, char **argv) {
       for (const std::string &s : e.items) { bytes += s; offs.push_back((uint32_t)bytes.size()); }
     std::vector<mrk_request> flat(reqs);
     for (mrk_request &q : flat) q.item_ids = nullptr;
-    mrk_item_ids ids{(const uint8_t *)bytes.data(), offs.data()};
+    mrk_item_ids ids{(const uint8_t *)bytes.data(), offs.data(), bytes.size()};
     resolve_requests(*prog, store, flat.data(), (int)flat.size(), &ids, hb);
     double fbest = 1e30;
     for (int i = 0; i < reps; ++i) {
