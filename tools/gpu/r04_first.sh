@@ -34,6 +34,14 @@ import json,sys
 d=json.load(open('$O/${v}_c4x.json')); print('$v'.ljust(6),'c4x',round(d['value']/1e6,1),'M items/s',{k: round(x['avg_ms']*x['launches_per_batch'],3) for k,x in d['kernels'].items()})" 2>&1 | tail -1
 done 2>&1 | tee -a $O/ab.txt
 
+# the UNFUSED path (pre-pass kernel + item-parallel assembly: tables through L2) under the same experiments: is the fused kernel still ahead?
+for v in base e145; do
+  MRK_RANK_FUSED=0 MRK_JIT_DEFINES="$(cat ab/$v/jit_defines)" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload c2 --steps 10 --warmup 2 --cpu-sample 0 \
+    --latency-requests 0 --e2e-seconds 0 > $O/${v}_c2_unfused.json 2> $O/${v}_c2_unfused.log || tail -3 $O/${v}_c2_unfused.log
+  python -c "
+import json
+d=json.load(open('$O/${v}_c2_unfused.json')); print('$v'.ljust(6),'c2 unfused',round(d['value']/1e6,1),'M items/s',{k: round(x['avg_ms']*x['launches_per_batch'],3) for k,x in d['kernels'].items()})" 2>&1 | tail -1
+done 2>&1 | tee -a $O/ab.txt
 # where an unloaded request's cycles go, default pre-pass vs sections on different wavefronts (32 requests: a workgroup per CU)
 for v in pc_base pc_e1; do
   MRK_JIT_DEFINES="$(cat ab/$v/jit_defines)" MRK_LIB=$PWD/ab/$v/libmrk_hip.so MRK_RANK_JIT=1 MRK_FUSED_SPLIT=1 timeout 200 python tools/phase_clocks.py c2 32 > $O/phase_$v.txt 2>&1
