@@ -39,6 +39,210 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 #endif
 constexpr int PROBE_W = MRK_PROBE_W;
 
+#ifdef MRK_TABLE_BUCKETS
+// ===== EXPERIMENT (-DMRK_TABLE_BUCKETS; compiled, checked on the host against a map, not yet run on a device) =====
+// The same tables probed by BUCKET: a table is cap / PROBE_W aligned buckets of PROBE_W entries, a key lives in the first
+// bucket of its probe sequence (home bucket, then the following ones, wrapping) that had room when it was inserted.  What
+// the code object says about the default (tools: a build with -gline-tables-only): table_get is 30 % and table_add 25 % of
+// the stock kernel's instructions, almost all of it in the LATER windows - a miss walks 8.5 entries on average at 75 % load
+// (primary clustering), the slowest of 64 lanes 20 - 30, so the wave-uniform loop runs 5 - 7 times per lookup, and every
+// entry of a later window pays its own wrap-around test.  Buckets end a miss at the first bucket with an EMPTY entry (a key
+// never lies beyond one: entries are never emptied) - 1.4 buckets on average, about 4 for the slowest of 64 lanes - read every
+// bucket at constant offsets from one address (a wrap-around test per bucket, not per entry) and examine it with the lean
+// lookup's per-window bookkeeping.  The host needs no change: cap is even and >= 8, cap / PROBE_W * PROBE_W >= the tokens
+// the table was sized for (features.cpp table_capacity: tokens / 0.75 + 2) as long as PROBE_W <= 4.
+static_assert(PROBE_W == 2 || PROBE_W == 4, "bucketed tables: 2 or 4 entries per bucket");
+
+// (the walk of one insert from bucket `bkt` on; `seen` buckets were found full of other keys already)
+__device__ __forceinline__ bool table_add_from(unsigned long long *tab, uint32_t nb, uint32_t tok, bool open, uint32_t bkt, uint32_t seen) {
+  const unsigned long long fresh = (unsigned long long)tok | (1ull << 32);
+  bool full = false;
+  while (wave_any(open)) {
+    unsigned long long *bp = tab + bkt * (uint32_t)PROBE_W;
+    unsigned long long e[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) e[k] = bp[k];
+    uint32_t stop = PROBE_W;  // the FIRST entry of the bucket that holds tok or is empty
+    bool at_key = false;
+#pragma unroll
+    for (int k = PROBE_W - 1; k >= 0; --k) {
+      const uint32_t key = (uint32_t)e[k];
+      if (key == tok || key == 0u) { stop = (uint32_t)k; at_key = key == tok; }
+    }
+    const bool here = open && stop < (uint32_t)PROBE_W;
+    unsigned long long *at = bp + (stop < (uint32_t)PROBE_W ? stop : 0u);
+    if (here && at_key) atomicAdd(at, 1ull << 32);
+    unsigned long long prev = ~0ull;
+    if (here && !at_key) prev = atomicCAS(at, 0ull, fresh);
+    const bool took = here && !at_key && prev == 0ull;
+    const bool same = here && !at_key && (uint32_t)prev == tok;    // another lane put tok there in the meantime
+    if (same) atomicAdd(at, 1ull << 32);
+    const bool done = here && (at_key || took || same);
+    // not done: the bucket holds other keys only (on to the next one), or its empty entry went to another key (the SAME
+    // bucket once more: it may have another empty entry)
+    const bool next = open && !here;
+    seen += next ? 1u : 0u;
+    bkt = next ? (bkt + 1u == nb ? 0u : bkt + 1u) : bkt;
+    full = full || (open && !done && seen >= nb);
+    open = open && !done && seen < nb;
+  }
+  return !full;
+}
+
+// (the walk of one lookup from bucket `bkt` on; `seen` buckets were looked at already)
+__device__ __forceinline__ uint32_t table_get_from(const unsigned long long *tab, uint32_t nb, uint32_t tok, bool open, uint32_t bkt, uint32_t seen,
+                                                   uint32_t res) {
+  for (; wave_any(open); ++seen) {
+    const unsigned long long *bp = tab + bkt * (uint32_t)PROBE_W;
+    unsigned long long e[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) e[k] = bp[k];
+    uint32_t r2 = 0u, lo = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) {
+      const uint32_t key = (uint32_t)e[k];
+      r2 = key == tok ? (uint32_t)(e[k] >> 32) : r2;
+      lo = min(lo, key);
+    }
+    res = open ? r2 : res;
+    open = open && r2 == 0u && lo != 0u && seen + 1u < nb;   // found, or an empty entry, or every bucket seen: done
+    bkt = bkt + 1u == nb ? 0u : bkt + 1u;
+  }
+  return res;
+}
+
+#ifdef MRK_TABLE_2CHOICE
+#ifdef MRK_GET_PAIR
+#error "MRK_TABLE_2CHOICE reads two buckets per lookup already: not together with MRK_GET_PAIR"
+#endif
+// ===== EXPERIMENT on top of the buckets (-DMRK_TABLE_BUCKETS -DMRK_TABLE_2CHOICE) =====
+// TWO home buckets per key.  With one home, a miss at the 75 % load the tables are sized for walks on while buckets are
+// full - the slowest of a wavefront's 64 lookups needs ~8 trips (simulated; the same for unaligned windows).  A key that may
+// go to the emptier of two buckets leaves far fewer buckets full: both are read in ONE trip, and only if both are full of
+// other keys does the lookup walk on from behind the second one - ~3 trips for the slowest of 64 at 75 % load, 1.1 at 55 %.
+// An insert looks for its key in both, else takes the first empty entry of the emptier one; two lanes inserting the same
+// new key at the same moment may put it into one bucket each, so a lookup ADDS what it finds in the two.
+__device__ __forceinline__ uint32_t tok_alt(uint32_t tok, uint32_t home, uint32_t nb) {   // the second bucket: never the first (nb >= 2)
+  const uint32_t b = home + 1u + __umulhi((tok ^ 0x9e3779b9u) * 0x85ebca6bu, nb - 1u);
+  return b >= nb ? b - nb : b;
+}
+
+__device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
+  const uint32_t nb = cap / (uint32_t)PROBE_W;
+  const uint32_t ba = tok_home(tok, nb), bb = tok_alt(tok, ba, nb);
+  unsigned long long *pa = tab + ba * (uint32_t)PROBE_W, *pb = tab + bb * (uint32_t)PROBE_W;
+  const unsigned long long fresh = (unsigned long long)tok | (1ull << 32);
+  bool open = want;
+  bool overflow = false;   // both buckets full of other keys: on to the buckets behind the second one
+  while (wave_any(open)) {
+    unsigned long long ea[PROBE_W], eb[PROBE_W];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) ea[k] = pa[k];
+#pragma unroll
+    for (int k = 0; k < PROBE_W; ++k) eb[k] = pb[k];
+    uint32_t key_a = PROBE_W, key_b = PROBE_W, emp_a = PROBE_W, emp_b = PROBE_W, n_emp_a = 0, n_emp_b = 0;  // first entry with tok / first empty entry / empties
+#pragma unroll
+    for (int k = PROBE_W - 1; k >= 0; --k) {
+      const uint32_t ka = (uint32_t)ea[k], kb = (uint32_t)eb[k];
+      if (ka == tok) key_a = (uint32_t)k;
+      if (kb == tok) key_b = (uint32_t)k;
+      if (ka == 0u) { emp_a = (uint32_t)k; n_emp_a += 1u; }
+      if (kb == 0u) { emp_b = (uint32_t)k; n_emp_b += 1u; }
+    }
+    const bool at_key = key_a < (uint32_t)PROBE_W || key_b < (uint32_t)PROBE_W;
+    const bool room = n_emp_a + n_emp_b > 0u;
+    const bool in_a = at_key ? key_a < (uint32_t)PROBE_W : n_emp_a >= n_emp_b;   // (room: the emptier bucket, the first on a tie)
+    const uint32_t slot = at_key ? (in_a ? key_a : key_b) : (in_a ? emp_a : emp_b);
+    const bool here = open && (at_key || room);
+    unsigned long long *at = (in_a ? pa : pb) + (slot < (uint32_t)PROBE_W ? slot : 0u);
+    if (here && at_key) atomicAdd(at, 1ull << 32);
+    unsigned long long prev = ~0ull;
+    if (here && !at_key) prev = atomicCAS(at, 0ull, fresh);
+    const bool took = here && !at_key && prev == 0ull;
+    const bool same = here && !at_key && (uint32_t)prev == tok;
+    if (same) atomicAdd(at, 1ull << 32);
+    const bool done = here && (at_key || took || same);
+    overflow = overflow || (open && !here);
+    open = open && here && !done;   // the empty entry went to another key: look at the two buckets again
+  }
+  if (nb <= 2u) return !overflow;   // (two buckets are the whole table)
+  return table_add_from(tab, nb, tok, overflow, bb + 1u == nb ? 0u : bb + 1u, 1u);   // (the walk passes the first bucket again: every bucket but the second)
+}
+
+__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok_in, bool want) {
+  if (!wave_any(want)) return 0u;
+  const uint32_t tok = want ? tok_in : 0u;   // a lane that rides along looks for key 0: an empty entry, count 0
+  const uint32_t nb = cap / (uint32_t)PROBE_W;
+  const uint32_t ba = tok_home(tok, nb), bb = tok_alt(tok, ba, nb);
+  const unsigned long long *pa = tab + ba * (uint32_t)PROBE_W, *pb = tab + bb * (uint32_t)PROBE_W;
+  unsigned long long ea[PROBE_W], eb[PROBE_W];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) ea[k] = pa[k];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) eb[k] = pb[k];
+  uint32_t ra = 0u, rb = 0u, lo = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t ka = (uint32_t)ea[k], kb = (uint32_t)eb[k];
+    ra = ka == tok ? (uint32_t)(ea[k] >> 32) : ra;
+    rb = kb == tok ? (uint32_t)(eb[k] >> 32) : rb;
+    lo = min(lo, min(ka, kb));
+  }
+  const uint32_t res = ra + rb;
+  // not found and no empty entry in either: the key may lie behind the second bucket
+  return table_get_from(tab, nb, tok, want && res == 0u && lo != 0u && nb > 2u, bb + 1u == nb ? 0u : bb + 1u, 1u, res);
+}
+#else  // one home bucket
+__device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
+  const uint32_t nb = cap / (uint32_t)PROBE_W;
+  return table_add_from(tab, nb, tok, want, tok_home(tok, nb), 0u);
+}
+
+__device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uint32_t cap, uint32_t tok_in, bool want) {
+  const uint32_t tok = want ? tok_in : 0u;   // a lane that rides along looks for key 0: an empty entry, count 0
+  const uint32_t nb = cap / (uint32_t)PROBE_W;
+  return table_get_from(tab, nb, tok, want, tok_home(tok, nb), 0u, 0u);
+}
+
+#ifdef MRK_GET_PAIR
+// two lookups whose home buckets travel together (see the linear-probing form below)
+__device__ __forceinline__ void table_get2(const unsigned long long *tab, uint32_t cap, uint32_t tok0_in, bool want0, uint32_t tok1_in, bool want1,
+                                           uint32_t &res0, uint32_t &res1) {
+  res0 = 0u;
+  res1 = 0u;
+  if (!wave_any(want0 || want1)) return;
+  const uint32_t tok0 = want0 ? tok0_in : 0u, tok1 = want1 ? tok1_in : 0u;
+  const uint32_t nb = cap / (uint32_t)PROBE_W;
+  uint32_t b0 = tok_home(tok0, nb), b1 = tok_home(tok1, nb);
+  const unsigned long long *p0 = tab + b0 * (uint32_t)PROBE_W, *p1 = tab + b1 * (uint32_t)PROBE_W;
+  unsigned long long e0[PROBE_W], e1[PROBE_W];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) e0[k] = p0[k];
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) e1[k] = p1[k];
+  uint32_t lo0 = 0xffffffffu, lo1 = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t key = (uint32_t)e0[k];
+    res0 = key == tok0 ? (uint32_t)(e0[k] >> 32) : res0;
+    lo0 = min(lo0, key);
+  }
+#pragma unroll
+  for (int k = 0; k < PROBE_W; ++k) {
+    const uint32_t key = (uint32_t)e1[k];
+    res1 = key == tok1 ? (uint32_t)(e1[k] >> 32) : res1;
+    lo1 = min(lo1, key);
+  }
+  b0 = b0 + 1u == nb ? 0u : b0 + 1u;
+  b1 = b1 + 1u == nb ? 0u : b1 + 1u;
+  res0 = table_get_from(tab, nb, tok0, want0 && res0 == 0u && lo0 != 0u && nb > 1u, b0, 1u, res0);
+  res1 = table_get_from(tab, nb, tok1, want1 && res1 == 0u && lo1 != 0u && nb > 1u, b1, 1u, res1);
+}
+#endif  // MRK_GET_PAIR
+#endif  // MRK_TABLE_2CHOICE
+
+#else  // linear probing (the default)
+
 __device__ __forceinline__ bool table_add(unsigned long long *tab, uint32_t cap, uint32_t tok, bool want) {
   // tab / cap may differ between lanes (item-parallel kernel: lanes of several requests in one wavefront)
   uint32_t idx = tok_home(tok, cap - (uint32_t)(PROBE_W - 1));
@@ -292,6 +496,7 @@ __device__ __forceinline__ void table_get2(const unsigned long long *tab, uint32
 }
 #endif  // MRK_LEAN_GET
 #endif  // MRK_GET_PAIR
+#endif  // MRK_TABLE_BUCKETS
 
 // The tokens of a list are fetched TOK_BATCH at a time (independent loads in flight together) before the
 // probes start: one trip to memory per batch instead of one per token.

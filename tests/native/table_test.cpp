@@ -2,7 +2,8 @@
 // primitives: the per-lane algorithm of every variant - the default lookup, MRK_LEAN_GET (bookkeeping per window; relies on
 // "no empty entry precedes a key on its probe sequence"), MRK_GET_PAIR (two home windows per trip) and both together - gives
 // the counts a std::map holds, for window widths 2 / 3 / 4 / 8 (-DMRK_PROBE_W), tables from 8 entries up, from almost empty
-// to completely full, tokens that collide, lookups of absent tokens, lanes that only ride along.  What a wavefront adds -
+// to completely full, tokens that collide, lookups of absent tokens, lanes that only ride along; and MRK_TABLE_BUCKETS (the
+// tables probed by aligned bucket; widths 2 / 4) and MRK_TABLE_2CHOICE (two home buckets per key), each variant building its own tables.  What a wavefront adds -
 // 64 lanes sharing one loop - is exercised by the GPU parity suites.
 #include <algorithm>
 #include <cstdint>
@@ -17,6 +18,17 @@ static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((ui
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long c, unsigned long long v) { const unsigned long long o = *p; if (o == c) *p = v; return o; }
 using std::min;
+
+// one namespace per variant (the header has no `#pragma once`); VARIANT wraps its entry points in a struct the checks template over
+#define VARIANT(NS, PAIR)                                                                                                          \
+  struct NS##_api {                                                                                                                  \
+    static constexpr bool has_pair = PAIR;                                                                                           \
+    static constexpr const char *name = #NS;                                                                                         \
+    static bool add(unsigned long long *t, uint32_t cap, uint32_t tok, bool want) { return NS::mrk::table_add(t, cap, tok, want); } \
+    static uint32_t get(const unsigned long long *t, uint32_t cap, uint32_t tok, bool want) { return NS::mrk::table_get(t, cap, tok, want); } \
+    static double sum(const uint32_t *toks, const unsigned long long *t, uint32_t cap, uint32_t len, double c) { return NS::mrk::table_sum_list(toks, t, cap, len, c); } \
+    static uint32_t add_list(const uint32_t *toks, unsigned long long *t, uint32_t cap, uint32_t len) { return NS::mrk::table_add_list(toks, t, cap, len); } \
+  };
 
 namespace plain {
 #include "table_device.hpp"
@@ -36,74 +48,135 @@ namespace lean_pair {
 namespace pair_only {
 #include "table_device.hpp"
 }
+#undef MRK_TABLE_DEVICE_HPP
+#undef MRK_GET_PAIR
+#if MRK_PROBE_W == 2 || MRK_PROBE_W == 4
+#define HAVE_BUCKETS 1
+#define MRK_TABLE_BUCKETS 1
+namespace buckets {
+#include "table_device.hpp"
+}
+#undef MRK_TABLE_DEVICE_HPP
+#define MRK_GET_PAIR 1
+namespace buckets_pair {
+#include "table_device.hpp"
+}
+#undef MRK_TABLE_DEVICE_HPP
+#undef MRK_GET_PAIR
+#define MRK_TABLE_2CHOICE 1
+namespace two_choice {
+#include "table_device.hpp"
+}
+#endif
+VARIANT(plain, false)
+VARIANT(lean, false)
+VARIANT(lean_pair, true)
+VARIANT(pair_only, true)
+#ifdef HAVE_BUCKETS
+VARIANT(buckets, false)
+VARIANT(buckets_pair, true)
+VARIANT(two_choice, false)
+#endif
+template <typename NSAPI> struct Pair;   // table_get2 exists only in the pair variants
+#define PAIR_OF(NS) template <> struct Pair<NS##_api> { static void get2(const unsigned long long *t, uint32_t cap, uint32_t a, bool wa, uint32_t b, bool wb, uint32_t &ra, uint32_t &rb) { NS::mrk::table_get2(t, cap, a, wa, b, wb, ra, rb); } };
+PAIR_OF(lean_pair)
+PAIR_OF(pair_only)
+#ifdef HAVE_BUCKETS
+PAIR_OF(buckets_pair)
+#endif
 
 static uint64_t rng_state = 0x243f6a8885a308d3ull;
 static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 
-int main() {
-  long long checks = 0, bad = 0;
-  const uint32_t caps[] = {8, 9, 11, 16, 37, 64, 100, 257, 1000, 4093};
+template <typename A>
+static void run(long long &checks, long long &bad, bool bucketed) {
+  rng_state = 0x243f6a8885a308d3ull;
+  const uint32_t caps[] = {8, 10, 12, 16, 38, 64, 100, 258, 1000, 4094};   // even, >= 8: what the host hands out
   for (uint32_t cap : caps) {
+    const uint32_t usable = bucketed ? cap / MRK_PROBE_W * MRK_PROBE_W : cap;
     for (int fill_pct : {0, 10, 50, 75, 90, 100, 130}) {
       for (int rep = 0; rep < 6; ++rep) {
         std::vector<unsigned long long> tab(cap, 0ull);
         std::map<uint32_t, uint32_t> ref;
         const uint32_t distinct = std::max<uint32_t>(fill_pct ? 1u : 0u, (uint32_t)((uint64_t)cap * fill_pct / 100));
-        // tokens from a small universe (collisions in the low bits of the hash) or a wide one
-        std::vector<uint32_t> universe;
+        std::vector<uint32_t> universe;   // a small universe (neighbouring ids) or a wide one
         for (uint32_t i = 0; i < distinct; ++i) universe.push_back(rep % 2 ? 1u + i : 1u + (uint32_t)(rnd() % 0x7fffffffu));
-        bool overflowed = false;
         for (uint32_t i = 0; i < distinct * 3; ++i) {
           const uint32_t tok = universe[rnd() % universe.size()];
-          const bool ok = plain::mrk::table_add(tab.data(), cap, tok, true);
-          if (ok) ref[tok] += 1;
-          else overflowed = true;   // the table is full of other keys: the device flags the request (ST_TABLE_FULL)
+          const bool ok = i % 5 == 4 ? A::add_list(&tok, tab.data(), cap, 1u) == 0u : A::add(tab.data(), cap, tok, true);
+          if (ok) ref[tok] += 1;   // refused: the table is full of other keys - the device flags the request (ST_TABLE_FULL)
           ++checks;
-          if (!ok && ref.size() < cap) { ++bad; printf("table_add refused with room left: cap %u keys %zu\n", cap, ref.size()); }
-          if (!ok && ref.count(tok)) { ++bad; printf("table_add refused a key it holds\n"); }
+          if (!ok && ref.size() < usable) { ++bad; printf("%s: table_add refused with room left: cap %u keys %zu\n", A::name, cap, ref.size()); }
+          if (!ok && ref.count(tok)) { ++bad; printf("%s: table_add refused a key it holds\n", A::name); }
         }
-        (void)overflowed;
-        (void)plain::mrk::table_add(tab.data(), cap, 12345u, false);   // a lane that rides along inserts nothing
-        // every entry is a key of the reference with its count
-        size_t used = 0;
+        (void)A::add(tab.data(), cap, 12345u, false);   // a lane that rides along inserts nothing
+        size_t used = 0;   // every entry is a key of the reference with its count, once
         for (unsigned long long e : tab)
-          if ((uint32_t)e) { ++used; if (!ref.count((uint32_t)e) || ref[(uint32_t)e] != (uint32_t)(e >> 32)) { ++bad; printf("entry mismatch\n"); } }
-        if (used != ref.size()) { ++bad; printf("cap %u: %zu entries for %zu keys\n", cap, used, ref.size()); }
-        // lookups: present keys, absent keys, riding lanes
-        std::vector<uint32_t> q;
+          if ((uint32_t)e) { ++used; if (!ref.count((uint32_t)e) || ref[(uint32_t)e] != (uint32_t)(e >> 32)) { ++bad; printf("%s: entry mismatch\n", A::name); } }
+        if (used != ref.size()) { ++bad; printf("%s: cap %u: %zu entries for %zu keys\n", A::name, cap, used, ref.size()); }
+        std::vector<uint32_t> q;   // lookups: present keys, absent keys, riding lanes
         for (auto &kv : ref) q.push_back(kv.first);
         for (int i = 0; i < 64; ++i) q.push_back(1u + (uint32_t)(rnd() % 0x7fffffffu));
         for (size_t i = 0; i < q.size(); ++i) {
           const uint32_t tok = q[i], exp = ref.count(tok) ? ref[tok] : 0u;
-          const uint32_t a = plain::mrk::table_get(tab.data(), cap, tok, true);
-          const uint32_t b = lean::mrk::table_get(tab.data(), cap, tok, true);
-          const uint32_t tok2 = q[(i * 7 + 3) % q.size()], exp2 = ref.count(tok2) ? ref[tok2] : 0u;
-          uint32_t c0, c1, d0, d1;
-          lean_pair::mrk::table_get2(tab.data(), cap, tok, true, tok2, true, c0, c1);
-          pair_only::mrk::table_get2(tab.data(), cap, tok, true, tok2, i % 3 != 0, d0, d1);
-          const uint32_t ride = lean::mrk::table_get(tab.data(), cap, tok, false) + plain::mrk::table_get(tab.data(), cap, tok, false);
-          checks += 6;
-          if (a != exp || b != exp || c0 != exp || c1 != exp2 || d0 != exp || d1 != (i % 3 != 0 ? exp2 : 0u) || ride != 0u) {
-            ++bad;
-            if (bad < 20) printf("cap %u fill %d: tok %u expected %u: plain %u lean %u pair %u/%u (exp2 %u) pair_only %u/%u ride %u\n", cap, fill_pct, tok, exp, a, b, c0, c1, exp2, d0, d1, ride);
+          const uint32_t a = A::get(tab.data(), cap, tok, true), ride = A::get(tab.data(), cap, tok, false);
+          checks += 2;
+          if (a != exp || ride != 0u) { ++bad; if (bad < 20) printf("%s: cap %u fill %d: tok %u expected %u got %u (riding %u)\n", A::name, cap, fill_pct, tok, exp, a, ride); }
+          if constexpr (A::has_pair) {
+            const uint32_t tok2 = q[(i * 7 + 3) % q.size()], exp2 = ref.count(tok2) ? ref[tok2] : 0u;
+            const bool w2 = i % 3 != 0;
+            uint32_t c0, c1;
+            Pair<A>::get2(tab.data(), cap, tok, true, tok2, w2, c0, c1);
+            checks += 2;
+            if (c0 != exp || c1 != (w2 ? exp2 : 0u)) { ++bad; if (bad < 20) printf("%s: pair %u/%u expected %u/%u\n", A::name, c0, c1, exp, w2 ? exp2 : 0u); }
           }
         }
-        // the list forms: sums in list order (integers: exact)
-        std::vector<uint32_t> list;
+        std::vector<uint32_t> list;   // the list form: sums in list order (integers: exact)
         for (int i = 0; i < 21; ++i) list.push_back(q[rnd() % q.size()]);
         for (uint32_t len : {0u, 1u, 7u, 8u, 9u, 21u}) {
           double exp = 0.5;
           for (uint32_t i = 0; i < len; ++i) exp += ref.count(list[i]) ? ref[list[i]] : 0u;
-          const double s0 = plain::mrk::table_sum_list(list.data(), tab.data(), cap, len, 0.5);
-          const double s1 = lean::mrk::table_sum_list(list.data(), tab.data(), cap, len, 0.5);
-          const double s2 = lean_pair::mrk::table_sum_list(list.data(), tab.data(), cap, len, 0.5);
-          const double s3 = pair_only::mrk::table_sum_list(list.data(), tab.data(), cap, len, 0.5);
-          checks += 4;
-          if (s0 != exp || s1 != exp || s2 != exp || s3 != exp) { ++bad; if (bad < 20) printf("sum_list len %u: %g %g %g %g expected %g\n", len, s0, s1, s2, s3, exp); }
+          const double s0 = A::sum(list.data(), tab.data(), cap, len, 0.5);
+          ++checks;
+          if (s0 != exp) { ++bad; if (bad < 20) printf("%s: sum_list len %u: %g expected %g\n", A::name, len, s0, exp); }
         }
       }
     }
   }
-  printf("PROBE_W %d: %lld checks, %lld bad\n", (int)plain::mrk::PROBE_W, checks, bad);
+}
+
+int main() {
+  long long checks = 0, bad = 0;
+  run<plain_api>(checks, bad, false);
+  run<lean_api>(checks, bad, false);
+  run<lean_pair_api>(checks, bad, false);
+  run<pair_only_api>(checks, bad, false);
+#ifdef HAVE_BUCKETS
+  run<buckets_api>(checks, bad, true);
+  run<buckets_pair_api>(checks, bad, true);
+  run<two_choice_api>(checks, bad, true);
+#endif
+#ifdef HAVE_BUCKETS
+  {  // what two lanes inserting the same NEW key at the same moment can leave behind: the key in both of its buckets
+    const uint32_t cap = 64, nb = cap / MRK_PROBE_W, tok = 4242u;
+    std::vector<unsigned long long> tab(cap, 0ull);
+    const uint32_t ba = two_choice::mrk::tok_home(tok, nb), bb = two_choice::mrk::tok_alt(tok, ba, nb);
+    tab[ba * MRK_PROBE_W + 1] = (unsigned long long)tok | (3ull << 32);
+    tab[bb * MRK_PROBE_W + 0] = (unsigned long long)tok | (2ull << 32);
+    checks += 3;
+    if (ba == bb) { ++bad; printf("two_choice: the second bucket is the first\n"); }
+    if (two_choice::mrk::table_get(tab.data(), cap, tok, true) != 5u) { ++bad; printf("two_choice: a key in both buckets is not summed\n"); }
+    two_choice::mrk::table_add(tab.data(), cap, tok, true);
+    if (two_choice::mrk::table_get(tab.data(), cap, tok, true) != 6u) { ++bad; printf("two_choice: insert of a key in both buckets\n"); }
+    for (uint32_t t = 1; t < 5000; ++t) {   // the second bucket is never the first, for any table size
+      for (uint32_t n : {2u, 3u, 5u, 16u, 50u, 1023u}) {
+        const uint32_t a = two_choice::mrk::tok_home(t, n), b = two_choice::mrk::tok_alt(t, a, n);
+        ++checks;
+        if (a >= n || b >= n || a == b) { ++bad; printf("two_choice: buckets %u %u of %u\n", a, b, n); }
+      }
+    }
+  }
+#endif
+  printf("PROBE_W %d: %lld checks, %lld bad\n", (int)MRK_PROBE_W, checks, bad);
   return bad ? 1 : 0;
 }

@@ -5,12 +5,15 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_first
 mkdir -p $O
-# e145 holds every experiment: one parity run covers them (a failure is narrowed down with e1 / e4 afterwards)
-MRK_LIB=$PWD/ab/e145/libmrk_hip.so MRK_JIT_DEFINES="$(cat ab/e145/jit_defines)" timeout 400 python -m pytest tests/test_known_answers.py tests/test_rank_parity.py \
-  tests/test_rank_one_gpu.py tests/test_big_sort_gpu.py tests/test_serving_loop.py -m gpu -x -q -p no:cacheprovider > $O/pytest_e145.log 2>&1
-echo "e145 parity rc=$?" | tee -a $O/pytest_e145.log
-grep -E "passed|failed|error" $O/pytest_e145.log | tail -3
-for rep in 1 2; do for v in ${VARIANTS:-base e1 e4 e4w2 e5 e45 e145}; do for w in c2 c3; do
+# e145 / e1_10p / e1_11 hold every experiment of the linear-probing, the bucketed and the two-choice tables: three parity runs cover them all
+# (a failure is narrowed down with the single-experiment builds afterwards)
+for pv in e1_11 e1_10p e145; do
+  MRK_LIB=$PWD/ab/$pv/libmrk_hip.so MRK_JIT_DEFINES="$(cat ab/$pv/jit_defines)" timeout 400 python -m pytest tests/test_known_answers.py tests/test_rank_parity.py \
+    tests/test_rank_one_gpu.py tests/test_big_sort_gpu.py tests/test_serving_loop.py -m gpu -x -q -p no:cacheprovider > $O/pytest_$pv.log 2>&1
+  echo "$pv parity rc=$?" | tee -a $O/pytest_$pv.log
+  grep -E "passed|failed|error" $O/pytest_$pv.log | tail -3
+done
+for rep in 1 2; do for v in ${VARIANTS:-base e1 e5 e45 e10 e10p e11 e1_10p e1_11 e145}; do for w in c2 c3; do
   D="$(cat ab/$v/jit_defines)"
   MRK_JIT_DEFINES="$D" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --cpu-sample 0 \
     --latency-requests $([ $w = c2 ] && echo 300 || echo 0) --e2e-seconds 0 > $O/${v}_${w}_$rep.json 2> $O/${v}_${w}_$rep.log || tail -3 $O/${v}_${w}_$rep.log
@@ -25,7 +28,7 @@ except Exception as e:
 PY
 done; done; done 2>&1 | tee $O/ab.txt
 # the out-of-cache gather (4 M candidates over an 8 M-item table): the lookups of MRK_GET_PAIR are in its kernel too
-for v in base e4 e5 e45; do
+for v in base e45 e10p e11; do
   D="$(cat ab/$v/jit_defines)"
   MRK_JIT_DEFINES="$D" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload c4x --steps 5 --warmup 1 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0 \
     > $O/${v}_c4x.json 2> $O/${v}_c4x.log || tail -3 $O/${v}_c4x.log
@@ -35,7 +38,7 @@ d=json.load(open('$O/${v}_c4x.json')); print('$v'.ljust(6),'c4x',round(d['value'
 done 2>&1 | tee -a $O/ab.txt
 
 # the UNFUSED path (pre-pass kernel + item-parallel assembly: tables through L2) under the same experiments: is the fused kernel still ahead?
-for v in base e145; do
+for v in base e1_10p e1_11; do
   MRK_RANK_FUSED=0 MRK_JIT_DEFINES="$(cat ab/$v/jit_defines)" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload c2 --steps 10 --warmup 2 --cpu-sample 0 \
     --latency-requests 0 --e2e-seconds 0 > $O/${v}_c2_unfused.json 2> $O/${v}_c2_unfused.log || tail -3 $O/${v}_c2_unfused.log
   python -c "
