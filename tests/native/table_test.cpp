@@ -9,20 +9,25 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <thread>
 #include <vector>
 
 #define __device__
 #define __forceinline__ inline
 static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
-static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long c, unsigned long long v) { const unsigned long long o = *p; if (o == c) *p = v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long c, unsigned long long v) {
+  __atomic_compare_exchange_n(p, &c, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return c;   // the value found there (== the expected one on success), like the device's atomicCAS
+}
 using std::min;
 
 // one namespace per variant (the header has no `#pragma once`); VARIANT wraps its entry points in a struct the checks template over
 #define VARIANT(NS, PAIR)                                                                                                          \
   struct NS##_api {                                                                                                                  \
     static constexpr bool has_pair = PAIR;                                                                                           \
+    static constexpr bool two_homes = sizeof(#NS) == sizeof("two_choice");                                                            \
     static constexpr const char *name = #NS;                                                                                         \
     static bool add(unsigned long long *t, uint32_t cap, uint32_t tok, bool want) { return NS::mrk::table_add(t, cap, tok, want); } \
     static uint32_t get(const unsigned long long *t, uint32_t cap, uint32_t tok, bool want) { return NS::mrk::table_get(t, cap, tok, want); } \
@@ -145,8 +150,54 @@ static void run(long long &checks, long long &bad, bool bucketed) {
   }
 }
 
+// Several host threads - each a one-lane wavefront - inserting into ONE table at the same time: what the wavefronts of a
+// workgroup do in the pre-pass (compare-and-swap races for an empty entry, the same new key from two sides at once, and - two
+// home buckets - a key ending up in both).  Afterwards every key's count is the number of its inserts.
+template <typename A>
+static void hammer(long long &checks, long long &bad) {
+  int twice = 0;   // rounds that left a key in two entries (two home buckets only)
+  for (int round = 0; round < 300; ++round) {
+    const uint32_t cap = (uint32_t[]){16, 24, 40, 64, 130}[round % 5];
+    const int n_thr = 6, per = (int)(cap * 3 / 4 / n_thr) * 4;      // occurrences: up to 3 x the distinct keys the table is sized for
+    const uint32_t universe = std::max(2u, cap * 3 / 4 - 2);          // distinct keys <= 75 % of the capacity - 2
+    std::vector<unsigned long long> tab(cap, 0ull);
+    std::vector<std::vector<uint32_t>> toks(n_thr);
+    std::vector<int> refused(n_thr, 0);
+    for (int t = 0; t < n_thr; ++t)
+      for (int i = 0; i < per; ++i) toks[t].push_back(1000u + (uint32_t)(rnd() % universe));
+    std::vector<std::thread> th;
+    int go = 0;   // all threads start together: the inserts really overlap
+    for (int t = 0; t < n_thr; ++t)
+      th.emplace_back([&, t] {
+        while (!__atomic_load_n(&go, __ATOMIC_ACQUIRE)) {}
+        for (uint32_t tok : toks[t]) if (!A::add(tab.data(), cap, tok, true)) refused[t] += 1;
+      });
+    __atomic_store_n(&go, 1, __ATOMIC_RELEASE);
+    for (auto &x : th) x.join();
+    size_t used = 0;
+    for (unsigned long long e : tab) used += (uint32_t)e ? 1 : 0;
+    { std::map<uint32_t, uint32_t> d; for (auto &v : toks) for (uint32_t tok : v) d[tok] = 1; if (used > d.size()) ++twice; }
+    std::map<uint32_t, uint32_t> ref;
+    for (auto &v : toks) for (uint32_t tok : v) ref[tok] += 1;
+    for (int t = 0; t < n_thr; ++t) { ++checks; if (refused[t]) { ++bad; printf("%s: concurrent insert refused (cap %u, %zu keys)\n", A::name, cap, ref.size()); } }
+    for (auto &kv : ref) {
+      ++checks;
+      const uint32_t got = A::get(tab.data(), cap, kv.first, true);
+      if (got != kv.second) { ++bad; if (bad < 20) printf("%s: concurrent inserts of %u: count %u, expected %u (cap %u)\n", A::name, kv.first, got, kv.second, cap); }
+    }
+  }
+  printf("%s: concurrent rounds with a key in two entries: %d\n", A::name, twice);
+  if (twice && !A::two_homes) { ++bad; printf("%s: a key twice in a table with one home per key\n", A::name); }
+}
+
 int main() {
   long long checks = 0, bad = 0;
+  hammer<plain_api>(checks, bad);
+  hammer<lean_api>(checks, bad);
+#ifdef HAVE_BUCKETS
+  hammer<buckets_api>(checks, bad);
+  hammer<two_choice_api>(checks, bad);
+#endif
   run<plain_api>(checks, bad, false);
   run<lean_api>(checks, bad, false);
   run<lean_pair_api>(checks, bad, false);
