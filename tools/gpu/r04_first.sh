@@ -1,7 +1,7 @@
 # Round 4, first GPU call: the gated experiments written at the end of round 3 (tools/r04_prep.sh builds ab/<variant> on
 # the CPU side first).  (1) the parity suites over the e145 build (all experiments; generic AND specialised kernels);
 # (ab/ is listed in .gpurunignore between such calls: take the line out first.)
-# (2) same-box A/B of every variant against base: c2, c3 and the single-request latency.   gpurun --timeout 900 -- 'bash tools/gpu/r04_first.sh'
+# (2) same-box A/B of every variant against base: c2, c3 and the single-request latency.   gpurun --timeout 2100 -- 'bash tools/gpu/r04_first.sh'  (about 30 GPU-minutes; VARIANTS="..." trims the A/B)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_first
 mkdir -p $O
