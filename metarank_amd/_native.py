@@ -32,7 +32,7 @@ def sources():
 
 # device headers that make up the translation unit of the run-time specialised assembly kernel (csrc/jit.cpp), in
 # include order
-JIT_HEADERS = ["device_types.hpp", "rank.hpp", "qs_device.hpp", "sort_device.hpp", "table_device.hpp", "rank_device.hpp"]
+JIT_HEADERS = ["device_types.hpp", "rank.hpp", "qs_device.hpp", "sort_device.hpp", "table_device.hpp", "wave_device.hpp", "rank_device.hpp"]
 
 
 def embed_jit_sources() -> str:

@@ -10,6 +10,7 @@
 #include "rank.hpp"
 #include "sort_device.hpp"
 #include "table_device.hpp"
+#include "wave_device.hpp"
 
 #ifdef MRK_PHASE_CLOCKS
 // measurement builds only (MRK_DEFINES=MRK_PHASE_CLOCKS): core-clock cycles thread 0 of every workgroup spends per phase
@@ -216,48 +217,7 @@ __device__ double median_of(double *s_vals, int n_raw, int *s_misc) {
 // results.  Taken when every diversity entry looks at no more than 64 candidates' values (`top` <= 64: the default is 20);
 // otherwise the workgroup-wide code below runs.
 
-// keeps the compiler from moving this wavefront's LDS accesses across (the LDS unit executes them in order anyway)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// exclusive prefix sum of a 0/1 flag over the wavefront + total
-__device__ __forceinline__ int wave_scan_flag(bool flag, int &total) {
-  const unsigned long long ball = __ballot(flag);
-  total = __popcll(ball);
-  return __popcll(ball & ((1ull << (threadIdx.x & 63)) - 1ull));
-}
-
-// median_of for n_raw <= 64 values, one wavefront (the rank-sort branch: one value per lane)
-__device__ __forceinline__ double wave_median_of(double *s_vals, int n_raw) {
-  const int lane = threadIdx.x & 63;
-  if (n_raw == 1) return s_vals[0];
-  const bool mine = lane < n_raw;
-  const double v = mine ? s_vals[lane] : 0.0;
-  const bool isn = v != v;
-  const int n_nan = __popcll(__ballot(mine && isn));
-  int rank = 0;
-  if (mine && !isn)
-    for (int j = 0; j < n_raw; ++j) {
-      const double w = s_vals[j];
-      rank += (w < v || (w == v && j < lane)) ? 1 : 0;
-    }
-  wave_lds_sync();
-  if (mine && !isn) s_vals[rank] = v;
-  wave_lds_sync();
-  const int m = n_raw - n_nan;
-  if (m <= 0) return d_nan();
-  const double pos = 0.5 * (double)(m + 1);
-  const double fpos = floor(pos);
-  const int ipos = (int)fpos;
-  const double dif = pos - fpos;
-  if (pos < 1.0) return s_vals[0];
-  if (pos >= (double)m) return s_vals[m - 1];
-  const double lower = s_vals[ipos - 1], upper = s_vals[ipos];
-  return __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
-}
+// (wave_lds_sync, wave_scan_flag, wave_median_of: wave_device.hpp - compiled for the host too, tests/native/wave_test.cpp)
 
 // (a function of the program alone: in a specialised kernel the other pre-pass is not even compiled)
 template <typename Prog>

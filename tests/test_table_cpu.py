@@ -20,3 +20,16 @@ def test_table_variants_agree_with_a_map(tmp_path, width):
     out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert f"PROBE_W {width}:" in out.stdout and " 0 bad" in out.stdout
+
+
+def test_wave_local_median_and_scan_with_64_threads(tmp_path):
+    """csrc/wave_device.hpp (the MRK_PREPASS_WAVES experiment's ballot scan and one-value-per-lane LEGACY median) compiled for
+    the host: 64 threads = 64 lanes, ballot and LDS ordering point = barriers (tests/native/wave_test.cpp), under
+    ThreadSanitizer - a lane reading what another has not yet written is a report, not a flaky number.  780 cases against a
+    sorted-array restatement of the percentile, bit for bit."""
+    exe = str(tmp_path / "wave_test")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-ffp-contract=off", "-fsanitize=thread", "-Wno-unknown-pragmas",
+                           "-I" + os.path.join(REPO, "metarank_amd", "csrc"), os.path.join(REPO, "tests", "native", "wave_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and not out.stderr.strip(), out.stdout[-2000:] + out.stderr[-3000:]
+    assert "780 cases, 0 bad" in out.stdout
