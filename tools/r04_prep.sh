@@ -29,6 +29,7 @@ variant e45 MRK_GET_PAIR=1 MRK_LEAN_GET=1
 variant e145 MRK_PREPASS_WAVES=1 MRK_GET_PAIR=1 MRK_LEAN_GET=1
 variant e10 MRK_TABLE_BUCKETS=1
 variant e10p MRK_TABLE_BUCKETS=1 MRK_GET_PAIR=1
+variant e1_10 MRK_PREPASS_WAVES=1 MRK_TABLE_BUCKETS=1
 variant e1_10p MRK_PREPASS_WAVES=1 MRK_TABLE_BUCKETS=1 MRK_GET_PAIR=1
 variant e11 MRK_TABLE_BUCKETS=1 MRK_TABLE_2CHOICE=1
 variant e1_11 MRK_PREPASS_WAVES=1 MRK_TABLE_BUCKETS=1 MRK_TABLE_2CHOICE=1
