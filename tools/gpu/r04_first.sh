@@ -14,6 +14,7 @@ for pv in e1_11 e1_10p e145; do
   grep -E "passed|failed|error" $O/pytest_$pv.log | tail -3
 done
 for rep in 1 2; do for v in ${VARIANTS:-base e1 e5 e45 e10 e10p e11 e1_10 e1_10p e1_11 e145}; do for w in c2 c3; do
+  [ $rep = 2 ] && [ $w = c3 ] && continue   # c3 once, c2 twice
   D="$(cat ab/$v/jit_defines)"
   MRK_JIT_DEFINES="$D" MRK_LIB=$PWD/ab/$v/libmrk_hip.so timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --cpu-sample 0 \
     --latency-requests $([ $w = c2 ] && echo 300 || echo 0) --e2e-seconds 0 > $O/${v}_${w}_$rep.json 2> $O/${v}_${w}_$rep.log || tail -3 $O/${v}_${w}_$rep.log
