@@ -28,6 +28,7 @@ static Switches read_switches() {
   s.rank_fused_score = flag("MRK_RANK_FUSED_SCORE", false);
   s.rank_serve = flag("MRK_RANK_SERVE", true);
   s.serve_idle_us = std::max(1, num("MRK_SERVE_IDLE_US", 2000));
+  s.serve_life_us = std::max(1, num("MRK_SERVE_LIFE_US", 20000));
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
   s.table_load_pct = std::max(10, std::min(90, num("MRK_TABLE_LOAD_PCT", 75)));
   s.host_threads = std::max(0, std::min(256, num("MRK_HOST_THREADS", 0)));

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <thread>
 
 #include <cstdlib>
 
@@ -1131,7 +1132,7 @@ struct mrk_server {
   const Program *prog = nullptr;
   bool f64 = true;
   void *jit_fn = nullptr;
-  uint64_t idle_ticks = 0;
+  uint64_t idle_ticks = 0, life_ticks = 0;
   std::vector<std::unique_ptr<ServeSlot>> slots;
   std::mutex mu;
   std::condition_variable cv;
@@ -1164,6 +1165,7 @@ void launch_slot(mrk_server &srv, ServeSlot &sl) {  // the caller holds the stor
   d.launch_id = sl.launch_id;
   d.last_seq = sl.seq - 1;  // the request just published is the first thing the workgroup sees
   d.idle_ticks = srv.idle_ticks;
+  d.life_ticks = srv.life_ticks;
   launch_rank_serve(sl.stream, ctx->store->device_view(), srv.prog->device_view(), qs_device_view(srv.model), qs_forest_view(srv.model), d,
                     SERVE_THREADS, SERVE_LDS, srv.f64, srv.jit_fn);
   sl.running = true;
@@ -1278,6 +1280,21 @@ static void quiesce_servers(mrk_ctx *ctx) {  // the caller holds the store exclu
     for (auto &sl : srv->slots)
       if (sl->running && !sl->dead) __atomic_store_n(&sl->ctl->stop, 1u, __ATOMIC_SEQ_CST);
     for (auto &sl : srv->slots) stop_slot(*sl);
+    // A retired slot (its workgroup missed the 5 s deadline) was told to stop when it was retired.  Slow is not hung: if
+    // its kernel is still on the device it still reads the store views it was launched with, and the caller is about to
+    // reallocate them - wait for it a while, and refuse the flush rather than free memory under a live kernel.
+    for (auto &sl : srv->slots) {
+      if (!sl->dead || !sl->running) continue;
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+      hipError_t q = hipStreamQuery(sl->stream);
+      while (q == hipErrorNotReady && std::chrono::steady_clock::now() < deadline) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        q = hipStreamQuery(sl->stream);
+      }
+      if (q == hipErrorNotReady)
+        throw StatusError(MRK_ERR_DEVICE, "a retired serving workgroup is still resident: the store is not reallocated under it");
+      sl->running = false;   // it left (or its launch failed): nothing of this slot touches the device any more
+    }
   }
 }
 }  // namespace mrk
@@ -1301,6 +1318,7 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
     srv->prog = &prog;
     srv->f64 = model->forest.backend == Backend::LightGBM;
     srv->idle_ticks = (uint64_t)std::max(1, switches().serve_idle_us) * 100ull;  // wall_clock64: 100 MHz
+    srv->life_ticks = (uint64_t)std::max(1, switches().serve_life_us) * 100ull;
     srv->jit_fn = jit_serve_function(prog, srv->f64);  // warm-up: the compile happens here, not under the first request
     for (int i = 0; i < n_slots; ++i) {
       std::unique_ptr<ServeSlot> sl(new ServeSlot());

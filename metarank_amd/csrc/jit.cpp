@@ -180,6 +180,7 @@ struct JitSlot {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   bool failed = false;
+  bool skip_disk = false;       // a code object found on disk did not load on this device (another architecture / a stale file): compile instead
   // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
   std::thread worker;
   std::atomic<int> state{0};    // 0 idle, 1 compiling, 2 code ready, 3 failed
@@ -286,11 +287,13 @@ static void *jit_function(const Program &prog, int kernel, bool f64, bool wait =
     if (code.empty()) code = read_file(shipped_path(src));
     return code;
   };
-  auto produce = [&prog, f64, kernel]() {  // host only: no device call (safe on any thread)
+  const bool skip_disk = sl.skip_disk;
+  auto produce = [&prog, f64, kernel, skip_disk]() {  // host only: no device call (safe on any thread)
     const std::string src = jit_source(prog, f64, kernel);
     const std::string path = cache_path(src);
-    std::vector<char> code = read_file(path);
-    if (code.empty()) code = read_file(shipped_path(src));
+    std::vector<char> code;
+    if (!skip_disk) code = read_file(path);
+    if (code.empty() && !skip_disk) code = read_file(shipped_path(src));
     if (code.empty()) {
       std::string log;
       code = jit_compile(src, log);
@@ -300,8 +303,9 @@ static void *jit_function(const Program &prog, int kernel, bool f64, bool wait =
   };
   try {
     std::vector<char> code;
-    if (mode == 4 && sl.state.load() == 0) code = cached();
-    if (!code.empty()) {
+    if (mode == 4 && sl.state.load() == 0 && !sl.skip_disk) code = cached();
+    const bool from_disk = !code.empty();
+    if (from_disk) {
       // on disk: loaded below, at once
     } else if (mode == 3 || mode == 4 || sl.state.load() != 0) {
       int st = sl.state.load();
@@ -330,7 +334,15 @@ static void *jit_function(const Program &prog, int kernel, bool f64, bool wait =
     } else {
       code = produce();
     }
-    MRK_HIP(hipModuleLoadData(&sl.mod, code.data()));
+    if (from_disk && hipModuleLoadData(&sl.mod, code.data()) != hipSuccess) {
+      // the default mode never pins a model to the generic kernel because of a file: the next call starts the background compile
+      (void)hipGetLastError();
+      sl.mod = nullptr;
+      sl.skip_disk = true;
+      fprintf(stderr, "[mrk] the code object on disk for %s ('%s') does not load on this device: compiling\n", JIT_KERNEL_NAME[kernel], prog.model.c_str());
+      return nullptr;
+    }
+    if (!from_disk) MRK_HIP(hipModuleLoadData(&sl.mod, code.data()));
     MRK_HIP(hipModuleGetFunction(&sl.fn, sl.mod, JIT_KERNEL_NAME[kernel]));
   } catch (const std::exception &e) {
     sl.failed = true;

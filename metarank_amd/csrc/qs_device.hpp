@@ -78,6 +78,9 @@ __device__ __forceinline__ uint32_t qs_bin_search_staged(qs_lds_double *T, uint3
   }
   pos = (uint32_t)(p - T);
   pos += below(p[0]) ? 1u : 0u;
+  // XGBoost's test is t <= x: x = +inf walks through the +inf padding (such a request fails with ST_XGB_INF anyway, but the
+  // cell it leaves behind stays inside the column's bins, as qs_bin_search's does)
+  if constexpr (!F64) pos = min(pos, len);
   return pos;
 }
 

@@ -150,6 +150,8 @@ struct ServeSlotDev {
   OneOut out;                // pinned output block
   uint32_t launch_id, last_seq;
   unsigned long long idle_ticks;   // wall_clock64 ticks (100 MHz) without a request after which the workgroup leaves
+  unsigned long long life_ticks;   // ... and the age at which it leaves after the request it is serving, however busy the slot is:
+                                   // hipFree / hipHostFree / a device-wide sync on ANY thread wait for every resident kernel
 };
 
 constexpr int SORT_MAX_ITEMS = 4096;   // per-request LDS sort

@@ -204,18 +204,17 @@ __device__ double median_of(double *s_vals, int n_raw, int *s_misc) {
   return __dadd_rn(lower, __dmul_rn(dif, __dsub_rn(upper, lower)));
 }
 
-#ifdef MRK_PREPASS_WAVES
-// ===== EXPERIMENT (compiled only with -DMRK_PREPASS_WAVES / MRK_JIT_DEFINES="MRK_PREPASS_WAVES=1"; written at the end of round 3
-// when the GPU budget was spent: it has been compiled, not yet run - tools/gpu/r04_first.sh runs the parity suite over it
-// and the A/B).  The sections of a request's pre-pass on DIFFERENT wavefronts of its workgroup.
-// Measured on the stock kernel (tools/phase_clocks.py c2 32): the interacted_with histograms are 37 k cycles of a request's
+// ---- The sections of a request's pre-pass on DIFFERENT wavefronts of its workgroup (round 4: c2 assembly -2 %, and
+// -11 % on a single request's latency: the sections are most of an unloaded request's critical path).
+// Measured on the round-3 kernel (tools/phase_clocks.py c2 32): the interacted_with histograms are 37 k cycles of a request's
 // 225 k, the diversity sections 28 k + 37 k + 8 k, one after the other - and in both only ONE wavefront has work (50
 // interacted items, the first `top` = 20 candidates) while the other waits at the section's barriers.  Here wavefront 0
 // runs the whole diversity section with wave-local scans (ballots instead of LDS totals + two barriers per scan; lanes
 // of one wavefront talk through LDS in program order) while the other wavefronts build the interacted_with tables; one
-// barrier at the end.  Tables of different entries are disjoint, the histograms do not depend on insertion order: same
-// results.  Taken when every diversity entry looks at no more than 64 candidates' values (`top` <= 64: the default is 20);
-// otherwise the workgroup-wide code below runs.
+// barrier at the end (same box, round 4: 244 k -> 205 k cycles).  Tables of different entries are disjoint, the histograms do
+// not depend on insertion order: same results.  Taken when every diversity entry looks at no more than 64 candidates' values
+// (`top` <= 64: the default is 20); otherwise the workgroup-wide code below runs (a program property: in a specialised kernel
+// only one of the two is compiled).
 
 // (wave_lds_sync, wave_scan_flag, wave_median_of: wave_device.hpp - compiled for the host too, tests/native/wave_test.cpp)
 
@@ -432,7 +431,6 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
     e0 = e1;
   }
 }
-#endif  // MRK_PREPASS_WAVES
 
 // The pre-pass of request r, run by one whole workgroup.  Tables live at tab_base + (po.tab_off - tab_sub)
 // (HBM arena: tab_sub = 0; LDS: tab_sub = the request's first arena entry); mode / scalar go to po_out[e].
@@ -467,7 +465,6 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
   }
   __syncthreads();
   MRK_PHASE(sc.clk, sc.acc[0]);
-#ifdef MRK_PREPASS_WAVES
   if (prepass_waves_ok(prog)) {   // (uniform) the sections side by side on different wavefronts
     const bool lone = nthr <= 64;   // a one-wavefront workgroup runs both, one after the other
     const int wave = tid >> 6;
@@ -477,7 +474,6 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
     MRK_PHASE(sc.clk, sc.acc[1]);
     return;
   }
-#endif
 
   // Per-group state lives in registers indexed at COMPILE time (every loop over the group is fully unrolled
   // and predicated on u < n): a run-time index into a register array costs a select chain per access.
@@ -1273,23 +1269,11 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
             const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
             const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
             double cnt = 0.0;
-#ifdef MRK_GET_PAIR
-            static_assert(IW_TOK % 2 == 0, "pairs");
-#pragma unroll
-            for (int t = 0; t < IW_TOK; t += 2) {
-              if (!wave_any((uint32_t)t < len)) break;
-              uint32_t g0, g1;
-              table_get2(tab, po.tab_cap, tk[u][t], (uint32_t)t < len, tk[u][t + 1], (uint32_t)(t + 1) < len, g0, g1);
-              cnt = cnt + (double)g0;
-              cnt = cnt + (double)g1;
-            }
-#else
 #pragma unroll
             for (int t = 0; t < IW_TOK; ++t) {
               if (!wave_any((uint32_t)t < len)) break;
               cnt = cnt + (double)table_get(tab, po.tab_cap, tk[u][t], (uint32_t)t < len);
             }
-#endif
             if (wave_any(len > (uint32_t)IW_TOK))  // the rest of longer lists, in list order
               cnt = table_sum_list(list_tokens(st, irec, fc[u].lo()) + IW_TOK, tab, po.tab_cap, len > (uint32_t)IW_TOK ? len - IW_TOK : 0u, cnt);
             sink.put(dst + f0 + u, cnt);
@@ -1312,22 +1296,11 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
           // the list's first TOK_BATCH tokens were fetched ahead; longer lists continue from memory, in list order
           const uint32_t len = list ? c.hi() : 0u;
           double wl = 0.0;
-#ifdef MRK_GET_PAIR
-#pragma unroll
-          for (int t = 0; t < TOK_BATCH; t += 2) {
-            if (!wave_any((uint32_t)t < len)) break;
-            uint32_t g0, g1;
-            table_get2(tab, po.tab_cap, pre.tok[t], (uint32_t)t < len, pre.tok[t + 1], (uint32_t)(t + 1) < len, g0, g1);
-            wl = wl + (double)g0;
-            wl = wl + (double)g1;
-          }
-#else
 #pragma unroll
           for (int t = 0; t < TOK_BATCH; ++t) {
             if (!wave_any((uint32_t)t < len)) break;
             wl = wl + (double)table_get(tab, po.tab_cap, pre.tok[t], (uint32_t)t < len);
           }
-#endif
           if (wave_any(len > (uint32_t)TOK_BATCH))
             wl = table_sum_list(list_tokens(st, irec, c.lo()) + TOK_BATCH, tab, po.tab_cap, len > (uint32_t)TOK_BATCH ? len - TOK_BATCH : 0u, wl);
           if (one || list) v = (one ? w1 : wl) / po.scalar;
@@ -1689,14 +1662,20 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
   volatile uint32_t *s_word = (volatile uint32_t *)(smem_base + slab_bytes + 8);   // [0] seq | STOP, [1] leave after this request
   uint32_t last = s.last_seq;
   unsigned long long idle_since = wall_clock64();
+  const unsigned long long born = idle_since;
   for (;;) {
     if (tid == 0) {
       uint32_t seq = last, leave = 0, stop = 0;
       for (;;) {
+        // A slot under sustained traffic never idles (the host hands out the most recently used slot first), and a
+        // resident kernel stalls every hipFree / reallocation / device-wide sync of the process: past `life_ticks` the
+        // workgroup takes its leave exactly as if it had been told to (a request already published is served first).
+        const unsigned long long now = wall_clock64();
+        const bool old = now - born > s.life_ticks;
         seq = __hip_atomic_load(&s.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (seq != last) break;
-        const bool told = __hip_atomic_load(&s.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-        if (told || wall_clock64() - idle_since > s.idle_ticks) {
+        if (seq != last && !old) break;
+        const bool told = old || __hip_atomic_load(&s.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        if (told || now - idle_since > s.idle_ticks) {
           __hip_atomic_store(&s.ctl->exited, s.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __threadfence_system();
           seq = __hip_atomic_load(&s.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

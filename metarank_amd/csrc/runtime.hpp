@@ -102,6 +102,7 @@ struct Switches {
   int fused_split = 0;         // MRK_FUSED_SPLIT=1|2|4: op split of the fused kernel's workgroups (0: 4 / 2 for batches of <= 16 requests)
   bool rank_combine = true;    // MRK_RANK_COMBINE=0: no batching front in mrk_rank
   bool rank_serve = true;      // MRK_RANK_SERVE=0: mrk_serve_rank never takes the persistent-workgroup queue (everything through mrk_rank)
+  int serve_life_us = 20000;   // MRK_SERVE_LIFE_US: ... and leaves after the request it is serving once it is this old, idle or not (bounds what a hipFree on another thread waits for)
   int serve_idle_us = 2000;    // MRK_SERVE_IDLE_US: a serving workgroup without a request for this long leaves its CU (relaunched by the next request)
   bool rank_fused_score = false; // MRK_RANK_FUSED_SCORE=1: full batches of small requests in ONE launch (assembly, forest, ordering per request workgroup) - measured slower than the three launches, kept for A/B
   bool rank_one = true;        // MRK_RANK_ONE=0: mrk_rank's small batches take the three-launch path instead of the one-launch kernel

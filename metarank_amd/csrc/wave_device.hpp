@@ -1,11 +1,10 @@
-// Wave-local helpers of the MRK_PREPASS_WAVES experiment (rank_device.hpp prepass_diversity_wave): a prefix scan by ballot and
+// Wave-local helpers of the wave-per-section pre-pass (rank_device.hpp prepass_diversity_wave): a prefix scan by ballot and
 // the commons-math LEGACY median of up to 64 values held one per lane - lanes of ONE wavefront talking through LDS in
 // program order, no workgroup barrier.  Its own header so that tests/native/wave_test.cpp can compile it for the host: 64
 // threads stand in for the 64 lanes, the ballot and the LDS ordering point become barriers (both are only ever reached by all
 // lanes together), and the medians are compared bit for bit with a sorted-array restatement of the percentile.
 #ifndef MRK_WAVE_DEVICE_HPP
 #define MRK_WAVE_DEVICE_HPP
-#ifdef MRK_PREPASS_WAVES
 
 namespace mrk {
 
@@ -58,5 +57,4 @@ __device__ __forceinline__ double wave_median_of(double *s_vals, int n_raw) {
 
 }  // namespace mrk
 
-#endif  // MRK_PREPASS_WAVES
 #endif  // MRK_WAVE_DEVICE_HPP

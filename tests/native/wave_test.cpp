@@ -1,4 +1,4 @@
-// CPU: the wave-local helpers of the MRK_PREPASS_WAVES experiment (csrc/wave_device.hpp) with 64 host threads standing in
+// CPU: the wave-local helpers of the wave-per-section pre-pass (csrc/wave_device.hpp) with 64 host threads standing in
 // for the 64 lanes of a wavefront.  Both places where lanes exchange anything - the ballot and the LDS ordering point - are
 // reached by all lanes together in this code, so each becomes a barrier; between them the threads run freely, which is a
 // WEAKER ordering than a wavefront's lock step (a result that needed lock step anywhere else would show up as a mismatch
@@ -34,7 +34,6 @@ static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v
 static inline double __dadd_rn(double a, double b) { return a + b; }
 static inline double __dsub_rn(double a, double b) { return a - b; }
 static inline double __dmul_rn(double a, double b) { return a * b; }
-#define MRK_PREPASS_WAVES 1
 #include "wave_device.hpp"
 
 static uint64_t rng_state = 0x13198a2e03707344ull;

@@ -170,6 +170,73 @@ def test_serving_queue_equals_mrk_rank(jit):
 
 
 @pytest.mark.gpu
+def test_busy_serving_workgroups_do_not_stall_reallocations():
+    """A persistent workgroup is a resident kernel, and hipFree / a reallocation on ANY thread waits for resident kernels.
+    Under sustained traffic a slot never idles (the most recently used slot is handed out first), so the workgroup must
+    bound its own residency (MRK_SERVE_LIFE_US): here three threads keep two slots busy with an idle time far beyond the
+    test while a fourth issues mrk_rank calls of growing size - each grows device buffers of the context.  Every such
+    call must return promptly and with the oracle's bytes, and the workgroups must have been relaunched on the way."""
+    import threading
+    import time
+
+    saved = with_env({"MRK_RANK_JIT": "1", "MRK_SERVE_IDLE_US": "6000000", "MRK_SERVE_LIFE_US": "3000"})
+    cfg = ranklens.ranklens_config()
+    orc, hip = OracleBackend(cfg, "xgboost"), HipBackend(cfg, "xgboost")
+    srv = None
+    try:
+        for b in (orc, hip):
+            ranklens.load_state(b, ranklens.generate_state(N_ITEMS, N_SESS))
+        small = ranklens.generate_requests(8, 100, N_ITEMS, N_SESS, seed=91)
+        q = ranklens.column_quantiles(np.concatenate([orc.matrix(ev) for ev in small[:4]]))
+        blob = synth.synthetic_lgbm_model(n_trees=300, n_features=24, quantiles=q, missing="per_feature")
+        orc.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        srv = hip.ranker.serve("xgboost", hip.booster, n_slots=2)
+        exp_small = [orc.rerank(ev) for ev in small]
+        srv.rerank(small[0])
+        stop = threading.Event()
+        bad = []
+
+        t_end = time.perf_counter() + 8.0   # (a broken bound must fail this test, not hang the box)
+
+        def hammer(t):
+            k = t
+            while not stop.is_set() and time.perf_counter() < t_end:
+                s, o = srv.rerank(small[k % len(small)])
+                e = exp_small[k % len(small)]
+                if not (same(s, e[1]) and o.tolist() == e[2].tolist()):
+                    bad.append(k)
+                k += 3
+
+        threads = [threading.Thread(target=hammer, args=(t,)) for t in range(3)]
+        for t in threads:
+            t.start()
+        worst = 0.0
+        try:
+            time.sleep(0.05)
+            for n in (129, 300, 700, 1500, 2900):   # each larger than the last: d_in / d_cells / d_sort grow every time
+                ev = ranklens.generate_requests(1, n, N_ITEMS, N_SESS, seed=100 + n)[0]
+                _, es, eo = orc.rerank(ev)
+                t0 = time.perf_counter()
+                _, s, o = hip.rerank(ev)
+                worst = max(worst, time.perf_counter() - t0)
+                assert same(s, es) and o.tolist() == eo.tolist(), n
+        finally:
+            stop.set()
+            for t in threads:
+                t.join()
+        assert not bad
+        st = srv.stats()
+        assert worst < 2.0, (worst, st)          # without the bound: as long as the traffic lasts (here: for ever)
+        assert st["launches"] > 4, st            # the workgroups did leave and come back
+    finally:
+        if srv is not None:
+            srv.close()
+        restore_env(saved)
+        hip.close()
+
+
+@pytest.mark.gpu
 def test_default_jit_mode_never_waits_for_the_compiler():
     """MRK_RANK_JIT=auto (the library's default): (a) the stock Ranklens program's kernels are shipped next to the library
     (metarank_amd/jit_cache, built by __graft_entry__.build()): the first mrk_rank of a fresh context takes milliseconds and
