@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MRK_ABI_VERSION 6
+#define MRK_ABI_VERSION 7
 
 typedef enum mrk_status {
   MRK_OK = 0,
@@ -141,6 +141,17 @@ int mrk_config_specialize(const char *json, size_t len, const char *model_name, 
  * require, async, auto = this default).  out_compiled (nullable): how many were not there yet. */
 int mrk_config_precompile(const char *json, size_t len, const char *model_name, int f64, unsigned kernel_mask, const char *dir,
                           int *out_compiled);
+/* The kernels that write the scorer's binned tile are keyed by the FOREST too - by its view signature: per matrix column
+ * which tile columns it fills (NaN / zero / categorical routing kinds) and how many 128-entry chunks its threshold table
+ * takes; not the thresholds, not the trees - and hold it as compile-time constants (no descriptor loads, no view loops).
+ * Retraining on the same features usually keeps the signature, hence the kernels.  The two entry points above know the
+ * config only: they build the signature-less kernels, which serve any model of the program while its own kernels compile.
+ * These two do the same for one serialised booster (backend / bytes as for mrk_model_load; the precision follows from the
+ * backend): what a deployment runs when it ships a model.  Host-only. */
+int mrk_config_specialize_for_model(const char *json, size_t len, const char *model_name, int backend, const uint8_t *model_bytes,
+                                    size_t model_len, int what, uint8_t *out, size_t cap, size_t *needed);
+int mrk_config_precompile_for_model(const char *json, size_t len, const char *model_name, int backend, const uint8_t *model_bytes,
+                                    size_t model_len, unsigned kernel_mask, const char *dir, int *out_compiled);
 /* Serve.maybeWarmup for the kernels: waits until the background compiles of this model's kernels that are under way have
  * finished (the next launch uses them).  A host calls it before it opens its port; nothing on the request path waits. */
 int mrk_config_warmup(mrk_ctx *ctx, const char *model_name);

@@ -139,6 +139,8 @@ SIGNATURES = {
     "mrk_model_dim": (_I, [_V, _S]),
     "mrk_config_specialize": (_I, [_S, C.c_size_t, _S, _I, _I, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mrk_config_precompile": (_I, [_S, C.c_size_t, _S, _I, C.c_uint, _S, C.POINTER(C.c_int)]),
+    "mrk_config_specialize_for_model": (_I, [_S, C.c_size_t, _S, _I, _P, C.c_size_t, _I, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mrk_config_precompile_for_model": (_I, [_S, C.c_size_t, _S, _I, _P, C.c_size_t, C.c_uint, _S, C.POINTER(C.c_int)]),
     "mrk_config_warmup": (_I, [_V, _S]),
     "mrk_store_put_double": (_I, [_V, _S, C.c_double]),
     "mrk_store_put_bool": (_I, [_V, _S, _I]),

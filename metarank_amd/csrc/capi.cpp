@@ -35,6 +35,7 @@ static Switches read_switches() {
   if (const char *e = getenv("MRK_RANK_JIT")) s.jit_mode = !strcmp(e, "require") ? 2 : !strcmp(e, "async") ? 3 : !strcmp(e, "auto") ? 4 : atoi(e) != 0 ? 1 : 0;
   s.jit_waves = num("MRK_JIT_WAVES", 0);
   s.jit_record_regs = flag("MRK_JIT_REGS", true);
+  s.jit_sig = flag("MRK_JIT_SIG", true);
   s.jit_shipped = flag("MRK_JIT_SHIPPED", true);
   if (const char *d = getenv("MRK_JIT_DEFINES")) s.jit_defines = d; else s.jit_defines.clear();
   s.thr_stage = flag("MRK_THR_STAGE", true);
@@ -145,6 +146,7 @@ static void upload_model(mrk_ctx *ctx, mrk_model *m) {
     up(m->d_qs_views, m->qs.views.data(), m->qs.views.size() * sizeof(QsView));
     up(m->d_qs_catnodes, m->qs.cat_nodes.data(), m->qs.cat_nodes.size() * sizeof(QsCatNode));
     up(m->d_qs_cat, m->qs.cat_bits.data(), m->qs.cat_bits.size() * 4);
+    m->qs_sig = qs_signature(m->qs, qs_stage_cap(m->qs));
   }
 }
 

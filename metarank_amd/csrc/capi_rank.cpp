@@ -398,11 +398,13 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
   const bool fused_score = !one && sort && lo == 0 && hi == b.total_items && cells && sw.rank_fused_score && b.fused_ok && b.fused_split == 1 &&
                            b.fused_slices == 1 && b.hb.max_items <= QS_TILE_ROWS && b.view.n_overrides == 0 && b.big.empty() && b.fused_threads <= 256 &&
                            rank_fused_score_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, qs_device_view(model).thr_cap, qs_device_view(model).n_views, f64) <= 64 * 1024;
+  // (the kernels that write the scorer's tile are keyed by the forest's view signature too: their sinks hold it as constants)
+  const QsSignature *sig = cells && sw.thr_stage ? &model->qs_sig : nullptr;
   void *jit_fn = !cells ? (b.fused_ok && model && b.fused_split == 1 && b.fused_slices == 1 ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too
-                        : one ? jit_one_function(*b.prog, f64)
-                        : fused_score ? jit_fused_score_function(*b.prog, f64)
-                        : !b.fused_ok ? jit_items_function(*b.prog, f64)
-                        : b.fused_split > 1 || b.fused_slices > 1 ? jit_split_function(*b.prog, f64) : jit_rank_function(*b.prog, f64);
+                        : one ? jit_one_function(*b.prog, f64, sig)
+                        : fused_score ? jit_fused_score_function(*b.prog, f64, sig)
+                        : !b.fused_ok ? jit_items_function(*b.prog, f64, sig)
+                        : b.fused_split > 1 || b.fused_slices > 1 ? jit_split_function(*b.prog, f64, sig) : jit_rank_function(*b.prog, f64, sig);
   LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
@@ -552,6 +554,61 @@ int mrk_config_specialize(const char *json, size_t len, const char *model_name, 
 }
 
 static const Program &program_of(mrk_ctx *ctx, const char *model_name);
+
+// host only: the view signature of a serialised booster (what mrk_model_load would key this model's kernels by)
+static QsSignature signature_of_bytes(int backend, const uint8_t *bytes, size_t len, bool &f64) {
+  if (!bytes || !len) throw StatusError(MRK_ERR_INVALID_ARG, "null model bytes");
+  Forest f;
+  if (backend == MRK_BACKEND_LIGHTGBM) f = parse_lightgbm_text((const char *)bytes, len);
+  else if (backend == MRK_BACKEND_XGBOOST) f = parse_xgboost(bytes, len);
+  else throw StatusError(MRK_ERR_INVALID_ARG, "unsupported booster tag " + std::to_string(backend));
+  f64 = f.backend == Backend::LightGBM;
+  const PackedForestQS qs = pack_forest_qs(f, f.n_features);
+  return qs.ok ? qs_signature(qs, qs_stage_cap(qs)) : QsSignature{};
+}
+
+int mrk_config_specialize_for_model(const char *json, size_t len, const char *model_name, int backend, const uint8_t *model_bytes, size_t model_len,
+                                    int what, uint8_t *out, size_t cap, size_t *needed) {
+  return guard([&] {
+    const int kernel = (what >> 8) - 1;
+    what &= 0xff;
+    if (!json || !model_name || !needed || (what != 0 && what != 1) || kernel < JIT_ALL || kernel >= JIT_KERNELS)
+      throw StatusError(MRK_ERR_INVALID_ARG, "null argument / unknown `what`");
+    bool f64 = true;
+    const QsSignature sig = signature_of_bytes(backend, model_bytes, model_len, f64);
+    Store st;
+    std::unique_ptr<Registry> reg = load_config(json, len, st, /*upload=*/false);
+    const Program *p = reg->program(model_name);
+    if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
+    const std::string src = jit_source(*p, f64, kernel, switches().jit_sig ? &sig : nullptr);
+    std::vector<char> code;
+    if (what == 1 && out) {
+      std::string log;
+      code = jit_compile(src, log);
+    }
+    const char *data = what == 0 ? src.data() : code.data();
+    const size_t n = what == 0 ? src.size() : code.size();
+    *needed = what == 1 && !out ? (size_t)1 << 22 : n;
+    if (cap < n || !out) throw StatusError(MRK_ERR_INVALID_ARG, "output buffer too small (see *needed)");
+    memcpy(out, data, n);
+  });
+}
+
+int mrk_config_precompile_for_model(const char *json, size_t len, const char *model_name, int backend, const uint8_t *model_bytes, size_t model_len,
+                                    unsigned kernel_mask, const char *dir, int *out_compiled) {
+  return guard([&] {
+    if (out_compiled) *out_compiled = 0;
+    if (!json || !model_name || !dir) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    bool f64 = true;
+    const QsSignature sig = signature_of_bytes(backend, model_bytes, model_len, f64);
+    Store st;
+    std::unique_ptr<Registry> reg = load_config(json, len, st, /*upload=*/false);
+    const Program *p = reg->program(model_name);
+    if (!p) throw StatusError(MRK_ERR_NOT_FOUND, std::string("model ") + model_name + " is not configured");
+    const int n = jit_precompile(*p, f64, kernel_mask, dir, &sig);
+    if (out_compiled) *out_compiled = n;
+  });
+}
 
 int mrk_config_precompile(const char *json, size_t len, const char *model_name, int f64, unsigned kernel_mask, const char *dir, int *out_compiled) {
   return guard([&] {
@@ -1319,7 +1376,7 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
     srv->f64 = model->forest.backend == Backend::LightGBM;
     srv->idle_ticks = (uint64_t)std::max(1, switches().serve_idle_us) * 100ull;  // wall_clock64: 100 MHz
     srv->life_ticks = (uint64_t)std::max(1, switches().serve_life_us) * 100ull;
-    srv->jit_fn = jit_serve_function(prog, srv->f64);  // warm-up: the compile happens here, not under the first request
+    srv->jit_fn = jit_serve_function(prog, srv->f64, switches().thr_stage ? &model->qs_sig : nullptr);  // warm-up: the compile happens here, not under the first request
     for (int i = 0; i < n_slots; ++i) {
       std::unique_ptr<ServeSlot> sl(new ServeSlot());
       MRK_HIP(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));

@@ -123,5 +123,15 @@ struct QsFeature {     // 16 B, one per matrix column (one s_load_dwordx4)
   uint16_t pad;
   uint32_t view_kinds;             // QsViewKind of view_begin + i in bits [4 i, 4 i + 4): at most 6 views per column
 };
+// What the assembly kernels need to know about a column to bin a value WITHOUT reading its descriptor: the part of a
+// QsFeature that survives a retraining on the same features (the thresholds themselves, their exact number and bin(0.0)
+// do not).  The per-column rows of a forest are its "view signature" (forest.hpp qs_signature); the run-time specialised
+// kernels (jit.cpp) are keyed by it and hold it as compile-time constants.
+struct QsSig {
+  uint32_t thr_off;                // = QS_STAGE_CHUNK x the chunks of the columns before this one (forest.cpp lays the tables out that way)
+  uint16_t chunks;                 // ceil(thr_len / QS_STAGE_CHUNK)
+  uint8_t view_begin, view_end;
+  uint32_t view_kinds;
+};
 
 }  // namespace mrk

@@ -825,4 +825,33 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
   return pf;
 }
 
+uint32_t qs_stage_cap(const PackedForestQS &pf) {
+  uint32_t longest = 1;
+  for (const QsFeature &f : pf.feats)
+    if (f.view_begin != f.view_end && f.thr_len <= 256u) longest = std::max<uint32_t>(longest, f.thr_len);
+  return (longest + QS_STAGE_CHUNK - 1) / QS_STAGE_CHUNK * QS_STAGE_CHUNK;
+}
+
+QsSignature qs_signature(const PackedForestQS &pf, uint32_t thr_cap) {
+  QsSignature sg;
+  if (!pf.ok || thr_cap == 0 || thr_cap % QS_STAGE_CHUNK) return sg;
+  sg.thr_cap = thr_cap;
+  sg.n_views = (int)pf.views.size();
+  uint32_t off = 0;
+  for (const QsFeature &f : pf.feats) {
+    const uint32_t chunks = (f.thr_len + QS_STAGE_CHUNK - 1) / QS_STAGE_CHUNK;
+    // pack_forest_qs lays the tables out in column order, each padded to whole chunks: a column's offset follows from the
+    // chunk counts before it (a different layout: no signature, the kernels keep reading descriptors)
+    if (f.thr_off != off || f.view_end - f.view_begin > 6 || f.view_end < f.view_begin) return QsSignature{};
+    sg.cols.push_back(QsSig{off, (uint16_t)chunks, f.view_begin, f.view_end, f.view_kinds});
+    sg.text += "{" + std::to_string(off) + "u," + std::to_string(chunks) + "," + std::to_string(f.view_begin) + "," + std::to_string(f.view_end) + "," +
+               std::to_string(f.view_kinds) + "u},";
+    off += chunks * QS_STAGE_CHUNK;
+  }
+  if ((size_t)off != pf.thr.size()) return QsSignature{};
+  sg.text = "/*cap " + std::to_string(thr_cap) + " views " + std::to_string(sg.n_views) + "*/" + sg.text;
+  sg.ok = true;
+  return sg;
+}
+
 }  // namespace mrk

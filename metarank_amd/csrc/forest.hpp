@@ -163,4 +163,19 @@ struct PackedForestQS {
 
 PackedForestQS pack_forest_qs(const Forest &f, int n_cols);
 
+// The forest's VIEW SIGNATURE: per matrix column its views (which tile columns, of which kinds) and the number of
+// 128-entry chunks its threshold table takes - what decides the CODE of a kernel that bins values for this forest, as
+// opposed to the data it reads (thresholds, bin(0.0), the trees).  Forests retrained on the same features usually keep it.
+// The run-time specialised assembly kernels are keyed by it (jit.cpp; device side: rank_device.hpp CellSink<F64, QS>).
+struct QsSignature {
+  bool ok = false;             // false: the image does not have the layout the signature assumes - kernels read descriptors
+  uint32_t thr_cap = 0;        // doubles per LDS staging buffer (QsDev::thr_cap)
+  int n_views = 0;
+  std::vector<QsSig> cols;     // n_features
+  std::string text;            // the rows as a C++ initialiser list: part of the specialised translation unit, and the key
+};
+// doubles per LDS staging buffer of the assembly kernels: the longest table they stage (<= 256 entries), in whole chunks
+uint32_t qs_stage_cap(const PackedForestQS &pf);
+QsSignature qs_signature(const PackedForestQS &pf, uint32_t thr_cap);
+
 }  // namespace mrk

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <map>
+#include <memory>
 #include <string>
 #include <sys/stat.h>
 #include <thread>
@@ -24,6 +26,7 @@
 #include <vector>
 
 #include "features.hpp"
+#include "forest.hpp"
 #include "jit.hpp"
 #include "runtime.hpp"
 
@@ -56,7 +59,7 @@ uint64_t fnv1a(const std::string &s) {
 
 }  // namespace
 
-std::string jit_source(const Program &prog, bool f64, int kernel) {
+std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignature *sig) {
   std::string s;
   s.reserve(strlen(k_device_source) + 8192);
   // experiments: MRK_JIT_DEFINES="A=1 B=2" - macros the device code reads (MRK_PROBE_W, MRK_PRE_GROUP_BUDGET); part of the text, so of the cache key
@@ -95,7 +98,18 @@ std::string jit_source(const Program &prog, bool f64, int kernel) {
   s += "struct JitProg {\n  static constexpr bool is_static = true;\n";
   s += "  static constexpr int32_t n_ops = " + std::to_string(prog.ops.size()) + ", n_prep = " + std::to_string(prog.prep.size()) +
        ", dim = " + std::to_string(prog.dim) + ", n_consts = " + std::to_string(prog.n_consts) + ", item_fixed = " + std::to_string(switches().jit_record_regs ? prog.item_fixed : 0) + ";\n";
-  s += "  JitOps ops;\n  JitPrep prep;\n  JitAux aux;\n};\n}  // namespace\n}  // namespace mrk\n\n";
+  s += "  JitOps ops;\n  JitPrep prep;\n  JitAux aux;\n};\n";
+  // the forest's view signature (forest.hpp): the sinks of the kernels that write the scorer's tile hold it as constants;
+  // without one (no bit-vector image, f64-matrix kernels, MRK_JIT_SIG=0) they read the column descriptors from memory
+  std::string qs = "mrk::QsDyn";
+  if (sig && sig->ok && kernel != JIT_MATRIX) {
+    table("JitSigRows", "QsSig", sig->cols.size(), sig->text);
+    s += "struct JitQs {\n  static constexpr bool is_static = true;\n  static constexpr int n_feats = " + std::to_string(sig->cols.size()) +
+         ", n_views = " + std::to_string(sig->n_views) + ";\n  static constexpr uint32_t thr_cap = " + std::to_string(sig->thr_cap) +
+         "u;\n  __device__ __forceinline__ constexpr QsSig operator[](int i) const { return JitSigRows{}[i]; }\n};\n";
+    qs = "mrk::JitQs";
+  }
+  s += "}  // namespace\n}  // namespace mrk\n\n";
   // Wavefronts per SIMD the compiler must leave room for (register cap 512 / n).  With the candidate's record and the
   // second trip of every op in registers the kernel would take ~200 VGPRs = 2 wavefronts per SIMD; measured on c2
   // (profiles/r02_c): 2 -> 0.436 ms, 3 -> 0.351, 4 -> 0.286 - the kernel hides its trips to memory with resident
@@ -112,13 +126,13 @@ std::string jit_source(const Program &prog, bool f64, int kernel) {
   if (kernel == JIT_ALL || kernel == JIT_RANK)
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_cells"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
-         "  mrk::rank_fused_cells_body<" + b64 + ", false>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
+         "  mrk::rank_fused_cells_body<" + b64 + ", false, " + qs + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
   // the same for a handful of requests (mrk_rank) or few large ones: up to 512 lanes per workgroup, the item lanes in
   // op_split copies that share the program's ops between them (rank_device.hpp op_owner), `slices` workgroups per request
   if (kernel == JIT_ALL || kernel == JIT_SPLIT)
     s += "extern \"C\" __global__ void __launch_bounds__(512)" + attr + "\nmrk_jit_rank_cells_split"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, uint16_t *cells, int mode) {\n"
-         "  mrk::rank_fused_cells_body<" + b64 + ", true>(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
+         "  mrk::rank_fused_cells_body<" + b64 + ", true, " + qs + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, cells, mode);\n}\n";
   // the same workgroup-per-request kernel writing the row-major f64 matrix (models scored by the tree walk, explain);
   // the matrix does not depend on the scorer's precision
   if ((kernel == JIT_ALL && f64) || kernel == JIT_MATRIX)
@@ -129,24 +143,24 @@ std::string jit_source(const Program &prog, bool f64, int kernel) {
   if (kernel == JIT_ALL || kernel == JIT_ITEMS)
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
          "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
-         "  mrk::assemble_cells_body<" + b64 + ">(st, mrk::JitProg{}, b, q, cells);\n}\n";
+         "  mrk::assemble_cells_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, q, cells);\n}\n";
   // pre-pass + assembly + forest + ordering of a small request in one launch (rank_device.hpp rank_one_body)
   if (kernel == JIT_ALL || kernel == JIT_ONE)
     // (a request's workgroup is 8 wavefronts = 2 per SIMD and a handful of them run at a time: nothing to gain from the
     //  128-register cap of the batch kernels)
     s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_one"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, mrk::QsForestDev f, int mode, mrk::OneOut out) {\n"
-         "  mrk::rank_one_body<" + b64 + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, mode, out);\n}\n";
+         "  mrk::rank_one_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, mode, out);\n}\n";
   // full batches of small requests: assembly + forest + ordering in the request's workgroup (rank_fused_score_body)
   if (kernel == JIT_ALL || kernel == JIT_FUSED_SCORE)
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_fused_score"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, mrk::QsForestDev f, uint16_t *cells) {\n"
-         "  mrk::rank_fused_score_body<" + b64 + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, cells);\n}\n";
+         "  mrk::rank_fused_score_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, cells);\n}\n";
   // ... and its persistent form (rank_device.hpp rank_serve_body)
   if (kernel == JIT_ALL || kernel == JIT_SERVE)
     s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_serve"
          "(mrk::StoreDev st, mrk::QsDev q, mrk::QsForestDev f, mrk::ServeSlotDev slot) {\n"
-         "  mrk::rank_serve_body<" + b64 + ">(st, mrk::JitProg{}, q, f, slot);\n}\n";
+         "  mrk::rank_serve_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, q, f, slot);\n}\n";
   return s;
 }
 
@@ -187,8 +201,16 @@ struct JitSlot {
   std::vector<char> code;
   std::string error;
 };
-struct JitKernels {
+struct JitSlotSet {
   JitSlot slot[JIT_KERNELS][2];   // [kernel][f64] (the matrix kernel lives in [JIT_MATRIX][1])
+};
+// A program's kernels, per view signature of the forest they bin for (forest.hpp QsSignature; "" = none: the kernel reads
+// the column descriptors from memory - the f64-matrix kernel, models without a bit-vector image, and what serves a
+// retrained model whose signature changed while its own kernel compiles).  Sets are never dropped while the program lives
+// (a module may have launches in flight); signatures change with the feature list or the missing-value kinds, not per
+// retraining, so there are few.
+struct JitKernels {
+  std::map<std::string, std::unique_ptr<JitSlotSet>> by_sig;
 };
 
 const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve", "mrk_jit_rank_fused_score"};
@@ -271,25 +293,31 @@ void write_file(const std::string &path, const std::vector<char> &data) {
 
 // Called WITHOUT the context's launch lock: the first batch of a shape compiles for seconds, and other batches keep
 // launching meanwhile.  The program's own mutex serialises callers that want a kernel of the same program.
-static void *jit_function(const Program &prog, int kernel, bool f64, bool wait = false) {
+// sig: the forest's view signature (nullptr / !ok: none).  no_compile: only what is loaded or on disk (the stand-in while
+// a signature's own kernel compiles in the background).
+static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool wait, const QsSignature *sig, bool no_compile) {
   const int mode = wait && jit_mode() >= 3 ? 1 : jit_mode();  // wait: a warm-up call - the one place that may wait for the compiler
   if (mode == 0) return nullptr;
-  std::lock_guard<std::mutex> lk(prog.jit_mu);
   if (!prog.jit) prog.jit = new JitKernels();
   JitKernels *k = (JitKernels *)prog.jit;
   if (kernel == JIT_MATRIX) f64 = true;
-  JitSlot &sl = k->slot[kernel][f64 ? 1 : 0];
+  const bool keyed = sig && sig->ok && kernel != JIT_MATRIX && switches().jit_sig;
+  std::unique_ptr<JitSlotSet> &set = k->by_sig[keyed ? sig->text : std::string()];
+  if (!set) set.reset(new JitSlotSet());
+  JitSlot &sl = set->slot[kernel][f64 ? 1 : 0];
   if (sl.fn) return (void *)sl.fn;
   if (sl.failed && mode != 2) return nullptr;
-  auto cached = [&prog, f64, kernel]() {   // the code object, if a previous process (or the build) left it on disk
-    const std::string src = jit_source(prog, f64, kernel);
+  // the lambdas run on a background thread too: they own a copy of the signature (the model may be freed meanwhile)
+  const std::shared_ptr<const QsSignature> sg = keyed ? std::make_shared<const QsSignature>(*sig) : nullptr;
+  auto cached = [&prog, f64, kernel, sg]() {   // the code object, if a previous process (or the build) left it on disk
+    const std::string src = jit_source(prog, f64, kernel, sg.get());
     std::vector<char> code = read_file(cache_path(src));
     if (code.empty()) code = read_file(shipped_path(src));
     return code;
   };
   const bool skip_disk = sl.skip_disk;
-  auto produce = [&prog, f64, kernel, skip_disk]() {  // host only: no device call (safe on any thread)
-    const std::string src = jit_source(prog, f64, kernel);
+  auto produce = [&prog, f64, kernel, skip_disk, sg]() {  // host only: no device call (safe on any thread)
+    const std::string src = jit_source(prog, f64, kernel, sg.get());
     const std::string path = cache_path(src);
     std::vector<char> code;
     if (!skip_disk) code = read_file(path);
@@ -301,15 +329,19 @@ static void *jit_function(const Program &prog, int kernel, bool f64, bool wait =
     }
     return code;
   };
+  // while this signature's kernel is not there: the program's signature-less kernel, if it is loaded or on disk
+  auto stand_in = [&]() -> void * { return keyed && !no_compile ? jit_function_locked(prog, kernel, f64, false, nullptr, true) : nullptr; };
   try {
     std::vector<char> code;
-    if (mode == 4 && sl.state.load() == 0 && !sl.skip_disk) code = cached();
+    if ((mode == 4 || no_compile) && sl.state.load() == 0 && !sl.skip_disk) code = cached();
     const bool from_disk = !code.empty();
     if (from_disk) {
       // on disk: loaded below, at once
+    } else if (no_compile && sl.state.load() == 0) {
+      return nullptr;
     } else if (mode == 3 || mode == 4 || sl.state.load() != 0) {
       int st = sl.state.load();
-      if (st == 0) {  // first sight of this (program, kernel, precision): start the compile, keep ranking with the generic kernel
+      if (st == 0) {  // first sight of this (program, signature, kernel, precision): start the compile, keep ranking with what there is
         sl.state.store(1);
         JitSlot *slot = &sl;
         sl.worker = std::thread([slot, produce]() {
@@ -321,11 +353,11 @@ static void *jit_function(const Program &prog, int kernel, bool f64, bool wait =
             slot->state.store(3);
           }
         });
-        return nullptr;
+        return stand_in();
       }
       if (st == 1) {
-        if (mode != 2 && mode != 1) return nullptr;  // still compiling
-        sl.worker.join();                            // a synchronous mode took over: wait for it
+        if (mode != 2 && mode != 1) return stand_in();  // still compiling
+        sl.worker.join();                               // a synchronous mode took over: wait for it
         st = sl.state.load();
       }
       if (sl.worker.joinable()) sl.worker.join();
@@ -353,14 +385,20 @@ static void *jit_function(const Program &prog, int kernel, bool f64, bool wait =
   return (void *)sl.fn;
 }
 
+static void *jit_function(const Program &prog, int kernel, bool f64, const QsSignature *sig, bool wait = false) {
+  if (jit_mode() == 0) return nullptr;
+  std::lock_guard<std::mutex> lk(prog.jit_mu);
+  return jit_function_locked(prog, kernel, f64, wait, sig, false);
+}
+
 // host only: make sure `dir` holds the code object of every kernel in `kernel_mask` (bit k = kernel k) for this program;
 // returns how many had to be compiled
-int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const std::string &dir) {
+int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const std::string &dir, const QsSignature *sig) {
   int compiled = 0;
   for (int k = 0; k < JIT_KERNELS; ++k) {
     if (!(kernel_mask & (1u << k))) continue;
     const bool kf64 = k == JIT_MATRIX ? true : f64;
-    const std::string src = jit_source(prog, kf64, k);
+    const std::string src = jit_source(prog, kf64, k, switches().jit_sig ? sig : nullptr);
     const std::string user = cache_path(src);
     const std::string name = user.empty() ? shipped_path(src) : user;
     if (name.empty()) throw StatusError(MRK_ERR_INVALID_ARG, "no cache file name");
@@ -377,26 +415,27 @@ int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const st
   return compiled;
 }
 
-void *jit_rank_function(const Program &prog, bool f64) { return jit_function(prog, JIT_RANK, f64); }
+void *jit_rank_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_RANK, f64, sig); }
 // the item-parallel kernel (nullptr under the same conditions)
-void *jit_items_function(const Program &prog, bool f64) { return jit_function(prog, JIT_ITEMS, f64); }
+void *jit_items_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_ITEMS, f64, sig); }
 // the op-split / sliced form of the fused kernel (small batches, few large requests)
-void *jit_split_function(const Program &prog, bool f64) { return jit_function(prog, JIT_SPLIT, f64); }
+void *jit_split_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_SPLIT, f64, sig); }
 // the f64-matrix form of the fused kernel
-void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_MATRIX, true); }
+void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_MATRIX, true, nullptr); }
 // the one-launch kernel of small requests
-void *jit_one_function(const Program &prog, bool f64) { return jit_function(prog, JIT_ONE, f64); }
-void *jit_fused_score_function(const Program &prog, bool f64) { return jit_function(prog, JIT_FUSED_SCORE, f64); }
-void *jit_serve_function(const Program &prog, bool f64) { return jit_function(prog, JIT_SERVE, f64, /*wait=*/true); }  // mrk_serve_start IS the warm-up
+void *jit_one_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_ONE, f64, sig); }
+void *jit_fused_score_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_FUSED_SCORE, f64, sig); }
+void *jit_serve_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_SERVE, f64, sig, /*wait=*/true); }  // mrk_serve_start IS the warm-up
 
 // waits for the background compiles of `prog` that are under way (a warm-up / measurement aid; the next launch loads them)
 void jit_wait(const Program &prog) {
   std::lock_guard<std::mutex> lk(prog.jit_mu);
   if (!prog.jit) return;
   JitKernels *k = (JitKernels *)prog.jit;
-  for (auto &per_kernel : k->slot)
-    for (JitSlot &sl : per_kernel)
-      if (sl.state.load() == 1 && sl.worker.joinable()) sl.worker.join();
+  for (auto &set : k->by_sig)
+    for (auto &per_kernel : set.second->slot)
+      for (JitSlot &sl : per_kernel)
+        if (sl.state.load() == 1 && sl.worker.joinable()) sl.worker.join();
 }
 
 #ifdef MRK_PHASE_CLOCKS
@@ -404,7 +443,10 @@ void jit_wait(const Program &prog) {
 extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *out64) {
   if (!prog || !prog->jit) return -1;
   JitKernels *k = (JitKernels *)prog->jit;
-  hipModule_t mod = k->slot[JIT_RANK][1].mod ? k->slot[JIT_RANK][1].mod : k->slot[JIT_RANK][0].mod;
+  hipModule_t mod = nullptr;
+  for (auto &set : k->by_sig)   // the fused kernel that was compiled last (a measurement build ranks one model)
+    for (int f = 1; f >= 0; --f)
+      if (set.second->slot[JIT_RANK][f].mod) mod = set.second->slot[JIT_RANK][f].mod;
   hipDeviceptr_t p = nullptr;
   size_t bytes = 0;
   if (!mod || hipModuleGetGlobal(&p, &bytes, mod, "mrk_phase_clocks") != hipSuccess || bytes < 64 * 8) return -2;
@@ -417,11 +459,12 @@ extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *o
 void jit_release(Program &prog) {
   if (!prog.jit) return;
   JitKernels *k = (JitKernels *)prog.jit;
-  for (auto &per_kernel : k->slot)
-    for (JitSlot &sl : per_kernel) {
-      if (sl.worker.joinable()) sl.worker.join();  // the worker reads `prog`
-      if (sl.mod) (void)hipModuleUnload(sl.mod);
-    }
+  for (auto &set : k->by_sig)
+    for (auto &per_kernel : set.second->slot)
+      for (JitSlot &sl : per_kernel) {
+        if (sl.worker.joinable()) sl.worker.join();  // the worker reads `prog`
+        if (sl.mod) (void)hipModuleUnload(sl.mod);
+      }
   delete k;
   prog.jit = nullptr;
 }

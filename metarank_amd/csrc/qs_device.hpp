@@ -64,8 +64,11 @@ __device__ __forceinline__ uint32_t qs_bin_search(P T, uint32_t len, double x) {
 // end (forest.cpp pads the tables), at most 256 entries - so the search is 7 or 8 steps with COMPILE-TIME strides: a step is one
 // ds_read_b64 at an immediate offset from the running address, one compare, one conditional add; no loop, no scalar
 // arithmetic (the run-time loop cost ~6 VALU + 4 SALU per step, 24 columns x 8 steps per candidate).
-template <bool F64>
-__device__ __forceinline__ uint32_t qs_bin_search_staged(qs_lds_double *T, uint32_t len, double x) {
+// `len` may be the table's length rounded up to whole chunks (what a kernel that holds the forest's view signature as
+// constants knows at compile time: the padding answers like the table's end); `real_len()` - the exact length, a scalar
+// load in such a kernel - is asked for by XGBoost's clamp only.
+template <bool F64, typename RealLen>
+__device__ __forceinline__ uint32_t qs_bin_search_staged(qs_lds_double *T, uint32_t len, double x, RealLen real_len) {
   if (len == 0u) return 0u;
   auto below = [&](double t) { return F64 ? (t < x) : (t <= x); };
   uint32_t pos = 0;
@@ -80,7 +83,7 @@ __device__ __forceinline__ uint32_t qs_bin_search_staged(qs_lds_double *T, uint3
   pos += below(p[0]) ? 1u : 0u;
   // XGBoost's test is t <= x: x = +inf walks through the +inf padding (such a request fails with ST_XGB_INF anyway, but the
   // cell it leaves behind stays inside the column's bins, as qs_bin_search's does)
-  if constexpr (!F64) pos = min(pos, len);
+  if constexpr (!F64) pos = min(pos, (uint32_t)real_len());
   return pos;
 }
 
@@ -89,6 +92,35 @@ __device__ __forceinline__ uint32_t qs_bin_search_staged(qs_lds_double *T, uint3
 // first level the lanes' ranges start at multiples of 256 B, i.e. in the same LDS bank, and the LDS pipe - shared by the 16
 // wavefronts of a CU - is the resource this kernel is short of, not the round trips of one wavefront.)
 // every view of the column: (view index, cell) -> emit
+// one view's cell of a binned value
+template <bool F64>
+__device__ __forceinline__ uint32_t qs_view_cell(uint32_t kind, double x, uint32_t pos, uint32_t zero_bin, bool isn, bool isz) {
+  uint32_t cell;
+  if (kind == QV_CAT) {
+    // the category id; the node's bitset is consulted by the scorer
+    if (isn) cell = QS_CAT_NAN;
+    else if constexpr (F64) {
+      // LightGBM Tree::CategoricalDecision: int(fval) < 0 goes right, like NaN
+      const int iv = (int)x;  // v_cvt_i32_f64 saturates
+      cell = iv < 0 ? (uint32_t)QS_CAT_NAN : (iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv);
+    } else {
+      // XGBoost common::Decision: negative or >= 2^24 is an invalid category (goes left)
+      if (x < 0.0 || x >= 16777216.0) cell = QS_CAT_INVALID;
+      else {
+        const int iv = (int)x;
+        cell = iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv;
+      }
+    }
+  } else if (kind == QV_NAN_ZERO) {
+    cell = isn ? zero_bin : pos;  // MissingType::None: NaN is compared as 0.0
+  } else {
+    const bool miss = (kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
+    const uint32_t mval = (kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
+    cell = miss ? mval : pos;
+  }
+  return cell;
+}
+
 template <bool F64, typename Emit>
 __device__ __forceinline__ void qs_emit_views(double x, uint32_t pos, const QsFeature ft, const QsView *__restrict__ views, Emit emit) {
   const bool isn = x != x;
@@ -96,30 +128,22 @@ __device__ __forceinline__ void qs_emit_views(double x, uint32_t pos, const QsFe
 #pragma unroll 1
   for (uint32_t v = ft.view_begin; v < ft.view_end; ++v) {  // 1 - 2 views per column: unrolling only grows the code
     const uint32_t kind = (ft.view_kinds >> (4u * (v - ft.view_begin))) & 15u;  // no load: the descriptor carries the kinds
-    uint32_t cell;
-    if (kind == QV_CAT) {
-      // the category id; the node's bitset is consulted by the scorer
-      if (isn) cell = QS_CAT_NAN;
-      else if constexpr (F64) {
-        // LightGBM Tree::CategoricalDecision: int(fval) < 0 goes right, like NaN
-        const int iv = (int)x;  // v_cvt_i32_f64 saturates
-        cell = iv < 0 ? (uint32_t)QS_CAT_NAN : (iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv);
-      } else {
-        // XGBoost common::Decision: negative or >= 2^24 is an invalid category (goes left)
-        if (x < 0.0 || x >= 16777216.0) cell = QS_CAT_INVALID;
-        else {
-          const int iv = (int)x;
-          cell = iv >= (int)QS_CAT_BEYOND ? (uint32_t)QS_CAT_BEYOND : (uint32_t)iv;
-        }
-      }
-    } else if (kind == QV_NAN_ZERO) {
-      cell = isn ? ft.zero_bin : pos;  // MissingType::None: NaN is compared as 0.0
-    } else {
-      const bool miss = (kind >= QV_MISS_RIGHT) ? (isn || isz) : isn;
-      const uint32_t mval = (kind & 1) ? 0u : (uint32_t)QS_RIGHT;  // *_LEFT kinds are odd
-      cell = miss ? mval : pos;
-    }
-    emit(v, cell);
+    emit(v, qs_view_cell<F64>(kind, x, pos, ft.zero_bin, isn, isz));
+  }
+}
+
+// the same for a column whose views are compile-time constants (QsSig): the loop unrolls, the kinds fold, `zero_bin()` -
+// a scalar load - is asked for by QV_NAN_ZERO views only
+constexpr int QS_SIG_MAX_VIEWS = 6;
+template <bool F64, typename ZeroBin, typename Emit>
+__device__ __forceinline__ void qs_emit_views_sig(double x, uint32_t pos, const QsSig s, ZeroBin zero_bin, Emit emit) {
+  const bool isn = x != x;
+  const bool isz = x == 0.0;
+#pragma unroll
+  for (int i = 0; i < QS_SIG_MAX_VIEWS; ++i) {
+    if ((uint32_t)s.view_begin + i >= s.view_end) break;
+    const uint32_t kind = (s.view_kinds >> (4u * i)) & 15u;
+    emit((uint32_t)s.view_begin + i, qs_view_cell<F64>(kind, x, pos, kind == QV_NAN_ZERO ? (uint32_t)zero_bin() : 0u, isn, isz));
   }
 }
 

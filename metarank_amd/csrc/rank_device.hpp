@@ -698,6 +698,17 @@ __device__ __forceinline__ long long long_div(long long a, long long b) {
   return a / b;
 }
 
+// (Long / Long).toDouble - what the normalised rate does with the GLOBAL counters (RateFeature.scala:334-350).  The operands
+// are request-level, so the compiler scalarises the 64-bit division: ~300 scalar instructions per period and WAVEFRONT (3 % of
+// the c2 kernel's scalar instructions).  Counters are counts: for 0 <= a < 2^52, 0 < b < 2^52 the quotient is
+// trunc(fl(a / b)) exactly - a division the vector unit has.  Proof: let k = floor(a / b) <= a < 2^52; if b divides a the
+// quotient is exact; else a / b <= k + 1 - 1 / b, and fl() could reach k + 1 only if 1 / b <= half the spacing of doubles
+// below k + 1, i.e. b >= 2^(53 - e) with 2^e <= k + 1 - which puts a >= k b >= 2^52.  Anything else takes the integer path.
+__device__ __forceinline__ double long_div_to_double(long long a, long long b) {
+  if ((unsigned long long)a < (1ull << 52) && (unsigned long long)b < (1ull << 52)) return trunc((double)a / (double)b);
+  return (double)long_div(a, b);
+}
+
 // ---- sinks: where an assembled value goes.  A sink is driven by whole wavefronts: lanes without an item
 // (`active` false) run the same program on a missing record and write nothing.
 struct MatrixSink {   // row-major f64 matrix, ClickthroughQuery's layout
@@ -709,12 +720,28 @@ struct MatrixSink {   // row-major f64 matrix, ClickthroughQuery's layout
   }
 };
 
-template <bool F64>
+// What a sink knows about the forest at compile time.  QsDyn: nothing - every column's descriptor (QsFeature) is read from
+// memory, a column ahead, by scalar loads.  A kernel specialised for a model (jit.cpp) is also keyed by the forest's view
+// signature and passes a type with `is_static`, `n_feats`, `n_views`, `thr_cap` and a constexpr `QsSig operator[](col)`:
+// descriptor loads, view-kind decoding, the view loop, the staging loop and the in-order wait all fold into straight-line
+// code with immediate offsets (they were 9 k of the stock kernel's 54 k instructions - and, being run once per column
+// and wavefront, as many dynamic ones, two thirds of them scalar).
+struct QsDyn { static constexpr bool is_static = false; };
+template <typename QS> __device__ __forceinline__ uint32_t qs_thr_cap(const QsDev &q) {
+  if constexpr (QS::is_static) return QS::thr_cap;
+  else return q.thr_cap;
+}
+template <typename QS> __device__ __forceinline__ int qs_n_views(const QsDev &q) {
+  if constexpr (QS::is_static) return QS::n_views;
+  else return q.n_views;
+}
+
+template <bool F64, typename QS = QsDyn>
 struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row] u16
   QsDev q;
   uint16_t *dst;      // &cells[tile][0][row]
   int32_t *status;    // the request's status word
-  qs_lds_double *thr_lds;  // two staging buffers of q.thr_cap doubles, private to this wavefront
+  qs_lds_double *thr_lds;  // two staging buffers of thr_cap() doubles, private to this wavefront
   bool active;
   // A column's threshold table is searched in LDS (a per-lane binary search in global memory would be log2(T)
   // scattered wave-loads per column).  Asking for the descriptor, then for the table, then searching costs two trips
@@ -722,38 +749,68 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
   // columns arrive in increasing order; while column c is searched in buffer c & 1, the table of c + 1 is on its way
   // into the other buffer (global_load_lds: no registers, no ds_write) and the descriptor of c + 2 into scalar
   // registers (constant address space: s_load).
-  mutable QsFeature ft_cur = {}, ft_next = {};   // feats[next_col], feats[next_col + 1]
+  mutable QsFeature ft_cur = {}, ft_next = {};   // feats[next_col], feats[next_col + 1]   (QsDyn only)
   mutable int next_col = -1;                     // the column whose table has been requested
   mutable uint32_t newer = 0;                    // cell stores this wavefront issued AFTER that request (vmcnt retires in order)
 
-  __device__ __forceinline__ bool staged(const QsFeature &ft) const { return ft.thr_len <= q.thr_cap && ft.view_begin != ft.view_end; }
+  __device__ __forceinline__ uint32_t thr_cap() const { return qs_thr_cap<QS>(q); }
+  __device__ __forceinline__ int n_feats() const {
+    if constexpr (QS::is_static) return QS::n_feats;
+    else return q.n_feats;
+  }
+  __device__ __forceinline__ bool staged(const QsFeature &ft) const { return ft.thr_len <= thr_cap() && ft.view_begin != ft.view_end; }
+  __device__ __forceinline__ QsFeatureK desc(int col) const { return (QsFeatureK)(unsigned long long)q.feats + col; }
   __device__ __forceinline__ QsFeature feature(int col) const {
     QsFeature ft = {};
-    if (col < q.n_feats) {
-      const QsFeatureK f = (QsFeatureK)(unsigned long long)q.feats + col;
-      ft.thr_off = f->thr_off;
-      ft.thr_len = f->thr_len;
-      ft.zero_bin = f->zero_bin;
-      ft.view_begin = f->view_begin;
-      ft.view_end = f->view_end;
-      ft.view_kinds = f->view_kinds;
+    if (col < n_feats()) {
+      if constexpr (QS::is_static) {
+        // constants; thr_len is the table's length in whole chunks when it is staged (the staged search and the staging loop
+        // treat the +inf padding as the table's end) - the exact length is read where it matters (real_len below)
+        const QsSig s = QS{}[col];
+        ft.thr_off = s.thr_off;
+        ft.view_begin = s.view_begin;
+        ft.view_end = s.view_end;
+        ft.view_kinds = s.view_kinds;
+        const uint32_t padded = (uint32_t)s.chunks * QS_STAGE_CHUNK;
+        ft.thr_len = (padded <= QS::thr_cap || s.view_begin == s.view_end) ? (uint16_t)padded : desc(col)->thr_len;
+      } else {
+        const QsFeatureK f = desc(col);
+        ft.thr_off = f->thr_off;
+        ft.thr_len = f->thr_len;
+        ft.zero_bin = f->zero_bin;
+        ft.view_begin = f->view_begin;
+        ft.view_end = f->view_end;
+        ft.view_kinds = f->view_kinds;
+      }
     }
     return ft;
   }
   __device__ __forceinline__ void request(const QsFeature &ft, int col) const {  // table of `col` -> buffer col & 1
     if (!staged(ft)) return;
-    const double *src = q.thr + ft.thr_off + 2 * (threadIdx.x & 63);  // lane l: entries 2 l, 2 l + 1 of the chunk (runs past the
-    qs_lds_double *buf = thr_lds + (size_t)(col & 1) * q.thr_cap;     // table's end into the next one / the slack after the last)
+    // lane l: entries 2 l, 2 l + 1 of the chunk (runs past the table's end into the next one / the slack after the last).
+    // Address = a uniform base (kernel argument + the column's offset) + the lane's byte offset, the latter behind an empty
+    // `asm volatile`: with every offset a constant the addresses are invariant across the rounds of the item loop, and the
+    // compiler computed all of them up front - 2 registers per column, 44 spilled VGPRs - instead of one add per request.
+    uint32_t lane_off = (threadIdx.x & 63u) * 16u;
+    if constexpr (QS::is_static) asm volatile("" : "+v"(lane_off));
+    qs_lds_double *buf = thr_lds + (size_t)(col & 1) * thr_cap();
+    if constexpr (QS::is_static) {
+#pragma unroll
+      for (uint32_t k0 = 0; k0 < ft.thr_len; k0 += QS_STAGE_CHUNK)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(q.thr + ft.thr_off + k0) + lane_off),
+                                         (__attribute__((address_space(3))) void *)(buf + k0), 16, 0, 0);
+    } else {
 #pragma unroll 1
-    for (uint32_t k0 = 0; k0 < ft.thr_len; k0 += QS_STAGE_CHUNK)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k0),
-                                       (__attribute__((address_space(3))) void *)(buf + k0), 16, 0, 0);
+      for (uint32_t k0 = 0; k0 < ft.thr_len; k0 += QS_STAGE_CHUNK)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(q.thr + ft.thr_off + k0) + lane_off),
+                                         (__attribute__((address_space(3))) void *)(buf + k0), 16, 0, 0);
+    }
   }
   // before the first put of an item
   __device__ __forceinline__ void begin() const { restart(0); }
   __device__ __forceinline__ void restart(int col) const {
     ft_cur = feature(col);
-    ft_next = feature(col + 1);
+    if constexpr (!QS::is_static) ft_next = feature(col + 1);
     next_col = col;
     newer = 0;
     request(ft_cur, col);
@@ -773,7 +830,7 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
 
   // `col` is uniform across the wavefront; every lane of the wavefront takes part (lanes without an item write nothing)
   __device__ __forceinline__ void put(int col, double v) const {
-    if (col >= q.n_feats) {  // a column the forest does not know: nothing to bin, but still part of XGBoost's DMatrix row
+    if (col >= n_feats()) {  // a column the forest does not know: nothing to bin, but still part of XGBoost's DMatrix row
       if constexpr (!F64) {
         bool fin;
         (void)qs_prep<F64>(v, fin);
@@ -782,24 +839,38 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
       return;
     }
     if (col != next_col) restart(col);  // a column out of order
-    const QsFeature ft = ft_cur;
-    wait_landed();   // this column's table (requested one column ago, before that column's cell stores)
-    ft_cur = ft_next;
-    request(ft_cur, col + 1);   // into the other buffer: the search that used it is over
-    ft_next = feature(col + 2);
+    const QsFeature ft = QS::is_static ? feature(col) : ft_cur;
+    if (!QS::is_static || staged(ft)) wait_landed();   // this column's table (requested one column ago, before that column's cell stores)
+    // the next column's table into the other buffer: the search that used it is over.  `newer` restarts with every request
+    // issued (a static signature knows which columns have no staged table: nothing is requested, nothing waited for)
+    if constexpr (QS::is_static) {
+      const QsFeature nx = feature(col + 1);
+      request(nx, col + 1);
+      if (staged(nx)) newer = 0;
+    } else {
+      ft_cur = ft_next;
+      request(ft_cur, col + 1);
+      ft_next = feature(col + 2);
+      newer = 0;
+    }
     next_col = col + 1;
-    newer = 0;
     bool ok;
     const double x = qs_prep<F64>(v, ok);
     // XGBoost's DMatrix rejects the whole row for an inf in ANY column, split on or not - every scorer path does the same
     if (!ok && active) atomicOr(status, ST_XGB_INF);
     if (ft.view_begin == ft.view_end) return;  // the forest never splits on this column
-    const uint32_t pos = staged(ft) ? qs_bin_search_staged<F64>(thr_lds + (size_t)(col & 1) * q.thr_cap, ft.thr_len, x)
+    const QsFeatureK f = desc(col);
+    const uint32_t pos = staged(ft) ? qs_bin_search_staged<F64>(thr_lds + (size_t)(col & 1) * thr_cap(), ft.thr_len, x,
+                                                                [&]() -> uint32_t { return QS::is_static ? f->thr_len : ft.thr_len; })
                                     : qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
-    newer = ft.view_end - ft.view_begin;   // one store per view below (at least one lane of the wavefront has an item)
+    newer += (uint32_t)(ft.view_end - ft.view_begin);   // one store per view below (at least one lane of the wavefront has an item)
     uint16_t *d = dst;
     const bool act = active;
-    qs_emit_views<F64>(x, pos, ft, q.views, [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; });
+    auto emit = [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; };
+    if constexpr (QS::is_static)
+      qs_emit_views_sig<F64>(x, pos, QS{}[col], [&]() -> uint32_t { return f->zero_bin; }, emit);
+    else
+      qs_emit_views<F64>(x, pos, ft, q.views, emit);
   }
 };
 
@@ -1219,7 +1290,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
                 if (sink.active) atomicOr(&b.status[r], ST_ARITHMETIC);
                 thrown = true;
               } else {
-                const double ratio = (double)long_div(gbv[u], gtv[u]);
+                const double ratio = long_div_to_double(gbv[u], gtv[u]);
                 const double num = __dadd_rn(op.d0, (double)tv[u]);
                 const double den = __dadd_rn(__dmul_rn(op.d0, ratio), (double)bv[u]);
                 v = num / den;
@@ -1508,7 +1579,7 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
 
 // One lane per candidate across many workgroups (requests too large for one workgroup, tables that do not fit LDS):
 // tables in the HBM arena, written by a previous pre-pass launch.  Straight into the scorer's binned tile.
-template <bool F64, typename Prog>
+template <bool F64, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, const QsDev &q, uint16_t *cells) {
   __shared__ __align__(16) double s_thr[ASM_THREADS / 64][2 * QS_LDS_THR];
   const int gi0 = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
@@ -1517,7 +1588,7 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
   const int gi = active ? gi0 : b.item_hi - 1;     // lanes without an item ride along on a missing record
   const int r = (int)b.item_req[gi];
   const ReqDev rq = b.reqs[r];
-  CellSink<F64> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r],
+  CellSink<F64, QS> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * qs_n_views<QS>(q) * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r],
                      (qs_lds_double *)s_thr[threadIdx.x >> 6], active};
   assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
 }
@@ -1530,11 +1601,11 @@ __device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const
 }
 
 // the hot-path instance of rank_fused_body: straight into the scorer's binned tile
-template <bool F64, bool SPLIT = false, typename Prog>
+template <bool F64, bool SPLIT = false, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
                                                       int vals_cap, const QsDev &q, uint16_t *cells, int mode = 1) {
-  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, q.thr_cap, mode, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
-    return CellSink<F64>{q, cells + (size_t)(gi / QS_TILE_ROWS) * q.n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
+  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
+    return CellSink<F64, QS>{q, cells + (size_t)(gi / QS_TILE_ROWS) * qs_n_views<QS>(q) * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
   });
 }
 
@@ -1547,21 +1618,21 @@ __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const 
 // Dynamic LDS: [slab: slab_bytes = V x 256][the request's status word, 16 B][the regions of rank_fused_body | afterwards:
 // leaf values, exit-leaf indices, sort keys of the scoring phase].  The status word lives in LDS too (the batch view the
 // assembly sees has its `status` pointer bent there): no global atomic, nothing to wait for before it is copied out.
-template <bool F64, typename Prog>
+template <bool F64, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                                               const QsDev &q, const QsForestDev &f, int mode, const OneOut &out) {
   extern __shared__ __align__(16) uint8_t smem_base[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
-  const uint32_t slab_bytes = (uint32_t)f.n_views * (QS_TILE_ROWS * 2);
+  const uint32_t slab_bytes = (uint32_t)qs_n_views<QS>(q) * (QS_TILE_ROWS * 2);
   for (uint32_t i = tid; i < slab_bytes / 4 + 4; i += nthr) ((uint32_t *)smem_base)[i] = 0u;  // rows past the request's last candidate; the status word
   int32_t *s_status = (int32_t *)(smem_base + slab_bytes);
   BatchDev bl = b;
   bl.status = s_status - r;   // &bl.status[r] is the LDS word
   __syncthreads();
-  rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, q.thr_cap, mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
-    return CellSink<F64>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active};
+  rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
+    return CellSink<F64, QS>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active};
   }, slab_bytes + 16);
   // (qs_score_tile_split starts with a barrier: the slab is complete, the assembly's LDS regions are free)
   constexpr int TREE_LEAF_BYTES = QS_LEAVES * (F64 ? 8 : 4);
@@ -1598,20 +1669,20 @@ __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &pr
 // the assembly waits on memory (55 % of a wavefront's life, profiles/r03_i), the forest is pure instruction issue; as two
 // kernels they met on a CU only by accident of two streams (the assembly kernel's workgroups take the whole LDS).
 // Dynamic LDS: max(rank_fused_body's regions, [slab V x 256][16][leaf values, exit-leaf indices of 8 x nw trees][128 sort keys]).
-template <bool F64, typename Prog>
+template <bool F64, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void rank_fused_score_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                                                       const QsDev &q, const QsForestDev &f, uint16_t *cells) {
   extern __shared__ __align__(16) uint8_t smem_base[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = blockIdx.x;
   const ReqDev rq = b.reqs[r];
-  const uint32_t slab_bytes = (uint32_t)f.n_views * (QS_TILE_ROWS * 2);
-  uint16_t *tile = cells + (size_t)r * f.n_views * QS_TILE_ROWS;
+  const uint32_t slab_bytes = (uint32_t)qs_n_views<QS>(q) * (QS_TILE_ROWS * 2);
+  uint16_t *tile = cells + (size_t)r * qs_n_views<QS>(q) * QS_TILE_ROWS;
   // rows past the request's last candidate (their cells only have to be harmless)
-  for (uint32_t i = tid; i < (uint32_t)f.n_views * QS_TILE_ROWS; i += nthr)
+  for (uint32_t i = tid; i < (uint32_t)qs_n_views<QS>(q) * QS_TILE_ROWS; i += nthr)
     if ((int)(i % QS_TILE_ROWS) >= rq.n_items) tile[i] = 0;
-  rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, q.thr_cap, 1, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
-    return CellSink<F64>{q, tile + (gi - rq.item_begin), &b.status[rr], s_thr, active};
+  rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), 1, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
+    return CellSink<F64, QS>{q, tile + (gi - rq.item_begin), &b.status[rr], s_thr, active};
   });
   // the tile has reached L2 (this CU's L1 holds none of its lines: nothing has read them), every table is dead
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1654,11 +1725,11 @@ __device__ __forceinline__ void rank_fused_score_body(const StoreDev &st, const 
 // announces `exited` and leaves (a persistent kernel must never outlive its use: hipFree and friends wait for it); the host
 // relaunches it with the next request.  If a request slips in between the announcement and the exit it is still served
 // (device: store exited, fence, read seq; host: store seq, fence, read exited - one side sees the other).
-template <bool F64, typename Prog>
+template <bool F64, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &s) {
   extern __shared__ __align__(16) uint8_t smem_base[];
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const uint32_t slab_bytes = (uint32_t)f.n_views * (QS_TILE_ROWS * 2);
+  const uint32_t slab_bytes = (uint32_t)qs_n_views<QS>(q) * (QS_TILE_ROWS * 2);
   volatile uint32_t *s_word = (volatile uint32_t *)(smem_base + slab_bytes + 8);   // [0] seq | STOP, [1] leave after this request
   uint32_t last = s.last_seq;
   unsigned long long idle_since = wall_clock64();
@@ -1719,7 +1790,7 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long t_in = wall_clock64();
-    rank_one_body<F64>(st, prog, b, tab_entries, (int)vals_cap, q, f, (int)mode, s.out);
+    rank_one_body<F64, QS>(st, prog, b, tab_entries, (int)vals_cap, q, f, (int)mode, s.out);
     const unsigned long long t_ranked = wall_clock64();
     __threadfence_system();   // every lane's results are in host memory before the acknowledgement
     __syncthreads();

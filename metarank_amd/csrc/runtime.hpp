@@ -115,6 +115,7 @@ struct Switches {
   std::string jit_defines;     // MRK_JIT_DEFINES: macros prepended to the specialised kernels' source (experiments)
   bool thr_stage = true;       // MRK_THR_STAGE=0: the assembly kernels search threshold tables in global memory instead of staging them in LDS (experiments)
   bool jit_shipped = true;     // MRK_JIT_SHIPPED=0: ignore the code objects shipped next to the library (tests of the compile paths)
+  bool jit_sig = true;         // MRK_JIT_SIG=0: the specialised kernels are keyed by the program only and read the forest's column descriptors from memory (A/B of the view-signature folding)
   bool jit_record_regs = true; // MRK_JIT_REGS=0: the specialised kernel reads the candidate's record cell by cell instead of keeping it in registers
   std::string jit_cache_dir;   // MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else ~/.cache/mrk_jit; "" / "off": none
   int big_sort_cap = 4096;     // MRK_BIG_SORT_CAP: pairs a bucket of the multi-workgroup sort orders in LDS (smaller: tests reach the global-memory path)
@@ -191,6 +192,7 @@ struct mrk_model {
   mrk::DevBuf d_image, d_trees, d_chunks, d_cat;
   // bit-vector image (forests of <= 16-leaf trees); qs.ok == false => tree-walk kernel only
   mrk::PackedForestQS qs;
+  mrk::QsSignature qs_sig;             // the image's view signature (forest.hpp): part of the key of the specialised assembly kernels
   mrk::DevBuf d_qs_nodes, d_qs_leaves, d_qs_thr, d_qs_feats, d_qs_views, d_qs_catnodes, d_qs_cat;
 };
 

@@ -505,10 +505,8 @@ QsDev qs_device_view(const mrk_model *m) {
   q.thr = m->d_qs_thr.as<double>();
   q.n_feats = (int32_t)m->qs.feats.size();
   q.n_views = (int32_t)m->qs.views.size();
-  uint32_t longest = 1;
-  for (const QsFeature &f : m->qs.feats)
-    if (f.view_begin != f.view_end && f.thr_len <= QS_LDS_THR) longest = std::max<uint32_t>(longest, f.thr_len);
-  q.thr_cap = switches().thr_stage ? (longest + QS_STAGE_CHUNK - 1) / QS_STAGE_CHUNK * QS_STAGE_CHUNK : 0u;
+  static_assert(QS_LDS_THR == 256u, "qs_stage_cap (forest.cpp) stages tables of up to QS_LDS_THR entries");
+  q.thr_cap = switches().thr_stage ? qs_stage_cap(m->qs) : 0u;
   return q;
 }
 

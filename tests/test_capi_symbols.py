@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_abi_version_and_error_paths_without_gpu():
     L = _native.lib()
-    assert L.mrk_abi_version() == 6
+    assert L.mrk_abi_version() == 7
     # null arguments are rejected before any device work
     assert L.mrk_model_predict_f64(None, None, 1, 1, None) == _native.ERR_INVALID_ARG
     assert b"null model" in L.mrk_last_error()

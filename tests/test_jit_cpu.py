@@ -30,9 +30,9 @@ def test_source_carries_the_program_as_constants():
     text = src.decode()
     # 18 features of the stock Ranklens model -> 18 ops, 24 matrix columns, 4 interacted_with fields + 5 diversity reductions
     assert "n_ops = 18, n_prep = 9, dim = 24" in text
-    assert "struct JitOps" in text and "rank_fused_cells_body<true, false>" in text and "mrk_jit_rank_cells_split" in text and "#include" not in text
+    assert "struct JitOps" in text and "rank_fused_cells_body<true, false, mrk::QsDyn>" in text and "mrk_jit_rank_cells_split" in text and "#include" not in text
     rc, src32 = specialize(cfg, 0, f64=0)
-    assert rc == 0 and b"rank_fused_cells_body<false, false>" in src32
+    assert rc == 0 and b"rank_fused_cells_body<false, false, mrk::QsDyn>" in src32
     # the normalised rate's weight travels as an exact hexadecimal literal (10.0)
     assert "0x1.4p+3" in text
     # what the library compiles by itself is ONE kernel per translation unit (the kernel a batch shape needs, 10 - 20 s of
@@ -46,6 +46,63 @@ def test_source_carries_the_program_as_constants():
         one = one.decode().replace("\n", "")
         assert rc == 0 and name in one and not any(o in one for o in names if o != name), name
     assert specialize(cfg, 0 | (9 << 8))[0] == _native.ERR_INVALID_ARG
+
+
+def specialize_for_model(cfg, backend, blob, what, model=b"xgboost"):
+    lib = _native.lib()
+    js = json.dumps(cfg).encode()
+    need = C.c_size_t(0)
+    rc = lib.mrk_config_specialize_for_model(js, len(js), model, backend, blob, len(blob), what, None, 0, C.byref(need))
+    if rc == _native.ERR_INVALID_ARG and need.value:
+        buf = (C.c_uint8 * need.value)()
+        rc = lib.mrk_config_specialize_for_model(js, len(js), model, backend, blob, len(blob), what, buf, need.value, C.byref(need))
+        return rc, bytes(buf[:need.value])
+    return rc, b""
+
+
+def test_source_carries_the_forests_view_signature():
+    """The kernels that write the scorer's tile are keyed by the forest too: per column its views and the chunks of its
+    threshold table, as constants (forest.hpp QsSignature) - not the thresholds."""
+    import re
+
+    from workloads import synth
+
+    cfg = ranklens.ranklens_config()
+    blob = synth.synthetic_lgbm_model(n_trees=40, n_features=24, missing="per_feature", cat_features=[7], cat_prob=0.05)
+    rc, src = specialize_for_model(cfg, 0, blob, 0 | (1 << 8))
+    assert rc == 0, _native.lib().mrk_last_error()
+    text = src.decode()
+    assert "struct JitQs" in text and "rank_fused_cells_body<true, false, mrk::JitQs>" in text and "n_feats = 24" in text
+    rows = re.search(r"struct JitSigRows \{.*?= \{(.*?)\};", text, re.S).group(1)
+    assert rows.count("{") == 24
+    # the f64-matrix kernel bins nothing: no signature in its translation unit
+    rc, msrc = specialize_for_model(cfg, 0, blob, 0 | (3 << 8))
+    assert rc == 0 and b"JitQs" not in msrc
+    # another forest over the same columns with the same missing-value kinds and table sizes: the same text, hence the same kernel
+    blob2 = synth.synthetic_lgbm_model(n_trees=40, n_features=24, missing="per_feature", cat_features=[7], cat_prob=0.05, seed=11)
+    rc, src2 = specialize_for_model(cfg, 0, blob2, 0 | (1 << 8))
+    assert rc == 0
+    same_sig = re.search(r"struct JitSigRows \{.*?= \{(.*?)\};", src2.decode(), re.S).group(1) == rows
+    assert (src2 == src) == same_sig
+    # XGBoost: f32 precision follows from the backend
+    xblob = synth.synthetic_xgb_model(n_trees=10, n_features=24, depth=3)
+    rc, xsrc = specialize_for_model(cfg, 1, xblob, 0 | (1 << 8))
+    assert rc == 0 and b"rank_fused_cells_body<false, false, mrk::JitQs>" in xsrc
+    assert specialize_for_model(cfg, 0, b"not a model", 0)[0] == _native.ERR_PARSE
+    assert specialize_for_model(cfg, 7, blob, 0)[0] == _native.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("backend", [0, 1])
+def test_hiprtc_compiles_the_signature_keyed_kernels(backend):
+    from workloads import synth
+
+    cfg = ranklens.ranklens_config()
+    blob = (synth.synthetic_lgbm_model(n_trees=40, n_features=24, missing="per_feature", cat_features=[7], cat_prob=0.05) if backend == 0
+            else synth.synthetic_xgb_model(n_trees=10, n_features=24, depth=3))
+    for kernel in (1, 5):   # the kernel of full batches, mrk_rank's one-launch kernel
+        rc, code = specialize_for_model(cfg, backend, blob, 1 | (kernel << 8))
+        assert rc == 0, _native.lib().mrk_last_error()
+        assert code[:4] == b"\x7fELF" and b"gfx950" in code
 
 
 def test_unknown_model_and_bad_arguments():

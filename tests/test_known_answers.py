@@ -97,6 +97,29 @@ def test_rate_normalized_long_division(mk):
     eq(b.matrix(ranking_event(["p1"])), [[0.11827956989247312, 0.11827956989247312]])
 
 
+def test_rate_normalized_long_division_at_the_edges_of_the_fast_path(mk):
+    """(Long / Long).toDouble of the global counters: the device takes the quotient of the doubles, truncated, where that is
+    exact (0 <= a, 0 < b, both below 2^52: rank_device.hpp long_div_to_double) and the integer division elsewhere - the cases
+    sit on both sides of that boundary, on quotients one below a multiple, on negative operands and on Long.MinValue / -1."""
+    def jdiv(a, b):  # Scala Long / Long: truncates toward zero, wraps at Long.MinValue / -1
+        q = abs(a) // abs(b) * (1 if (a < 0) == (b < 0) else -1)
+        return (q + 2 ** 63) % 2 ** 64 - 2 ** 63
+
+    big = 2 ** 52
+    cases = [(93, 10), (big - 1, 1), (big - 1, big - 1), (big - 2, big - 1), (big - 1, 3), (big, 3), (big - 1, big), (big + 1, 7), (2 ** 53 + 1, 3),
+             (3 * (2 ** 50) - 1, 3), ((2 ** 26 + 1) * (2 ** 25 - 1) - 1, 2 ** 25 - 1), (2 ** 62 + 12345, 2 ** 31 + 7), (-93, 10), (93, -10), (-(2 ** 63), -1),
+             (-(2 ** 63), 1), (2 ** 63 - 1, 2), (0, 5), (4, 5), (5, 5)]
+    for gimp, gclick in cases:
+        b = mk(single_feature_config(dict(RATE, normalize={"weight": 10})))
+        b.put_periodic("item=p1/ctr_click", [1, 2])
+        b.put_periodic("item=p1/ctr_impression", [3, 5])
+        b.put_periodic("global/ctr_click_norm", [gclick, 10])
+        b.put_periodic("global/ctr_impression_norm", [gimp, 93])
+        ratio = float(jdiv(gimp, gclick))
+        exp = (10.0 + 1.0) / (10.0 * ratio + 3.0)
+        eq(b.matrix(ranking_event(["p1"])), [[exp, (10.0 + 2.0) / (10.0 * 9.0 + 5.0)]])
+
+
 def test_rate_normalized_zero_global_clicks_throws(mk):
     b = mk(single_feature_config(dict(RATE, normalize={"weight": 10})))
     b.put_periodic("item=p1/ctr_click", [1, 1])

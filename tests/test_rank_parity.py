@@ -167,7 +167,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
     import os
 
     hip = HipBackend(ranklens.ranklens_config(), "xgboost")
-    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT", "MRK_FUSED_SPLIT", "MRK_FUSED_SLICES", "MRK_FUSED_THREADS")}
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT", "MRK_JIT_SIG", "MRK_FUSED_SPLIT", "MRK_FUSED_SLICES", "MRK_FUSED_THREADS")}
     try:
         load(hip)
         reqs = ranklens.generate_requests(30, 100, N_ITEMS, N_SESS, seed=21)
@@ -190,9 +190,12 @@ def test_assembly_paths_agree(oracle_c2, kind):
         # (fused, cells, jit): the hot path runs the kernel specialised for this model's feature list at run time
         # ("require": a hiprtc failure is an error, not a fall-back); "0" = the generic kernel that interprets the program
         # cells "0" + jit "require": the specialised kernel's f64-matrix form (the path of models scored by the tree walk)
-        for fused, cells, jit in (("1", "1", "require"), ("1", "1", "0"), ("1", "0", "require"), ("1", "0", "0"), ("0", "1", "require"), ("0", "1", "0"), ("0", "0", "0")):
+        # sig "0": the specialised kernel keyed by the program only (it reads the forest's column descriptors from memory - what
+        # serves a retrained model while the kernel keyed by its view signature compiles); default: keyed by both
+        for fused, cells, jit, sig in (("1", "1", "require", "1"), ("1", "1", "require", "0"), ("1", "1", "0", "1"), ("1", "0", "require", "1"), ("1", "0", "0", "1"),
+                                       ("0", "1", "require", "1"), ("0", "1", "require", "0"), ("0", "1", "0", "1"), ("0", "0", "0", "1")):
             if True:
-                os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = fused, cells, jit
+                os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"], os.environ["MRK_JIT_SIG"] = fused, cells, jit, sig
                 M.reload_switches()
                 batch = hip.ranker.prepare("xgboost", reqs)
                 batch.run(hip.booster)

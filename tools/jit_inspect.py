@@ -3,7 +3,7 @@
 host-only entry point mrk_config_specialize (hiprtc, gfx950) and prints each kernel's register / scratch / LDS use and
 code size from the code object's metadata (llvm-readelf --notes).
 
-    python tools/jit_inspect.py [c2|c3|c5] [--f32] [--save out.co] [--asm out.s]
+    python tools/jit_inspect.py [c2|c3|c5] [--f32] [--model] [--kernel k] [--save out.co] [--asm out.s]
 """
 import ctypes as C
 import json
@@ -29,11 +29,43 @@ def specialise(cfg: dict, model: str, f64: bool, what: int) -> bytes:
     return bytes(buf[:need.value])
 
 
+def bench_like_model(cfg: dict, wl: str) -> bytes:
+    """A forest shaped like bench.py's (500 leaf-wise 16-leaf trees, thresholds at the columns' quantiles, one missing type per
+    column, a categorical column): the sample matrix comes from the CPU oracle over a small generated state."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from backends import OracleBackend
+    from workloads import synth
+
+    orc = OracleBackend(cfg, "xgboost")
+    ranklens.load_state(orc, ranklens.generate_state(2000, 200, c3=(wl == "c3")))
+    sample = np.concatenate([orc.matrix(ev) for ev in ranklens.generate_requests(16, 100, 2000, 200, seed=ranklens.SEED + 99)])
+    return synth.synthetic_lgbm_model(n_trees=500, n_features=sample.shape[1], num_leaves=16, max_depth=8, quantiles=ranklens.column_quantiles(sample),
+                                      cat_features=[7], cat_prob=0.007, missing="per_feature")
+
+
+def specialise_for_model(cfg: dict, model: str, blob_model: bytes, what: int) -> bytes:
+    lib = _native.lib()
+    blob = json.dumps({"features": cfg["features"], "models": cfg["models"]}).encode()
+    need = C.c_size_t(0)
+    lib.mrk_config_specialize_for_model(blob, len(blob), model.encode(), 0, blob_model, len(blob_model), what, None, 0, C.byref(need))
+    buf = (C.c_uint8 * need.value)()
+    _native.check(lib.mrk_config_specialize_for_model(blob, len(blob), model.encode(), 0, blob_model, len(blob_model), what, buf, need.value, C.byref(need)))
+    return bytes(buf[:need.value])
+
+
 def main():
     wl = next((a for a in sys.argv[1:] if not a.startswith("-")), "c2")
     f64 = "--f32" not in sys.argv
     cfg = {"c2": ranklens.ranklens_config, "c3": ranklens.c3_config, "c5": ranklens.c5_config}[wl]()
-    code = specialise(cfg, "xgboost", f64, 1)
+    what = 1
+    if "--kernel" in sys.argv:   # one kernel's translation unit (0 the workgroup-per-request kernel, ... as in jit.hpp)
+        what |= (int(sys.argv[sys.argv.index("--kernel") + 1]) + 1) << 8
+    if "--model" in sys.argv:    # keyed by the view signature of a bench-like LightGBM forest too (the kernels the benchmark runs)
+        code = specialise_for_model(cfg, "xgboost", bench_like_model(cfg, wl), what)
+    else:
+        code = specialise(cfg, "xgboost", f64, what)
     path = "/tmp/mrk_jit_inspect.co"
     if "--save" in sys.argv:
         path = sys.argv[sys.argv.index("--save") + 1]

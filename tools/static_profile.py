@@ -27,9 +27,17 @@ lib = _native.lib()
 js = json.dumps(cfg).encode()
 need = C.c_size_t(0)
 what = 0 | (kernel << 8)
-lib.mrk_config_specialize(js, len(js), b"xgboost", 1, what, None, 0, C.byref(need))
-buf = (C.c_uint8 * need.value)()
-assert lib.mrk_config_specialize(js, len(js), b"xgboost", 1, what, buf, need.value, C.byref(need)) == 0
+if os.environ.get("MRK_STATIC_MODEL"):   # keyed by the view signature of a bench-like forest too (tools/jit_inspect.py --model)
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from jit_inspect import bench_like_model
+    mb = bench_like_model(cfg, wl)
+    lib.mrk_config_specialize_for_model(js, len(js), b"xgboost", 0, mb, len(mb), what, None, 0, C.byref(need))
+    buf = (C.c_uint8 * need.value)()
+    assert lib.mrk_config_specialize_for_model(js, len(js), b"xgboost", 0, mb, len(mb), what, buf, need.value, C.byref(need)) == 0
+else:
+    lib.mrk_config_specialize(js, len(js), b"xgboost", 1, what, None, 0, C.byref(need))
+    buf = (C.c_uint8 * need.value)()
+    assert lib.mrk_config_specialize(js, len(js), b"xgboost", 1, what, buf, need.value, C.byref(need)) == 0
 tmp = tempfile.mkdtemp(prefix="mrk_static_")
 tu = os.path.join(tmp, "tu.hip")
 with open(tu, "wb") as f:
@@ -79,3 +87,5 @@ for f, c in per_func.most_common(20):
 print("lines:")
 for ln, c in per_line.most_common(15):
     print(f"  {ln:5d} {c:5d}  {func_of(ln):22s} {src[ln - 1].strip()[:100]}")
+if os.environ.get("MRK_STATIC_KEEP"):   # the annotated disassembly, for a closer look
+    open(os.environ["MRK_STATIC_KEEP"], "w").write(asm)
