@@ -338,6 +338,14 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
   if (b.n_req <= 0) return;
   int mode = (op_split > 1 ? op_split : 1) | ((slices > 1 ? slices : 1) << 8);  // rank_device.hpp rank_fused_body
   const unsigned grid = (unsigned)b.n_req * (unsigned)(slices > 1 ? slices : 1);
+  // A sliced batch (few large requests: c3) used to run every request's pre-pass once per SLICE - each slice re-read the
+  // session's items (c3 traffic 3.05x the algorithmic bytes) and spent a quarter of its life building tables its neighbour
+  // built too.  Now the pre-pass of the whole batch runs first, once per request (its tables built in LDS, copied to the
+  // arena), and a slice copies its request's finished tables into its own LDS.  MRK_SLICE_PREPASS=0: the old way.
+  if (slices > 1 && prog.n_prep > 0 && switches().slice_prepass) {
+    launch_prepass(ctx, st, prog, b, tab_entries);
+    mode |= 1 << 16;
+  }
   size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u);
   if (switches().fused_lds_min > 0) lds = std::max(lds, (size_t)switches().fused_lds_min);  // experiments: cap the kernel's residency (co-residency with the scorer)
   {

@@ -1523,18 +1523,21 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 // Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
 // Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][PREP_INTS ints]
 //              [threshold staging: 2 buffers x thr_cap x 8 B per wavefront]
-// `mode` = op_split | slices << 8.
+// `mode` = op_split | slices << 8 | tables_ready << 16.
 //   op_split (1 | 2 | 4; SPLIT kernels only): the workgroup's lanes are op_split copies of the item lanes (see op_owner).
 //   slices (>= 1; SPLIT kernels only): a request is covered by `slices` workgroups; each runs the request's pre-pass (its tables are private,
 //     in its own LDS) and assembles one slice of the candidates.  A batch of few large requests - 384 requests x 1 000
 //     candidates is 1.5 workgroups per CU, each looping four times over its lanes - fills the chip this way: the
 //     pre-pass is paid `slices` times, the dependent chain of a workgroup shrinks by the same factor.
+//   tables_ready (SPLIT kernels only; round 4): ... unless the host ran the pre-pass of the whole batch first (prepass_kernel, one
+//     workgroup per request): then a slice only copies its request's finished tables from the arena into its LDS.
 // lds_skip: bytes at the start of the dynamic LDS that belong to the caller (the one-launch kernel keeps the scorer's slab there).
 template <bool SPLIT, typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
                                                 int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink, uint32_t lds_skip = 0) {
   const int op_split = SPLIT ? ((mode & 255) > 1 ? (mode & 255) : 1) : 1;
-  const int slices = SPLIT ? ((mode >> 8) > 1 ? (mode >> 8) : 1) : 1;   // (the plain kernel keeps its registers for the ops)
+  const int slices = SPLIT ? (((mode >> 8) & 255) > 1 ? ((mode >> 8) & 255) : 1) : 1;   // (the plain kernel keeps its registers for the ops)
+  const bool tables_ready = SPLIT && ((mode >> 16) & 1) != 0;
   extern __shared__ __align__(16) uint8_t smem_base[];
   uint8_t *smem = smem_base + lds_skip;
   unsigned long long *s_tab = (unsigned long long *)smem;
@@ -1557,7 +1560,17 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
 #ifdef MRK_PHASE_CLOCKS
   sc.clk = clock64();
 #endif
-  prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
+  if (tables_ready) {
+    // a sliced batch whose pre-pass ran ONCE per request in a launch of its own (prepass_kernel: results in b.prep_out - just
+    // copied -, tables in the arena): every slice copies the request's tables into its LDS instead of building them again
+    uint32_t n_ent = 0;
+    for (int e = 0; e < prog.n_prep; ++e) n_ent = max(n_ent, s_po[e].tab_off - (uint32_t)rq.arena_begin + s_po[e].tab_cap);
+    const unsigned long long *src = b.arena + (size_t)rq.arena_begin;
+    for (uint32_t i = threadIdx.x; i < n_ent; i += blockDim.x) s_tab[i] = src[i];
+    __syncthreads();
+  } else {
+    prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
+  }
   const int og = (int)threadIdx.x / item_lanes, il = (int)threadIdx.x % item_lanes;
   for (int base = slice_lo; base < slice_hi; base += item_lanes) {
     const int i = base + il;
