@@ -380,7 +380,12 @@ def main():
     # this run's shape.
     traffic = traffic_raw = None
     valu_issue = {}
+    pmc_stale = None   # None: no committed counters for this shape; True: they were collected on OTHER code and are not quoted
     jit_on = os.environ.get("MRK_RANK_JIT", "1") not in ("0",)
+    # WHICH code this run measured: the library's source digest and the key (hash of the translation unit) of every
+    # specialised kernel loaded for the model.  tools/pmc_summary.py copies the same object out of the profiled run's
+    # output into each committed summary; counters of another build or another kernel are dropped here, not quoted.
+    provenance = {"build_id": M.lib().mrk_build_id().decode(), "jit_kernels": ranker.kernel_keys(model_name)}
     # the kernel behind `dominant` in the newest committed summary of this workload (names change with the batch shape:
     # mrk_jit_rank_cells / _split / mrk_jit_assemble_cells; qs_score_wave_kernel / qs_score_split_kernel)
     prefixes = {"rank_fused": ("mrk_jit_rank_fused_score", "rank_fused_score"), "score": ("qs_score",), "assemble": ("mrk_jit_rank_cells", "mrk_jit_assemble_cells") if jit_on else ("rank_fused_cells", "assemble_cells")}
@@ -390,10 +395,18 @@ def main():
         shape_ok = n_gpus == 1 and args.backend == "lightgbm" and (
             (wl == "c2" and args.requests == 3840) or (wl == "c3" and args.requests == 384) or (wl == "c4x" and args.items == 4_000_000 and args.clones == 79))
         files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_{wl}_summary.json")), reverse=True)
-        if files and shape_ok:
-            summary = json.load(open(files[0]))
+        summary = json.load(open(files[0])) if files and shape_ok else None
+        if summary is not None:
+            prov = summary.get("_provenance") or {}
+            pj, cj = prov.get("jit_kernels") or {}, provenance["jit_kernels"]
+            both = set(pj) & set(cj)   # (a profiled run may have loaded fewer kernels than this one: the ones both ran must be the same code)
+            same_code = prov.get("build_id") == provenance["build_id"] and all(pj[k] == cj[k] for k in both) and (bool(both) or not cj)
+            pmc_stale = not same_code
+            if not same_code:
+                summary = None
+        if summary is not None:
             for name, d in summary.items():
-                if name.startswith(prefixes.get(dominant, ())) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                if name.startswith(prefixes.get(dominant, ())) and isinstance(d, dict) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                     pmc_kernel = name
                     traffic_raw = (d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
                     traffic = (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
@@ -404,7 +417,7 @@ def main():
             # 2.4 GHz; frac = that floor / this run's measured launch time.
             for kname in ("assemble", "score", "rank_fused"):
                 for name, d in summary.items():
-                    if kname in kernels and name.startswith(prefixes[kname]) and "SQ_INSTS_VALU" in d:
+                    if kname in kernels and name.startswith(prefixes[kname]) and isinstance(d, dict) and "SQ_INSTS_VALU" in d:
                         floor_ms = d["SQ_INSTS_VALU"]["mean"] * 4.0 / 1024.0 / 2.4e9 * 1e3
                         valu_issue[kname] = {"kernel": name, "valu_wave_instructions": d["SQ_INSTS_VALU"]["mean"], "floor_ms": floor_ms,
                                              "avg_launch_ms": kernels[kname]["avg_ms"], "frac": floor_ms / kernels[kname]["avg_ms"],
@@ -415,7 +428,7 @@ def main():
     dur_s = kernels[dominant]["avg_ms"] * 1e-3
     achieved = alg[dominant] / dur_s / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "traffic_kernel": pmc_kernel, "algorithmic_bytes_per_launch": alg[dominant],
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "traffic_kernel": pmc_kernel, "pmc_stale": pmc_stale, "algorithmic_bytes_per_launch": alg[dominant],
                 "bytes_per_item": b_item, "items_per_launch": my_items, "model_bytes_per_launch": model_bytes,
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
                 # `frac` prices the SURVEY 8(d) bytes against HBM; when the item table fits the 256 MiB Infinity Cache none of
@@ -665,6 +678,7 @@ def main():
             "kernels": kernels,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "provenance": provenance,
         }
         print(json.dumps(out), flush=True)
     for bt in batches:

@@ -63,6 +63,8 @@ typedef struct mrk_batch mrk_batch;   /* a prepared, device-resident request bat
 /* ---------------------------------------------------------------- lifecycle */
 
 int mrk_abi_version(void);
+/* identifies the library's SOURCES (hex digest over csrc/ and this header, fixed when the library is built) */
+const char *mrk_build_id(void);
 const char *mrk_last_error(void);
 
 /* device_ids[0]: the HIP ordinal this context drives; n_devices must be 1 - multi-GPU is one context per device (one
@@ -152,6 +154,11 @@ int mrk_config_specialize_for_model(const char *json, size_t len, const char *mo
                                     size_t model_len, int what, uint8_t *out, size_t cap, size_t *needed);
 int mrk_config_precompile_for_model(const char *json, size_t len, const char *model_name, int backend, const uint8_t *model_bytes,
                                     size_t model_len, unsigned kernel_mask, const char *dir, int *out_compiled);
+/* Which specialised kernels of this model are loaded, as text: one line "<kernel name> <key> program|program+forest" each;
+ * <key> = the stem of the kernel's cache file (hash and size of its translation unit, compiler version).  With mrk_build_id
+ * this is what a measurement records to say WHICH code it measured (bench.py `provenance`).  MRK_ERR_INVALID_ARG with *needed
+ * set (bytes incl. the terminating 0) when `out` is NULL or `cap` too small. */
+int mrk_config_kernel_keys(mrk_ctx *ctx, const char *model_name, char *out, size_t cap, size_t *needed);
 /* Serve.maybeWarmup for the kernels: waits until the background compiles of this model's kernels that are under way have
  * finished (the next launch uses them).  A host calls it before it opens its port; nothing on the request path waits. */
 int mrk_config_warmup(mrk_ctx *ctx, const char *model_name);

@@ -54,14 +54,33 @@ def embed_jit_sources() -> str:
     return path
 
 
+def write_build_id() -> str:
+    """csrc/build_id.inc: a string literal with the digest of every source of the library (csrc/ without the generated
+    files, include/mrk.h) - what mrk_build_id() returns.  Generated, not committed; only capi.cpp includes it."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".cpp", ".hip", ".hpp")):
+            h.update(f.encode() + b"\0" + open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(REPO, "include", "mrk.h"), "rb").read())
+    out = '"' + h.hexdigest()[:16] + '"\n'
+    path = os.path.join(CSRC, "build_id.inc")
+    if not os.path.exists(path) or open(path).read() != out:
+        with open(path, "w") as f:
+            f.write(out)
+    return path
+
+
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every source into metarank_amd/libmrk_hip.so (in-tree).  One object per source under
     metarank_amd/build/ (compiled in parallel, rebuilt when the source or any header is newer), then one link."""
     from concurrent.futures import ThreadPoolExecutor
 
     embed_jit_sources()
+    build_id = write_build_id()
     srcs = sources()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + [os.path.join(REPO, "include", "mrk.h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc")) and f != "build_id.inc"] + [os.path.join(REPO, "include", "mrk.h")]
     hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -77,7 +96,8 @@ def build(force: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+        newest = max(os.path.getmtime(src), hdr_time, os.path.getmtime(build_id) if src.endswith("capi.cpp") else 0)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
             subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
             return obj, True
         return obj, False
@@ -125,6 +145,8 @@ class mrk_item_ids(C.Structure):
 _V, _I, _P, _S = C.c_void_p, C.c_int, C.c_void_p, C.c_char_p
 SIGNATURES = {
     "mrk_abi_version": (_I, []),
+    "mrk_build_id": (_S, []),
+    "mrk_config_kernel_keys": (_I, [_P, _S, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mrk_last_error": (_S, []),
     "mrk_init": (_I, [_P, _I, C.POINTER(_V)]),
     "mrk_shutdown": (None, [_V]),

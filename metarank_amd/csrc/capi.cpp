@@ -178,6 +178,11 @@ mrk_ctx::~mrk_ctx() { mrk::free_rank_state(this); }
 extern "C" {
 
 int mrk_abi_version(void) { return MRK_ABI_VERSION; }
+const char *mrk_build_id(void) {
+  return
+#include "build_id.inc"
+      ;
+}
 /* not part of include/mrk.h: tests / measurement scripts that change an experiment switch inside one process */
 void mrk_debug_reload_switches(void) { mrk::reload_switches(); }
 const char *mrk_last_error(void) { return g_last_error.c_str(); }

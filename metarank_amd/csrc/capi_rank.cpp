@@ -635,6 +635,21 @@ int mrk_config_warmup(mrk_ctx *ctx, const char *model_name) {
   });
 }
 
+int mrk_config_kernel_keys(mrk_ctx *ctx, const char *model_name, char *out, size_t cap, size_t *needed) {
+  return guard([&] {
+    if (!ctx || !model_name || !needed) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    const Program *p;
+    {
+      std::shared_lock<std::shared_mutex> sl(ctx->store_mu);
+      p = &program_of(ctx, model_name);
+    }
+    const std::string keys = jit_loaded_keys(*p);
+    *needed = keys.size() + 1;
+    if (!out || cap < keys.size() + 1) throw StatusError(MRK_ERR_INVALID_ARG, "output buffer too small (see *needed)");
+    memcpy(out, keys.c_str(), keys.size() + 1);
+  });
+}
+
 #ifdef MRK_PHASE_CLOCKS
 extern "C" int mrk_debug_phase_clocks(const mrk::Program *prog, unsigned long long *out64);
 // measurement builds only (not part of include/mrk.h): read-and-reset the per-phase cycle sums of the specialised kernel

@@ -194,6 +194,7 @@ struct JitSlot {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   bool failed = false;
+  std::string key;              // the stem of its cache file name: hash of the translation unit, its size, the compiler (mrk_config_kernel_keys)
   bool skip_disk = false;       // a code object found on disk did not load on this device (another architecture / a stale file): compile instead
   // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
   std::thread worker;
@@ -227,9 +228,8 @@ namespace {
 
 // code objects are kept on disk between processes: $MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else
 // ~/.cache/mrk_jit; the key covers the whole translation unit and the compiler's version
-std::string cache_path(const std::string &src) {
-  const std::string &d = switches().jit_cache_dir;
-  if (d.empty()) return "";
+// the file name (no directory, no extension) of a translation unit's code object: its hash, its size, the compiler
+std::string cache_stem(const std::string &src) {
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
   char name[96];
@@ -238,8 +238,14 @@ std::string cache_path(const std::string &src) {
 #else
   const char *flavour = "";
 #endif
-  snprintf(name, sizeof name, "/%016llx-%zu-rtc%d.%d-gfx950%s.co", (unsigned long long)fnv1a(src), src.size(), major, minor, flavour);
-  return d + name;
+  snprintf(name, sizeof name, "%016llx-%zu-rtc%d.%d-gfx950%s", (unsigned long long)fnv1a(src), src.size(), major, minor, flavour);
+  return name;
+}
+
+std::string cache_path(const std::string &src) {
+  const std::string &d = switches().jit_cache_dir;
+  if (d.empty()) return "";
+  return d + "/" + cache_stem(src) + ".co";
 }
 
 // <directory of libmrk_hip.so>/jit_cache: code objects built ahead of time (read-only; same file names as the user's cache)
@@ -252,16 +258,7 @@ std::string shipped_path(const std::string &src) {
     return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_cache";
   }();
   if (dir.empty() || !switches().jit_shipped) return "";
-  int major = 0, minor = 0;
-  (void)hiprtcVersion(&major, &minor);
-  char name[96];
-#ifdef MRK_PHASE_CLOCKS
-  const char *flavour = "-clk";
-#else
-  const char *flavour = "";
-#endif
-  snprintf(name, sizeof name, "/%016llx-%zu-rtc%d.%d-gfx950%s.co", (unsigned long long)fnv1a(src), src.size(), major, minor, flavour);
-  return dir + name;
+  return dir + "/" + cache_stem(src) + ".co";
 }
 
 std::vector<char> read_file(const std::string &path) {
@@ -376,6 +373,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
     }
     if (!from_disk) MRK_HIP(hipModuleLoadData(&sl.mod, code.data()));
     MRK_HIP(hipModuleGetFunction(&sl.fn, sl.mod, JIT_KERNEL_NAME[kernel]));
+    sl.key = cache_stem(jit_source(prog, f64, kernel, sg.get()));
   } catch (const std::exception &e) {
     sl.failed = true;
     if (mode == 2) throw;
@@ -426,6 +424,19 @@ void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_M
 void *jit_one_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_ONE, f64, sig); }
 void *jit_fused_score_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_FUSED_SCORE, f64, sig); }
 void *jit_serve_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_SERVE, f64, sig, /*wait=*/true); }  // mrk_serve_start IS the warm-up
+
+// "<kernel name> <key>\n" for every specialised kernel of `prog` that is loaded (measurement provenance: which code ran)
+std::string jit_loaded_keys(const Program &prog) {
+  std::lock_guard<std::mutex> lk(prog.jit_mu);
+  std::string out;
+  if (!prog.jit) return out;
+  JitKernels *k = (JitKernels *)prog.jit;
+  for (auto &set : k->by_sig)
+    for (int kn = 0; kn < JIT_KERNELS; ++kn)
+      for (JitSlot &sl : set.second->slot[kn])
+        if (sl.fn) out += std::string(JIT_KERNEL_NAME[kn]) + " " + sl.key + (set.first.empty() ? " program" : " program+forest") + "\n";
+  return out;
+}
 
 // waits for the background compiles of `prog` that are under way (a warm-up / measurement aid; the next launch loads them)
 void jit_wait(const Program &prog) {

@@ -32,6 +32,7 @@ void *jit_serve_function(const Program &prog, bool f64, const QsSignature *sig);
 void *jit_fused_score_function(const Program &prog, bool f64, const QsSignature *sig);
 int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const std::string &dir, const QsSignature *sig = nullptr);
 void jit_wait(const Program &prog);
+std::string jit_loaded_keys(const Program &prog);
 void jit_release(Program &prog);
 
 }  // namespace mrk

@@ -267,6 +267,18 @@ class HipRanker:
         """mrk_config_warmup: waits for the background compiles of this model's specialised kernels that are under way"""
         N.check(N.lib().mrk_config_warmup(self.ctx.handle, model_name.encode()))
 
+    def kernel_keys(self, model_name: str) -> dict:
+        """mrk_config_kernel_keys: {kernel name: "<key> program|program+forest"} of this model's loaded specialised kernels"""
+        need = C.c_size_t(0)
+        N.lib().mrk_config_kernel_keys(self.ctx.handle, model_name.encode(), None, 0, C.byref(need))
+        buf = C.create_string_buffer(max(need.value, 1))
+        N.check(N.lib().mrk_config_kernel_keys(self.ctx.handle, model_name.encode(), buf, len(buf), C.byref(need)))
+        out = {}
+        for ln in buf.value.decode().splitlines():
+            name, _, rest = ln.partition(" ")
+            out.setdefault(name, []).append(rest)
+        return out
+
     def prepare(self, model_name: str, events) -> Batch:
         return Batch(self, model_name, events)
 

@@ -6,6 +6,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -27,4 +28,19 @@ for d in sys.argv[1:]:
         for row in csv.DictReader(open(f)):
             out.setdefault(short(row["Name"]), {})["duration"] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]),
                                                                   "pct": float(row["Percentage"])}
+# which code the counters belong to: the `provenance` object of bench.py's JSON line in each pass's captured output
+# (<dir>.log next to <dir>); bench.py quotes a committed summary only when it is running the same build and kernels
+provs = []
+for d in sys.argv[1:]:
+    log = d.rstrip("/") + ".log"
+    if os.path.exists(log):
+        for ln in open(log, errors="replace"):
+            if ln.startswith('{"metric"'):
+                try:
+                    provs.append(json.loads(ln).get("provenance"))
+                except ValueError:
+                    pass
+provs = [p for p in provs if p]
+if provs:
+    out["_provenance"] = dict(provs[0], consistent=all(p == provs[0] for p in provs), passes=len(provs))
 json.dump(out, sys.stdout, indent=1)
