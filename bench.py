@@ -343,6 +343,8 @@ def main():
     ctx.profile_enable(True)
     prof_steps = max(5, min(args.steps, 20))
     for _ in range(prof_steps):
+        if qtok is not None:   # c5: the forward pass of the batch's queries ("encoder": events on the encoder's own stream)
+            enc.embed_ids(*qtok[0])
         if sharded:
             batch.run_shard(booster, rank, n_gpus)
             batch.sort()
@@ -350,7 +352,7 @@ def main():
             batch.run(booster)
         batch.sync()
     kernels = {}
-    for k in ("prepass", "assemble", "override", "bin", "score", "sort", "rank_fused"):
+    for k in ("encoder", "prepass", "assemble", "override", "bin", "score", "sort", "rank_fused"):
         ms, n = ctx.profile_get(k)
         if n:
             kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / prof_steps}
@@ -369,7 +371,12 @@ def main():
     b_item = 8 * dim + 48 + 4 + 8 + (384 * 4 if wl == "c5" else 0)
     model_bytes = int(info["n_nodes"]) * 16 + int(info["n_leaves"]) * (8 if args.backend == "lightgbm" else 4)
     alg_path = my_items * b_item + model_bytes      # the whole fused path (8d)
-    alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass", "rank_fused")}
+    alg = {k: alg_path for k in ("assemble", "score", "bin", "prepass", "rank_fused", "encoder")}
+    enc_flops = None
+    if enc is not None:   # matrix-core work of one forward pass over the batch's REAL tokens (packed): 4 H^2 + 2 H I per token and layer in the products, 4 H per token pair in attention, x 2
+        L_, H_, I_ = enc.info["layers"], enc.info["hidden"], enc.info["intermediate"]
+        lens_ = np.asarray(qtok[0][2]).sum(axis=1).astype(np.int64)
+        enc_flops = int(lens_.sum()) * L_ * 2 * (4 * H_ * H_ + 2 * H_ * I_) + int((lens_ * lens_).sum()) * L_ * 4 * H_
     alg["sort"] = total_items * (8 + 4)
     alg["override"] = 0
     # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE, KB per launch,
@@ -442,6 +449,14 @@ def main():
                          f"in {kernels['score']['avg_ms']:.3f} ms") if "score" in kernels else
                         "rank_fused = pre-pass + assembly + forest + ordering of a request in its own workgroup, ONE launch per batch "
                         "(MRK_RANK_FUSED_SCORE=0: the three-launch path with per-kernel times)"}
+
+    if dominant == "encoder":   # config 5: the launch sequence that dominates is GEMM-shaped - priced against the dense f16 MFMA peak
+        roofline = {"bound": "mfma", "kernel": "encoder", "achieved": enc_flops / dur_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": enc_flops / dur_s / 1e12 / 2500.0, "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": kernels[dominant]["avg_ms"],
+                    "what": "one forward pass of the step's queries (embedding ... mean pooling; ~40 launches, HIP events on the encoder's stream); "
+                            "peak = dense f16 MFMA, MI355X_MICROARCH.md",
+                    "hbm_view_of_the_rank_batch": {"kernel": "assemble", "achieved": alg_path / (kernels["assemble"]["avg_ms"] * 1e-3) / 1e9,
+                                                   "frac": alg_path / (kernels["assemble"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS} if "assemble" in kernels else None}
 
     # ---- end to end: FRESH requests every device batch (host part + upload of the id bytes + device-side id resolution
     #      + run + download into pinned memory), several batches in flight, one host thread

@@ -358,13 +358,14 @@ void mrk_batch_free(mrk_batch *batch);
  * (more than 128 candidates, per-item field overrides, a model with a request-normalised column, all slots busy) go
  * through mrk_rank transparently.  A workgroup that has seen no request for a while (2 ms; MRK_SERVE_IDLE_US) leaves
  * its CU and is relaunched by the next request; store flushes stop the workgroups for their duration.
- * mrk_serve_stats: out9 = {requests through the queue, requests through mrk_rank, workgroup launches; then, summed over the
+ * mrk_serve_stats: out10 = {requests through the queue, requests through mrk_rank, workgroup launches; then, summed over the
  * queue's requests, in ns: host resolve + pack, host publish -> acknowledgement, host copy-out, device input copy + cache drops,
- * device ranking, device result write-back}. */
+ * device ranking, device result write-back; last: the SHADER CYCLES of the device ranking summed the same way - cycles / ns = the
+ * clock the requests ran at (a lone workgroup on an otherwise idle device does not see the boost clock)}. */
 typedef struct mrk_server mrk_server;
 int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int n_slots, mrk_server **out);
 int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, int32_t *out_order);
-int mrk_serve_stats(mrk_server *srv, int64_t *out9);
+int mrk_serve_stats(mrk_server *srv, int64_t *out10);
 void mrk_serve_stop(mrk_server *srv);
 
 /* ------------------------------------------------ multi-GPU (RCCL over xGMI) */

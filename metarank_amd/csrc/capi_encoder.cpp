@@ -235,8 +235,13 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
   }
   const int f_seq = packed ? max_len : seq, f_packed = packed ? (int)M : 0;
 
+  // mrk_profile_enable: the forward pass (embedding lookup ... pooling / classifier, no copies) between two events on the
+  // encoder's own stream, accumulated under the name "encoder" (bench.py: the dominant launch sequence of config 5)
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  const bool timed = e.ctx->profile && !(switches().encoder_graph && !e.dev.f32) && hipEventCreate(&ev_a) == hipSuccess && hipEventCreate(&ev_b) == hipSuccess;
   auto enqueue = [&]() {
     MRK_HIP(hipMemcpyAsync(e.scratch.ids.p, h, id_words * 4, hipMemcpyHostToDevice, e.stream));
+    if (timed) (void)hipEventRecord(ev_a, e.stream);
     if (packed) encoder_forward_packed(e.dev, e.scratch, n, f_seq, f_packed, e.stream);
     else encoder_forward(e.dev, e.scratch, n, seq, e.stream);
     const float *src = e.scratch.x.as<float>();
@@ -245,6 +250,7 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
       if (mode == MODE_POOL) encoder_meanpool(e.dev, e.scratch, n, f_seq, f_packed, e.scratch.out.as<float>(), e.stream);
       else encoder_classify(e.dev, e.scratch, n, f_seq, f_packed, e.scratch.out.as<float>(), e.stream);
     }
+    if (timed) (void)hipEventRecord(ev_b, e.stream);
     MRK_HIP(hipMemcpyAsync(e.h_out.p, src, out_n * 4, hipMemcpyDeviceToHost, e.stream));
   };
   // Small shapes (a request's query, a request's item pairs) are ~40 kernels of a few microseconds each; their launch
@@ -279,7 +285,19 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
   } else {
     enqueue();
   }
-  MRK_HIP(hipStreamSynchronize(e.stream));
+  const hipError_t sync_rc = hipStreamSynchronize(e.stream);
+  if (timed && sync_rc == hipSuccess) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess) {
+      std::lock_guard<std::mutex> lk(e.ctx->mu);
+      auto &t = e.ctx->timers["encoder"];
+      t.total_ms += ms;
+      t.launches += 1;
+    }
+  }
+  if (ev_a) (void)hipEventDestroy(ev_a);
+  if (ev_b) (void)hipEventDestroy(ev_b);
+  MRK_HIP(sync_rc);
   memcpy(out, e.h_out.p, out_n * 4);
 }
 

@@ -29,7 +29,7 @@ size_t big_sort_scratch_bytes(int n);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
-                           uint16_t *cells, bool f64, void *jit_fn);
+                           uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, int op_split, int slices, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap);
@@ -446,7 +446,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
       launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, b.fused_slices, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     } else {
       launch_prepass(ctx, st, pd, b.view, b.fused_entries);
-      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn);
+      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn, b.fused_entries);
     }
     b.matrix_valid = false;
     // lo is a multiple of the tile size: the scorer sees rows [lo, hi) as its rows [0, hi - lo)
@@ -1212,7 +1212,7 @@ struct mrk_server {
   size_t dead_slots = 0;
   bool closing = false;
   std::atomic<uint64_t> n_queue{0}, n_fallback{0}, n_launches{0};
-  std::atomic<uint64_t> dev_ticks[3] = {{0}, {0}, {0}};   // device-side 100 MHz ticks: input copy, ranking, result write-back
+  std::atomic<uint64_t> dev_ticks[4] = {{0}, {0}, {0}, {0}};   // device-side 100 MHz ticks: input copy, ranking, result write-back; [3]: shader cycles of the ranking
   std::atomic<uint64_t> host_ns[3] = {{0}, {0}, {0}};     // host-side ns: resolve + pack, publish -> acknowledgement, copy-out
 };
 
@@ -1333,7 +1333,7 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   const int32_t *hs = (const int32_t *)(sl.h_out + 1536);
   status = hs[0] | hs[1];
   const unsigned long long *clk = (const unsigned long long *)(hs + 16);
-  for (int k = 0; k < 3; ++k) srv.dev_ticks[k].fetch_add(clk[k]);
+  for (int k = 0; k < 4; ++k) srv.dev_ticks[k].fetch_add(clk[k]);
   const auto h3 = std::chrono::steady_clock::now();
   srv.host_ns[0].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(h1 - h0).count());
   srv.host_ns[1].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(h2 - h1).count());
@@ -1431,8 +1431,10 @@ int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, 
   return code;
 }
 
-int mrk_serve_stats(mrk_server *srv, int64_t *out9) {
+int mrk_serve_stats(mrk_server *srv, int64_t *out10) {
+  int64_t *out9 = out10;
   if (!srv || !out9) return MRK_ERR_INVALID_ARG;
+  out10[9] = (int64_t)srv->dev_ticks[3].load();
   out9[0] = (int64_t)srv->n_queue.load();
   out9[1] = (int64_t)srv->n_fallback.load();
   out9[2] = (int64_t)srv->n_launches.load();

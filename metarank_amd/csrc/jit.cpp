@@ -142,8 +142,8 @@ std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignat
   // the item-parallel form (requests too large for one workgroup: tables from a previous pre-pass launch, in HBM)
   if (kernel == JIT_ALL || kernel == JIT_ITEMS)
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
-         "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells) {\n"
-         "  mrk::assemble_cells_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, q, cells);\n}\n";
+         "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells, uint32_t lds_entries) {\n"
+         "  mrk::assemble_cells_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, q, cells, lds_entries);\n}\n";
   // pre-pass + assembly + forest + ordering of a small request in one launch (rank_device.hpp rank_one_body)
   if (kernel == JIT_ALL || kernel == JIT_ONE)
     // (a request's workgroup is 8 wavefronts = 2 per SIMD and a handful of them run at a time: nothing to gain from the

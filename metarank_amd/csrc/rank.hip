@@ -73,8 +73,8 @@ assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
 
 template <bool F64>
 __global__ void __launch_bounds__(ASM_THREADS)
-assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_t *cells) {
-  assemble_cells_body<F64>(st, prog, b, q, cells);
+assemble_cells_kernel(StoreDev st, ProgramDev prog, BatchDev b, QsDev q, uint16_t *cells, uint32_t lds_entries) {
+  assemble_cells_body<F64>(st, prog, b, q, cells, lds_entries);
 }
 
 // (the interpreting kernels always carry the op split: they are the fall-back, not the hot path)
@@ -304,20 +304,26 @@ static void launch_override_cells(mrk_ctx *ctx, const BatchDev &b, const QsDev &
 
 // assembly straight into the scorer's binned tile (tables from a previous launch_prepass); jit_fn: the specialised
 // mrk_jit_assemble_cells of this program, or nullptr = the kernel that interprets the program
+// max_req_entries: the largest request's table entries (the pre-pass launch's figure): when they fit ITEMS_LDS_TABLE_BYTES,
+// single-request workgroups copy their request's tables into LDS (rank_device.hpp assemble_cells_body); MRK_ITEMS_LDS=0: never
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
-                           uint16_t *cells, bool f64, void *jit_fn) {
+                           uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries) {
   if (b.item_hi <= b.item_lo) return;
   {
     ScopedKernelTimer timer(ctx, "assemble");
     const dim3 grid((b.item_hi - b.item_lo + ASM_THREADS - 1) / ASM_THREADS);
+    // 16 KB of static threshold staging + <= 24 KB of tables: four workgroups per CU, what 128 VGPRs allow anyway
+    constexpr uint32_t ITEMS_LDS_TABLE_BYTES = 24 * 1024;
+    uint32_t lds_entries = switches().items_lds && prog.n_prep > 0 && (uint64_t)max_req_entries * 8 <= ITEMS_LDS_TABLE_BYTES ? max_req_entries : 0u;
+    const size_t lds = (size_t)lds_entries * 8;
     if (jit_fn) {  // the kernel specialised for this model's program (jit.cpp)
       StoreDev a_st = st;
       BatchDev a_b = b;
       QsDev a_q = q;
-      void *args[] = {&a_st, &a_b, &a_q, &cells};
-      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, grid.x, 1, 1, ASM_THREADS, 1, 1, 0, ctx->launch, args, nullptr));
-    } else if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), 0, ctx->launch, st, prog, b, q, cells);
-    else hipLaunchKernelGGL(assemble_cells_kernel<false>, grid, dim3(ASM_THREADS), 0, ctx->launch, st, prog, b, q, cells);
+      void *args[] = {&a_st, &a_b, &a_q, &cells, &lds_entries};
+      MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, grid.x, 1, 1, ASM_THREADS, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
+    } else if (f64) hipLaunchKernelGGL(assemble_cells_kernel<true>, grid, dim3(ASM_THREADS), lds, ctx->launch, st, prog, b, q, cells, lds_entries);
+    else hipLaunchKernelGGL(assemble_cells_kernel<false>, grid, dim3(ASM_THREADS), lds, ctx->launch, st, prog, b, q, cells, lds_entries);
     MRK_HIP(hipGetLastError());
   }
   launch_override_cells(ctx, b, q, cells, f64);
@@ -338,14 +344,6 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
   if (b.n_req <= 0) return;
   int mode = (op_split > 1 ? op_split : 1) | ((slices > 1 ? slices : 1) << 8);  // rank_device.hpp rank_fused_body
   const unsigned grid = (unsigned)b.n_req * (unsigned)(slices > 1 ? slices : 1);
-  // A sliced batch (few large requests: c3) used to run every request's pre-pass once per SLICE - each slice re-read the
-  // session's items (c3 traffic 3.05x the algorithmic bytes) and spent a quarter of its life building tables its neighbour
-  // built too.  Now the pre-pass of the whole batch runs first, once per request (its tables built in LDS, copied to the
-  // arena), and a slice copies its request's finished tables into its own LDS.  MRK_SLICE_PREPASS=0: the old way.
-  if (slices > 1 && prog.n_prep > 0 && switches().slice_prepass) {
-    launch_prepass(ctx, st, prog, b, tab_entries);
-    mode |= 1 << 16;
-  }
   size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u);
   if (switches().fused_lds_min > 0) lds = std::max(lds, (size_t)switches().fused_lds_min);  // experiments: cap the kernel's residency (co-residency with the scorer)
   {

@@ -1523,21 +1523,21 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 // Both phases of one request in one workgroup; hash tables, pre-pass results and the median scratch in LDS.
 // Dynamic LDS: [tables: tab_entries x 8 B][median values: vals_cap x 8 B][PrepOut x FUSED_MAX_PREP][PREP_INTS ints]
 //              [threshold staging: 2 buffers x thr_cap x 8 B per wavefront]
-// `mode` = op_split | slices << 8 | tables_ready << 16.
+// `mode` = op_split | slices << 8.
 //   op_split (1 | 2 | 4; SPLIT kernels only): the workgroup's lanes are op_split copies of the item lanes (see op_owner).
 //   slices (>= 1; SPLIT kernels only): a request is covered by `slices` workgroups; each runs the request's pre-pass (its tables are private,
 //     in its own LDS) and assembles one slice of the candidates.  A batch of few large requests - 384 requests x 1 000
 //     candidates is 1.5 workgroups per CU, each looping four times over its lanes - fills the chip this way: the
 //     pre-pass is paid `slices` times, the dependent chain of a workgroup shrinks by the same factor.
-//   tables_ready (SPLIT kernels only; round 4): ... unless the host ran the pre-pass of the whole batch first (prepass_kernel, one
-//     workgroup per request): then a slice only copies its request's finished tables from the arena into its LDS.
+//     (Round 4 measured the alternative - the whole batch's pre-pass once per request in a launch of its own, slices copying the
+//     finished tables from the arena: c3 assembly 0.306 -> 0.278 ms but + 0.045 ms of pre-pass launch, 869 -> 814 M items/s same
+//     box, profiles/r04_d_ab.txt.  Not kept.)
 // lds_skip: bytes at the start of the dynamic LDS that belong to the caller (the one-launch kernel keeps the scorer's slab there).
 template <bool SPLIT, typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
                                                 int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink, uint32_t lds_skip = 0) {
   const int op_split = SPLIT ? ((mode & 255) > 1 ? (mode & 255) : 1) : 1;
   const int slices = SPLIT ? (((mode >> 8) & 255) > 1 ? ((mode >> 8) & 255) : 1) : 1;   // (the plain kernel keeps its registers for the ops)
-  const bool tables_ready = SPLIT && ((mode >> 16) & 1) != 0;
   extern __shared__ __align__(16) uint8_t smem_base[];
   uint8_t *smem = smem_base + lds_skip;
   unsigned long long *s_tab = (unsigned long long *)smem;
@@ -1560,17 +1560,7 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
 #ifdef MRK_PHASE_CLOCKS
   sc.clk = clock64();
 #endif
-  if (tables_ready) {
-    // a sliced batch whose pre-pass ran ONCE per request in a launch of its own (prepass_kernel: results in b.prep_out - just
-    // copied -, tables in the arena): every slice copies the request's tables into its LDS instead of building them again
-    uint32_t n_ent = 0;
-    for (int e = 0; e < prog.n_prep; ++e) n_ent = max(n_ent, s_po[e].tab_off - (uint32_t)rq.arena_begin + s_po[e].tab_cap);
-    const unsigned long long *src = b.arena + (size_t)rq.arena_begin;
-    for (uint32_t i = threadIdx.x; i < n_ent; i += blockDim.x) s_tab[i] = src[i];
-    __syncthreads();
-  } else {
-    prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
-  }
+  prepass_request(st, prog, b, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, sc);
   const int og = (int)threadIdx.x / item_lanes, il = (int)threadIdx.x % item_lanes;
   for (int base = slice_lo; base < slice_hi; base += item_lanes) {
     const int i = base + il;
@@ -1590,12 +1580,38 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
 }
 
 
-// One lane per candidate across many workgroups (requests too large for one workgroup, tables that do not fit LDS):
-// tables in the HBM arena, written by a previous pre-pass launch.  Straight into the scorer's binned tile.
+// One lane per candidate across many workgroups (requests too large for one workgroup, tables that do not fit the fused
+// kernel's LDS): the tables were built by a previous pre-pass launch and lie in the HBM arena.  Straight into the scorer's
+// binned tile.
+// lds_entries: dynamic LDS of the launch, in table entries (0: none).  A workgroup whose lanes all belong to ONE request -
+// every workgroup of a C4 batch - copies that request's finished tables into LDS first (coalesced, a few KB out of L2) when
+// they fit: every table lookup of its candidates (interacted_with: up to IW_TOK tokens x fields, a dependent trip each) is
+// then an LDS round trip instead of one to L2 / HBM.  Same-box: c4x (4 M candidates) assembly 0.99 -> see LOG.md.
 template <bool F64, typename QS = QsDyn, typename Prog>
-__device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, const QsDev &q, uint16_t *cells) {
+__device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, const QsDev &q, uint16_t *cells,
+                                                    uint32_t lds_entries) {
   __shared__ __align__(16) double s_thr[ASM_THREADS / 64][2 * QS_LDS_THR];
-  const int gi0 = b.item_lo + blockIdx.x * ASM_THREADS + threadIdx.x;
+  extern __shared__ __align__(16) unsigned long long s_tab_copy[];
+  const int wg_lo = b.item_lo + (int)blockIdx.x * ASM_THREADS;
+  if (wg_lo >= b.item_hi) return;                  // (uniform)
+  const int wg_hi = min(wg_lo + ASM_THREADS, b.item_hi) - 1;
+  const int r_lo = (int)b.item_req[wg_lo], r_hi = (int)b.item_req[wg_hi];
+  bool in_lds = false;
+  uint32_t tab_sub = 0;
+  if (lds_entries > 0u && r_lo == r_hi && prog.n_prep > 0) {
+    const PrepOut *po = &b.prep_out[(size_t)r_lo * prog.n_prep];
+    const uint32_t a0 = b.reqs[r_lo].arena_begin;
+    uint32_t n_ent = 0;
+    for (int e = 0; e < prog.n_prep; ++e) n_ent = max(n_ent, po[e].tab_off - a0 + po[e].tab_cap);
+    in_lds = n_ent <= lds_entries;                 // (uniform: the whole workgroup takes one branch)
+    if (in_lds) {
+      const unsigned long long *src = b.arena + (size_t)a0;
+      for (uint32_t i = threadIdx.x; i < n_ent; i += ASM_THREADS) s_tab_copy[i] = src[i];
+      tab_sub = a0;
+      __syncthreads();
+    }
+  }
+  const int gi0 = wg_lo + (int)threadIdx.x;
   const bool active = gi0 < b.item_hi;
   if (!__any(active)) return;                      // whole wavefront past the end
   const int gi = active ? gi0 : b.item_hi - 1;     // lanes without an item ride along on a missing record
@@ -1603,7 +1619,9 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
   const ReqDev rq = b.reqs[r];
   CellSink<F64, QS> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * qs_n_views<QS>(q) * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r],
                      (qs_lds_double *)s_thr[threadIdx.x >> 6], active};
-  assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
+  // (two instantiations: through a selected pointer the table accesses would be flat instead of ds / global operations)
+  if (in_lds) assemble_item(st, prog, b, gi, r, rq, s_tab_copy, tab_sub, &b.prep_out[(size_t)r * prog.n_prep], sink);
+  else assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
 }
 
 // rank_fused_body writing ClickthroughQuery's row-major f64 matrix
@@ -1803,7 +1821,9 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long t_in = wall_clock64();
+    const unsigned long long c_in = clock64();   // shader cycles next to the 100 MHz wall clock: the clock the request actually ran at
     rank_one_body<F64, QS>(st, prog, b, tab_entries, (int)vals_cap, q, f, (int)mode, s.out);
+    const unsigned long long c_ranked = clock64();
     const unsigned long long t_ranked = wall_clock64();
     __threadfence_system();   // every lane's results are in host memory before the acknowledgement
     __syncthreads();
@@ -1814,6 +1834,7 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
       clk[0] = t_in - t_seen;
       clk[1] = t_ranked - t_in;
       clk[2] = wall_clock64() - t_ranked;
+      clk[3] = c_ranked - c_in;
       __threadfence_system();
       __hip_atomic_store(&s.ctl->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

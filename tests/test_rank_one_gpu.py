@@ -191,6 +191,16 @@ def test_busy_serving_workgroups_do_not_stall_reallocations():
         blob = synth.synthetic_lgbm_model(n_trees=300, n_features=24, quantiles=q, missing="per_feature")
         orc.load_model(blob, 0)
         hip.load_model(blob, 0)
+        # the kernels of the batch shapes ranked below, compiled (and left in the disk cache) by ANOTHER context: what is timed
+        # here is a reallocation next to resident workgroups, not hiprtc (the kernels are keyed by this forest's view signature)
+        warm = HipBackend(cfg, "xgboost")
+        try:
+            ranklens.load_state(warm, ranklens.generate_state(N_ITEMS, N_SESS))
+            warm.load_model(blob, 0)
+            for n in (129, 300, 700, 1500, 2900):
+                warm.rerank(ranklens.generate_requests(1, n, N_ITEMS, N_SESS, seed=100 + n)[0])
+        finally:
+            warm.close()
         srv = hip.ranker.serve("xgboost", hip.booster, n_slots=2)
         exp_small = [orc.rerank(ev) for ev in small]
         srv.rerank(small[0])

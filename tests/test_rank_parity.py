@@ -167,7 +167,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
     import os
 
     hip = HipBackend(ranklens.ranklens_config(), "xgboost")
-    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT", "MRK_JIT_SIG", "MRK_FUSED_SPLIT", "MRK_FUSED_SLICES", "MRK_FUSED_THREADS", "MRK_SLICE_PREPASS")}
+    saved = {k: os.environ.get(k) for k in ("MRK_RANK_FUSED", "MRK_RANK_CELLS", "MRK_RANK_JIT", "MRK_JIT_SIG", "MRK_FUSED_SPLIT", "MRK_FUSED_SLICES", "MRK_FUSED_THREADS", "MRK_ITEMS_LDS")}
     try:
         load(hip)
         reqs = ranklens.generate_requests(30, 100, N_ITEMS, N_SESS, seed=21)
@@ -214,6 +214,20 @@ def test_assembly_paths_agree(oracle_c2, kind):
                 s2, o2, _ = batch.fetch()
                 assert same(s2, scores) and (o2 == order).all()
                 batch.close()
+        # the item-parallel kernel probing the tables in the HBM arena only (default: a workgroup whose lanes share one request
+        # copies that request's tables into its LDS first - the 300-candidate requests have such workgroups, the others straddle)
+        for jit in ("require", "0"):
+            os.environ.update(MRK_RANK_FUSED="0", MRK_RANK_CELLS="1", MRK_RANK_JIT=jit, MRK_ITEMS_LDS="0")
+            M.reload_switches()
+            batch = hip.ranker.prepare("xgboost", reqs)
+            batch.run(hip.booster)
+            scores, order, _ = batch.fetch()
+            assert (batch.status() == 0).all()
+            for r, (_, es, eo) in enumerate(expected):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), ("items, arena tables", jit, r)
+            batch.close()
+        os.environ.pop("MRK_ITEMS_LDS", None)
         # op split (what a handful of requests gets by itself): the item lanes in 2 / 4 copies that share the ops,
         # specialised kernel (tile), interpreting kernels (tile and f64 matrix)
         for split in ("2", "4"):
@@ -233,12 +247,9 @@ def test_assembly_paths_agree(oracle_c2, kind):
         # slices (what a batch of few LARGE requests gets by itself): several workgroups per request, each with its own
         # pre-pass tables and a slice of the candidates; with 64 item lanes the 300-candidate requests take 5 rounds, so
         # up to 5 slices, the 100-candidate ones 2, the single-candidate ones 1 (the other workgroups leave at once)
-        # (default: the batch's pre-pass runs once per request in a launch of its own and the slices copy the finished tables;
-        #  MRK_SLICE_PREPASS=0: every slice builds them itself)
-        for slices, split, shared in (("2", "1", "1"), ("2", "1", "0"), ("5", "1", "1"), ("3", "2", "1"), ("3", "2", "0")):
+        for slices, split in (("2", "1"), ("5", "1"), ("3", "2")):
             for cells, jit in (("1", "require"), ("1", "0"), ("0", "0")):
-                os.environ.update(MRK_FUSED_SLICES=slices, MRK_FUSED_SPLIT=split, MRK_FUSED_THREADS="64", MRK_RANK_FUSED="1", MRK_RANK_CELLS=cells, MRK_RANK_JIT=jit,
-                                  MRK_SLICE_PREPASS=shared)
+                os.environ.update(MRK_FUSED_SLICES=slices, MRK_FUSED_SPLIT=split, MRK_FUSED_THREADS="64", MRK_RANK_FUSED="1", MRK_RANK_CELLS=cells, MRK_RANK_JIT=jit)
                 M.reload_switches()
                 batch = hip.ranker.prepare("xgboost", reqs)
                 batch.run(hip.booster)
@@ -249,7 +260,7 @@ def test_assembly_paths_agree(oracle_c2, kind):
                     assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), (slices, split, cells, jit, r)
                     assert same(mat[lo:hi], mats[r]), (slices, split, cells, jit, r)
                 batch.close()
-        for k in ("MRK_FUSED_SLICES", "MRK_FUSED_SPLIT", "MRK_FUSED_THREADS", "MRK_SLICE_PREPASS"):
+        for k in ("MRK_FUSED_SLICES", "MRK_FUSED_SPLIT", "MRK_FUSED_THREADS"):
             os.environ.pop(k, None)
         # single requests: mrk_rank without / with the explain matrix
         os.environ["MRK_RANK_FUSED"], os.environ["MRK_RANK_CELLS"], os.environ["MRK_RANK_JIT"] = "1", "1", "require"
