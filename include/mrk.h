@@ -445,8 +445,12 @@ int mrk_encoder_load(mrk_ctx *ctx, const uint8_t *weights, size_t len, const cha
  * f32 operands with f32 accumulation, exact erf / exp - the arithmetic of the reference's fp32 ONNX session (onnxruntime on
  * the CPU, OnnxSession.scala:42-56); cosines within 1e-5 of transformers' fp32 output (the reference's own tests accept 1e-3,
  * OnnxBiencoderTest.scala:23-25).  About 20x slower than the fp16 path: a parity instrument and the mode for a host that
- * must reproduce the JVM's numbers. */
-enum { MRK_ENCODER_FP16 = 0, MRK_ENCODER_F32 = 1 };
+ * must reproduce the JVM's numbers.
+ * MRK_ENCODER_AUTO: both sets of matrices on the device; a call over at most 4 sequences - the query of ONE request, i.e.
+ * mrk_rank / mrk_serve_rank - runs in f32, larger calls (the queries of a packed batch) in fp16.  A host maps its
+ * `precision: f16 | f32 | auto` setting of a field_match feature to this argument; INTEGRATION.md has the measured price of
+ * fp16 (scores moving by more than 1e-5, requests whose order changes) and bench.py's config-5 line reports it per run. */
+enum { MRK_ENCODER_FP16 = 0, MRK_ENCODER_F32 = 1, MRK_ENCODER_AUTO = 2 };
 int mrk_encoder_load_ex(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
                         int precision, mrk_encoder **out);
 int mrk_encoder_get_info(mrk_encoder *enc, mrk_encoder_info *info);

@@ -171,8 +171,17 @@ void drop_graphs(mrk_encoder &e) {
 }
 
 // one forward pass over a padded id batch; `out` is host memory sized by the mode
-void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const int32_t *mask, int n, int seq, int mode, float *out) {
+// which arithmetic a call over `n_texts` sequences runs in: the handle's own (fp16 / f32), or - MRK_ENCODER_AUTO - f32 for the
+// few sequences of a single request (a 9-token query at the plain kernels' rate is noise next to the rest of mrk_rank,
+// and its cosines are the fp32 graph's to 1e-7) and fp16 on the matrix cores for packed batches
+constexpr size_t ENCODER_AUTO_F32_TEXTS = 4;
+bool call_in_f32(const mrk_encoder &e, size_t n_texts) {
+  return e.precision == MRK_ENCODER_F32 || (e.precision == MRK_ENCODER_AUTO && n_texts <= ENCODER_AUTO_F32_TEXTS);
+}
+
+void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const int32_t *mask, int n, int seq, int mode, float *out, bool f32) {
   if (n == 0) return;
+  e.dev.f32 = f32 && !e.dev.layers32.empty();
   const EncoderShape &sh = e.dev.shape;
   if (seq > sh.max_pos) throw StatusError(MRK_ERR_INVALID_ARG, "encoder: sequence length " + std::to_string(seq) + " exceeds the model's " +
                                           std::to_string(sh.max_pos) + " positions");
@@ -301,12 +310,12 @@ void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const
   memcpy(out, e.h_out.p, out_n * 4);
 }
 
-void encode_texts(mrk_encoder &e, const char *const *a, const char *const *b, int n, int mode, float *out) {
+void encode_texts(mrk_encoder &e, const char *const *a, const char *const *b, int n, int mode, float *out, bool f32) {
   std::vector<Encoding> rows;
   const int len = e.tok.encode_batch(a, b, n, rows);
   std::vector<int32_t> ids((size_t)n * len), types((size_t)n * len), mask((size_t)n * len);
   flatten(rows, len, ids.data(), types.data(), mask.data());
-  run_encoder(e, ids.data(), types.data(), mask.data(), n, len, mode, out);
+  run_encoder(e, ids.data(), types.data(), mask.data(), n, len, mode, out, f32);
 }
 
 }  // namespace
@@ -319,10 +328,14 @@ void encoder_embed_cached(mrk_encoder *e, const std::vector<std::string> &texts,
   std::lock_guard<std::mutex> lk(e->mu);
   const int H = e->dev.shape.hidden;
   out.assign(texts.size(), std::vector<float>());
+  // (the arithmetic follows from the size of the CALL, not from what happens to be cached: a text embedded both ways keeps
+  //  one embedding per arithmetic)
+  const bool f32 = call_in_f32(*e, texts.size());
+  auto &cache = f32 ? e->cache32 : e->cache;
   std::vector<size_t> miss;
   for (size_t i = 0; i < texts.size(); ++i) {
-    auto it = e->cache.find(texts[i]);
-    if (it != e->cache.end()) out[i] = it->second; else miss.push_back(i);
+    auto it = cache.find(texts[i]);
+    if (it != cache.end()) out[i] = it->second; else miss.push_back(i);
   }
   constexpr size_t CHUNK = 256, CACHE_MAX = 1 << 16;
   std::vector<float> buf;
@@ -331,11 +344,11 @@ void encoder_embed_cached(mrk_encoder *e, const std::vector<std::string> &texts,
     std::vector<const char *> ptrs(n);
     for (size_t k = 0; k < n; ++k) ptrs[k] = texts[miss[at + k]].c_str();
     buf.resize(n * H);
-    encode_texts(*e, ptrs.data(), nullptr, (int)n, MODE_POOL, buf.data());
-    if (e->cache.size() + n > CACHE_MAX) e->cache.clear();
+    encode_texts(*e, ptrs.data(), nullptr, (int)n, MODE_POOL, buf.data(), f32);
+    if (cache.size() + n > CACHE_MAX) cache.clear();
     for (size_t k = 0; k < n; ++k) {
       out[miss[at + k]].assign(buf.begin() + k * H, buf.begin() + (k + 1) * H);
-      e->cache[texts[miss[at + k]]] = out[miss[at + k]];
+      cache[texts[miss[at + k]]] = out[miss[at + k]];
     }
   }
 }
@@ -357,7 +370,7 @@ void encoder_score_rows(mrk_encoder *e, const std::vector<Encoding> &rows, float
       std::copy(r.type_ids.begin(), r.type_ids.end(), types.begin() + k * len);
       std::copy(r.mask.begin(), r.mask.end(), mask.begin() + k * len);
     }
-    run_encoder(*e, ids.data(), types.data(), mask.data(), (int)n, (int)len, MODE_LOGIT, out + at);
+    run_encoder(*e, ids.data(), types.data(), mask.data(), (int)n, (int)len, MODE_LOGIT, out + at, call_in_f32(*e, rows.size()));
   }
 }
 
@@ -417,13 +430,14 @@ int mrk_encoder_load_ex(mrk_ctx *ctx, const uint8_t *weights, size_t len, const 
                         int precision, mrk_encoder **out) {
   return guard([&] {
     need(ctx && weights && tokenizer_json && out, "mrk_encoder_load: null argument");
-    need(precision == MRK_ENCODER_FP16 || precision == MRK_ENCODER_F32, "mrk_encoder_load_ex: unknown precision");
+    need(precision == MRK_ENCODER_FP16 || precision == MRK_ENCODER_F32 || precision == MRK_ENCODER_AUTO, "mrk_encoder_load_ex: unknown precision");
     std::unique_ptr<mrk_encoder> e(new mrk_encoder);
     e->tok = Tokenizer::from_json(tokenizer_json, tok_len);
     Checkpoint ck = read_checkpoint(weights, len);
     if (heads > 0) ck.heads = heads;
     MRK_HIP(hipSetDevice(ctx->device));
-    build_encoder(*e, ck, precision == MRK_ENCODER_F32);
+    build_encoder(*e, ck, precision != MRK_ENCODER_FP16);   // (f32 and auto keep the matrices as f32 too)
+    e->precision = precision;
     MRK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->ctx = ctx;
     ctx_retain(ctx);
@@ -470,7 +484,7 @@ int mrk_encoder_hidden_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *
   return guard([&] {
     need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_hidden_ids: bad argument");
     std::lock_guard<std::mutex> lk(enc->mu);
-    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_HIDDEN, out);
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_HIDDEN, out, call_in_f32(*enc, (size_t)n));
   });
 }
 
@@ -479,7 +493,7 @@ int mrk_encoder_embed_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *t
   return guard([&] {
     need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_embed_ids: bad argument");
     std::lock_guard<std::mutex> lk(enc->mu);
-    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_POOL, out);
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_POOL, out, call_in_f32(*enc, (size_t)n));
   });
 }
 
@@ -488,7 +502,7 @@ int mrk_encoder_score_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *t
   return guard([&] {
     need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_score_ids: bad argument");
     std::lock_guard<std::mutex> lk(enc->mu);
-    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_LOGIT, out);
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_LOGIT, out, call_in_f32(*enc, (size_t)n));
   });
 }
 
@@ -497,7 +511,7 @@ int mrk_encoder_embed(mrk_encoder *enc, const char *const *texts, int n, float *
     need(enc && (texts || n == 0) && out && n >= 0, "mrk_encoder_embed: bad argument");
     if (n == 0) return;
     std::lock_guard<std::mutex> lk(enc->mu);
-    encode_texts(*enc, texts, nullptr, n, MODE_POOL, out);
+    encode_texts(*enc, texts, nullptr, n, MODE_POOL, out, call_in_f32(*enc, (size_t)n));
   });
 }
 
@@ -506,7 +520,7 @@ int mrk_encoder_score_pairs(mrk_encoder *enc, const char *const *a, const char *
     need(enc && ((a && b) || n == 0) && out && n >= 0, "mrk_encoder_score_pairs: bad argument");
     if (n == 0) return;  // OnnxCrossEncoder.scala:23-24: empty batch -> empty result
     std::lock_guard<std::mutex> lk(enc->mu);
-    encode_texts(*enc, a, b, n, MODE_LOGIT, out);
+    encode_texts(*enc, a, b, n, MODE_LOGIT, out, call_in_f32(*enc, (size_t)n));
   });
 }
 

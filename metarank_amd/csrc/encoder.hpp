@@ -103,5 +103,7 @@ struct mrk_encoder {
   int64_t device_bytes = 0;
   // EmbeddingCache: query text -> embedding (FieldMatchBiencoderFeature.scala:96-99)
   std::map<std::string, std::vector<float>> cache;
+  std::map<std::string, std::vector<float>> cache32;   // ... of the calls that ran in f32 (MRK_ENCODER_F32 / _AUTO)
+  int precision = 0;       // MRK_ENCODER_FP16 | _F32 | _AUTO (mrk_encoder_load_ex)
   std::atomic<int> refs{1};
 };

@@ -69,12 +69,17 @@ class HipTokenizer:
 
 
 class HipEncoder:
-    def __init__(self, weights: bytes, tokenizer_json: bytes | str, heads: int = 0, ctx: Context | None = None, f32: bool = False):
-        """f32: mrk_encoder_load_ex(MRK_ENCODER_F32) - f32 operands everywhere (the fp32 ONNX session's arithmetic; slow)"""
+    def __init__(self, weights: bytes, tokenizer_json: bytes | str, heads: int = 0, ctx: Context | None = None, f32: bool = False,
+                 precision: str | None = None):
+        """precision (mrk_encoder_load_ex): "f16" (default: fp16 operands on the matrix cores), "f32" (f32 operands everywhere -
+        the fp32 ONNX session's arithmetic; slow; `f32=True` is the same), "auto" (f32 for calls over <= 4 sequences - one
+        request's query -, fp16 for packed batches)"""
         self.ctx = ctx or default_context()
         tj = tokenizer_json.encode() if isinstance(tokenizer_json, str) else tokenizer_json
         self._h = C.c_void_p()
-        N.check(N.lib().mrk_encoder_load_ex(self.ctx.handle, weights, len(weights), tj, len(tj), heads, 1 if f32 else 0, C.byref(self._h)))
+        self.precision = precision or ("f32" if f32 else "f16")
+        code = {"f16": 0, "f32": 1, "auto": 2}[self.precision]
+        N.check(N.lib().mrk_encoder_load_ex(self.ctx.handle, weights, len(weights), tj, len(tj), heads, code, C.byref(self._h)))
         info = N.mrk_encoder_info()
         N.check(N.lib().mrk_encoder_get_info(self._h, C.byref(info)))
         self.info = {k: getattr(info, k) for k, _ in info._fields_}

@@ -405,6 +405,28 @@ def test_f32_mode_reproduces_the_fp32_graph():
         enc.close()
 
 
+def test_auto_precision_is_f32_for_a_requests_query_and_fp16_for_batches():
+    """mrk_encoder_load_ex(MRK_ENCODER_AUTO): a call over <= 4 sequences (ONE request's query: mrk_rank) gives the bits of an
+    encoder held to f32, a larger call (the queries of a packed batch) the bits of the fp16 encoder - by the size of the call,
+    whatever was embedded before (a text keeps one cached embedding per arithmetic)."""
+    w = synth.synthetic_bert(**MINILM, classifier=False)
+    tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
+    blob = synth.bert_safetensors(w, 12)
+    auto, e16, e32 = HipEncoder(blob, tj, precision="auto"), HipEncoder(blob, tj), HipEncoder(blob, tj, precision="f32")
+    try:
+        texts = synth.synthetic_queries(12, seed=5)
+        np.testing.assert_array_equal(auto.embed(texts[:3]), e32.embed(texts[:3]))
+        np.testing.assert_array_equal(auto.embed(texts), e16.embed(texts))
+        np.testing.assert_array_equal(auto.embed(texts[:1]), e32.embed(texts[:1]))       # ... also after the batch embedded it in fp16
+        assert not np.array_equal(e16.embed(texts[:3]), e32.embed(texts[:3]))
+        ids, types, mask = HipTokenizer(tj).encode_batch(texts)
+        np.testing.assert_array_equal(auto.embed_ids(ids[:4], types[:4], mask[:4]), e32.embed_ids(ids[:4], types[:4], mask[:4]))
+        np.testing.assert_array_equal(auto.embed_ids(ids[:5], types[:5], mask[:5]), e16.embed_ids(ids[:5], types[:5], mask[:5]))
+    finally:
+        for e in (auto, e16, e32):
+            e.close()
+
+
 def test_c5_against_the_fp32_embedding_not_against_itself():
     """BASELINE config 5 with the oracle fed an INDEPENDENT embedding - numpy's fp32 run of the graph - instead of the device's
     own: with the encoder in f32 mode the device's cosine column is within 1e-6 of the oracle's, and every score the
