@@ -643,6 +643,26 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         latency = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "n": len(lat),
                    "items": args.items, "path": "mrk_rank: one upload, ONE launch (pre-pass + assembly + forest + ordering), results written to pinned memory"}
+        if enc is not None:
+            # the encoder is "auto": the single query of these calls ran in f32 (the fp32 ONNX session's arithmetic); the same
+            # requests with an encoder held to fp16 - what BASELINE config 5 names - for comparison
+            latency["query_precision"] = "f32 (MRK_ENCODER_AUTO: calls over <= 4 texts)"
+            try:
+                enc16 = HipEncoder(enc_weights, tok_json, ctx=ctx, precision="f16")
+                ranker.bind_encoder("title_match", enc16)
+                for r in warm[:5]:
+                    ranker.rerank(model_name, r, booster)
+                l16 = []
+                for r in reqs:
+                    t1 = time.perf_counter()
+                    ranker.rerank(model_name, r, booster)
+                    l16.append((time.perf_counter() - t1) * 1e3)
+                latency["fp16_query_p50_ms"] = float(np.percentile(l16, 50))
+                ranker.bind_encoder("title_match", enc)
+                enc16.close()
+            except Exception as e:  # noqa: BLE001
+                latency["fp16_query_p50_ms"] = None
+                latency["fp16_query_error"] = str(e)
         # the same ONE request over and over: its session, its candidates' records and tables are in L2 - what is left of the
         # distance to `p50_ms` (distinct requests, cold lines) is memory latency of the request's dependent trips, not the path
         hot = []

@@ -539,9 +539,60 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
   }
 }
 
+// The same product for M <= 16 rows - ONE request's query, which MRK_ENCODER_AUTO runs in f32.  The tiled kernel above puts
+// such a product on N / 64 workgroups that walk K sixteen entries at a time, a trip to memory each: 40 - 150 us per product,
+// 1.9 ms per query (measured, profiles/r04_f_ab.txt) against 0.43 ms for the fp16 path.  Here a workgroup owns 16 output
+// columns and its 256 lanes split K sixteen ways (lane = column + 16 x part): every lane walks a contiguous K / 16 slice of
+// its weight row with 16-byte loads, the rows of A are read through the same-address broadcast of the lanes of a part, and
+// the sixteen partial sums of an output meet in LDS and are added in part order.  (A row's bits therefore depend on
+// whether its call had more than 16 rows - within the f32 mode's tolerances, tests/test_encoder_gpu.py; the fp16 path's
+// "a row does not depend on its batch" property is untouched.)
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+                                                              const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
+  constexpr int MR = 16, PARTS = 16, COLS = 16;
+  __shared__ float part[PARTS][MR][COLS + 1];
+  const int tid = threadIdx.x, c = tid & (COLS - 1), p = tid >> 4;
+  const int n = blockIdx.x * COLS + c;
+  const int ks = K / PARTS;   // a multiple of 4: K is a multiple of 64
+  const float *w = W + (size_t)n * K + (size_t)p * ks;
+  const float *a0 = A + (size_t)p * ks;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  for (int k0 = 0; k0 < ks; k0 += 4) {
+    const float4 wv = *(const float4 *)(w + k0);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m >= M) break;   // (uniform)
+      const float4 av = *(const float4 *)(a0 + (size_t)m * K + k0);
+      acc[m] = __fmaf_rn(av.x, wv.x, acc[m]);
+      acc[m] = __fmaf_rn(av.y, wv.y, acc[m]);
+      acc[m] = __fmaf_rn(av.z, wv.z, acc[m]);
+      acc[m] = __fmaf_rn(av.w, wv.w, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) part[p][m][c] = acc[m];
+  __syncthreads();
+  const int m = tid >> 4;   // lane -> (row, column) of the output
+  if (m < M) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) v += part[q][m][c];
+    v += bias[n];
+    if (EPI == EPI32_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    if (EPI == EPI32_RES) v += res[(size_t)m * N + n];
+    out[(size_t)m * N + n] = v;
+  }
+}
+
 template <int EPI>
 void launch_gemm_f32(const float *A, const float *W, const float *bias, const float *res, float *out, int M, int N, int K, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+  if (M <= 16 && K % 64 == 0 && N % 16 == 0)
+    hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI>), dim3(N / 16), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
 }
 
 // one wavefront per (query row, head, sequence): scores over the sequence's live keys, softmax, weighted sum of V.

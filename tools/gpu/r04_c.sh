@@ -1,6 +1,7 @@
-# Round 4, measurement pass of the adopted default (wave-per-section pre-pass + bucketed tables): the whole -m gpu suite,
-# the bench line of every workload, kernel stats of the default bench command, PMC passes of c2 / c3 / c4x.
-#   gpurun --timeout 1500 -- 'TAG=r04_c bash tools/gpu/r04_c.sh'
+# Round 4, measurement pass: the whole -m gpu suite, the bench line of every workload, kernel stats of the default bench
+# command, PMC passes of c2 / c3 / c4x (summaries carry the provenance of the run they were taken on).
+#   gpurun --timeout 1500 -- 'TAG=r04_c bash tools/gpu/r04_c.sh'            (first pass of the round: c2 / c3 only)
+#   gpurun --timeout 1800 -- 'TAG=r04_g XGB=1 bash tools/gpu/r04_c.sh'      (final pass: everything)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${TAG:-r04_c}
 O=gpurun_out/$TAG
@@ -26,6 +27,9 @@ for w in ${WORKLOADS:-c3 c4 c4x c5}; do
   timeout 600 python bench.py --workload $w --cpu-sample 0 > $O/bench_$w.json 2> $O/bench_$w.log || tail -5 $O/bench_$w.log
   show $w $O/bench_$w.json
 done
+if [ -n "$XGB" ]; then
+  timeout 600 python bench.py --backend xgboost --trees 100 --depth 6 --cpu-sample 0 > $O/bench_c2_xgb100_d6.json 2> $O/bench_c2_xgb100_d6.log; show "config 2 as written (xgboost 100 x depth 6)" $O/bench_c2_xgb100_d6.json
+fi
 # kernel stats of the default bench command (2 streams: what the driver's line is made of)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o s -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0 > $O/stats_c2.log 2>&1
 PMC="--steps 3 --warmup 1 --batches-per-step 1 --streams 1 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0"
