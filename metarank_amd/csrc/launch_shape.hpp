@@ -59,11 +59,14 @@ inline int scorer_waves_per_tile(long long n_tiles, int V, bool f64, int n_cus, 
     if (resident > best_waves) { best_waves = resident; nw = n; }
     if (resident >= 28) break;
   }
-  int fill = 1;  // few tiles: fill the chip
-  if (n_tiles * 16 <= simds / 2) fill = 16;
-  else if (n_tiles * 8 <= 2 * simds) fill = 8;
-  else if (n_tiles * 4 <= 2 * simds) fill = 4;
-  else if (n_tiles * 2 <= 2 * simds) fill = 2;
+  // Few tiles: the kernel is bound by instruction issue and wants ~6 wavefronts per SIMD to keep the VALU fed - the smallest
+  // split that gets there, at most 16.  Same box (profiles/r04_h_ab.txt, 500 trees): 100 000 rows = 782 tiles: 4 -> 0.098 ms,
+  // 8 -> 0.083, 16 -> 0.083; 20 000 rows = 157 tiles: 4 -> 0.066, 8 -> 0.045, 16 -> 0.032; 400 000 rows = 3 125 tiles: 4 -> 0.231,
+  // 8 -> 0.233, 16 -> 0.242 (round 3's rule aimed at 2 wavefronts per SIMD and gave the first two 4 and 8).
+  if (V <= 0) return nw;   // a forest of single-leaf trees: nothing to evaluate, one wavefront adds the leaves
+  int fill = 1;
+  const long long want = 6 * simds;
+  while (fill < 16 && n_tiles * fill < want) fill *= 2;
   return std::max(nw, fill);
 }
 

@@ -55,7 +55,10 @@ def test_slices_never_exceed_the_rounds_or_one_residency(lib):
     (384_000, 41, 1, 4, "c2 (V = 41): 1 -> 0.283 ms, 2 -> 0.317, 4 -> 0.218, 8 -> 0.220, 16 -> 0.230"),
     (384_000, 100, 1, 8, "c3-like (V ~ 100): 1 -> 0.547 ms, 4 -> 0.280, 8 -> 0.248"),
     (100, 41, 1, 16, "a single request: one tile, every wavefront the kernel has"),
-    (100_000, 41, 1, 4, "c4: 782 tiles"),
+    (100_000, 41, 1, 8, "c4: 782 tiles (r04_h: 4 -> 0.098 ms, 8 -> 0.083, 16 -> 0.083)"),
+    (20_000, 41, 1, 16, "157 tiles (r04_h: 4 -> 0.066 ms, 8 -> 0.045, 16 -> 0.032)"),
+    (400_000, 41, 1, 4, "3 125 tiles (r04_h: 4 -> 0.231 ms, 8 -> 0.233, 16 -> 0.242)"),
+    (4_000_000, 41, 1, 4, "c4x: 31 250 tiles"),
     (384_000, 0, 1, 1, "a forest of single-leaf trees has no views (and no division by zero: r02_m)"),
 ])
 def test_scorer_wavefronts_per_tile(lib, rows, views, f64, want, why):
