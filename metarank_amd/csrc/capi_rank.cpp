@@ -95,11 +95,6 @@ struct mrk_batch {
   DevBuf d_in, d_prep_out, d_arena, d_matrix;
   hipStream_t stream = nullptr;   // batches made by mrk_batch_prepare / _create own a stream: several can be in flight on one device
   hipStream_t s() const { return stream ? stream : ctx->stream; }
-  // the ordering of a batch's small requests runs on a stream of its own with the HIGHEST priority, between two events: next
-  // to another batch's assembly workgroups - which fill the CUs - a 14 us sort kernel waited ~100 us for a place
-  // (profiles/r04_c_c2_bench_kernel_stats.csv: 107 us average), and the batch's own next launches wait behind it
-  hipStream_t sort_stream = nullptr;
-  hipEvent_t ev_scored = nullptr, ev_sorted = nullptr;
   DevBuf d_out;              // [scores: (T + shard padding) f64][order: T i32][status: n_req i32][load status: n_req i32], fetched with ONE copy
                              // (load status: what the id-resolution kernel found at load time - ST_BAD_IDS; status is zeroed by every run)
   size_t out_order_off = 0, out_status_off = 0, out_bytes = 0;
@@ -351,29 +346,6 @@ static int shard_chunk(const mrk_batch &b, int count) { return (int)mrk_shard_ch
 
 static void sort_batch(mrk_batch &b) {
   mrk_ctx *ctx = b.ctx;
-  if (switches().sort_priority && b.stream && b.big.empty() && b.n_req > 1) {
-    if (!b.sort_stream) {
-      int least = 0, greatest = 0;
-      MRK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      MRK_HIP(hipStreamCreateWithPriority(&b.sort_stream, hipStreamNonBlocking, greatest));
-      MRK_HIP(hipEventCreateWithFlags(&b.ev_scored, hipEventDisableTiming));
-      MRK_HIP(hipEventCreateWithFlags(&b.ev_sorted, hipEventDisableTiming));
-    }
-    MRK_HIP(hipEventRecord(b.ev_scored, b.s()));
-    MRK_HIP(hipStreamWaitEvent(b.sort_stream, b.ev_scored, 0));
-    hipStream_t back = ctx->launch;   // (the caller holds ctx->mu: LaunchOn)
-    ctx->launch = b.sort_stream;
-    try {
-      launch_sort(ctx, b.view, b.hb.max_items);
-    } catch (...) {
-      ctx->launch = back;
-      throw;
-    }
-    ctx->launch = back;
-    MRK_HIP(hipEventRecord(b.ev_sorted, b.sort_stream));
-    MRK_HIP(hipStreamWaitEvent(b.s(), b.ev_sorted, 0));
-    return;
-  }
   launch_sort(ctx, b.view, b.hb.max_items);
   if (b.big.empty()) return;
   ScopedKernelTimer timer(ctx, "sort");
@@ -1503,12 +1475,6 @@ void mrk_batch_free(mrk_batch *batch) {
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(batch->s());
-    if (batch->sort_stream) {
-      (void)hipStreamSynchronize(batch->sort_stream);
-      (void)hipStreamDestroy(batch->sort_stream);
-      (void)hipEventDestroy(batch->ev_scored);
-      (void)hipEventDestroy(batch->ev_sorted);
-    }
     if (batch->stream) (void)hipStreamDestroy(batch->stream);
     delete batch;
     ctx_release(ctx);

@@ -990,11 +990,10 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
   hb.prep_out.assign((size_t)n_req * prog.prep.size(), PrepOut{0, 0, 0.0, 0, 0});
   for (int r = 0; r < n_req; ++r) hb.reqs[r].item_begin = begins[r];
   const uint64_t load_pct = table_load_pct();
-  // Small batches (one request of mrk_rank) are not worth a thread.  A batch whose ids the device resolves leaves ~70 ns of
-  // host work per REQUEST (user / session slots, constants, table sizing): 0.28 ms for the 3 840 requests of a c2 batch on one
-  // thread - which was fine while a device batch took 0.41 ms and became the limit of the serving loop at 0.335 ms (round 4:
-  // e2e 0.89 of the device-resident rate): one worker per 1 024 requests from 2 048 on.
-  const int n_workers = device_ids ? (n_req >= 2048 ? std::min(host_threads(), n_req / 1024) : 1) : (total >= 16384 ? host_threads() : 1);
+  // small batches (one request of mrk_rank) are not worth a thread; neither is a batch whose ids the device resolves (~70 ns of
+  // host work per request: round 4 tried one worker per 1 024 requests of a 3 840-request batch - the threads cost more than
+  // they saved, mrk_batch_load 0.285 -> 0.371 ms, profiles/r04_i_ab.txt)
+  const int n_workers = (device_ids ? n_req >= 16384 : total >= 16384) ? host_threads() : 1;
   // the ops that ask something of the REQUEST (constants, table sizes); plain per-item columns do not
   std::vector<const HostOp *> request_ops;
   for (const HostOp &ho : prog.host_ops) {

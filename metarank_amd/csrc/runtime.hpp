@@ -115,7 +115,6 @@ struct Switches {
   std::string jit_defines;     // MRK_JIT_DEFINES: macros prepended to the specialised kernels' source (experiments)
   bool thr_stage = true;       // MRK_THR_STAGE=0: the assembly kernels search threshold tables in global memory instead of staging them in LDS (experiments)
   bool jit_shipped = true;     // MRK_JIT_SHIPPED=0: ignore the code objects shipped next to the library (tests of the compile paths)
-  bool sort_priority = true;   // MRK_SORT_PRIORITY=0: a batch's small-request sort on the batch's own stream instead of a highest-priority stream between two events
   bool items_lds = true;       // MRK_ITEMS_LDS=0: the item-parallel assembly kernel probes the pre-pass tables in the HBM arena even where a workgroup's request's tables fit its LDS
   bool jit_sig = true;         // MRK_JIT_SIG=0: the specialised kernels are keyed by the program only and read the forest's column descriptors from memory (A/B of the view-signature folding)
   bool jit_record_regs = true; // MRK_JIT_REGS=0: the specialised kernel reads the candidate's record cell by cell instead of keeping it in registers

@@ -199,6 +199,7 @@ def test_busy_serving_workgroups_do_not_stall_reallocations():
             warm.load_model(blob, 0)
             for n in (129, 300, 700, 1500, 2900):
                 warm.rerank(ranklens.generate_requests(1, n, N_ITEMS, N_SESS, seed=100 + n)[0])
+            warm.rerank(small[0])   # ... and mrk_rank's one-launch kernel: a hammer thread that finds both slots busy falls back to it
         finally:
             warm.close()
         srv = hip.ranker.serve("xgboost", hip.booster, n_slots=2)

@@ -27,6 +27,11 @@ for w in ${WORKLOADS:-c3 c4 c4x c5}; do
   timeout 600 python bench.py --workload $w --cpu-sample 0 > $O/bench_$w.json 2> $O/bench_$w.log || tail -5 $O/bench_$w.log
   show $w $O/bench_$w.json
 done
+if [ -n "$E2E2" ]; then   # the serving loop driven by two host threads (each its own batches)
+  timeout 600 python bench.py --cpu-sample 0 --latency-requests 0 --e2e-threads 2 > $O/bench_c2_e2e2.json 2> $O/bench_c2_e2e2.log; show "c2, 2 host threads" $O/bench_c2_e2e2.json
+  timeout 600 python bench.py --cpu-sample 0 --latency-requests 0 --e2e-threads 2 --e2e-batches 3 > $O/bench_c2_e2e2b3.json 2> $O/bench_c2_e2e2b3.log; show "c2, 2 host threads x 3 batches" $O/bench_c2_e2e2b3.json
+  timeout 600 env MRK_JIT_SIG=0 python bench.py --workload c3 --cpu-sample 0 --latency-requests 0 --e2e-seconds 0 > $O/bench_c3_sig0.json 2> $O/bench_c3_sig0.log; show "c3, program-only kernels (same box)" $O/bench_c3_sig0.json
+fi
 if [ -n "$XGB" ]; then
   timeout 600 python bench.py --backend xgboost --trees 100 --depth 6 --cpu-sample 0 > $O/bench_c2_xgb100_d6.json 2> $O/bench_c2_xgb100_d6.log; show "config 2 as written (xgboost 100 x depth 6)" $O/bench_c2_xgb100_d6.json
 fi
