@@ -743,6 +743,12 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
   int32_t *status;    // the request's status word
   qs_lds_double *thr_lds;  // two staging buffers of thr_cap() doubles, private to this wavefront
   bool active;
+  // false when `dst` is LDS (the one-launch kernels keep the request's tile there): its stores are ds_writes, which vmcnt does
+  // not count at all - the in-order wait below must then never count them (round 4: the one-launch kernel waited vmcnt(1 | 2)
+  // for a table that was still on its way and binned against a half-landed table once in a few runs - found when the
+  // signature-keyed sink shortened the time between request and search; the batch kernels, whose cells go to global memory,
+  // were never affected)
+  bool vm_stores = true;
   // A column's threshold table is searched in LDS (a per-lane binary search in global memory would be log2(T)
   // scattered wave-loads per column).  Asking for the descriptor, then for the table, then searching costs two trips
   // to memory per column - measured: 70 % of the assembly phase - so the tables travel one column ahead of the search:
@@ -863,7 +869,7 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
     const uint32_t pos = staged(ft) ? qs_bin_search_staged<F64>(thr_lds + (size_t)(col & 1) * thr_cap(), ft.thr_len, x,
                                                                 [&]() -> uint32_t { return QS::is_static ? f->thr_len : ft.thr_len; })
                                     : qs_bin_search<F64>(q.thr + ft.thr_off, ft.thr_len, x);
-    newer += (uint32_t)(ft.view_end - ft.view_begin);   // one store per view below (at least one lane of the wavefront has an item)
+    if (vm_stores) newer += (uint32_t)(ft.view_end - ft.view_begin);   // one store per view below (at least one lane of the wavefront has an item)
     uint16_t *d = dst;
     const bool act = active;
     auto emit = [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; };
@@ -1663,7 +1669,7 @@ __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &pr
   bl.status = s_status - r;   // &bl.status[r] is the LDS word
   __syncthreads();
   rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
-    return CellSink<F64, QS>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active};
+    return CellSink<F64, QS>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active, /*vm_stores=*/false};
   }, slab_bytes + 16);
   // (qs_score_tile_split starts with a barrier: the slab is complete, the assembly's LDS regions are free)
   constexpr int TREE_LEAF_BYTES = QS_LEAVES * (F64 ? 8 : 4);

@@ -43,6 +43,28 @@ def test_abi_version_and_error_paths_without_gpu():
     assert L.mrk_encoder_load_ex(None, None, 0, None, 0, 0, 1, C.byref(out)) == _native.ERR_INVALID_ARG
     assert L.mrk_config_warmup(None, b"m") == _native.ERR_INVALID_ARG
     assert L.mrk_shard_chunk(1000, 8) == 128 and L.mrk_shard_chunk(1025, 8) == 256
+    # ABI 7: what a measurement records to say which code it ran
+    bid = L.mrk_build_id()
+    assert re.fullmatch(rb"[0-9a-f]{16}", bid), bid
+    need = C.c_size_t(0)
+    assert L.mrk_config_kernel_keys(None, b"m", None, 0, C.byref(need)) == _native.ERR_INVALID_ARG
+    assert L.mrk_config_precompile_for_model(None, 0, b"m", 0, None, 0, 1, b"/tmp", None) == _native.ERR_INVALID_ARG
+    assert L.mrk_config_specialize_for_model(b"{}", 2, b"m", 0, None, 0, 0, None, 0, C.byref(need)) == _native.ERR_INVALID_ARG   # no model bytes
+
+
+def test_build_id_follows_the_sources(tmp_path):
+    """mrk_build_id() is the digest _native.write_build_id() takes over csrc/ and include/mrk.h when the library is built: the
+    library on disk was built from the sources on disk (bench.py quotes profiler counters only for the build they were taken on)."""
+    import hashlib
+
+    csrc = os.path.join(REPO, "metarank_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".cpp", ".hip", ".hpp")):
+            h.update(f.encode() + b"\0" + open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(REPO, "include", "mrk.h"), "rb").read())
+    _native.build()
+    assert _native.lib().mrk_build_id().decode() == h.hexdigest()[:16]
 
 
 def test_no_product_file_references_the_oracle():

@@ -75,6 +75,14 @@ def test_one_launch_equals_three_launches_and_the_oracle(kind, jit):
             for one in ("1", "0"):
                 _, s, o = got[one][k]
                 assert same(s, es) and o.tolist() == eo.tolist(), (kind, jit, one, k)
+        # ... again and again: the kernel's waits are counted (`vmcnt(n)` behind an LDS-DMA), and a wait that is one too weak
+        # shows up as a wrong cell once in many launches (round 4 found one that way: cells stored to LDS are not vm operations)
+        many = ranklens.generate_requests(60, 100, N_ITEMS, N_SESS, seed=1234)
+        want = [orc.rerank(ev) for ev in many]
+        for rep in range(3):
+            for k, ev in enumerate(many):
+                _, s, o = hip.ranker.rerank("xgboost", ev, hip.booster)
+                assert same(s, want[k][1]) and o.tolist() == want[k][2].tolist(), (kind, jit, "repeat", rep, k)
         # concurrent callers: the batching front hands the one-launch kernel up to 16 requests at a time
         with ThreadPoolExecutor(12) as ex:
             res = list(ex.map(lambda ev: hip.ranker.rerank("xgboost", ev, hip.booster), reqs * 3))
@@ -290,3 +298,30 @@ def test_default_jit_mode_never_waits_for_the_compiler():
                 hip.close()
     finally:
         restore_env(saved)
+
+
+@pytest.mark.gpu
+def test_kernel_keys_say_which_specialised_kernels_ran():
+    """mrk_config_kernel_keys: after a batch has run with the compiler waited for, the model's fused kernel is listed with the key
+    of its translation unit - keyed by program AND forest by default, by the program only under MRK_JIT_SIG=0 - and the two
+    keys differ (bench.py's `provenance`)."""
+    cfg = ranklens.ranklens_config()
+    keys = {}
+    for sig in ("1", "0"):
+        saved = with_env({"MRK_RANK_JIT": "1", "MRK_JIT_SIG": sig})
+        hip = HipBackend(cfg, "xgboost")
+        try:
+            ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
+            hip.load_model(synth.synthetic_lgbm_model(n_trees=50, n_features=24, missing="per_feature"), 0)
+            batch = hip.ranker.prepare("xgboost", ranklens.generate_requests(40, 100, N_ITEMS, N_SESS, seed=7))
+            batch.run(hip.booster)
+            batch.fetch()
+            batch.close()
+            got = hip.ranker.kernel_keys("xgboost")
+            assert list(got) == ["mrk_jit_rank_cells"] and len(got["mrk_jit_rank_cells"]) == 1, got
+            keys[sig] = got["mrk_jit_rank_cells"][0]
+        finally:
+            hip.close()
+            restore_env(saved)
+    assert keys["1"].endswith(" program+forest") and keys["0"].endswith(" program") and keys["1"].split()[0] != keys["0"].split()[0]
+
