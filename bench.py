@@ -76,10 +76,11 @@ def main():
                     help="device batches one step runs (default: c2 / c3 96, c4 128, c5 8: a step is about 50 ms of device work)")
     ap.add_argument("--e2e-seconds", type=float, default=1.5, help="timed length of the end-to-end serving loop (0 = skip)")
     ap.add_argument("--e2e-batches", type=int, default=4, help="batches in flight per host thread in the end-to-end loop")
-    ap.add_argument("--e2e-threads", type=int, default=1,
-                    help="host threads driving the end-to-end loop (each its own batches).  One keeps up with the device (0.28 ms of host "
-                         "work per device batch); through Python more threads only add GIL hand-overs (measured: 683 / 592 / 636 M items/s "
-                         "with 1 / 2 / 3)")
+    ap.add_argument("--e2e-threads", type=int, default=2,
+                    help="host threads driving the end-to-end loop (each its own batches).  Round 4: with the device batch at 0.335 ms the "
+                         "0.28 ms of host work per batch (mrk_batch_load) make ONE thread the limit of the loop - 1 028 M items/s = 0.90 of the "
+                         "device-resident rate, two threads 1 116 M = 0.97 (same box, profiles/r04_j_bench_c2_e2e2.json); while a batch took "
+                         "0.41 ms one thread kept up and more only added GIL hand-overs (round 3: 683 / 592 / 636 M with 1 / 2 / 3)")
     ap.add_argument("--e2e-sets", type=int, default=6, help="distinct request sets the end-to-end loop cycles through")
     ap.add_argument("--drop-features", default="", help="experiments only: comma-separated features removed from the model")
     ap.add_argument("--catalogue", type=int, default=100_000)

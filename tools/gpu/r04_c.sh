@@ -7,7 +7,7 @@ TAG=${TAG:-r04_c}
 O=gpurun_out/$TAG
 mkdir -p $O
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 1000 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+  timeout 1000 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
   grep -E "passed|failed|error" $O/pytest.log | tail -3
 fi
 show() { python - "$1" "$2" <<'PY'
