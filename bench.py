@@ -12,7 +12,7 @@ HIP stream.  `value` is that device-resident throughput (the contract: inputs in
 
 The JSON line also carries "e2e": the serving loop with FRESH requests every device batch - mrk_batch_load (host part
 of the request + upload of the id bytes; item ids are resolved to store slots by a kernel) -> run -> download of
-scores / order / status into pinned memory, `--e2e-threads` host threads (default 1) with `--e2e-batches` batches in
+scores / order / status into pinned memory, `--e2e-threads` host threads (default 2) with `--e2e-batches` batches in
 flight each, >= 1 s of timed work.
 
 --workload c2 (default)  the configuration BASELINE.json's metric is quoted on: 100-item requests, the

@@ -207,7 +207,10 @@ def test_busy_serving_workgroups_do_not_stall_reallocations():
             warm.load_model(blob, 0)
             for n in (129, 300, 700, 1500, 2900):
                 warm.rerank(ranklens.generate_requests(1, n, N_ITEMS, N_SESS, seed=100 + n)[0])
-            warm.rerank(small[0])   # ... and mrk_rank's one-launch kernel: a hammer thread that finds both slots busy falls back to it
+            # ... and mrk_rank's one-launch kernel (no explain matrix): a hammer thread that finds both slots busy falls back
+            # to it, and under MRK_RANK_JIT=1 its first use would compile for ~4 s with the batching front's leadership held -
+            # exactly the wait this test must not mistake for a stalled reallocation
+            warm.ranker.rerank("xgboost", small[0], warm.booster, explain=False)
         finally:
             warm.close()
         srv = hip.ranker.serve("xgboost", hip.booster, n_slots=2)
