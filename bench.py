@@ -465,6 +465,13 @@ def main():
                         "rank_fused = pre-pass + assembly + forest + ordering of a request in its own workgroup, ONE launch per batch "
                         "(MRK_RANK_FUSED_SCORE=0: the three-launch path with per-kernel times)"}
 
+    if wl == "c4x" and "assemble" in kernels:
+        # the out-of-cache gather is the ONE launch of this path where the HBM roofline is the right yardstick: its own
+        # figures next to the dominant kernel's - 8(d) bytes, and the 384-byte records it cannot avoid touching
+        g_ms = kernels["assemble"]["avg_ms"]
+        rec_bytes = my_items * ranker.item_stride()
+        roofline["gather"] = {"kernel": "assemble", "avg_launch_ms": g_ms, "achieved": alg_path / (g_ms * 1e-3) / 1e9, "frac": alg_path / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "record_bytes_per_launch": rec_bytes, "frac_by_records": rec_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if dominant == "encoder":   # config 5: the launch sequence that dominates is GEMM-shaped - priced against the dense f16 MFMA peak
         roofline = {"bound": "mfma", "kernel": "encoder", "achieved": enc_flops / dur_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": enc_flops / dur_s / 1e12 / 2500.0, "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": kernels[dominant]["avg_ms"],
