@@ -339,6 +339,18 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
     } else if (mode == 3 || mode == 4 || sl.state.load() != 0) {
       int st = sl.state.load();
       if (st == 0) {  // first sight of this (program, signature, kernel, precision): start the compile, keep ranking with what there is
+        // The stand-ins FIRST, all of them: loading a code object while another thread is inside the compiler waits for it
+        // (seen on the GPU box: the first mrk_rank of a model took 4.0 s - one compile - when the background thread reached
+        // the compiler before the request's thread reached hipModuleLoadData; hiprtc / comgr serialise).  Once the
+        // program-only kernels that are on disk are loaded, no request of this program touches the loader while its
+        // signature's kernels compile.
+        void *fallback = nullptr;
+        if (keyed && !no_compile) {
+          for (int kn = 0; kn < JIT_KERNELS; ++kn) {
+            void *f = jit_function_locked(prog, kn, kn == JIT_MATRIX ? true : f64, false, nullptr, true);
+            if (kn == kernel) fallback = f;
+          }
+        }
         sl.state.store(1);
         JitSlot *slot = &sl;
         sl.worker = std::thread([slot, produce]() {
@@ -350,7 +362,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
             slot->state.store(3);
           }
         });
-        return stand_in();
+        return fallback;
       }
       if (st == 1) {
         if (mode != 2 && mode != 1) return stand_in();  // still compiling
