@@ -291,7 +291,10 @@ def test_default_jit_mode_never_waits_for_the_compiler():
                 first_ms = (time.perf_counter() - t0) * 1e3
                 _, es, eo = orc.rerank(reqs[0])
                 assert same(s, es) and o.tolist() == eo.tolist()
-                assert first_ms < 50.0, (variant, first_ms)   # a hiprtc compile of this kernel takes seconds
+                # a hiprtc compile of this kernel takes 3 - 20 s depending on the host; what the first request does pay since
+                # round 4 is the loading of the program-only kernels that are on disk (seven modules, before the background
+                # compile starts: jit.cpp) - milliseconds on a fast host, more on the pool's slow ones
+                assert first_ms < 1000.0, (variant, first_ms)
                 hip.ranker.warmup_kernels("xgboost")            # the background compile (variant "new") is done after this
                 for ev in reqs:
                     _, s, o = hip.ranker.rerank("xgboost", ev, hip.booster)
