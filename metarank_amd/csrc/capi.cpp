@@ -54,6 +54,7 @@ static Switches read_switches() {
   s.encoder_graph = flag("MRK_ENCODER_GRAPH", false);
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
   s.encoder_packed = flag("MRK_ENCODER_PACKED", true);
+  s.encoder_f32_mfma = flag("MRK_ENCODER_F32_MFMA", true);
   return s;
 }
 static Switches &switches_storage() {

@@ -491,11 +491,174 @@ void launch_gemm(const uint16_t *A, const uint16_t *W, const float *bias, const 
 }
 
 // ---- precision f32 (mrk_encoder_load_ex(MRK_ENCODER_F32)): the arithmetic of the reference's fp32 ONNX session - f32
-// operands, f32 accumulation, libm erf / exp.  Plain tiled kernels: this path exists to REPRODUCE numbers (cosines within
-// 1e-5 of transformers' fp32 output where the fp16 path is within 3e-3), not to be fast.
+// operands, f32 accumulation, libm erf / exp - on the matrix cores.  gfx950's f32-input MFMA (v_mfma_f32_16x16x4_f32) is
+// bit for bit a chain of f32 fma's, one rounding per product, at the f32 vector rate (157 TF dense): exact f32, no TF32-like
+// shortcut exists on this chip.  EVERY f32 product here - 128 x 128 tiles, 64 x 64 tiles, the <= 32-row kernel of a single
+// request's query, and the plain-VALU twin kept as the test instrument - accumulates an output element as ONE chain that
+// starts at 0 and walks k in the same canonical order, so a row's bits depend on neither the kernel nor the batch it
+// travelled in: the order a lane's 16-byte operand loads give without any shuffling,
+//     for t in 0 .. K/16:  for c in 0..4:  for q in 0..4:  k = 16 t + 4 q + c        (f32_chain_k below)
+// (lane (r, q) of a 16x16x4 operand holds k-slot q of row r; it loads row r's floats 16t + 4q .. + 3 at once and feeds
+// component c to the c-th of four MFMAs).  The products are computed TRANSPOSED - the weight rows are the MFMA's A operand,
+// the token rows its B operand - so that a lane ends up with 4 consecutive output columns of one token: one 16-byte store,
+// one 16-byte bias / residual load.  (a x b is commutative: the transposition does not change a bit.)
 enum { EPI32_NONE = 0, EPI32_GELU = 1, EPI32_RES = 2 };
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int F32_BK = 32, F32_LD = F32_BK + 4;   // row stride 36 floats: a 16-lane group's 16-byte fragment reads cover all 64 banks once
 
-// C[M, N] = A[M, K] W[N, K]^T + bias (+ GELU | + res): 64 x 64 tiles, 4 x 4 outputs per lane, k in ascending order
+__host__ __device__ constexpr int f32_chain_k(int i) { return 16 * (i >> 4) + 4 * (i & 3) + ((i >> 2) & 3); }  // i-th k of the chain
+
+// bias, then GELU / residual, of the 4 consecutive columns n4 .. n4 + 3 of row m
+template <int EPI>
+__device__ __forceinline__ void store_f32_quad(const floatx4 &acc, int m, int n4, int M, int N, const float *__restrict__ bias, const float *__restrict__ res,
+                                               float *__restrict__ out) {
+  if (m >= M) return;
+  const floatx4 bv = *(const floatx4 *)(bias + n4);
+  floatx4 rv = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == EPI32_RES) rv = *(const floatx4 *)(res + (size_t)m * N + n4);
+  floatx4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = acc[e] + bv[e];
+    if (EPI == EPI32_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    if (EPI == EPI32_RES) v += rv[e];
+    o[e] = v;
+  }
+  *(floatx4 *)(out + (size_t)m * N + n4) = o;
+}
+
+// C[M, N] = A[M, K] W[N, K]^T + bias (+ GELU | + res).  Four wavefronts in 2 x 2, each TM x TN blocks of 16 x 16
+// (TM = TN = 4: 128 x 128 tiles, 64 accumulator registers; 2: 64 x 64 tiles for grids that would not cover the chip).
+// Operands staged through LDS in their natural layout, one 32-wide k block at a time, the next block's global loads in
+// flight during the MFMAs (at 1/16 of the f16 rate a k block is ~4 000 cycles of matrix work per wavefront: prologue and
+// barriers are noise here, unlike in gemm_kernel).  N % (32 TN) == 0, K % 32 == 0.
+template <int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+                                                            const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  __shared__ float As[BM][F32_LD];
+  __shared__ float Bs[BN][F32_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  // the XCD fold of gemm_kernel: one XCD's workgroups walk the N tiles of the same rows of A back to back
+  const int n_tiles = N / BN, m_tiles = (M + BM - 1) / BM, per_xcd = (m_tiles + 7) / 8;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int m_tile = xcd * per_xcd + slot / n_tiles;
+  if (m_tile >= m_tiles) return;
+  const int m0 = m_tile * BM, n0 = (slot % n_tiles) * BN;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;   // staging: row within a 32-row slab, 4-float chunk of the k block
+
+  floatx4 ra[TM], rb[TN];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int m = m0 + i * 32 + lr;
+      m = m < M ? m : M - 1;
+      ra[i] = *(const floatx4 *)(A + (size_t)m * K + k0 + lc);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) rb[j] = *(const floatx4 *)(W + (size_t)(n0 + j * 32 + lr) * K + k0 + lc);
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) *(floatx4 *)&As[i * 32 + lr][lc] = ra[i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) *(floatx4 *)&Bs[j * 32 + lr][lc] = rb[j];
+  };
+
+  floatx4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = K / F32_BK;
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  const int fr = lane & 15, fq = (lane >> 4) * 4;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) load_tiles((kt + 1) * F32_BK);
+#pragma unroll
+    for (int g = 0; g < F32_BK; g += 16) {
+      floatx4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *(const floatx4 *)&As[(wr * TM + i) * 16 + fr][g + fq];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *(const floatx4 *)&Bs[(wc * TN + j) * 16 + fr][g + fq];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][c], fa[i][c], acc[j][i], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < KT) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+  // D[i = weight row][j = token]: the lane owns token fr of its block and output columns fq .. fq + 3
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      store_f32_quad<EPI>(acc[j][i], m0 + (wr * TM + i) * 16 + fr, n0 + (wc * TN + j) * 16 + fq, M, N, bias, res, out);
+}
+
+// The same product for M <= 16 MT rows - ONE request's query (MRK_ENCODER_AUTO / _F32 through mrk_rank), where the critical
+// path is what counts.  One workgroup per 16 output columns; its four wavefronts each read a quarter of the K range straight
+// from global memory into registers (every load in flight at once) and continue ONE accumulator chain in turn, handing it
+// over through LDS - the chain of gemm_f32_mfma_kernel, hence its bits.  GROUPS = 16-wide k groups per wavefront = K / 64.
+template <int MT, int GROUPS, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+                                                              const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
+  __shared__ floatx4 hand[MT][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fq = (lane >> 4) * 4;
+  const int n0 = blockIdx.x * 16, kbase = wave * GROUPS * 16 + fq;
+  const float *wrow = W + (size_t)(n0 + fr) * K + kbase;
+  floatx4 b[GROUPS], a[MT][GROUPS];
+#pragma unroll
+  for (int t = 0; t < GROUPS; ++t) b[t] = *(const floatx4 *)(wrow + 16 * t);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = i * 16 + fr;
+    const float *arow = A + (size_t)(m < M ? m : M - 1) * K + kbase;
+#pragma unroll
+    for (int t = 0; t < GROUPS; ++t) a[i][t] = *(const floatx4 *)(arow + 16 * t);
+  }
+  floatx4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      if (w > 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = hand[i][lane];
+      }
+#pragma unroll
+      for (int t = 0; t < GROUPS; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[t][c], a[i][t][c], acc[i], 0, 0, 0);
+      if (w < 3) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) hand[i][lane] = acc[i];
+      }
+    }
+    if (w < 3) __syncthreads();
+  }
+  if (wave != 3) return;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) store_f32_quad<EPI>(acc[i], i * 16 + fr, n0 + fq, M, N, bias, res, out);
+}
+
+// The test instrument: the same chain on the vector unit (v_fma_f32, one output element per chain, k in f32_chain_k order).
+// MRK_ENCODER_F32_MFMA=0 routes every f32 product here; tests/test_encoder_gpu.py requires the bits of the MFMA kernels.
+// 64 x 64 tiles, 4 x 4 outputs per lane.  N % 64 == 0, K % 16 == 0.
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
                                                        const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
@@ -513,14 +676,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KB; ++k) {
+    for (int kk = 0; kk < KB; ++kk) {
+      const int k = f32_chain_k(kk);
       float a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Ws[k][tx * 4 + i]; }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(b[j], a[i], acc[i][j]);
     }
     __syncthreads();
   }
@@ -539,64 +703,120 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
   }
 }
 
-// The same product for M <= 16 rows - ONE request's query, which MRK_ENCODER_AUTO runs in f32.  The tiled kernel above puts
-// such a product on N / 64 workgroups that walk K sixteen entries at a time, a trip to memory each: 40 - 150 us per product,
-// 1.9 ms per query (measured, profiles/r04_f_ab.txt) against 0.43 ms for the fp16 path.  Here a workgroup owns 16 output
-// columns and its 256 lanes split K sixteen ways (lane = column + 16 x part): every lane walks a contiguous K / 16 slice of
-// its weight row with 16-byte loads, the rows of A are read through the same-address broadcast of the lanes of a part, and
-// the sixteen partial sums of an output meet in LDS and are added in part order.  (A row's bits therefore depend on
-// whether its call had more than 16 rows - within the f32 mode's tolerances, tests/test_encoder_gpu.py; the fp16 path's
-// "a row does not depend on its batch" property is untouched.)
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-                                                              const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
-  constexpr int MR = 16, PARTS = 16, COLS = 16;
-  __shared__ float part[PARTS][MR][COLS + 1];
-  const int tid = threadIdx.x, c = tid & (COLS - 1), p = tid >> 4;
-  const int n = blockIdx.x * COLS + c;
-  const int ks = K / PARTS;   // a multiple of 4: K is a multiple of 64
-  const float *w = W + (size_t)n * K + (size_t)p * ks;
-  const float *a0 = A + (size_t)p * ks;
-  float acc[MR];
-#pragma unroll
-  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-  for (int k0 = 0; k0 < ks; k0 += 4) {
-    const float4 wv = *(const float4 *)(w + k0);
-#pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      if (m >= M) break;   // (uniform)
-      const float4 av = *(const float4 *)(a0 + (size_t)m * K + k0);
-      acc[m] = __fmaf_rn(av.x, wv.x, acc[m]);
-      acc[m] = __fmaf_rn(av.y, wv.y, acc[m]);
-      acc[m] = __fmaf_rn(av.z, wv.z, acc[m]);
-      acc[m] = __fmaf_rn(av.w, wv.w, acc[m]);
-    }
+template <int MT, int EPI>
+bool launch_f32_skinny(const float *A, const float *W, const float *bias, const float *res, float *out, int M, int N, int K, hipStream_t s) {
+#define MRK_SKINNY32(G)                                                                                                          \
+  case G:                                                                                                                        \
+    hipLaunchKernelGGL((gemm_f32_skinny_kernel<MT, G, EPI>), dim3(N / 16), dim3(256), 0, s, A, W, bias, res, out, M, N, K);        \
+    return true;
+  if (K % 64 || N % 16) return false;
+  switch (K / 64) {
+    MRK_SKINNY32(1) MRK_SKINNY32(2) MRK_SKINNY32(4) MRK_SKINNY32(6) MRK_SKINNY32(8) MRK_SKINNY32(12) MRK_SKINNY32(16) MRK_SKINNY32(24)
+    default: return false;
   }
-#pragma unroll
-  for (int m = 0; m < MR; ++m) part[p][m][c] = acc[m];
-  __syncthreads();
-  const int m = tid >> 4;   // lane -> (row, column) of the output
-  if (m < M) {
-    float v = 0.f;
-#pragma unroll
-    for (int q = 0; q < PARTS; ++q) v += part[q][m][c];
-    v += bias[n];
-    if (EPI == EPI32_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-    if (EPI == EPI32_RES) v += res[(size_t)m * N + n];
-    out[(size_t)m * N + n] = v;
-  }
+#undef MRK_SKINNY32
 }
 
 template <int EPI>
 void launch_gemm_f32(const float *A, const float *W, const float *bias, const float *res, float *out, int M, int N, int K, hipStream_t s) {
-  if (M <= 16 && K % 64 == 0 && N % 16 == 0)
-    hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI>), dim3(N / 16), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
-  else
-    hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+  if (switches().encoder_f32_mfma && K % F32_BK == 0 && N % 64 == 0) {
+    if (M <= 16 && launch_f32_skinny<1, EPI>(A, W, bias, res, out, M, N, K, s)) return;
+    if (M > 16 && M <= 32 && launch_f32_skinny<2, EPI>(A, W, bias, res, out, M, N, K, s)) return;
+    // 128 x 128 tiles once the grid still covers the chip with them (two workgroups per CU), 64 x 64 tiles otherwise
+    const bool big = N % 128 == 0 && (size_t)((M + 127) / 128) * (N / 128) >= 512;
+    auto grid_of = [&](int bm, int bn) { return dim3((unsigned)(8 * (((M + bm - 1) / bm + 7) / 8) * (N / bn))); };
+    if (big) hipLaunchKernelGGL((gemm_f32_mfma_kernel<4, 4, EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, EPI>), grid_of(64, 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    return;
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
 }
 
-// one wavefront per (query row, head, sequence): scores over the sequence's live keys, softmax, weighted sum of V.
-// Dynamic LDS: 4 wavefronts x seq floats (the probabilities).  Same conventions as attention_kernel (padded | packed).
+// f32 attention on the same instruction: one wavefront per (16 queries, head, sequence), scores transposed (keys x
+// queries) as in attention_kernel, so a lane owns one query column: softmax = a per-lane reduction over its 4 keys plus
+// two exchanges (lane ^ 16, lane ^ 32), and the probabilities are already the B operand of O^T = V^T P^T (k-slot q of the
+// MFMA = key 4 q + c = the lane's own p[c]).  Running maximum / sum over key blocks of 16, libm expf.  A query row's
+// arithmetic depends on its own sequence only: dead keys contribute exact zeros, dead key blocks leave the state untouched.
+template <int DH>
+__global__ __launch_bounds__(64 * ATT_HEADS) void attention_f32_mfma_kernel(const float *__restrict__ qkv, const int32_t *__restrict__ mask,
+                                                                           const int32_t *__restrict__ cu, int seq_pad, int H, int heads, float scale,
+                                                                           float *__restrict__ ctx) {
+  constexpr int KG = DH / 16;
+  const int lane = threadIdx.x & 63, r = lane & 15, q4 = (lane >> 4) * 4;
+  const int q0 = blockIdx.x * 16, head = blockIdx.y * ATT_HEADS + ((int)threadIdx.x >> 6), b = blockIdx.z;
+  if (head >= heads) return;
+  const size_t row = (size_t)3 * H;
+  const size_t first = cu ? (size_t)cu[b] : (size_t)b * seq_pad;
+  const int seq = cu ? cu[b + 1] - cu[b] : seq_pad;
+  if (q0 >= seq) return;
+  const float *base = qkv + first * row + head * DH;
+  const int32_t *mrow = mask ? mask + first : nullptr;
+  const int qi = q0 + r < seq ? q0 + r : seq - 1;
+  floatx4 qf[KG];
+#pragma unroll
+  for (int t = 0; t < KG; ++t) qf[t] = *(const floatx4 *)(base + (size_t)qi * row + 16 * t + q4);
+  floatx4 o[KG];
+#pragma unroll
+  for (int d = 0; d < KG; ++d) o[d] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int k0 = 0; k0 < seq; k0 += 16) {
+    const int kr = k0 + r < seq ? k0 + r : seq - 1;
+    floatx4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KG; ++t) {
+      const floatx4 kf = *(const floatx4 *)(base + (size_t)kr * row + H + 16 * t + q4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c], qf[t][c], st, 0, 0, 0);
+    }
+    float p[4];
+    float bm = -FLT_MAX;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = k0 + q4 + e;
+      const bool live = key < seq && (mrow == nullptr || mrow[key < seq ? key : seq - 1] != 0);
+      p[e] = live ? st[e] * scale : -FLT_MAX;
+      bm = fmaxf(bm, p[e]);
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float m_new = fmaxf(m_run, bm);
+    const float alpha = expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[e] = p[e] == -FLT_MAX && m_new != -FLT_MAX ? 0.f : expf(p[e] - m_new);
+      ls += p[e];
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < KG; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[d][e] *= alpha;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int key = k0 + q4 + c;
+      key = key < seq ? key : seq - 1;
+#pragma unroll
+      for (int d = 0; d < KG; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(base[(size_t)key * row + 2 * H + d * 16 + r], p[c], o[d], 0, 0, 0);
+    }
+  }
+  if (q0 + r >= seq) return;
+  const float inv = 1.0f / l_run;
+  float *dst = ctx + (first + q0 + r) * H + head * DH;
+#pragma unroll
+  for (int d = 0; d < KG; ++d) {
+    floatx4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = o[d][e] * inv;
+    *(floatx4 *)(dst + d * 16 + q4) = v;
+  }
+}
+
+// head sizes the MFMA kernel does not cover: one wavefront per (query row, head, sequence): scores over the sequence's live
+// keys, softmax, weighted sum of V.  Dynamic LDS: 4 wavefronts x seq floats (the probabilities).
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ qkv, const int32_t *__restrict__ mask, const int32_t *__restrict__ cu,
                                                             int seq_pad, int H, int DH, float scale, float *__restrict__ ctx) {
   extern __shared__ float att_p[];
@@ -673,8 +893,14 @@ static void forward_impl(const EncoderDev &enc, EncoderScratch &sc, int n, int s
       const LayerDev &L = enc.layers[l];
       const LayerDev32 &W = enc.layers32[l];
       launch_gemm_f32<EPI32_NONE>(x, W.wqkv, L.bqkv, nullptr, qf, M, 3 * H, H, s);
-      hipLaunchKernelGGL(attention_f32_kernel, dim3((seq + 3) / 4, sh.heads, n), dim3(256), (size_t)4 * seq * sizeof(float), s, (const float *)qf, mask, cu, seq, H,
-                         DH, scale, cf);
+      const dim3 ag32((seq + 15) / 16, (sh.heads + ATT_HEADS - 1) / ATT_HEADS, n);
+      if (switches().encoder_f32_mfma && DH == 32)
+        hipLaunchKernelGGL((attention_f32_mfma_kernel<32>), ag32, dim3(64 * ATT_HEADS), 0, s, (const float *)qf, mask, cu, seq, H, sh.heads, scale, cf);
+      else if (switches().encoder_f32_mfma && DH == 64)
+        hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), ag32, dim3(64 * ATT_HEADS), 0, s, (const float *)qf, mask, cu, seq, H, sh.heads, scale, cf);
+      else
+        hipLaunchKernelGGL(attention_f32_kernel, dim3((seq + 3) / 4, sh.heads, n), dim3(256), (size_t)4 * seq * sizeof(float), s, (const float *)qf, mask, cu, seq, H,
+                           DH, scale, cf);
       launch_gemm_f32<EPI32_RES>(cf, W.wo, L.bo, x, y, M, H, H, s);
       hipLaunchKernelGGL(ln_kernel, dim3(row_blocks), dim3(256), 0, s, (const float *)y, M, H, L.ln1g, L.ln1b, sh.eps, x, (_Float16 *)xh);
       launch_gemm_f32<EPI32_GELU>(x, W.w1, L.b1, nullptr, mf, M, I, H, s);

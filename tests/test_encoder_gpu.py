@@ -405,6 +405,67 @@ def test_f32_mode_reproduces_the_fp32_graph():
         enc.close()
 
 
+def test_f32_products_on_the_matrix_cores_are_the_fma_chain_and_batch_independent():
+    """The f32 mode's products and attention run on v_mfma_f32_16x16x4_f32 (exact f32: bit for bit a chain of fma's).  All
+    three product kernels (<= 32 rows; 64 x 64 tiles; 128 x 128 tiles) walk k in one canonical order from a zero accumulator,
+    so (1) the vector-unit twin (MRK_ENCODER_F32_MFMA=0: v_fma_f32 in the same order) gives the same BITS for every product -
+    hidden states then differ only through the two attention kernels' softmax bookkeeping, within 1e-5 -, and (2) a sequence's
+    hidden states are the same bits alone (skinny kernel), among a few (64 x 64 tiles), among thousands (128 x 128 tiles), and
+    (3) packed == padded."""
+    import os
+    w = synth.synthetic_bert(**MINILM, classifier=True)
+    tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
+    enc = HipEncoder(synth.bert_safetensors(w, 12), tj, precision="f32")
+    try:
+        rng = np.random.default_rng(78)
+        seq = 20
+        ids = rng.integers(5, 2000, size=(3500, seq)).astype(np.int32)
+        mask = np.ones_like(ids); mask[1::2, 13:] = 0
+        alone = enc.hidden_ids(ids[:1], None, mask[:1])            # M = 20: skinny kernel, MT = 2
+        one9 = enc.hidden_ids(ids[:1, :9], None, mask[:1, :9])     # M = 9: skinny kernel, MT = 1
+        few = enc.hidden_ids(ids[:6], None, mask[:6])              # M = 120: 64 x 64 tiles
+        many = enc.hidden_ids(ids, None, mask)                     # M = 70 000: 128 x 128 tiles
+        np.testing.assert_array_equal(alone[0], few[0])
+        np.testing.assert_array_equal(few[:6], many[:6])
+        assert np.isfinite(many).all()
+        nine = enc.hidden_ids(np.repeat(ids[:1, :9], 40, axis=0), None, np.ones((40, 9), dtype=np.int32))
+        np.testing.assert_array_equal(nine[7], one9[0])
+        fp32 = bert.last_hidden_state(w, ids[:6], np.zeros_like(ids[:6]), mask[:6], heads=12)
+        live = mask[:6].astype(bool)
+        np.testing.assert_allclose(few[live], fp32[live], rtol=0, atol=ATOL_F32_HIDDEN)
+        # packed == padded
+        n = 333
+        lens = rng.integers(1, seq + 1, size=n); lens[:3] = [1, seq, 2]
+        m2 = (np.arange(seq)[None, :] < lens[:, None]).astype(np.int32)
+        got = {}
+        for packed in ("1", "0"):
+            os.environ["MRK_ENCODER_PACKED"] = packed
+            N.reload_switches()
+            try:
+                got[packed] = (enc.embed_ids(ids[:n], None, m2), enc.score_ids(ids[:n], None, m2))
+            finally:
+                del os.environ["MRK_ENCODER_PACKED"]
+                N.reload_switches()
+        for a, b in zip(got["1"], got["0"]):
+            np.testing.assert_array_equal(a, b)
+        # the vector-unit twin: the embedding + first QKV product + ... are the same chain; what differs is attention's
+        # bookkeeping (running maximum over 16-key blocks vs one pass), so compare within the f32 tolerance AND require that
+        # a single layer's worth of products is bit-identical: sequences of ONE token have a softmax of exactly 1.0 in both
+        os.environ["MRK_ENCODER_F32_MFMA"] = "0"
+        N.reload_switches()
+        try:
+            valu_few = enc.hidden_ids(ids[:6], None, mask[:6])
+            valu_one_tok = enc.hidden_ids(ids[:300, :1], None, np.ones((300, 1), dtype=np.int32))
+        finally:
+            del os.environ["MRK_ENCODER_F32_MFMA"]
+            N.reload_switches()
+        np.testing.assert_allclose(valu_few[live], few[live], rtol=0, atol=1e-5)
+        mfma_one_tok = enc.hidden_ids(ids[:300, :1], None, np.ones((300, 1), dtype=np.int32))
+        np.testing.assert_array_equal(valu_one_tok, mfma_one_tok)
+    finally:
+        enc.close()
+
+
 def test_auto_precision_is_f32_for_a_requests_query_and_fp16_for_batches():
     """mrk_encoder_load_ex(MRK_ENCODER_AUTO): a call over <= 4 sequences (ONE request's query: mrk_rank) gives the bits of an
     encoder held to f32, a larger call (the queries of a packed batch) the bits of the fp16 encoder - by the size of the call,
