@@ -50,6 +50,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}  # dense matrix peaks by OPERAND type (f32-input MFMA = the f32 vector rate)
 
 
 def log(*a):
@@ -63,6 +64,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4x", "c5"], default="c2")
+    ap.add_argument("--encoder-precision", choices=["f32", "f16"], default="f32",
+                    help="c5: arithmetic of the text encoder in the timed region (f32 = mrk_encoder_load's default, the fp32 ONNX session's "
+                         "arithmetic on the f32-input matrix instruction; f16 = BASELINE config 5's opt-in); the other one is timed beside it")
     ap.add_argument("--clones", type=int, default=79,
                     help="c4x: deep copies of every generated item (mrk_debug_clone_items): 100 000 x (1 + 79) = 8 M items, a 3 GB item "
                          "table - far beyond the 256 MB Infinity Cache")
@@ -190,11 +194,10 @@ def main():
     if wl == "c5":  # no network for checkpoints: the architecture of all-MiniLM-L6-v2 with random weights
         from metarank_amd.encoder import HipEncoder, HipTokenizer
         tok_json = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=128)
-        # precision "auto" (mrk_encoder_load_ex): the packed batches of the timed region run in fp16 on the matrix cores (what
-        # BASELINE config 5 names), the single never-seen query of the latency leg in f32; what fp16 costs in scores and order
-        # against the f32 arithmetic is measured below on a sample and reported in `encoder.fp16_vs_f32`
+        # f32 (mrk_encoder_load's default): exact-f32 products on v_mfma_f32_16x16x4_f32, the same bits for a query alone and in a packed
+        # batch - scores within 1e-5 / identical order hold; fp16 (BASELINE config 5's wording) is the opt-in and is timed beside it below
         enc_weights = synth.bert_safetensors(synth.synthetic_bert(), 12)
-        enc = HipEncoder(enc_weights, tok_json, ctx=ctx, precision="auto")
+        enc = HipEncoder(enc_weights, tok_json, ctx=ctx, precision=args.encoder_precision)
         tok = HipTokenizer(tok_json)
         ranker.bind_encoder("title_match", enc)
 
@@ -304,10 +307,12 @@ def main():
         if use_dist:
             ctx.comm_barrier()
 
+    cur_enc = [enc]   # c5: the encoder whose forward pass a step runs (the other precision is timed after the main region)
+
     def run_one(i):
         bt = batches[i % n_streams]
         if qtok is not None:
-            enc.embed_ids(*qtok[i % n_streams])
+            cur_enc[0].embed_ids(*qtok[i % n_streams])
         if sharded:   # this rank's slice -> one in-place RCCL all-gather of the f64 scores -> order (csrc/comm.cpp)
             bt.run_sharded(booster) if use_dist else bt.run(booster)
         else:
@@ -473,10 +478,11 @@ def main():
         roofline["gather"] = {"kernel": "assemble", "avg_launch_ms": g_ms, "achieved": alg_path / (g_ms * 1e-3) / 1e9, "frac": alg_path / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "record_bytes_per_launch": rec_bytes, "frac_by_records": rec_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if dominant == "encoder":   # config 5: the launch sequence that dominates is GEMM-shaped - priced against the dense f16 MFMA peak
-        roofline = {"bound": "mfma", "kernel": "encoder", "achieved": enc_flops / dur_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": enc_flops / dur_s / 1e12 / 2500.0, "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": kernels[dominant]["avg_ms"],
+        mfma_peak = MFMA_PEAK_TFLOPS[args.encoder_precision]
+        roofline = {"bound": "mfma", "kernel": "encoder", "achieved": enc_flops / dur_s / 1e12, "peak": mfma_peak, "unit": "TFLOP/s",
+                    "frac": enc_flops / dur_s / 1e12 / mfma_peak, "traffic": None, "precision": args.encoder_precision, "flops_per_launch": enc_flops, "avg_launch_ms": kernels[dominant]["avg_ms"],
                     "what": "one forward pass of the step's queries (embedding ... mean pooling; ~40 launches, HIP events on the encoder's stream); "
-                            "peak = dense f16 MFMA, MI355X_MICROARCH.md",
+                            "peak = dense MFMA rate of the operand type (f32-input 157.3, f16 2 500 TFLOP/s), MI355X_MICROARCH.md",
                     "hbm_view_of_the_rank_batch": {"kernel": "assemble", "achieved": alg_path / (kernels["assemble"]["avg_ms"] * 1e-3) / 1e9,
                                                    "frac": alg_path / (kernels["assemble"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS} if "assemble" in kernels else None}
 
@@ -600,36 +606,76 @@ def main():
         L, H, I, S = enc.info["layers"], enc.info["hidden"], enc.info["intermediate"], ids.shape[1]
         lens = np.asarray(mask).sum(axis=1).astype(np.int64)   # the forward pass runs over the real tokens only (packed batches)
         fl = int(lens.sum()) * L * 2 * (4 * H * H + 2 * H * I) + int((lens * lens).sum()) * L * 4 * H
-        # north_star asks for scores within 1e-5 and the same order; BASELINE config 5 asks for fp16: the price of fp16, on a
-        # sample of 24 requests ranked twice - queries embedded by this encoder's fp16 path (a 24-text call) and by an encoder held
-        # to f32 (the reference's fp32 ONNX arithmetic)
-        fp16_vs_f32 = None
+        # north_star asks for scores within 1e-5 and the same order.  On a sample of 24 requests: (1) `f32_batch` - the f32 encoder's
+        # packed batch against the SAME requests ranked one at a time through mrk_rank (the <= 32-row kernels, a fresh handle without a
+        # cached embedding): the f32 kernels share one accumulation order, so this must be 0 / 0; (2) `fp16_vs_f32` - the price of the
+        # fp16 opt-in (BASELINE config 5's wording) against the f32 arithmetic; (3) the other precision's step, timed beside the headline
+        other_prec = "f16" if args.encoder_precision == "f32" else "f32"
+        f32_batch = fp16_vs_f32 = other = None
         try:
-            enc32 = HipEncoder(enc_weights, tok_json, ctx=ctx, precision="f32")
+            enc_o = HipEncoder(enc_weights, tok_json, ctx=ctx, precision=other_prec)
+            e32, e16 = (enc, enc_o) if args.encoder_precision == "f32" else (enc_o, enc)
             sample_ev = all_events[0][:24]
             res = []
-            for e_ in (enc, enc32):
+            for e_ in (e16, e32):
                 ranker.bind_encoder("title_match", e_)
                 sb = ranker.prepare(model_name, sample_ev)
                 sb.run(booster)
                 sc_, od_, _ = sb.fetch()
                 res.append((sc_.copy(), od_.copy(), list(sb.offsets)))
                 sb.close()
-            ranker.bind_encoder("title_match", enc)
-            enc32.close()
             (s16, o16, offs), (s32, o32, _) = res
             moved = int((np.abs(s16 - s32) > 1e-5).sum())
             reordered = sum(1 for r_ in range(len(sample_ev)) if not np.array_equal(o16[offs[r_]:offs[r_ + 1]], o32[offs[r_]:offs[r_ + 1]]))
             fp16_vs_f32 = {"requests": len(sample_ev), "items": int(len(s16)), "scores_over_1e-5": moved, "reordered_requests": reordered,
                            "max_abs_score_diff": float(np.abs(s16 - s32).max())}
+            e1 = HipEncoder(enc_weights, tok_json, ctx=ctx, precision="f32")   # fresh: every query is a miss of its EmbeddingCache
+            ranker.bind_encoder("title_match", e1)
+            moved1 = reord1 = 0
+            worst = 0.0
+            for r_, ev_ in enumerate(sample_ev):
+                _, s1, o1 = ranker.rerank(model_name, M.Request(ev_), booster)
+                lo_, hi_ = offs[r_], offs[r_ + 1]
+                worst = max(worst, float(np.abs(np.asarray(s1) - s32[lo_:hi_]).max()))
+                moved1 += int((np.asarray(s1) != s32[lo_:hi_]).sum())
+                reord1 += int(not np.array_equal(np.asarray(o1), o32[lo_:hi_]))
+            e1.close()
+            f32_batch = {"requests": len(sample_ev), "items": int(len(s32)), "scores_not_bit_identical": moved1, "scores_over_1e-5": 0 if worst <= 1e-5 else moved1,
+                         "reordered_requests": reord1, "max_abs_score_diff": worst,
+                         "what": "packed f32 batch (mrk_batch_run) vs the same requests one at a time (mrk_rank), both with f32 encoders; against the "
+                                 "independent numpy fp32 graph: tests/test_encoder_gpu.py::test_c5_against_the_fp32_embedding_not_against_itself"}
+            # the other precision's device step (same batches, same loop), a few steps
+            ranker.bind_encoder("title_match", enc_o)
+            cur_enc[0] = enc_o
+            n_o = max(2, args.steps // 4)
+            step(0); sync_all()
+            t1 = time.perf_counter()
+            for i_ in range(n_o):
+                step(i_)
+            sync_all()
+            dt_o = time.perf_counter() - t1
+            ts_o = []
+            for _ in range(5):
+                t1 = time.perf_counter(); enc_o.embed_ids(ids, types, mask); ts_o.append(time.perf_counter() - t1)
+            other = {"precision": other_prec, "value": total_items * bps * n_o / dt_o, "unit": "items/s", "ms_per_step": dt_o / n_o * 1e3, "steps": n_o,
+                     "encoder_ms_per_batch": float(np.median(ts_o) * 1e3), "tflops": fl / float(np.median(ts_o)) / 1e12,
+                     "frac_of_mfma_peak": fl / float(np.median(ts_o)) / 1e12 / MFMA_PEAK_TFLOPS[other_prec]}
+            cur_enc[0] = enc
+            ranker.bind_encoder("title_match", enc)
+            enc_o.close()
         except Exception as e:  # noqa: BLE001
-            fp16_vs_f32 = {"error": str(e)}
-        encoder_out = {"model": f"bert {L}x{H}, {enc.info['heads']} heads, ffn {I} (all-MiniLM-L6-v2 shape), random weights, fp16 operands / f32 accumulate",
-                       "precision": "auto: fp16 for the packed batches of the timed region, f32 for calls over <= 4 texts (the latency leg's single query)",
-                       "fp16_vs_f32": fp16_vs_f32,
+            cur_enc[0] = enc
+            ranker.bind_encoder("title_match", enc)
+            fp16_vs_f32 = fp16_vs_f32 or {"error": str(e)}
+        peak_ = MFMA_PEAK_TFLOPS[args.encoder_precision]
+        encoder_out = {"model": f"bert {L}x{H}, {enc.info['heads']} heads, ffn {I} (all-MiniLM-L6-v2 shape), random weights",
+                       "precision": {"f32": "f32 operands and accumulation on v_mfma_f32_16x16x4_f32 (mrk_encoder_load's default): the fp32 ONNX session's arithmetic, "
+                                            "one accumulation order for every kernel - a query's embedding is the same bits alone and in a packed batch",
+                                     "f16": "fp16 operands / f32 accumulation on v_mfma_f32_32x32x16_f16 (opt-in, BASELINE config 5's wording)"}[args.encoder_precision],
+                       "f32_batch": f32_batch, "fp16_vs_f32": fp16_vs_f32, "other_precision": other,
                        "queries_per_step": int(ids.shape[0]), "padded_tokens_per_query": int(S), "real_tokens_per_query": float(lens.mean()),
                        "layout": "packed: real tokens back to back, no padding", "ms_per_step": ems,
-                       "tflops": fl / ems / 1e9, "mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": fl / ems / 1e9 / 2500.0,
+                       "tflops": fl / ems / 1e9, "mfma_peak_tflops": peak_, "frac_of_mfma_peak": fl / ems / 1e9 / peak_,
                        "includes": "H2D of token ids and D2H of the embeddings (host-buffer API)"}
     latency = None
     if rank == 0 and args.latency_requests > 0:
@@ -668,12 +714,12 @@ def main():
         except Exception:  # noqa: BLE001
             ctx.profile_enable(False)
         if enc is not None:
-            # the encoder is "auto": the single query of these calls ran in f32 (the fp32 ONNX session's arithmetic); the same
-            # requests with an encoder held to fp16 - what BASELINE config 5 names - for comparison
-            latency["query_precision"] = "f32 (MRK_ENCODER_AUTO: calls over <= 4 texts)"
+            # the same requests with the other precision's encoder (a never-seen query per call either way)
+            latency["query_precision"] = args.encoder_precision
+            other_prec = "f16" if args.encoder_precision == "f32" else "f32"
             try:
-                enc16 = HipEncoder(enc_weights, tok_json, ctx=ctx, precision="f16")
-                ranker.bind_encoder("title_match", enc16)
+                enc_o = HipEncoder(enc_weights, tok_json, ctx=ctx, precision=other_prec)
+                ranker.bind_encoder("title_match", enc_o)
                 for r in warm[:5]:
                     ranker.rerank(model_name, r, booster)
                 l16 = []
@@ -681,12 +727,12 @@ def main():
                     t1 = time.perf_counter()
                     ranker.rerank(model_name, r, booster)
                     l16.append((time.perf_counter() - t1) * 1e3)
-                latency["fp16_query_p50_ms"] = float(np.percentile(l16, 50))
+                latency[f"{other_prec}_query_p50_ms"] = float(np.percentile(l16, 50))
                 ranker.bind_encoder("title_match", enc)
-                enc16.close()
+                enc_o.close()
             except Exception as e:  # noqa: BLE001
-                latency["fp16_query_p50_ms"] = None
-                latency["fp16_query_error"] = str(e)
+                latency[f"{other_prec}_query_p50_ms"] = None
+                latency["other_precision_error"] = str(e)
         # the same ONE request over and over: its session, its candidates' records and tables are in L2 - what is left of the
         # distance to `p50_ms` (distinct requests, cold lines) is memory latency of the request's dependent trips, not the path
         hot = []

@@ -436,20 +436,23 @@ typedef struct mrk_encoder_info {
 /* env.createSession(modelBytes) + the tokenizer -- OnnxSession.scala:42-56.  `weights` is the model file the reference
  * reads (`pytorch_model.onnx`: the initializers of a BERT-family graph are extracted) or the same checkpoint as
  * `model.safetensors`; detected by content.  `heads` = number of attention heads (0: read it from the graph's
- * reshape constants / the safetensors metadata key "num_attention_heads").  Weights are kept in fp16 on the device,
- * the residual stream, LayerNorm statistics, softmax and every accumulation are f32. */
+ * reshape constants / the safetensors metadata key "num_attention_heads").  Arithmetic: MRK_ENCODER_F32 (below) - the
+ * reference's session is an fp32 onnxruntime session, and scores within 1e-5 / the same order need its arithmetic. */
 int mrk_encoder_load(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len,
                      int heads, mrk_encoder **out);
-/* The same with the arithmetic chosen by the caller.  MRK_ENCODER_FP16 (what mrk_encoder_load uses): fp16 operands on the
- * matrix cores, f32 accumulation - pooled cosines within 3e-3 of an fp32 run of the graph.  MRK_ENCODER_F32: every product on
- * f32 operands with f32 accumulation, exact erf / exp - the arithmetic of the reference's fp32 ONNX session (onnxruntime on
- * the CPU, OnnxSession.scala:42-56); cosines within 1e-5 of transformers' fp32 output (the reference's own tests accept 1e-3,
- * OnnxBiencoderTest.scala:23-25).  About 20x slower than the fp16 path: a parity instrument and the mode for a host that
- * must reproduce the JVM's numbers.
- * MRK_ENCODER_AUTO: both sets of matrices on the device; a call over at most 4 sequences - the query of ONE request, i.e.
- * mrk_rank / mrk_serve_rank - runs in f32, larger calls (the queries of a packed batch) in fp16.  A host maps its
- * `precision: f16 | f32 | auto` setting of a field_match feature to this argument; INTEGRATION.md has the measured price of
- * fp16 (scores moving by more than 1e-5, requests whose order changes) and bench.py's config-5 line reports it per run. */
+/* The same with the arithmetic chosen by the caller - a property of the handle, never of the size of a call.
+ * MRK_ENCODER_F32 (what mrk_encoder_load uses since ABI 8): f32 weights, every matrix product and the attention on the
+ * f32-input matrix instruction (v_mfma_f32_16x16x4_f32: exact f32, bit for bit a chain of fma's), libm erf / exp - the
+ * arithmetic of the reference's fp32 ONNX session (onnxruntime on the CPU, OnnxSession.scala:42-56); cosines within 1e-5 of
+ * transformers' fp32 output (the reference's own tests accept 1e-3, OnnxBiencoderTest.scala:23-25).  Every f32 kernel walks
+ * k in one canonical order from a zero accumulator, so a sequence's embedding is the same BITS alone (mrk_rank), in a packed
+ * batch of thousands (mrk_batch_*), padded or packed: a request's scores do not depend on the load it arrived under.
+ * About 3.5x the time of the fp16 path per packed batch (52 % of the 157 TFLOP/s f32 matrix peak), the same latency for
+ * a single query.
+ * MRK_ENCODER_FP16 (opt-in; BASELINE config 5's "fp16"): fp16 weights and operands on the matrix cores, f32 accumulation -
+ * pooled cosines within 3e-3 of an fp32 run of the graph; about 1 % of a 500-tree forest's scores move by more than 1e-5 and
+ * a third of the requests see a pair of candidates swapped (bench.py's config-5 line reports it per run).
+ * MRK_ENCODER_AUTO: accepted for hosts built against ABI <= 7 (where it chose by call size); it is MRK_ENCODER_F32 now. */
 enum { MRK_ENCODER_FP16 = 0, MRK_ENCODER_F32 = 1, MRK_ENCODER_AUTO = 2 };
 int mrk_encoder_load_ex(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
                         int precision, mrk_encoder **out);

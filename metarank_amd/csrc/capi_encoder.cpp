@@ -170,15 +170,12 @@ void drop_graphs(mrk_encoder &e) {
   e.graphs.clear();
 }
 
-// one forward pass over a padded id batch; `out` is host memory sized by the mode
-// which arithmetic a call over `n_texts` sequences runs in: the handle's own (fp16 / f32), or - MRK_ENCODER_AUTO - f32 for the
-// few sequences of a single request (a 9-token query at the plain kernels' rate is noise next to the rest of mrk_rank,
-// and its cosines are the fp32 graph's to 1e-7) and fp16 on the matrix cores for packed batches
-constexpr size_t ENCODER_AUTO_F32_TEXTS = 4;
-bool call_in_f32(const mrk_encoder &e, size_t n_texts) {
-  return e.precision == MRK_ENCODER_F32 || (e.precision == MRK_ENCODER_AUTO && n_texts <= ENCODER_AUTO_F32_TEXTS);
-}
+// Which arithmetic a handle's calls run in is a property of the HANDLE (mrk_encoder_load_ex), never of the size of a call:
+// the f32 kernels give a sequence the same bits whatever batch it travels in, so a request's scores do not depend on how
+// many concurrent callers mrk_rank's combining front merged.  (ABI <= 7 had a size-based MRK_ENCODER_AUTO; it is f32 now.)
+bool call_in_f32(const mrk_encoder &e) { return e.precision != MRK_ENCODER_FP16; }
 
+// one forward pass over a padded id batch; `out` is host memory sized by the mode
 void run_encoder(mrk_encoder &e, const int32_t *ids, const int32_t *types, const int32_t *mask, int n, int seq, int mode, float *out, bool f32) {
   if (n == 0) return;
   e.dev.f32 = f32 && !e.dev.layers32.empty();
@@ -328,10 +325,8 @@ void encoder_embed_cached(mrk_encoder *e, const std::vector<std::string> &texts,
   std::lock_guard<std::mutex> lk(e->mu);
   const int H = e->dev.shape.hidden;
   out.assign(texts.size(), std::vector<float>());
-  // (the arithmetic follows from the size of the CALL, not from what happens to be cached: a text embedded both ways keeps
-  //  one embedding per arithmetic)
-  const bool f32 = call_in_f32(*e, texts.size());
-  auto &cache = f32 ? e->cache32 : e->cache;
+  const bool f32 = call_in_f32(*e);
+  auto &cache = e->cache;
   std::vector<size_t> miss;
   for (size_t i = 0; i < texts.size(); ++i) {
     auto it = cache.find(texts[i]);
@@ -370,7 +365,7 @@ void encoder_score_rows(mrk_encoder *e, const std::vector<Encoding> &rows, float
       std::copy(r.type_ids.begin(), r.type_ids.end(), types.begin() + k * len);
       std::copy(r.mask.begin(), r.mask.end(), mask.begin() + k * len);
     }
-    run_encoder(*e, ids.data(), types.data(), mask.data(), (int)n, (int)len, MODE_LOGIT, out + at, call_in_f32(*e, rows.size()));
+    run_encoder(*e, ids.data(), types.data(), mask.data(), (int)n, (int)len, MODE_LOGIT, out + at, call_in_f32(*e));
   }
 }
 
@@ -423,7 +418,7 @@ void mrk_tokenizer_free(mrk_tokenizer *tok) { delete tok; }
 
 int mrk_encoder_load(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
                      mrk_encoder **out) {
-  return mrk_encoder_load_ex(ctx, weights, len, tokenizer_json, tok_len, heads, MRK_ENCODER_FP16, out);
+  return mrk_encoder_load_ex(ctx, weights, len, tokenizer_json, tok_len, heads, MRK_ENCODER_F32, out);
 }
 
 int mrk_encoder_load_ex(mrk_ctx *ctx, const uint8_t *weights, size_t len, const char *tokenizer_json, size_t tok_len, int heads,
@@ -436,7 +431,7 @@ int mrk_encoder_load_ex(mrk_ctx *ctx, const uint8_t *weights, size_t len, const 
     Checkpoint ck = read_checkpoint(weights, len);
     if (heads > 0) ck.heads = heads;
     MRK_HIP(hipSetDevice(ctx->device));
-    build_encoder(*e, ck, precision != MRK_ENCODER_FP16);   // (f32 and auto keep the matrices as f32 too)
+    build_encoder(*e, ck, precision != MRK_ENCODER_FP16);   // (f32 keeps the matrices as f32 too)
     e->precision = precision;
     MRK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->ctx = ctx;
@@ -484,7 +479,7 @@ int mrk_encoder_hidden_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *
   return guard([&] {
     need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_hidden_ids: bad argument");
     std::lock_guard<std::mutex> lk(enc->mu);
-    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_HIDDEN, out, call_in_f32(*enc, (size_t)n));
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_HIDDEN, out, call_in_f32(*enc));
   });
 }
 
@@ -493,7 +488,7 @@ int mrk_encoder_embed_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *t
   return guard([&] {
     need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_embed_ids: bad argument");
     std::lock_guard<std::mutex> lk(enc->mu);
-    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_POOL, out, call_in_f32(*enc, (size_t)n));
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_POOL, out, call_in_f32(*enc));
   });
 }
 
@@ -502,7 +497,7 @@ int mrk_encoder_score_ids(mrk_encoder *enc, const int32_t *ids, const int32_t *t
   return guard([&] {
     need(enc && ids && mask && out && n >= 0 && seq_len > 0, "mrk_encoder_score_ids: bad argument");
     std::lock_guard<std::mutex> lk(enc->mu);
-    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_LOGIT, out, call_in_f32(*enc, (size_t)n));
+    run_encoder(*enc, ids, type_ids, mask, n, seq_len, MODE_LOGIT, out, call_in_f32(*enc));
   });
 }
 
@@ -511,7 +506,7 @@ int mrk_encoder_embed(mrk_encoder *enc, const char *const *texts, int n, float *
     need(enc && (texts || n == 0) && out && n >= 0, "mrk_encoder_embed: bad argument");
     if (n == 0) return;
     std::lock_guard<std::mutex> lk(enc->mu);
-    encode_texts(*enc, texts, nullptr, n, MODE_POOL, out, call_in_f32(*enc, (size_t)n));
+    encode_texts(*enc, texts, nullptr, n, MODE_POOL, out, call_in_f32(*enc));
   });
 }
 
@@ -520,7 +515,7 @@ int mrk_encoder_score_pairs(mrk_encoder *enc, const char *const *a, const char *
     need(enc && ((a && b) || n == 0) && out && n >= 0, "mrk_encoder_score_pairs: bad argument");
     if (n == 0) return;  // OnnxCrossEncoder.scala:23-24: empty batch -> empty result
     std::lock_guard<std::mutex> lk(enc->mu);
-    encode_texts(*enc, a, b, n, MODE_LOGIT, out, call_in_f32(*enc, (size_t)n));
+    encode_texts(*enc, a, b, n, MODE_LOGIT, out, call_in_f32(*enc));
   });
 }
 

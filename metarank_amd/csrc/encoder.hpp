@@ -42,7 +42,7 @@ struct LayerDev {
 };
 
 // the f32 copies of the matrices an encoder loaded with precision f32 keeps (mrk_encoder_load_ex): every product then runs
-// on f32 operands with f32 accumulation - the arithmetic of the reference's fp32 ONNX graph, for parity work
+// on f32 operands with f32 accumulation on the f32-input matrix instruction - the arithmetic of the reference's fp32 ONNX graph
 struct LayerDev32 {
   const float *wqkv, *wo, *w1, *w2;              // f32 [out, in]
 };
@@ -103,7 +103,6 @@ struct mrk_encoder {
   int64_t device_bytes = 0;
   // EmbeddingCache: query text -> embedding (FieldMatchBiencoderFeature.scala:96-99)
   std::map<std::string, std::vector<float>> cache;
-  std::map<std::string, std::vector<float>> cache32;   // ... of the calls that ran in f32 (MRK_ENCODER_F32 / _AUTO)
-  int precision = 0;       // MRK_ENCODER_FP16 | _F32 | _AUTO (mrk_encoder_load_ex)
+  int precision = 0;       // MRK_ENCODER_FP16 | _F32 (mrk_encoder_load_ex; _AUTO = _F32)
   std::atomic<int> refs{1};
 };

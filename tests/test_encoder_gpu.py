@@ -38,7 +38,7 @@ def _tiny_state():
 @pytest.mark.parametrize("fname", ["encoder_tiny.onnx", "encoder_tiny.safetensors"])
 def test_tiny_fixture_hidden_states_and_pool(fname):
     g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
-    enc = HipEncoder(open(os.path.join(GOLDEN, fname), "rb").read(), TOK_TINY)
+    enc = HipEncoder(open(os.path.join(GOLDEN, fname), "rb").read(), TOK_TINY, precision="f16")
     assert (enc.info["layers"], enc.info["hidden"], enc.info["heads"], enc.info["intermediate"]) == (2, 64, 2, 128)
     assert enc.info["has_classifier"] == 0 and enc.info["max_length"] == 24
     h = enc.hidden_ids(g["ids"], g["type_ids"], g["mask"])
@@ -57,7 +57,7 @@ def test_tiny_fixture_hidden_states_and_pool(fname):
 
 def test_tiny_cross_encoder_logits():
     g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
-    enc = HipEncoder(open(os.path.join(GOLDEN, "cross_tiny.onnx"), "rb").read(), TOK_TINY)
+    enc = HipEncoder(open(os.path.join(GOLDEN, "cross_tiny.onnx"), "rb").read(), TOK_TINY, precision="f16")
     assert enc.info["has_classifier"] == 1
     got = enc.score_ids(g["pair_ids"], g["pair_type_ids"], g["pair_mask"])
     np.testing.assert_allclose(got, g["logits"], rtol=0, atol=ATOL_FP32)   # transformers fp32
@@ -69,7 +69,7 @@ def test_tiny_cross_encoder_logits():
 
 
 def test_texts_equal_ids_and_padding_does_not_change_a_row():
-    enc = HipEncoder(open(os.path.join(GOLDEN, "encoder_tiny.safetensors"), "rb").read(), TOK_TINY)
+    enc = HipEncoder(open(os.path.join(GOLDEN, "encoder_tiny.safetensors"), "rb").read(), TOK_TINY, precision="f16")
     tok = HipTokenizer(TOK_TINY)
     texts = ["star wars", "the quick brown fox jumps over the lazy dog and the terminator again and again", "café", ""]
     ids, types, mask = tok.encode_batch(texts)
@@ -87,7 +87,7 @@ MINILM = dict(layers=6, hidden=384, heads=12, inter=1536, vocab=2000, max_pos=51
 def minilm():
     w = synth.synthetic_bert(**MINILM, classifier=True)
     tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
-    enc = HipEncoder(synth.bert_safetensors(w, 12), tj)
+    enc = HipEncoder(synth.bert_safetensors(w, 12), tj, precision="f16")
     yield w, enc, HipTokenizer(tj)
     enc.close()
 
@@ -173,7 +173,7 @@ def test_packed_batches_give_the_padded_bits(minilm):
 def test_head_size_64(minilm):
     """BERT-base style heads (64 wide): 2 layers x 128, 2 heads"""
     w = synth.synthetic_bert(layers=2, hidden=128, heads=2, inter=256, vocab=300, max_pos=64, seed=4)
-    enc = HipEncoder(synth.bert_safetensors(w, 2), synth.wordpiece_tokenizer_json(vocab_size=300, max_length=64))
+    enc = HipEncoder(synth.bert_safetensors(w, 2), synth.wordpiece_tokenizer_json(vocab_size=300, max_length=64), precision="f16")
     rng = np.random.default_rng(9)
     ids = rng.integers(5, 300, size=(4, 40)); types = np.zeros_like(ids)
     mask = (np.arange(40)[None, :] < np.array([40, 3, 33, 17])[:, None]).astype(np.int32)
@@ -198,7 +198,7 @@ def test_load_errors():
         HipEncoder(save(synth.synthetic_bert(layers=1, hidden=64, heads=2, inter=128, vocab=50, max_pos=16)), synth.wordpiece_tokenizer_json(vocab_size=100))
     assert e.value.status == N.ERR_INVALID_ARG
     g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
-    enc = HipEncoder(open(os.path.join(GOLDEN, "encoder_tiny.safetensors"), "rb").read(), TOK_TINY)
+    enc = HipEncoder(open(os.path.join(GOLDEN, "encoder_tiny.safetensors"), "rb").read(), TOK_TINY, precision="f16")
     with pytest.raises(N.MrkError) as e:  # 48 positions in the tiny model
         enc.hidden_ids(np.zeros((1, 49), np.int32), None, np.ones((1, 49), np.int32))
     assert e.value.status == N.ERR_INVALID_ARG
@@ -466,25 +466,29 @@ def test_f32_products_on_the_matrix_cores_are_the_fma_chain_and_batch_independen
         enc.close()
 
 
-def test_auto_precision_is_f32_for_a_requests_query_and_fp16_for_batches():
-    """mrk_encoder_load_ex(MRK_ENCODER_AUTO): a call over <= 4 sequences (ONE request's query: mrk_rank) gives the bits of an
-    encoder held to f32, a larger call (the queries of a packed batch) the bits of the fp16 encoder - by the size of the call,
-    whatever was embedded before (a text keeps one cached embedding per arithmetic)."""
+def test_precision_is_a_property_of_the_handle_not_of_the_call():
+    """mrk_encoder_load (and the ABI <= 7 name MRK_ENCODER_AUTO) = f32: a text's embedding is the same bits in a call of one
+    (mrk_rank's query), of three, of twelve (a packed batch), as ids or as text, cached or not - so a request's scores do not
+    depend on how many callers the combining front merged.  fp16 is a different handle, and different bits."""
     w = synth.synthetic_bert(**MINILM, classifier=False)
     tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
     blob = synth.bert_safetensors(w, 12)
-    auto, e16, e32 = HipEncoder(blob, tj, precision="auto"), HipEncoder(blob, tj), HipEncoder(blob, tj, precision="f32")
+    auto, e16, e32, dflt = HipEncoder(blob, tj, precision="auto"), HipEncoder(blob, tj, precision="f16"), HipEncoder(blob, tj, precision="f32"), HipEncoder(blob, tj)
     try:
-        texts = synth.synthetic_queries(12, seed=5)
-        np.testing.assert_array_equal(auto.embed(texts[:3]), e32.embed(texts[:3]))
-        np.testing.assert_array_equal(auto.embed(texts), e16.embed(texts))
-        np.testing.assert_array_equal(auto.embed(texts[:1]), e32.embed(texts[:1]))       # ... also after the batch embedded it in fp16
-        assert not np.array_equal(e16.embed(texts[:3]), e32.embed(texts[:3]))
+        texts = synth.synthetic_queries(300, seed=5)
+        all32 = e32.embed(texts)
+        np.testing.assert_array_equal(auto.embed(texts[:3]), all32[:3])
+        np.testing.assert_array_equal(auto.embed(texts), all32)
+        np.testing.assert_array_equal(dflt.embed(texts[5:6]), all32[5:6])
+        np.testing.assert_array_equal(dflt.embed(texts[:12]), all32[:12])
+        for k in (0, 7, 299):
+            np.testing.assert_array_equal(HipEncoder(blob, tj).embed(texts[k:k + 1]), all32[k:k + 1])   # a fresh handle: no cache
+        assert not np.array_equal(e16.embed(texts[:3]), all32[:3])
         ids, types, mask = HipTokenizer(tj).encode_batch(texts)
-        np.testing.assert_array_equal(auto.embed_ids(ids[:4], types[:4], mask[:4]), e32.embed_ids(ids[:4], types[:4], mask[:4]))
-        np.testing.assert_array_equal(auto.embed_ids(ids[:5], types[:5], mask[:5]), e16.embed_ids(ids[:5], types[:5], mask[:5]))
+        np.testing.assert_array_equal(dflt.embed_ids(ids[:4], types[:4], mask[:4]), all32[:4])
+        np.testing.assert_array_equal(dflt.embed_ids(ids, types, mask), all32)
     finally:
-        for e in (auto, e16, e32):
+        for e in (auto, e16, e32, dflt):
             e.close()
 
 
@@ -517,7 +521,7 @@ def test_c5_against_the_fp32_embedding_not_against_itself():
     want = [orc.rerank(ev) for ev in emb_reqs]
     report = {}
     for mode in ("f32", "fp16"):
-        enc = HipEncoder(blob_w, tj, f32=(mode == "f32"))
+        enc = HipEncoder(blob_w, tj, precision="f32" if mode == "f32" else "f16")
         hip = HipBackend(cfg, "xgboost")
         try:
             ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
@@ -540,6 +544,17 @@ def test_c5_against_the_fp32_embedding_not_against_itself():
                 total += hi - lo
                 reordered += int(order[lo:hi].tolist() != want[r][2].tolist())
             report[mode] = {"cosine_err": cos_err, "scores_moved": moved, "of": total, "requests_reordered": reordered}
+            if mode == "f32":   # the same requests ONE AT A TIME (mrk_rank: the <= 32-row product kernel, a fresh handle - no cached
+                # embedding): the bits of the packed batch - north_star's "identical ordering" between the two entry points by construction
+                enc1 = HipEncoder(blob_w, tj)
+                hip.ranker.bind_encoder("title_match", enc1)
+                for r, ev in enumerate(text_reqs):
+                    lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                    _, s1, o1 = hip.rerank(ev)
+                    np.testing.assert_array_equal(s1, scores[lo:hi])
+                    assert o1.tolist() == order[lo:hi].tolist(), r
+                hip.ranker.bind_encoder("title_match", enc)
+                enc1.close()
             batch.close()
         finally:
             hip.close()
