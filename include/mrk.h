@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MRK_ABI_VERSION 7
+#define MRK_ABI_VERSION 8
 
 typedef enum mrk_status {
   MRK_OK = 0,
@@ -67,9 +67,15 @@ int mrk_abi_version(void);
 const char *mrk_build_id(void);
 const char *mrk_last_error(void);
 
-/* device_ids[0]: the HIP ordinal this context drives; n_devices must be 1 - multi-GPU is one context per device (one
- * process per GPU), joined into an RCCL communicator by mrk_comm_init below. */
+/* One context per listed HIP ordinal, all in the calling process: out[0 .. n_devices) (HipConfig(inner, devices: List[Int]),
+ * SURVEY 8b touch point 1; the reference's host is ONE JVM, M/main/command/Serve.scala:72-128).  A context owns its streams,
+ * its replica of the feature store, its models and batches; every entry point selects its context's device for the calling
+ * thread, nothing is per-process, so contexts are driven concurrently from different host threads (one thread per context
+ * for the serving loop; puts may come from any thread).  The same ordinal may appear more than once (independent contexts
+ * sharing a GPU).  n_devices = 1 is the single-device case.  On failure nothing is created.  Contexts of one process are
+ * joined into an RCCL communicator by mrk_comm_init_local, contexts of different processes by mrk_comm_init. */
 int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out);
+int mrk_device_count(void); /* HIP devices visible to this process (0: none / no driver): what HipConfig.devices is validated against */
 void mrk_shutdown(mrk_ctx *ctx);
 
 /* ------------------------------------------------- model (replaces Booster) */
@@ -358,14 +364,15 @@ void mrk_batch_free(mrk_batch *batch);
  * (more than 128 candidates, per-item field overrides, a model with a request-normalised column, all slots busy) go
  * through mrk_rank transparently.  A workgroup that has seen no request for a while (2 ms; MRK_SERVE_IDLE_US) leaves
  * its CU and is relaunched by the next request; store flushes stop the workgroups for their duration.
- * mrk_serve_stats: out10 = {requests through the queue, requests through mrk_rank, workgroup launches; then, summed over the
+ * mrk_serve_stats: the first min(n_out, MRK_SERVE_STATS) of {requests through the queue, requests through mrk_rank, workgroup launches; then, summed over the
  * queue's requests, in ns: host resolve + pack, host publish -> acknowledgement, host copy-out, device input copy + cache drops,
  * device ranking, device result write-back; last: the SHADER CYCLES of the device ranking summed the same way - cycles / ns = the
  * clock the requests ran at (a lone workgroup on an otherwise idle device does not see the boost clock)}. */
 typedef struct mrk_server mrk_server;
 int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int n_slots, mrk_server **out);
 int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, int32_t *out_order);
-int mrk_serve_stats(mrk_server *srv, int64_t *out10);
+#define MRK_SERVE_STATS 10
+int mrk_serve_stats(mrk_server *srv, int64_t *out, int n_out);
 void mrk_serve_stop(mrk_server *srv);
 
 /* ------------------------------------------------ multi-GPU (RCCL over xGMI) */
@@ -377,6 +384,11 @@ void mrk_serve_stop(mrk_server *srv);
 #define MRK_COMM_ID_BYTES 128
 int mrk_comm_unique_id(uint8_t *out_id /* MRK_COMM_ID_BYTES */);
 int mrk_comm_init(mrk_ctx *ctx, const uint8_t *id, int rank, int world);
+/* The same for ranks that live in ONE process: ctxs[i] becomes rank i of a world of n (ncclCommInitRank per context inside
+ * ncclGroupStart / ncclGroupEnd - no id to pass around).  One rank per GPU: two contexts on the same ordinal are
+ * MRK_ERR_INVALID_ARG.  Afterwards each context's host thread issues the collective calls below like a rank of a
+ * multi-process job. */
+int mrk_comm_init_local(mrk_ctx *const *ctxs, int n);
 int mrk_comm_rank(mrk_ctx *ctx);   /* 0 without a communicator */
 int mrk_comm_world(mrk_ctx *ctx);  /* 1 without a communicator */
 /* host-value collectives for drivers: max over the ranks (in place), and a barrier */

@@ -149,6 +149,7 @@ SIGNATURES = {
     "mrk_config_kernel_keys": (_I, [_P, _S, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mrk_last_error": (_S, []),
     "mrk_init": (_I, [_P, _I, C.POINTER(_V)]),
+    "mrk_device_count": (_I, []),
     "mrk_shutdown": (None, [_V]),
     "mrk_model_load": (_I, [_V, _I, _P, C.c_size_t, C.POINTER(_V)]),
     "mrk_model_load_container": (_I, [_V, _P, C.c_size_t, C.POINTER(_S), _I, C.POINTER(_V)]),
@@ -204,10 +205,11 @@ SIGNATURES = {
     "mrk_batch_free": (None, [_V]),
     "mrk_serve_start": (_I, [_V, _V, _S, _I, C.POINTER(_V)]),
     "mrk_serve_rank": (_I, [_V, C.POINTER(mrk_request), _P, _P]),
-    "mrk_serve_stats": (_I, [_V, _P]),
+    "mrk_serve_stats": (_I, [_V, _P, _I]),
     "mrk_serve_stop": (None, [_V]),
     "mrk_comm_unique_id": (_I, [_P]),
     "mrk_comm_init": (_I, [_V, _P, _I, _I]),
+    "mrk_comm_init_local": (_I, [C.POINTER(_V), _I]),
     "mrk_comm_rank": (_I, [_V]),
     "mrk_comm_world": (_I, [_V]),
     "mrk_comm_max_f64": (_I, [_V, C.POINTER(C.c_double)]),

@@ -19,13 +19,35 @@ LIGHTGBM, XGBOOST = 0, 1
 
 
 class Context:
-    """mrk_ctx: one per process per device."""
+    """mrk_ctx: one per device; several may live in one process (create_many), each driven by its own host thread."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _handle=None):
+        self.device = device
+        if _handle is not None:
+            self._h = _handle
+            return
         self._h = C.c_void_p()
         ids = (C.c_int * 1)(device)
         N.check(N.lib().mrk_init(ids, 1, C.byref(self._h)))
-        self.device = device
+
+    @staticmethod
+    def device_count() -> int:
+        return N.lib().mrk_device_count()
+
+    @classmethod
+    def create_many(cls, devices) -> list["Context"]:
+        """mrk_init(device_ids, n): one context per listed ordinal, all in THIS process (HipConfig(devices: List[Int]))"""
+        n = len(devices)
+        ids = (C.c_int * n)(*devices)
+        hs = (C.c_void_p * n)()
+        N.check(N.lib().mrk_init(ids, n, hs))
+        return [cls(d, _handle=C.c_void_p(h)) for d, h in zip(devices, hs)]
+
+    @staticmethod
+    def comm_init_local(ctxs) -> None:
+        """mrk_comm_init_local: the contexts of this process become ranks 0..n-1 of one RCCL communicator"""
+        hs = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+        N.check(N.lib().mrk_comm_init_local(hs, len(ctxs)))
 
     @property
     def handle(self):

@@ -188,33 +188,54 @@ const char *mrk_build_id(void) {
 void mrk_debug_reload_switches(void) { mrk::reload_switches(); }
 const char *mrk_last_error(void) { return g_last_error.c_str(); }
 
+int mrk_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return count;
+}
+
+// one context on one device (streams, flags); mrk_init makes one per listed device
+static mrk_ctx *make_context(int device) {
+  std::unique_ptr<mrk_ctx> ctx(new mrk_ctx());
+  ctx->device = device;
+  MRK_HIP(hipSetDevice(ctx->device));
+  hipDeviceProp_t prop;
+  MRK_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  ctx->n_cus = prop.multiProcessorCount;
+  ctx->lds_per_block = prop.sharedMemPerBlock;
+  MRK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->launch = ctx->stream;
+  ctx->d_flag.reserve(256);
+  ctx->h_flag.reserve(4096);
+  MRK_HIP(hipMemset(ctx->d_flag.p, 0, 256));
+  return ctx.release();
+}
+
 int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out) {
   return guard([&] {
     if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
-    *out = nullptr;
+    for (int i = 0; i < std::max(n_devices, 1); ++i) out[i] = nullptr;
     if (n_devices < 1 || !device_ids) throw StatusError(MRK_ERR_INVALID_ARG, "need at least one device id");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
       throw StatusError(MRK_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
-    if (device_ids[0] < 0 || device_ids[0] >= count)
-      throw StatusError(MRK_ERR_INVALID_ARG, "device id out of range");
-    if (n_devices > 1)
-      throw StatusError(MRK_ERR_UNSUPPORTED, "a context drives one device: create one context per device (one process per GPU) and "
-                                             "join them with mrk_comm_unique_id / mrk_comm_init");
-    std::unique_ptr<mrk_ctx> ctx(new mrk_ctx());
-    ctx->device = device_ids[0];
-    MRK_HIP(hipSetDevice(ctx->device));
-    hipDeviceProp_t prop;
-    MRK_HIP(hipGetDeviceProperties(&prop, ctx->device));
-    ctx->n_cus = prop.multiProcessorCount;
-    ctx->lds_per_block = prop.sharedMemPerBlock;
-    MRK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    ctx->launch = ctx->stream;
-    ctx->d_flag.reserve(256);
-    ctx->h_flag.reserve(4096);
-    MRK_HIP(hipMemset(ctx->d_flag.p, 0, 256));
-    *out = ctx.release();
+    for (int i = 0; i < n_devices; ++i)
+      if (device_ids[i] < 0 || device_ids[i] >= count) throw StatusError(MRK_ERR_INVALID_ARG, "device id out of range");
+    // HipConfig(devices: List[Int]) inside ONE host process (SURVEY 8b touch point 1): a context per listed device, each with its
+    // own streams, store replica and models; nothing in the library is per-process, every entry point selects its context's
+    // device for the calling thread.  The same ordinal may be listed more than once (independent contexts sharing a GPU).
+    std::vector<std::unique_ptr<mrk_ctx>> made;
+    try {
+      for (int i = 0; i < n_devices; ++i) made.emplace_back(make_context(device_ids[i]));
+    } catch (...) {
+      for (auto &c : made) mrk_shutdown(c.release());
+      throw;
+    }
+    for (int i = 0; i < n_devices; ++i) out[i] = made[(size_t)i].release();
   });
 }
 

@@ -77,7 +77,6 @@ int status_to_code(int st, std::string &msg) {
   if (st & ST_ILLEGAL_ARG) { msg = "requirement failed: Duration is limited to +-(2^63-1)ns (ca. 292 years)"; return MRK_ERR_INVALID_ARG; }
   if (st & 32) { msg = "Input data contains `inf` or a value too large, while `missing` is not set to `inf`"; return MRK_ERR_INVALID_ARG; }
   if (st & ST_BAD_IDS) { msg = "item id offsets descend or pass bytes_len (mrk_item_ids)"; return MRK_ERR_INVALID_ARG; }
-  if (st & ST_NORM_TOO_MANY) { msg = "norm: position over more than 4096 candidates is not supported on the device"; return MRK_ERR_UNSUPPORTED; }
   if (st & ST_TOO_MANY) { msg = "diversity over more values than the device pre-pass supports: set `top`"; return MRK_ERR_UNSUPPORTED; }
   if (st & ST_TABLE_FULL) { msg = "internal: pre-pass hash table under-sized (store changed between prepare and run?)"; return MRK_ERR_DEVICE; }
   return MRK_OK;
@@ -1188,6 +1187,7 @@ struct ServeSlot {
   uint32_t seq = 0, launch_id = 0;
   bool running = false;         // a workgroup was launched and has not been seen to leave (owner: whoever holds the slot + the store shared, or the store exclusively)
   bool dead = false;            // its workgroup did not answer in time: never handed out again (a late answer would land in the next request's buffers)
+  bool stuck = false;           // ... and was still resident after a flush waited 2 s for it: later flushes ask once, without waiting again
 };
 
 constexpr size_t SERVE_OUT_BYTES = 2048;          // scores 128 x 8 | order 128 x 4 | status 2 x 4
@@ -1357,14 +1357,19 @@ static void quiesce_servers(mrk_ctx *ctx) {  // the caller holds the store exclu
     // reallocate them - wait for it a while, and refuse the flush rather than free memory under a live kernel.
     for (auto &sl : srv->slots) {
       if (!sl->dead || !sl->running) continue;
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+      // (the 2 s are spent ONCE per stuck slot: while it stays resident every later flush fails at once instead of holding
+      //  the store exclusively for another 2 s per request - one stuck workgroup is an error state, not a stall of the service)
+      const auto deadline = std::chrono::steady_clock::now() + (sl->stuck ? std::chrono::seconds(0) : std::chrono::seconds(2));
       hipError_t q = hipStreamQuery(sl->stream);
       while (q == hipErrorNotReady && std::chrono::steady_clock::now() < deadline) {
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
         q = hipStreamQuery(sl->stream);
       }
-      if (q == hipErrorNotReady)
+      if (q == hipErrorNotReady) {
+        sl->stuck = true;
         throw StatusError(MRK_ERR_DEVICE, "a retired serving workgroup is still resident: the store is not reallocated under it");
+      }
+      sl->stuck = false;
       sl->running = false;   // it left (or its launch failed): nothing of this slot touches the device any more
     }
   }
@@ -1431,17 +1436,18 @@ int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, 
   return code;
 }
 
-int mrk_serve_stats(mrk_server *srv, int64_t *out10) {
-  int64_t *out9 = out10;
-  if (!srv || !out9) return MRK_ERR_INVALID_ARG;
-  out10[9] = (int64_t)srv->dev_ticks[3].load();
-  out9[0] = (int64_t)srv->n_queue.load();
-  out9[1] = (int64_t)srv->n_fallback.load();
-  out9[2] = (int64_t)srv->n_launches.load();
+int mrk_serve_stats(mrk_server *srv, int64_t *out, int n_out) {
+  if (!srv || !out || n_out < 0) return MRK_ERR_INVALID_ARG;
+  int64_t v[MRK_SERVE_STATS] = {};
+  v[0] = (int64_t)srv->n_queue.load();
+  v[1] = (int64_t)srv->n_fallback.load();
+  v[2] = (int64_t)srv->n_launches.load();
   for (int k = 0; k < 3; ++k) {
-    out9[3 + k] = (int64_t)srv->host_ns[k].load();
-    out9[6 + k] = (int64_t)(srv->dev_ticks[k].load() * 10);   // 100 MHz ticks -> ns
+    v[3 + k] = (int64_t)srv->host_ns[k].load();
+    v[6 + k] = (int64_t)(srv->dev_ticks[k].load() * 10);   // 100 MHz ticks -> ns
   }
+  v[9] = (int64_t)srv->dev_ticks[3].load();
+  for (int k = 0; k < n_out && k < MRK_SERVE_STATS; ++k) out[k] = v[k];   // never past the caller's buffer, whatever ABI it was built for
   return MRK_OK;
 }
 

@@ -1,4 +1,5 @@
-// Multi-GPU inside the library: one process per GPU, one context per process, RCCL over xGMI linked
+// Multi-GPU inside the library: one context per GPU - in one process per GPU (mrk_comm_init, a rendezvous by
+// unique id) or all in ONE host process (mrk_comm_init_local: the JVM of HipConfig(devices)) -, RCCL over xGMI linked
 // directly - the host language never sees a collective.  The reference has no counterpart (it scores a request on one
 // JVM thread, ml/Ranker.scala:27-83; scale-out is whole-request replicas, doc/dev/production-recommendations.md): the
 // only exchange this path has is the merge of score slices -
@@ -12,6 +13,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "runtime.hpp"
 
@@ -98,6 +100,46 @@ int mrk_comm_init(mrk_ctx *ctx, const uint8_t *id, int rank, int world) {
     ctx->comm_rank = rank;
     ctx->comm_world = world;
     ctx->d_comm.reserve(256);
+  });
+}
+
+// The ranks of a communicator living in ONE process (the JVM with HipConfig(devices = List(0, 1, ...)): mrk_init made the
+// contexts): one ncclCommInitRank per context between ncclGroupStart / ncclGroupEnd - no rendezvous channel, no second
+// process.  Rank i = ctxs[i].  Afterwards each context is driven by its own host thread exactly like a rank of a
+// multi-process job (mrk_batch_run_sharded and friends; every rank must issue the collectives in the same order).
+int mrk_comm_init_local(mrk_ctx *const *ctxs, int n) {
+  return guard([&] {
+    if (!ctxs || n < 1) throw StatusError(MRK_ERR_INVALID_ARG, "bad communicator arguments");
+    for (int i = 0; i < n; ++i) {
+      if (!ctxs[i]) throw StatusError(MRK_ERR_INVALID_ARG, "null context");
+      if (ctxs[i]->comm) throw StatusError(MRK_ERR_INVALID_ARG, "this context already has a communicator");
+      for (int j = 0; j < i; ++j)
+        if (ctxs[j] == ctxs[i] || ctxs[j]->device == ctxs[i]->device)
+          throw StatusError(MRK_ERR_INVALID_ARG, "mrk_comm_init_local: two ranks on device " + std::to_string(ctxs[i]->device) +
+                                                     " (RCCL wants one rank per GPU; contexts sharing a GPU rank independently, without a communicator)");
+    }
+    ncclUniqueId uid;
+    MRK_NCCL(ncclGetUniqueId(&uid));
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    MRK_NCCL(ncclGroupStart());
+    ncclResult_t rc = ncclSuccess;
+    for (int i = 0; i < n && rc == ncclSuccess; ++i) {
+      if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
+      rc = ncclCommInitRank(&comms[(size_t)i], n, uid, i);
+    }
+    const ncclResult_t end = ncclGroupEnd();
+    if (rc != ncclSuccess || end != ncclSuccess) {
+      for (ncclComm_t c : comms) if (c) (void)ncclCommAbort(c);
+      throw StatusError(MRK_ERR_DEVICE, std::string("mrk_comm_init_local: ") + ncclGetErrorString(rc != ncclSuccess ? rc : end));
+    }
+    for (int i = 0; i < n; ++i) {
+      std::lock_guard<std::mutex> lk(ctxs[i]->mu);
+      MRK_HIP(hipSetDevice(ctxs[i]->device));
+      ctxs[i]->comm = comms[(size_t)i];
+      ctxs[i]->comm_rank = i;
+      ctxs[i]->comm_world = n;
+      ctxs[i]->d_comm.reserve(256);
+    }
   });
 }
 

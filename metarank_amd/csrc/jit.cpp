@@ -196,6 +196,7 @@ struct JitSlot {
   bool failed = false;
   std::string key;              // the stem of its cache file name: hash of the translation unit, its size, the compiler (mrk_config_kernel_keys)
   bool skip_disk = false;       // a code object found on disk did not load on this device (another architecture / a stale file): compile instead
+  bool not_on_disk = false;     // a no-compile lookup (the stand-in of a signature's kernel) found no file: not probed again on the request path
   // MRK_RANK_JIT=async: the code object is produced by a background thread while requests are served by the generic kernel
   std::thread worker;
   std::atomic<int> state{0};    // 0 idle, 1 compiling, 2 code ready, 3 failed
@@ -303,7 +304,11 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
   if (!set) set.reset(new JitSlotSet());
   JitSlot &sl = set->slot[kernel][f64 ? 1 : 0];
   if (sl.fn) return (void *)sl.fn;
-  if (sl.failed && mode != 2) return nullptr;
+  if (no_compile && sl.not_on_disk) return nullptr;   // O(1) after the first miss: no translation unit rebuilt, no file probed per request
+  // while this signature's kernel is not there (compiling, failed, its file unloadable): the program's signature-less
+  // kernel, if it is loaded or on disk - never the interpreting kernel when a specialised one exists
+  auto stand_in = [&]() -> void * { return keyed && !no_compile ? jit_function_locked(prog, kernel, f64, false, nullptr, true) : nullptr; };
+  if (sl.failed && mode != 2) return stand_in();
   // the lambdas run on a background thread too: they own a copy of the signature (the model may be freed meanwhile)
   const std::shared_ptr<const QsSignature> sg = keyed ? std::make_shared<const QsSignature>(*sig) : nullptr;
   auto cached = [&prog, f64, kernel, sg]() {   // the code object, if a previous process (or the build) left it on disk
@@ -326,8 +331,6 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
     }
     return code;
   };
-  // while this signature's kernel is not there: the program's signature-less kernel, if it is loaded or on disk
-  auto stand_in = [&]() -> void * { return keyed && !no_compile ? jit_function_locked(prog, kernel, f64, false, nullptr, true) : nullptr; };
   try {
     std::vector<char> code;
     if ((mode == 4 || no_compile) && sl.state.load() == 0 && !sl.skip_disk) code = cached();
@@ -335,6 +338,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
     if (from_disk) {
       // on disk: loaded below, at once
     } else if (no_compile && sl.state.load() == 0) {
+      sl.not_on_disk = true;
       return nullptr;
     } else if (mode == 3 || mode == 4 || sl.state.load() != 0) {
       int st = sl.state.load();
@@ -381,7 +385,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
       sl.mod = nullptr;
       sl.skip_disk = true;
       fprintf(stderr, "[mrk] the code object on disk for %s ('%s') does not load on this device: compiling\n", JIT_KERNEL_NAME[kernel], prog.model.c_str());
-      return nullptr;
+      return stand_in();
     }
     if (!from_disk) MRK_HIP(hipModuleLoadData(&sl.mod, code.data()));
     MRK_HIP(hipModuleGetFunction(&sl.fn, sl.mod, JIT_KERNEL_NAME[kernel]));

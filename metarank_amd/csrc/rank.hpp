@@ -87,7 +87,6 @@ enum : int32_t {
   ST_DIM = 16,          // embedding shorter than the query
   ST_XGB_INF = 32,      // XGBoost: a value that is +-inf after the Double -> Float narrowing
   ST_BAD_IDS = 128,     // flat item ids: an item's offsets descend or pass bytes_len (set by resolve_ids_kernel at load time)
-  ST_NORM_TOO_MANY = 64,  // norm: position over more candidates than the device sorts in one workgroup
 };
 
 struct ProgramDev {

@@ -3,8 +3,8 @@ big request) with a replicated store; the only exchange is one all-gather of the
 
 On the GPU the collective lives INSIDE the library (csrc/comm.cpp: RCCL linked directly, mrk_comm_* /
 mrk_batch_run_sharded); what is left for the host is handing rank 0's 128-byte communicator id to the other ranks -
-`exchange_unique_id` below does it with one TCP message per rank, no torch.  The torch.distributed helpers further down
-restate the sharding / merge arithmetic for the CPU test (tests/test_dist_cpu.py, gloo, world size 2)."""
+`exchange_unique_id` below does it with one TCP message per rank.  No torch anywhere in this package: the gloo restatement of
+the merge for the CPU tests lives in tests/dist_helpers.py."""
 from __future__ import annotations
 
 import socket
@@ -85,43 +85,8 @@ def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_scores(local, sizes=None, group=None):
-    """Merge per-rank score shards (1-D tensors) into the full list on every rank.
-    sizes: number of scores of every rank (exchanged first when not given)."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    if sizes is None:
-        mine = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-        allsz = torch.empty(world, dtype=torch.int64, device=local.device)
-        dist.all_gather_into_tensor(allsz, mine, group=group)
-        sizes = [int(x) for x in allsz.tolist()]
-    if len(set(sizes)) == 1:
-        out = torch.empty(sum(sizes), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
-    pad = max(sizes)
-    buf = torch.zeros(pad, dtype=local.dtype, device=local.device)
-    buf[:local.numel()] = local
-    parts = [torch.empty(pad, dtype=local.dtype, device=local.device) for _ in range(world)]
-    dist.all_gather(parts, buf, group=group)
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)])
-
-
 def padded_chunk(n: int, world: int, tile: int = 128) -> int:
     """items per shard of an item-sharded run (== mrk_batch_shard_chunk): ceil(n / world) rounded up to
     whole scorer tiles, so every shard starts on a tile boundary and all shards have the same length"""
     per = -(-n // world)
     return -(-per // tile) * tile
-
-
-def all_gather_padded(buf, chunk: int, group=None):
-    """In-place merge of an item-sharded run: `buf` (1-D, >= world * chunk elements) already holds this
-    rank's scores in buf[rank * chunk : (rank + 1) * chunk]; afterwards it holds every rank's slice."""
-    import torch.distributed as dist
-
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    mine = buf[rank * chunk:(rank + 1) * chunk].clone()  # no aliasing between the collective's input and output
-    dist.all_gather_into_tensor(buf[:world * chunk], mine, group=group)
-    return buf

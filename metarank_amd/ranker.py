@@ -311,7 +311,7 @@ class Server:
 
     def stats(self) -> dict:
         out = (C.c_int64 * 10)()
-        N.check(N.lib().mrk_serve_stats(self._h, out))
+        N.check(N.lib().mrk_serve_stats(self._h, out, 10))
         n = max(out[0], 1)
         return {"queue": out[0], "fallback": out[1], "launches": out[2], "device_rank_mhz": out[9] / max(out[7], 1) * 1e3,
                 "us_per_request": {"host_resolve_pack": out[3] / n / 1e3, "host_publish_to_ack": out[4] / n / 1e3, "host_copy_out": out[5] / n / 1e3,

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 from backends import OracleBackend  # noqa: E402
 from workloads import ranklens, synth  # noqa: E402
-from metarank_amd.dist import all_gather_padded, all_gather_scores, padded_chunk, shard_range  # noqa: E402
+from metarank_amd.dist import padded_chunk, shard_range  # noqa: E402
+from dist_helpers import all_gather_padded, all_gather_scores  # noqa: E402
 
 
 def main():

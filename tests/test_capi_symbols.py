@@ -1,4 +1,5 @@
 """CPU: libmrk_hip.so loads and exports every symbol include/mrk.h declares (no compute calls)."""
+import pytest
 import ctypes as C
 import os
 import re
@@ -27,7 +28,7 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_abi_version_and_error_paths_without_gpu():
     L = _native.lib()
-    assert L.mrk_abi_version() == 7
+    assert L.mrk_abi_version() == 8
     # null arguments are rejected before any device work
     assert L.mrk_model_predict_f64(None, None, 1, 1, None) == _native.ERR_INVALID_ARG
     assert b"null model" in L.mrk_last_error()
@@ -38,7 +39,7 @@ def test_abi_version_and_error_paths_without_gpu():
     out = C.c_void_p()
     assert L.mrk_serve_start(None, None, b"m", 2, C.byref(out)) == _native.ERR_INVALID_ARG and not out.value
     assert L.mrk_serve_rank(None, None, None, None) == _native.ERR_INVALID_ARG
-    assert L.mrk_serve_stats(None, None) == _native.ERR_INVALID_ARG
+    assert L.mrk_serve_stats(None, None, 0) == _native.ERR_INVALID_ARG
     L.mrk_serve_stop(None)
     assert L.mrk_encoder_load_ex(None, None, 0, None, 0, 0, 1, C.byref(out)) == _native.ERR_INVALID_ARG
     assert L.mrk_config_warmup(None, b"m") == _native.ERR_INVALID_ARG
@@ -76,3 +77,16 @@ def test_no_product_file_references_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|oracle/|liboracle", src, flags=re.M):
                     bad.append(f)
     assert bad == []
+
+
+def test_header_is_plain_c99():
+    """include/mrk.h is what a JNA / cgo / ctypes binding is written against: it must compile as C (no C++ isms, no torch
+    types), alone, with -std=c99 -pedantic."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(REPO, "include", "mrk.h")
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -294,6 +294,148 @@ def test_rccl_code_path_with_a_world_of_one(oracle_c2):
         ctx.close()
 
 
+def _drive(hip, reqs, rounds, out, errs, k):
+    """one host thread's serving loop on ITS context: single requests through mrk_rank and device batches, interleaved"""
+    try:
+        for r in range(rounds):
+            batch = hip.ranker.prepare("xgboost", reqs)
+            batch.run(hip.booster)
+            for ev in reqs[:6]:
+                _, s1, o1 = hip.ranker.rerank("xgboost", ev, hip.booster)
+                out.setdefault((k, "one", ev["id"]), []).append((s1.copy(), o1.copy()))
+            s, o, _ = batch.fetch()
+            assert (batch.status() == 0).all()
+            out.setdefault((k, "batch"), []).append((s.copy(), o.copy(), list(batch.offsets)))
+            batch.close()
+    except Exception as e:  # noqa: BLE001
+        errs.append((k, e))
+
+
+@pytest.mark.gpu
+def test_two_contexts_in_one_process_on_separate_threads(oracle_c2):
+    """HipConfig(devices: List[Int]) inside ONE host process (SURVEY 8b touch point 1; M/config/BoosterConfig.scala:96-104, the
+    reference's host is one JVM): mrk_init with two ordinals returns two contexts - here both on device 0, which is what one
+    GPU box can show of the threading -, each with its own store replica, model and specialised kernels.  Two host threads
+    drive mrk_rank and device batches on their context CONCURRENTLY while a third thread keeps writing to both stores
+    (state of items no request names, so results stay comparable): every result of either context equals the oracle's,
+    bit for bit, and nothing deadlocks.  mrk_comm_init_local: a world of one works, two ranks on one GPU are refused."""
+    assert M.Context.device_count() >= 1
+    with pytest.raises(M.MrkError):
+        M.Context.create_many([0, M.Context.device_count()])      # out of range: nothing is created
+    ctxs = M.Context.create_many([0, 0])
+    assert len(ctxs) == 2 and ctxs[0].handle.value != ctxs[1].handle.value
+    hips = [HipBackend(ranklens.ranklens_config(), "xgboost", c) for c in ctxs]
+    try:
+        for h in hips:
+            ranklens.load_state(h, ranklens.generate_state(N_ITEMS, N_SESS))
+        reqs = ranklens.generate_requests(24, 100, N_ITEMS, N_SESS, seed=171) + ranklens.generate_requests(2, 700, N_ITEMS, N_SESS, seed=172)
+        q = ranklens.column_quantiles(np.concatenate([oracle_c2.matrix(ev) for ev in reqs[:6]]))
+        blob = synth.synthetic_lgbm_model(n_trees=150, n_features=24, quantiles=q)
+        oracle_c2.load_model(blob, 0)
+        for h in hips:
+            h.load_model(blob, 0)
+            h.ranker.rerank("xgboost", reqs[0], h.booster)     # first use: kernels compiled / loaded per context
+        want = [oracle_c2.rerank(ev) for ev in reqs]
+        out, errs, stop = {}, [], threading.Event()
+
+        def writer():
+            i = 0
+            try:
+                while not stop.is_set():
+                    for h in hips:
+                        h.put_double(f"item=fresh{i % 4000}/popularity", float(i))       # new slots, dirty ranges, table growth -> flushes under the readers
+                        h.put_string_list(f"item=fresh{i % 4000}/genre", ["drama", "comedy"][: 1 + i % 2])
+                    i += 1
+            except Exception as e:  # noqa: BLE001
+                errs.append(("writer", e))
+
+        threads = [threading.Thread(target=_drive, args=(hips[k], reqs, 6, out, errs, k)) for k in range(2)] + [threading.Thread(target=writer)]
+        for t in threads:
+            t.start()
+        for t in threads[:2]:
+            t.join(timeout=300)
+        stop.set()
+        threads[2].join(timeout=60)
+        assert not any(t.is_alive() for t in threads), "a serving thread did not finish"
+        assert not errs, errs
+        for k in range(2):
+            for s, o, offs in out[(k, "batch")]:
+                for r in range(len(reqs)):
+                    lo, hi = offs[r], offs[r + 1]
+                    assert same(s[lo:hi], want[r][1]) and o[lo:hi].tolist() == want[r][2].tolist(), (k, r)
+            for r, ev in enumerate(reqs[:6]):
+                for s1, o1 in out[(k, "one", ev["id"])]:
+                    assert same(s1, want[r][1]) and o1.tolist() == want[r][2].tolist(), (k, r)
+        # communicators of contexts living in one process
+        with pytest.raises(M.MrkError):
+            M.Context.comm_init_local(ctxs)                      # two ranks on ONE GPU: RCCL wants one rank per device
+        assert ctxs[0].comm_world == 1 and ctxs[1].comm_world == 1
+        M.Context.comm_init_local(ctxs[:1])                      # a world of one
+        assert ctxs[0].comm_world == 1 and ctxs[0].comm_rank == 0 and ctxs[0].comm_max(1.5) == 1.5
+        b = hips[0].ranker.prepare("xgboost", reqs)
+        b.run_sharded(hips[0].booster)
+        s, o, _ = b.fetch()
+        for r in range(len(reqs)):
+            lo, hi = b.offsets[r], b.offsets[r + 1]
+            assert same(s[lo:hi], want[r][1]) and o[lo:hi].tolist() == want[r][2].tolist(), r
+        b.close()
+    finally:
+        for h in hips:
+            h.close()
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_item_sharded_rank_over_two_devices_of_one_process(oracle_c2):
+    """mrk_comm_init_local over two GPUs of this process (skipped on a one-GPU box): each context's thread runs
+    mrk_batch_run_sharded on its replica - slice, in-place ncclAllGather, sort - and BOTH ranks end with the unsharded
+    oracle's scores and order for a 6 000-candidate request."""
+    if M.Context.device_count() < 2:
+        pytest.skip("needs two GPUs in one process")
+    ctxs = M.Context.create_many([0, 1])
+    hips = [HipBackend(ranklens.ranklens_config(), "xgboost", c) for c in ctxs]
+    try:
+        for h in hips:
+            ranklens.load_state(h, ranklens.generate_state(N_ITEMS, N_SESS))
+        M.Context.comm_init_local(ctxs)
+        assert [c.comm_rank for c in ctxs] == [0, 1] and all(c.comm_world == 2 for c in ctxs)
+        reqs = ranklens.generate_requests(1, 6000, N_ITEMS, N_SESS, seed=192) + ranklens.generate_requests(3, 100, N_ITEMS, N_SESS, seed=193)
+        q = ranklens.column_quantiles(np.concatenate([oracle_c2.matrix(ev) for ev in reqs[1:]]))
+        blob = synth.synthetic_lgbm_model(n_trees=120, n_features=24, quantiles=q)
+        oracle_c2.load_model(blob, 0)
+        for h in hips:
+            h.load_model(blob, 0)
+        got, errs = [None, None], []
+
+        def rank_thread(k):
+            try:
+                b = hips[k].ranker.prepare("xgboost", reqs)
+                b.run_sharded(hips[k].booster)
+                s, o, _ = b.fetch()
+                got[k] = (s.copy(), o.copy(), list(b.offsets))
+                b.close()
+            except Exception as e:  # noqa: BLE001
+                errs.append((k, e))
+
+        ts = [threading.Thread(target=rank_thread, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not errs and not any(t.is_alive() for t in ts), errs
+        for k in range(2):
+            s, o, offs = got[k]
+            for r, ev in enumerate(reqs):
+                _, es, eo = oracle_c2.rerank(ev)
+                assert same(s[offs[r]:offs[r + 1]], es) and o[offs[r]:offs[r + 1]].tolist() == eo.tolist(), (k, r)
+    finally:
+        for h in hips:
+            h.close()
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.gpu
 def test_item_id_offsets_from_the_wire_are_checked(oracle_c2):
     """mrk_item_ids.offsets is untrusted input: a last offset past bytes_len refuses the whole load; an item whose
