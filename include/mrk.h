@@ -142,7 +142,7 @@ int mrk_config_specialize(const char *json, size_t len, const char *model_name, 
 /* Host-only: writes into directory `dir` the gfx950 code object of every specialised kernel in `kernel_mask` (bit k: 0 the
  * workgroup-per-request kernel, 1 its op-split / sliced form, 2 the f64-matrix form, 3 the item-parallel kernel, 4 the
  * one-launch kernel of mrk_rank, 5 the persistent workgroup of the serving queue, 6 the one-launch kernel of FULL batches
- * behind MRK_RANK_FUSED_SCORE=1) for this config's model - what a
+ * behind MRK_RANK_FUSED_SCORE=1, 7 the stand-alone pre-pass of requests too large for one workgroup) for this config's model - what a
  * deployment ships next to libmrk_hip.so (directory `jit_cache`) so that no process ever compiles: the library looks
  * there, then in the user's cache ($MRK_JIT_CACHE_DIR, ~/.cache/mrk_jit), and only then compiles - in the BACKGROUND,
  * ranking with the kernel that interprets the program meanwhile (MRK_RANK_JIT: 0 never specialise, 1 wait for the compiler,

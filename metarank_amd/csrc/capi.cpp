@@ -47,6 +47,9 @@ static Switches read_switches() {
   if (s.jit_cache_dir == "off") s.jit_cache_dir.clear();
   s.big_sort_cap = num("MRK_BIG_SORT_CAP", 4096);
   s.big_sort_tile = num("MRK_BIG_SORT_TILE", 0);
+  s.big_sort_bucket = num("MRK_BIG_SORT_BUCKET", 0);
+  s.jit_prepass = flag("MRK_JIT_PREPASS", true);
+  s.big_sort_fold = flag("MRK_BIG_SORT_FOLD", true);
   s.qs_split = num("MRK_QS_SPLIT", -1);
   s.qs_kernel = num("MRK_QS_KERNEL", 1);
   s.qs_r = num("MRK_QS_R", 2);
@@ -55,6 +58,7 @@ static Switches read_switches() {
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
   s.encoder_packed = flag("MRK_ENCODER_PACKED", true);
   s.encoder_f32_mfma = flag("MRK_ENCODER_F32_MFMA", true);
+  s.encoder_f32_waves = num("MRK_ENCODER_F32_WAVES", 2);
   return s;
 }
 static Switches &switches_storage() {

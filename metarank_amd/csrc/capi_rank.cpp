@@ -17,7 +17,7 @@
 
 namespace mrk {
 
-void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries);
+void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries, void *jit_fn);
 void launch_assemble(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b);
 void launch_sort(mrk_ctx *ctx, const BatchDev &b, int max_items);
 void launch_status_or(hipStream_t stream, const int32_t *all, int world, int n_req, int32_t *status);
@@ -324,7 +324,7 @@ static void assemble_matrix(mrk_batch &b, const StoreDev &st, const ProgramDev &
   if (b.fused_ok) {
     launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, jit_matrix_fn ? 1 : b.fused_slices, nullptr, nullptr, true, jit_matrix_fn);
   } else {
-    launch_prepass(ctx, st, pd, b.view, b.fused_entries);
+    launch_prepass(ctx, st, pd, b.view, b.fused_entries, nullptr);
     launch_assemble(ctx, st, pd, b.view);
   }
   for (const Program::NormCol &nc : b.prog->norm_cols)  // schema.norm.scale over the request's column (Normalize.scala:13-45)
@@ -404,6 +404,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
                         : fused_score ? jit_fused_score_function(*b.prog, f64, sig)
                         : !b.fused_ok ? jit_items_function(*b.prog, f64, sig)
                         : b.fused_split > 1 || b.fused_slices > 1 ? jit_split_function(*b.prog, f64, sig) : jit_rank_function(*b.prog, f64, sig);
+  void *jit_prep_fn = cells && !one && !fused_score && !b.fused_ok && b.prog->prep.size() && sw.jit_prepass ? jit_prepass_function(*b.prog) : nullptr;   // (before LaunchOn: a first use may compile)
   LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
   const ProgramDev pd = b.prog->device_view();
@@ -444,7 +445,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
     if (b.fused_ok) {
       launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, b.fused_slices, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     } else {
-      launch_prepass(ctx, st, pd, b.view, b.fused_entries);
+      launch_prepass(ctx, st, pd, b.view, b.fused_entries, jit_prep_fn);
       launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn, b.fused_entries);
     }
     b.matrix_valid = false;

@@ -532,8 +532,8 @@ __device__ __forceinline__ void store_f32_quad(const floatx4 &acc, int m, int n4
 // Operands staged through LDS in their natural layout, one 32-wide k block at a time, the next block's global loads in
 // flight during the MFMAs (at 1/16 of the f16 rate a k block is ~4 000 cycles of matrix work per wavefront: prologue and
 // barriers are noise here, unlike in gemm_kernel).  N % (32 TN) == 0, K % 32 == 0.
-template <int TM, int TN, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+template <int TM, int TN, int EPI, int WPE = 2>   // WPE: wavefronts per SIMD the register allocation leaves room for
+__global__ __launch_bounds__(256, WPE) void gemm_f32_mfma_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
                                                             const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   __shared__ float As[BM][F32_LD];
@@ -725,7 +725,8 @@ void launch_gemm_f32(const float *A, const float *W, const float *bias, const fl
     // 128 x 128 tiles once the grid still covers the chip with them (two workgroups per CU), 64 x 64 tiles otherwise
     const bool big = N % 128 == 0 && (size_t)((M + 127) / 128) * (N / 128) >= 512;
     auto grid_of = [&](int bm, int bn) { return dim3((unsigned)(8 * (((M + bm - 1) / bm + 7) / 8) * (N / bn))); };
-    if (big) hipLaunchKernelGGL((gemm_f32_mfma_kernel<4, 4, EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    if (big && switches().encoder_f32_waves == 3) hipLaunchKernelGGL((gemm_f32_mfma_kernel<4, 4, EPI, 3>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    else if (big) hipLaunchKernelGGL((gemm_f32_mfma_kernel<4, 4, EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, EPI>), grid_of(64, 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
     return;
   }

@@ -102,7 +102,7 @@ std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignat
   // the forest's view signature (forest.hpp): the sinks of the kernels that write the scorer's tile hold it as constants;
   // without one (no bit-vector image, f64-matrix kernels, MRK_JIT_SIG=0) they read the column descriptors from memory
   std::string qs = "mrk::QsDyn";
-  if (sig && sig->ok && kernel != JIT_MATRIX) {
+  if (sig && sig->ok && kernel != JIT_MATRIX && kernel != JIT_PREPASS) {
     table("JitSigRows", "QsSig", sig->cols.size(), sig->text);
     s += "struct JitQs {\n  static constexpr bool is_static = true;\n  static constexpr int n_feats = " + std::to_string(sig->cols.size()) +
          ", n_views = " + std::to_string(sig->n_views) + ";\n  static constexpr uint32_t thr_cap = " + std::to_string(sig->thr_cap) +
@@ -156,6 +156,12 @@ std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignat
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_rank_fused_score"
          "(mrk::StoreDev st, mrk::BatchDev b, uint32_t tab_entries, int vals_cap, mrk::QsDev q, mrk::QsForestDev f, uint16_t *cells) {\n"
          "  mrk::rank_fused_score_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, tab_entries, vals_cap, q, f, cells);\n}\n";
+  // the pre-pass of requests too large for one workgroup's assembly (config 4: ONE workgroup per request builds the tables the
+  // item-parallel kernel reads; on the critical path of the request, so no register cap)
+  if ((kernel == JIT_ALL && f64) || kernel == JIT_PREPASS)
+    s += "extern \"C\" __global__ void __launch_bounds__(256)\nmrk_jit_prepass"
+         "(mrk::StoreDev st, mrk::BatchDev b, uint32_t lds_entries) {\n"
+         "  mrk::prepass_body(st, mrk::JitProg{}, b, lds_entries);\n}\n";
   // ... and its persistent form (rank_device.hpp rank_serve_body)
   if (kernel == JIT_ALL || kernel == JIT_SERVE)
     s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_serve"
@@ -215,7 +221,9 @@ struct JitKernels {
   std::map<std::string, std::unique_ptr<JitSlotSet>> by_sig;
 };
 
-const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve", "mrk_jit_rank_fused_score"};
+const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve", "mrk_jit_rank_fused_score", "mrk_jit_prepass"};
+// kernels that neither write the scorer's tile nor depend on the scorer's precision: one per program, kept in slot [kernel][1]
+static inline bool jit_program_only(int kernel) { return kernel == JIT_MATRIX || kernel == JIT_PREPASS; }
 
 // 0 off; 1 on: the first rank of a model waits for the compile (a failure falls back to the generic kernel with a warning);
 // 2 required: a failure is an error; 3 async: compile in the background, rank with the generic kernel until it is ready;
@@ -298,8 +306,8 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
   if (mode == 0) return nullptr;
   if (!prog.jit) prog.jit = new JitKernels();
   JitKernels *k = (JitKernels *)prog.jit;
-  if (kernel == JIT_MATRIX) f64 = true;
-  const bool keyed = sig && sig->ok && kernel != JIT_MATRIX && switches().jit_sig;
+  if (jit_program_only(kernel)) f64 = true;
+  const bool keyed = sig && sig->ok && !jit_program_only(kernel) && switches().jit_sig;
   std::unique_ptr<JitSlotSet> &set = k->by_sig[keyed ? sig->text : std::string()];
   if (!set) set.reset(new JitSlotSet());
   JitSlot &sl = set->slot[kernel][f64 ? 1 : 0];
@@ -351,7 +359,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
         void *fallback = nullptr;
         if (keyed && !no_compile) {
           for (int kn = 0; kn < JIT_KERNELS; ++kn) {
-            void *f = jit_function_locked(prog, kn, kn == JIT_MATRIX ? true : f64, false, nullptr, true);
+            void *f = jit_function_locked(prog, kn, jit_program_only(kn) ? true : f64, false, nullptr, true);
             if (kn == kernel) fallback = f;
           }
         }
@@ -411,7 +419,7 @@ int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const st
   int compiled = 0;
   for (int k = 0; k < JIT_KERNELS; ++k) {
     if (!(kernel_mask & (1u << k))) continue;
-    const bool kf64 = k == JIT_MATRIX ? true : f64;
+    const bool kf64 = jit_program_only(k) ? true : f64;
     const std::string src = jit_source(prog, kf64, k, switches().jit_sig ? sig : nullptr);
     const std::string user = cache_path(src);
     const std::string name = user.empty() ? shipped_path(src) : user;
@@ -436,6 +444,7 @@ void *jit_items_function(const Program &prog, bool f64, const QsSignature *sig) 
 void *jit_split_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_SPLIT, f64, sig); }
 // the f64-matrix form of the fused kernel
 void *jit_matrix_function(const Program &prog) { return jit_function(prog, JIT_MATRIX, true, nullptr); }
+void *jit_prepass_function(const Program &prog) { return jit_function(prog, JIT_PREPASS, true, nullptr); }
 // the one-launch kernel of small requests
 void *jit_one_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_ONE, f64, sig); }
 void *jit_fused_score_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_FUSED_SCORE, f64, sig); }

@@ -9,7 +9,7 @@ struct Program;
 struct QsSignature;  // forest.hpp: the forest's view signature - the kernels that write the scorer's tile are keyed by it too
 
 // the specialised kernels of a program; each is compiled (and cached on disk) by itself when a batch first needs it
-enum { JIT_RANK = 0, JIT_SPLIT = 1, JIT_MATRIX = 2, JIT_ITEMS = 3, JIT_ONE = 4, JIT_SERVE = 5, JIT_FUSED_SCORE = 6, JIT_KERNELS = 7, JIT_ALL = -1 };
+enum { JIT_RANK = 0, JIT_SPLIT = 1, JIT_MATRIX = 2, JIT_ITEMS = 3, JIT_ONE = 4, JIT_SERVE = 5, JIT_FUSED_SCORE = 6, JIT_PREPASS = 7, JIT_KERNELS = 8, JIT_ALL = -1 };
 // the translation unit hiprtc compiles for this model's program: the shared device code + the program as constants +
 // the kernel `kernel` (JIT_ALL: every kernel - inspection tools)
 std::string jit_source(const Program &prog, bool f64, int kernel = JIT_ALL, const QsSignature *sig = nullptr);
@@ -24,6 +24,8 @@ void *jit_items_function(const Program &prog, bool f64, const QsSignature *sig);
 void *jit_split_function(const Program &prog, bool f64, const QsSignature *sig);
 // the fused kernel writing the row-major f64 matrix (mrk_jit_rank_matrix), same conditions
 void *jit_matrix_function(const Program &prog);
+// the pre-pass alone (mrk_jit_prepass: requests too large for one workgroup's assembly - config 4), keyed by the program only
+void *jit_prepass_function(const Program &prog);
 // pre-pass + assembly + forest + ordering of a small request in one launch (mrk_jit_rank_one), same conditions
 void *jit_one_function(const Program &prog, bool f64, const QsSignature *sig);
 // the persistent workgroup of the serving queue (mrk_jit_rank_serve), same conditions

@@ -33,31 +33,9 @@ namespace mrk {
 
 namespace {
 
-// The pre-pass alone (requests too large for one workgroup's assembly - C4 - or whose tables exceed the fused kernel's
-// LDS budget).  The item-parallel kernels that follow read the tables from the HBM arena, but a request's tables depend
-// on its session and `top`, not on its candidate count: when they fit the `lds_entries` of dynamic LDS they are BUILT
-// there (every insert / probe a `ds_cmpst` instead of a global atomic round trip) and copied out once.
+// the pre-pass alone, interpreting the program (rank_device.hpp prepass_body)
 __global__ void __launch_bounds__(PREP_THREADS)
-prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t lds_entries) {
-  __shared__ double s_vals[PREP_MAX_VALUES];
-  __shared__ int s_ints[PREP_INTS];
-  extern __shared__ __align__(16) unsigned long long s_tables[];
-  const int r = blockIdx.x;
-  const ReqDev rq = b.reqs[r];
-  if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
-  PrepScratch sc{s_vals, PREP_MAX_VALUES, s_ints, 0ull, {0, 0, 0, 0, 0, 0}};
-  PrepOut *po = &b.prep_out[(size_t)r * prog.n_prep];
-  uint32_t n_ent = 0;  // this request's table entries: [arena_begin, arena_begin + n_ent)
-  for (int e = 0; e < prog.n_prep; ++e) n_ent = max(n_ent, po[e].tab_off - rq.arena_begin + po[e].tab_cap);
-  const bool in_lds = n_ent <= lds_entries;  // uniform
-  if (!in_lds) {
-    prepass_request(st, prog, b, r, rq, b.arena, 0u, po, sc);
-  } else {  // (two instantiations: with a selected pointer the table accesses would be flat instead of ds operations)
-    prepass_request(st, prog, b, r, rq, s_tables, rq.arena_begin, po, sc);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_ent; i += blockDim.x) b.arena[(size_t)rq.arena_begin + i] = s_tables[i];
-  }
-}
+prepass_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t lds_entries) { prepass_body(st, prog, b, lds_entries); }
 
 __global__ void __launch_bounds__(ASM_THREADS)
 assemble_kernel(StoreDev st, ProgramDev prog, BatchDev b) {
@@ -266,15 +244,24 @@ normalize_kernel(BatchDev b, int dim, int col, int mode) {
 
 void launch_big_sort(hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch);  // bigsort.hip
 
-void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries) {
+// jit_fn: mrk_jit_prepass of this program (jit.cpp), or nullptr = the kernel that interprets the program
+void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries, void *jit_fn) {
   if (b.n_req <= 0 || prog.n_prep <= 0) return;
   // tables in LDS when the largest request's fit next to the kernel's 33 KB of static scratch (MRK_PREPASS_LDS=0: HBM arena)
   constexpr uint32_t LDS_TABLE_BUDGET = 96 * 1024;
-  const uint32_t lds_entries = switches().prepass_lds && (uint64_t)max_req_entries * 8 <= LDS_TABLE_BUDGET ? max_req_entries : 0;
+  uint32_t lds_entries = switches().prepass_lds && (uint64_t)max_req_entries * 8 <= LDS_TABLE_BUDGET ? max_req_entries : 0;
   static std::once_flag once;
   std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TABLE_BUDGET)); });  // static + dynamic <= 160 KB
   ScopedKernelTimer timer(ctx, "prepass");
-  hipLaunchKernelGGL(prepass_kernel, dim3(b.n_req), dim3(PREP_THREADS), (size_t)lds_entries * 8, ctx->launch, st, prog, b, lds_entries);
+  // (a module function keeps the default 64 KB limit on static + dynamic LDS: 33 KB are static here)
+  if (jit_fn && (size_t)lds_entries * 8 <= 30 * 1024) {
+    StoreDev a_st = st;
+    BatchDev a_b = b;
+    void *args[] = {&a_st, &a_b, &lds_entries};
+    MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, PREP_THREADS, 1, 1, (unsigned)((size_t)lds_entries * 8), ctx->launch, args, nullptr));
+  } else {
+    hipLaunchKernelGGL(prepass_kernel, dim3(b.n_req), dim3(PREP_THREADS), (size_t)lds_entries * 8, ctx->launch, st, prog, b, lds_entries);
+  }
   MRK_HIP(hipGetLastError());
 }
 

@@ -679,6 +679,33 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
   __syncthreads();
 }
 
+// The pre-pass alone, one workgroup per request (requests too large for one workgroup's assembly - config 4 - or whose tables
+// exceed the fused kernel's LDS budget).  The item-parallel kernels that follow read the tables from the HBM arena, but a
+// request's tables depend on its session and `top`, not on its candidate count: when they fit the `lds_entries` of dynamic LDS
+// they are BUILT there (every insert / probe a `ds_cmpst` instead of a global atomic round trip) and copied out once.
+// Two shapes: prepass_kernel (rank.hip) interprets the program; mrk_jit_prepass (jit.cpp) has it as constants.
+template <typename Prog>
+__device__ __forceinline__ void prepass_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t lds_entries) {
+  __shared__ double s_vals[PREP_MAX_VALUES];
+  __shared__ int s_ints[PREP_INTS];
+  extern __shared__ __align__(16) unsigned long long s_tables[];
+  const int r = blockIdx.x;
+  const ReqDev rq = b.reqs[r];
+  if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
+  PrepScratch sc{s_vals, PREP_MAX_VALUES, s_ints, 0ull, {0, 0, 0, 0, 0, 0}};
+  PrepOut *po = &b.prep_out[(size_t)r * prog.n_prep];
+  uint32_t n_ent = 0;  // this request's table entries: [arena_begin, arena_begin + n_ent)
+  for (int e = 0; e < prog.n_prep; ++e) n_ent = max(n_ent, po[e].tab_off - rq.arena_begin + po[e].tab_cap);
+  const bool in_lds = n_ent <= lds_entries;  // uniform
+  if (!in_lds) {
+    prepass_request(st, prog, b, r, rq, b.arena, 0u, po, sc);
+  } else {  // (two instantiations: with a selected pointer the table accesses would be flat instead of ds operations)
+    prepass_request(st, prog, b, r, rq, s_tables, rq.arena_begin, po, sc);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_ent; i += blockDim.x) b.arena[(size_t)rq.arena_begin + i] = s_tables[i];
+  }
+}
+
 // ---------------------------------------------------------------- assemble
 constexpr int ASM_THREADS = 256;
 

@@ -100,6 +100,31 @@ def test_several_large_and_small_requests_in_one_batch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"MRK_BIG_SORT_FOLD": "0"}, {"MRK_BIG_SORT_BUCKET": "256"}, {"MRK_BIG_SORT_TILE": "256"},
+                                 {"MRK_BIG_SORT_BUCKET": "128", "MRK_BIG_SORT_TILE": "2048"}])
+def test_every_launch_shape_of_the_sample_sort_gives_the_same_order(env):
+    """Counts -> offsets inside the classify pass's last workgroup (tables of <= 128 rows: the default for <= 131 072 candidates) or in
+    a launch of its own (MRK_BIG_SORT_FOLD=0, and always for more rows: MRK_BIG_SORT_TILE=256 makes 391 of them); smaller buckets
+    (more splitters, shorter local sorts): the order is the stable sort's whatever the shape."""
+    for k, v in env.items():
+        os.environ[k] = v
+    M.reload_switches()
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        for n in (100_000, 7000):
+            dev = DeviceScores(hip, [n])
+            rng = np.random.default_rng(n + 1)
+            for name, s in distributions(n, rng):
+                assert np.array_equal(dev.order_of(s), expected_order(s)), (env, n, name)
+            dev.batch.close()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+        M.reload_switches()
+        hip.close()
+
+
+@pytest.mark.gpu
 def test_a_bucket_that_outgrows_lds_is_sorted_in_global_memory():
     os.environ["MRK_BIG_SORT_CAP"] = "300"   # buckets hold ~1 000 pairs: every one takes the global-memory path
     M.reload_switches()
