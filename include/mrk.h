@@ -113,6 +113,11 @@ typedef struct mrk_model_info {
   int32_t tile_columns;  /* bitvector: columns ("views") of the scorer's binned tile */
 } mrk_model_info;
 int mrk_model_get_info(mrk_model *model, mrk_model_info *out);
+/* Host-only (no context, no device): reads, validates and packs a booster exactly as mrk_model_load would and reports what it
+ * found (device_bytes = what the load would place in HBM) - MRK_ERR_PARSE for malformed bytes, MRK_ERR_UNSUPPORTED for a
+ * well-formed model the scorer does not implement (dart, multi-output, vector leaves, num_parallel_tree > 1, a non-identity
+ * objective, linear trees, random-forest averaging).  What a host calls when it validates a config. */
+int mrk_model_inspect(int backend, const uint8_t *bytes, size_t len, mrk_model_info *out);
 
 void mrk_model_retain(mrk_model *model);
 void mrk_model_free(mrk_model *model); /* drops one reference; idempotent at zero (close()/isClosed()) */

@@ -40,8 +40,6 @@ constexpr int BS_LOCAL_CAP = 4096;     // pairs a bucket's workgroup sorts in LD
 constexpr int BS_MAX_BUCKETS = 16384;
 constexpr int BS_LDS_SPLITTERS = 4096; // more splitters than this are searched in global memory (n > 4 M)
 constexpr int BS_ONE_WG = 4096;        // pairs ONE workgroup sorts (sample sort, 1 024 lanes)
-constexpr int BS_FOLD_CHUNK = 32;      // rows of a column a lane of that workgroup holds in registers at a time
-constexpr int BS_FOLD_ROWS = 128;      // classify passes of at most this many workgroups turn their counts into offsets themselves (last workgroup)
 
 __device__ __forceinline__ int sample_pos(int i, int n, int samples) {
   const long long lo = (long long)i * n / samples, hi = (long long)(i + 1) * n / samples;  // stratum i: hi > lo (n >= samples)
@@ -180,12 +178,10 @@ ss_pick_splitters_kernel(const unsigned long long *__restrict__ smp_k, const int
 // step 2.  Dynamic LDS: [nb u64 splitter keys][nb i32 splitter indices][nb u32 counters] (LDS_SPL), else the counters only.
 // A workgroup leaves its tile's counts per bucket in ITS row of `table` ([n_wg][nb], coalesced) - no global atomics: 512
 // workgroups x 4 096 buckets were 1.8 M device-scope atomics per pass, twice (round 3's first version: 250 us of a 4 M order).
-// FOLD (small tables: n_wg <= BS_FOLD_ROWS rows): the last workgroup to finish also does step 2b below - one launch less,
-// and a lane holds 32 rows of its bucket's column in registers (loads in flight together) instead of walking it.
-template <bool LDS_SPL, bool FOLD>
+template <bool LDS_SPL>
 __global__ void __launch_bounds__(BS_THREADS)
 ss_classify_kernel(SortSrc src, int n, int tile, int nb, const unsigned long long *__restrict__ spl_k, const int *__restrict__ spl_i,
-                   uint16_t *__restrict__ bucket, uint32_t *__restrict__ table, uint32_t *ticket, uint32_t *__restrict__ base) {
+                   uint16_t *__restrict__ bucket, uint32_t *__restrict__ table) {
   extern __shared__ unsigned long long bs_smem[];
   unsigned long long *s_k = bs_smem;
   int *s_i = (int *)(s_k + (LDS_SPL ? nb : 0));
@@ -211,56 +207,6 @@ ss_classify_kernel(SortSrc src, int n, int tile, int nb, const unsigned long lon
   __syncthreads();
   uint32_t *row = table + (size_t)blockIdx.x * nb;
   for (int j = tid; j < nb; j += BS_THREADS) row[j] = s_hist[j];
-  if constexpr (FOLD) {
-    __shared__ int s_last;
-    __shared__ uint32_t s_part[BS_THREADS];
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const int n_wg = (int)gridDim.x;            // <= BS_FOLD_ROWS
-    // pass 1: every lane's buckets b = tid, tid + 256, ...: the column into registers, exclusive prefix back, total kept in LDS
-    // (rows written by other workgroups of this launch: read past the L1 with device-scope atomic loads)
-    uint32_t *s_tot = s_hist;                    // nb counters: free again
-    for (int bkt = tid; bkt < nb; bkt += BS_THREADS) {
-      uint32_t run = 0;
-      for (int w0 = 0; w0 < n_wg; w0 += BS_FOLD_CHUNK) {   // a chunk of the column in flight together (all of it would be 2 x 128 address registers)
-        uint32_t v[BS_FOLD_CHUNK];
-        uint32_t *col = table + (size_t)w0 * nb + bkt;
-#pragma unroll
-        for (int w = 0; w < BS_FOLD_CHUNK; ++w) v[w] = w0 + w < n_wg ? __hip_atomic_load(col + (size_t)w * nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-        for (int w = 0; w < BS_FOLD_CHUNK; ++w) {
-          if (w0 + w < n_wg) col[(size_t)w * nb] = run;
-          run += v[w];
-        }
-      }
-      s_tot[bkt] = run;
-    }
-    __syncthreads();
-    // pass 2: bucket starts = exclusive scan of the totals (a lane's contiguous share, then the 256 partial sums by lane 0)
-    const int per = (nb + BS_THREADS - 1) / BS_THREADS;
-    uint32_t sum = 0;
-    for (int q = 0; q < per; ++q) {
-      const int j = tid * per + q;
-      if (j < nb) sum += s_tot[j];
-    }
-    s_part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t run = 0;
-      for (int t = 0; t < BS_THREADS; ++t) { const uint32_t c = s_part[t]; s_part[t] = run; run += c; }
-    }
-    __syncthreads();
-    uint32_t run = s_part[tid];
-    for (int q = 0; q < per; ++q) {
-      const int j = tid * per + q;
-      if (j < nb) { base[j] = run; run += s_tot[j]; }
-    }
-    if (tid == 0) base[nb] = (uint32_t)n;
-  }
 }
 
 // step 2b: one lane per bucket walks its column of the table - table[w][b] becomes the number of bucket-b pairs of the
@@ -448,22 +394,17 @@ void sort_level(hipStream_t s, const std::vector<Level> &lv, size_t k, const Sor
                        L.smp_order, L.nb, L.spl_k, L.spl_i, L.ticket);
   }
   static std::once_flag once;  // 4 096 buckets: 64 KB of dynamic LDS next to the kernel's static 1 KB
-  std::call_once(once, [] {
-    MRK_HIP(hipFuncSetAttribute((const void *)ss_classify_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS_SPLITTERS * 16));
-    MRK_HIP(hipFuncSetAttribute((const void *)ss_classify_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS_SPLITTERS * 16));
-  });
-  const bool fold = L.n_wg <= BS_FOLD_ROWS && L.nb <= BS_LDS_SPLITTERS && switches().big_sort_fold;
-  if (fold)
-    hipLaunchKernelGGL((ss_classify_kernel<true, true>), dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 16, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
-                       L.bucket, L.table, L.ticket, L.base);
-  else if (L.nb <= BS_LDS_SPLITTERS)
-    hipLaunchKernelGGL((ss_classify_kernel<true, false>), dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 16, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
-                       L.bucket, L.table, L.ticket, L.base);
+  std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)ss_classify_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS_SPLITTERS * 16)); });
+  if (L.nb <= BS_LDS_SPLITTERS)
+    hipLaunchKernelGGL(ss_classify_kernel<true>, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 16, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
+                       L.bucket, L.table);
   else
-    hipLaunchKernelGGL((ss_classify_kernel<false, false>), dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 4, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
-                       L.bucket, L.table, L.ticket, L.base);
-  if (!fold)
-    hipLaunchKernelGGL(ss_offsets_kernel, dim3((L.nb + BS_THREADS - 1) / BS_THREADS), dim3(BS_THREADS), 0, s, L.table, L.n_wg, L.nb, L.n, L.totals, L.ticket, L.base);
+    hipLaunchKernelGGL(ss_classify_kernel<false>, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 4, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
+                       L.bucket, L.table);
+  // (round 5 measured counts -> offsets folded into the classify pass's last workgroup for tables of <= 128 rows - one launch
+  //  less: 38.2 vs 35.6 us per 100 000-candidate order, profiles/r05_c_sort_bench.txt: the serial tail of one workgroup costs more
+  //  than the launch it saves.  Not kept.  What did pay: no memset command for the ticket - the sample kernel zeroes it.)
+  hipLaunchKernelGGL(ss_offsets_kernel, dim3((L.nb + BS_THREADS - 1) / BS_THREADS), dim3(BS_THREADS), 0, s, L.table, L.n_wg, L.nb, L.n, L.totals, L.ticket, L.base);
   hipLaunchKernelGGL(ss_scatter_kernel, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 4, s, src, L.n, L.tile, L.nb, L.bucket, L.table, L.base, L.keys,
                      L.idx);
   hipLaunchKernelGGL(ss_local_sort_kernel, dim3(L.nb), dim3(BS_THREADS), 0, s, L.base, L.keys, L.idx, out_order, lds_cap);

@@ -49,7 +49,6 @@ static Switches read_switches() {
   s.big_sort_tile = num("MRK_BIG_SORT_TILE", 0);
   s.big_sort_bucket = num("MRK_BIG_SORT_BUCKET", 0);
   s.jit_prepass = flag("MRK_JIT_PREPASS", true);
-  s.big_sort_fold = flag("MRK_BIG_SORT_FOLD", true);
   s.qs_split = num("MRK_QS_SPLIT", -1);
   s.qs_kernel = num("MRK_QS_KERNEL", 1);
   s.qs_r = num("MRK_QS_R", 2);
@@ -58,7 +57,7 @@ static Switches read_switches() {
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
   s.encoder_packed = flag("MRK_ENCODER_PACKED", true);
   s.encoder_f32_mfma = flag("MRK_ENCODER_F32_MFMA", true);
-  s.encoder_f32_waves = num("MRK_ENCODER_F32_WAVES", 2);
+  s.encoder_f32_mfma32 = flag("MRK_ENCODER_F32_MFMA32", false);
   return s;
 }
 static Switches &switches_storage() {
@@ -122,6 +121,9 @@ static int guard(F &&f) {
   } catch (const std::bad_alloc &) {
     set_last_error("out of host memory");
     return MRK_ERR_DEVICE;
+  } catch (const UnsupportedModel &e) {
+    set_last_error(e.what());
+    return MRK_ERR_UNSUPPORTED;
   } catch (const std::exception &e) {
     set_last_error(e.what());
     return MRK_ERR_PARSE;
@@ -352,6 +354,32 @@ int mrk_model_get_info(mrk_model *model, mrk_model_info *out) {
     out->base_score = f.base_score;
     out->bitvector = model->qs.ok ? 1 : 0;
     out->tile_columns = model->qs.ok ? (int32_t)model->qs.views.size() : 0;
+  });
+}
+
+// Host-only: parse + validate + pack a booster exactly as mrk_model_load does, without a device (a config check, CPU tests)
+int mrk_model_inspect(int backend, const uint8_t *bytes, size_t len, mrk_model_info *out) {
+  return guard([&] {
+    if (!out || (!bytes && len)) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    Forest f;
+    if (backend == MRK_BACKEND_LIGHTGBM) f = parse_lightgbm_text((const char *)bytes, len);
+    else if (backend == MRK_BACKEND_XGBOOST) f = parse_xgboost(bytes, len);
+    else throw StatusError(MRK_ERR_INVALID_ARG, "unsupported booster tag " + std::to_string(backend));
+    if (f.average_output) throw StatusError(MRK_ERR_UNSUPPORTED, "lightgbm: average_output (random forest) models are not supported");
+    const PackedForest packed = pack_forest(f, score_chunk_budget());
+    const PackedForestQS qs = pack_forest_qs(f, f.n_features);
+    out->backend = (int)f.backend;
+    out->n_trees = (int)f.trees.size();
+    out->max_depth = f.max_depth();
+    out->n_features = f.n_features;
+    out->is_f64 = f.backend == Backend::LightGBM ? 1 : 0;
+    out->n_categorical = (int)f.n_categorical();
+    out->n_nodes = f.n_nodes();
+    out->n_leaves = f.n_leaves();
+    out->device_bytes = (int64_t)(packed.image.size() + packed.trees.size() * sizeof(TreeRef) + packed.chunks.size() * sizeof(ChunkRef) + f.cat_bits.size() * 4);
+    out->base_score = f.base_score;
+    out->bitvector = qs.ok ? 1 : 0;
+    out->tile_columns = qs.ok ? (int32_t)qs.views.size() : 0;
   });
 }
 

@@ -135,6 +135,20 @@ double parse_f64(const std::string &s) {
 
 }  // namespace
 
+// Booster::Predict (C_API_PREDICT_NORMAL, what lightgbm4j's predictForMat asks for) passes the summed leaves through the
+// objective's ConvertOutput: the identity for lambdarank / rank_xendcg (what Metarank trains, LambdaMARTRanker.scala:148-170)
+// and the plain regression losses; sigmoid / exp / softmax for the rest - not implemented here, so refused, not mis-scored.
+static void check_lgbm_objective(const std::string &objective) {
+  if (objective.empty()) return;
+  const std::string name = objective.substr(0, objective.find(' '));
+  const char *identity[] = {"lambdarank", "rank_xendcg", "regression", "regression_l2", "l2", "mean_squared_error", "mse", "regression_l1", "l1",
+                            "mean_absolute_error", "mae", "huber", "fair", "quantile", "mape", "custom", "none"};
+  bool ok = false;
+  for (const char *o : identity) ok = ok || name == o;
+  if (ok && objective.find("sqrt") != std::string::npos) ok = false;   // reg_sqrt: sign(x) * x^2 on the way out
+  if (!ok) throw UnsupportedModel("lightgbm: objective '" + objective.substr(0, 64) + "' converts the raw score on output (sigmoid / exp / softmax): only identity-output objectives such as lambdarank are supported");
+}
+
 Forest parse_lightgbm_text(const char *text, size_t len) {
   Forest f;
   f.backend = Backend::LightGBM;
@@ -158,7 +172,7 @@ Forest parse_lightgbm_text(const char *text, size_t len) {
     if (num_leaves < 1) throw std::runtime_error("lightgbm: bad num_leaves");
     int num_cat = get("num_cat") ? atoi(get("num_cat")->c_str()) : 0;
     if (get("is_linear") && atoi(get("is_linear")->c_str()) != 0)
-      throw std::runtime_error("lightgbm: linear trees are not supported");
+      throw UnsupportedModel("lightgbm: linear trees are not supported");
     const std::string *lv = get("leaf_value");
     if (!lv) throw std::runtime_error("lightgbm: tree without leaf_value");
     t.leaf = split_parse<double>(*lv, parse_f64);
@@ -249,13 +263,14 @@ Forest parse_lightgbm_text(const char *text, size_t len) {
   if (header.count("num_class")) num_class = atoi(header["num_class"].c_str());
   if (header.count("num_tree_per_iteration")) num_tree_per_iteration = atoi(header["num_tree_per_iteration"].c_str());
   if (num_class != 1 || num_tree_per_iteration != 1)
-    throw std::runtime_error("lightgbm: only single-output models are supported (num_class=1)");
+    throw UnsupportedModel("lightgbm: only single-output models are supported (num_class=1)");
   if (header.count("max_feature_idx")) {
     const long mfi = strtol(header["max_feature_idx"].c_str(), nullptr, 10);
     if (mfi < -1 || mfi >= MAX_FEATURE_INDEX) throw std::runtime_error("lightgbm: max_feature_idx out of range");
     f.n_features = (int)mfi + 1;
   }
   if (header.count("objective")) f.objective = header["objective"];
+  check_lgbm_objective(f.objective);
   f.average_output = header.count("average_output") > 0;
   for (auto &t : f.trees)
     for (auto ft : t.feat) f.n_features = std::max(f.n_features, ft + 1);
@@ -280,7 +295,7 @@ void check_objective(const std::string &objective) {
   const char *ok[] = {"rank:pairwise", "rank:ndcg", "rank:map", "reg:squarederror", "reg:linear"};
   bool found = false;
   for (auto o : ok) found = found || objective == o;
-  if (!found) throw std::runtime_error("xgboost: objective '" + objective + "' is not supported (need an identity-link objective such as rank:ndcg)");
+  if (!found) throw UnsupportedModel("xgboost: objective '" + objective.substr(0, 64) + "' is not supported (need an identity-link objective such as rank:ndcg)");
 }
 
 // Renumber (internal nodes and leaves get their own index spaces, deleted nodes drop out) and append to the forest
@@ -408,12 +423,12 @@ Forest parse_xgboost_legacy(const uint8_t *bytes, size_t len) {
   memcpy(&num_feature, mp + 4, 4);
   memcpy(&num_class, mp + 8, 4);
   memcpy(&major, mp + 20, 4);
-  if (num_class > 1) throw std::runtime_error("xgboost: multi-class models are not supported");
+  if (num_class > 1) throw UnsupportedModel("xgboost: multi-class models are not supported");
   if (num_feature > (1u << 24)) throw std::runtime_error("xgboost: not a legacy binary model (num_feature out of range)");
   f.n_features = (int)num_feature;
   f.objective = in.str();
   const std::string booster = in.str();
-  if (booster != "gbtree") throw std::runtime_error("xgboost: only gbtree boosters are supported (found '" + booster.substr(0, 32) + "')");
+  if (booster != "gbtree") throw UnsupportedModel("xgboost: only gbtree boosters are supported (found '" + booster.substr(0, 32) + "')");
   check_objective(f.objective);
   f.base_score = (double)base_score;  // identity-link objectives: ProbToMargin (applied to pre-1.0 files) is the identity
   if (major > 3) throw std::runtime_error("xgboost: unknown serialisation (not JSON / UBJSON, and the legacy header carries major version " + std::to_string(major) + ")");
@@ -480,25 +495,44 @@ Forest parse_xgboost(const uint8_t *bytes, size_t len) {
   f.backend = Backend::XGBoost;
   const json::Value &learner = root.at("learner");
   const json::Value &lmp = learner.at("learner_model_param");
-  f.base_score = (double)lmp.at("base_score").as_float();  // margin space for rank:* objectives (identity link)
+  // base_score as every writer spells it: a JSON number, the string "5E-1" (1.x / 2.x), the bracketed string "[5E-1]" (3.x: one
+  // value per target) or a JSON / UBJSON array of one value; margin space for rank:* objectives (identity link)
+  {
+    const json::Value &bs = lmp.at("base_score");
+    if (bs.is_array()) {
+      if (bs.arr.size() != 1) throw UnsupportedModel("xgboost: base_score with " + std::to_string(bs.arr.size()) + " values (multi-target models are not supported)");
+      f.base_score = (double)bs.arr[0].as_float();
+    } else {
+      if (bs.is_string() && bs.as_string().find(',') != std::string::npos) throw UnsupportedModel("xgboost: base_score with several values (multi-target models are not supported)");
+      f.base_score = (double)bs.as_float();
+    }
+    if (!std::isfinite(f.base_score)) throw std::runtime_error("xgboost: base_score is not finite");
+  }
   if (const json::Value *nf = lmp.find("num_feature")) {
     const int64_t v = nf->as_int();
     if (v < 0 || v > MAX_FEATURE_INDEX) throw std::runtime_error("xgboost: num_feature out of range");
     f.n_features = (int)v;
   }
   if (const json::Value *nc = lmp.find("num_class"))
-    if (nc->as_int() > 1) throw std::runtime_error("xgboost: multi-class models are not supported");
+    if (nc->as_int() > 1) throw UnsupportedModel("xgboost: multi-class models are not supported");
+  if (const json::Value *nt = lmp.find("num_target"))
+    if (nt->as_int() > 1) throw UnsupportedModel("xgboost: multi-target models are not supported");
   if (const json::Value *obj = learner.find("objective"))
     if (const json::Value *nm = obj->find("name")) f.objective = nm->as_string();
   check_objective(f.objective);
   const json::Value &gb = learner.at("gradient_booster");
   if (const json::Value *nm = gb.find("name"))
-    if (nm->as_string() != "gbtree") throw std::runtime_error("xgboost: only gbtree boosters are supported");
+    if (nm->as_string() != "gbtree")   // dart scales every tree by weight_drop, gblinear has no trees
+      throw UnsupportedModel("xgboost: only gbtree boosters are supported (found '" + nm->as_string().substr(0, 32) + "')");
+  if (gb.find("weight_drop")) throw UnsupportedModel("xgboost: dart boosters (weight_drop) are not supported");
   const json::Value &model = gb.at("model");
   const json::Value &trees = model.at("trees");
   if (!trees.is_array()) throw std::runtime_error("xgboost: trees is not an array");
 
   for (const json::Value &jt : trees.arr) {
+    if (const json::Value *tp = jt.find("tree_param"))
+      if (const json::Value *slv = tp->find("size_leaf_vector"))
+        if (slv->as_int() > 1) throw UnsupportedModel("xgboost: vector leaves (size_leaf_vector > 1) are not supported");
     const auto &lc = jt.at("left_children").arr;
     const auto &rc = jt.at("right_children").arr;
     const auto &si = jt.at("split_indices").arr;
@@ -536,7 +570,18 @@ Forest parse_xgboost(const uint8_t *bytes, size_t len) {
   }
   if (const json::Value *ti = model.find("tree_info"))
     for (auto &g : ti->arr)
-      if (g.as_int() != 0) throw std::runtime_error("xgboost: multi-group models are not supported");
+      if (g.as_int() != 0) throw UnsupportedModel("xgboost: multi-group models are not supported");
+  // one tree per boosting round is what the scorer's "base + sum of leaves" means without further thought: random-forest rounds
+  // (num_parallel_tree > 1) and multi-output rounds are refused rather than assumed
+  if (const json::Value *mp = model.find("gbtree_model_param")) {
+    if (const json::Value *npt = mp->find("num_parallel_tree"))
+      if (npt->as_int() > 1) throw UnsupportedModel("xgboost: num_parallel_tree > 1 is not supported");
+    if (const json::Value *slv = mp->find("size_leaf_vector"))
+      if (slv->as_int() > 1) throw UnsupportedModel("xgboost: vector leaves (size_leaf_vector > 1) are not supported");
+  }
+  if (const json::Value *ip = model.find("iteration_indptr"))
+    for (size_t i = 0; i < ip->arr.size(); ++i)
+      if (ip->arr[i].as_int() != (int64_t)i) throw UnsupportedModel("xgboost: more than one tree per boosting round (iteration_indptr) is not supported");
   for (auto &t : f.trees)
     for (auto ft : t.feat) f.n_features = std::max(f.n_features, ft + 1);
   return f;

@@ -1,6 +1,7 @@
 // Forest IR + model readers + device packing for the scorer.
 #pragma once
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -9,6 +10,13 @@
 namespace mrk {
 
 enum class Backend : int { LightGBM = 0, XGBoost = 1 };
+
+// a well-formed model that uses something the scorer does not implement (dart, multi-output, vector leaves, a non-identity
+// objective ...): MRK_ERR_UNSUPPORTED at the C ABI, never a silently different score; malformed input is std::runtime_error
+// (MRK_ERR_PARSE)
+struct UnsupportedModel : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
 
 // decision flags of one internal node (already normalised across both libraries)
 enum : uint8_t {

@@ -72,7 +72,7 @@ struct Value {
       char buf[64];
       return strtof(tokz(buf, sizeof buf), nullptr);
     }
-    if (type == Type::String) return (float)parse_string_number();
+    if (type == Type::String) return parse_string_float();   // (strtof, not strtod + narrowing: one rounding, as the library's own reader)
     if (type == Type::Bool) return b ? 1.f : 0.f;
     throw std::runtime_error("json: value is not a number");
   }
@@ -109,6 +109,12 @@ struct Value {
     return buf;
   }
   // XGBoost writes some numbers as strings ("5E-1", "[5E-1]", "127").
+  float parse_string_float() const {
+    std::string s = str;
+    if (!s.empty() && s.front() == '[') s = s.substr(1);
+    if (!s.empty() && s.back() == ']') s.pop_back();
+    return strtof(s.c_str(), nullptr);
+  }
   double parse_string_number() const {
     std::string s = str;
     if (!s.empty() && s.front() == '[') s = s.substr(1);

@@ -122,7 +122,6 @@ struct Switches {
   int big_sort_cap = 4096;     // MRK_BIG_SORT_CAP: pairs a bucket of the multi-workgroup sort orders in LDS (smaller: tests reach the global-memory path)
   bool jit_prepass = true;     // MRK_JIT_PREPASS=0: the stand-alone pre-pass (config 4) interprets the program even when the assembly is specialised
   int big_sort_bucket = 0;     // MRK_BIG_SORT_BUCKET: target pairs per bucket of the multi-workgroup sort (0: 1 024)
-  bool big_sort_fold = true;   // MRK_BIG_SORT_FOLD=0: counts -> offsets in a launch of its own even for small tables
   int big_sort_tile = 0;       // MRK_BIG_SORT_TILE: candidates per workgroup of its classify / scatter passes (0: n / 512, at least 1 024)
   int qs_split = -1;           // MRK_QS_SPLIT
   int qs_kernel = 1;           // MRK_QS_KERNEL
@@ -131,7 +130,7 @@ struct Switches {
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY
   bool encoder_packed = true;  // MRK_ENCODER_PACKED=0: padded batches for pooled / logit calls too
-  int encoder_f32_waves = 2;   // MRK_ENCODER_F32_WAVES=3: the 128 x 128 f32 product compiled for 3 wavefronts per SIMD (<= 168 registers)
+  bool encoder_f32_mfma32 = false;  // MRK_ENCODER_F32_MFMA32=1: the 128 x 128 f32 product on v_mfma_f32_32x32x2_f32 (experiment)
   bool encoder_f32_mfma = true;  // MRK_ENCODER_F32_MFMA=0: the f32 products / attention on the vector unit (the test instrument)
 };
 const Switches &switches();

@@ -178,7 +178,14 @@ def parse_ubjson(b: bytes):
 
 # --------------------------------------------------------------------------- XGBoost
 def _num(x) -> float:
+    """a scalar as the XGBoost writers spell it: a number, "5E-1", "[5E-1]" (3.x: one value per target) or a one-element array"""
+    if isinstance(x, (list, tuple)):
+        if len(x) != 1:
+            raise ValueError("multi-target models are not supported")
+        return _num(x[0])
     if isinstance(x, str):
+        if "," in x:
+            raise ValueError("multi-target models are not supported")
         return float(x.strip("[]"))
     return float(x)
 

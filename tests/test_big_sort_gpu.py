@@ -100,12 +100,10 @@ def test_several_large_and_small_requests_in_one_batch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"MRK_BIG_SORT_FOLD": "0"}, {"MRK_BIG_SORT_BUCKET": "256"}, {"MRK_BIG_SORT_TILE": "256"},
-                                 {"MRK_BIG_SORT_BUCKET": "128", "MRK_BIG_SORT_TILE": "2048"}])
+@pytest.mark.parametrize("env", [{"MRK_BIG_SORT_BUCKET": "256"}, {"MRK_BIG_SORT_TILE": "256"}, {"MRK_BIG_SORT_BUCKET": "128", "MRK_BIG_SORT_TILE": "2048"}])
 def test_every_launch_shape_of_the_sample_sort_gives_the_same_order(env):
-    """Counts -> offsets inside the classify pass's last workgroup (tables of <= 128 rows: the default for <= 131 072 candidates) or in
-    a launch of its own (MRK_BIG_SORT_FOLD=0, and always for more rows: MRK_BIG_SORT_TILE=256 makes 391 of them); smaller buckets
-    (more splitters, shorter local sorts): the order is the stable sort's whatever the shape."""
+    """More / smaller workgroups per classify pass, smaller buckets (more splitters, shorter local sorts): the order is the stable
+    sort's whatever the shape."""
     for k, v in env.items():
         os.environ[k] = v
     M.reload_switches()

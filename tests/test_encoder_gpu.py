@@ -428,6 +428,13 @@ def test_f32_products_on_the_matrix_cores_are_the_fma_chain_and_batch_independen
         np.testing.assert_array_equal(alone[0], few[0])
         np.testing.assert_array_equal(few[:6], many[:6])
         assert np.isfinite(many).all()
+        os.environ["MRK_ENCODER_F32_MFMA32"] = "1"                 # the 128 x 128 tile on the 32 x 32 x 2 form of the instruction: the same chain
+        N.reload_switches()
+        try:
+            np.testing.assert_array_equal(enc.hidden_ids(ids, None, mask), many)
+        finally:
+            del os.environ["MRK_ENCODER_F32_MFMA32"]
+            N.reload_switches()
         nine = enc.hidden_ids(np.repeat(ids[:1, :9], 40, axis=0), None, np.ones((40, 9), dtype=np.int32))
         np.testing.assert_array_equal(nine[7], one9[0])
         fp32 = bert.last_hidden_state(w, ids[:6], np.zeros_like(ids[:6]), mask[:6], heads=12)

@@ -30,6 +30,14 @@ def test_mutated_model_blobs_never_corrupt_memory(tmp_path):
         "container:xgb.container": synth.write_container([f"f{i}" for i in range(6)], 1, synth.synthetic_xgb_model(
             n_trees=3, n_features=6, depth=3, quantiles=q, fmt="json"), version=2),
     }
+    # structured mutants as seeds too: another key order and unknown keys at every level (tests/test_model_loaders_cpu.py), then the
+    # byte-level mutations on top of them
+    import json
+    import random
+    from test_model_loaders_cpu import _shuffled, shuffled_lgbm
+    rng = random.Random(3)
+    seeds["xgb:xgb.shuffled.json"] = json.dumps(_shuffled(json.loads(seeds["xgb:xgb.json"]), rng, ["zz_new", "stats"])).encode()
+    seeds["lgbm:lgbm.shuffled.txt"] = shuffled_lgbm(lgbm.decode() if isinstance(lgbm, (bytes, bytearray)) else lgbm, rng).encode()
     args = []
     for name, blob in seeds.items():
         kind, fname = name.split(":")
@@ -62,5 +70,5 @@ def test_mutated_model_blobs_never_corrupt_memory(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=2048", UBSAN_OPTIONS="print_stacktrace=1")
     out = subprocess.run([exe, "2500"] + args, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:] + out.stderr[-6000:])
-    assert "survived 17500 mutants" in out.stdout, out.stdout
+    assert "survived 22500 mutants" in out.stdout, out.stdout
     assert out.stdout.count(": rejected") == len(crafted), out.stdout

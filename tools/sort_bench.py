@@ -14,7 +14,7 @@ import metarank_amd as M  # noqa: E402
 from backends import HipBackend  # noqa: E402
 from workloads import ranklens  # noqa: E402
 
-VARIANTS = [{}, {"MRK_BIG_SORT_FOLD": "0"}, {"MRK_BIG_SORT_BUCKET": "512"}, {"MRK_BIG_SORT_BUCKET": "256"}, {"MRK_BIG_SORT_BUCKET": "128"},
+VARIANTS = [{}, {"MRK_BIG_SORT_BUCKET": "512"}, {"MRK_BIG_SORT_BUCKET": "256"}, {"MRK_BIG_SORT_BUCKET": "128"},
             {"MRK_BIG_SORT_BUCKET": "256", "MRK_BIG_SORT_TILE": "512"}, {"MRK_BIG_SORT_BUCKET": "2048"}]
 
 
