@@ -570,6 +570,38 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     self.err = e
 
+        # the same loop driven by a native host (tools/native/serve_driver.cpp: C++ threads against include/mrk.h only, no Python
+        # between the calls): what ONE host thread of a compiled host can feed - reported beside the Python harness's own figure
+        native = None
+        drv_path = os.path.join(REPO, "tools", "native", "libserve_driver.so")
+        if os.path.exists(drv_path):
+            import ctypes as C
+            from metarank_amd import _native as N_
+            drv = C.CDLL(drv_path)
+            fn = drv.mrk_bench_serve_loop
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+            set_ptrs = (C.c_void_p * n_sets)(*[C.cast(rs_.arr, C.c_void_p) for rs_ in sets])
+            set_n = (C.c_int * n_sets)(*[rs_.n_req for rs_ in sets])
+            set_ids = (N_.mrk_item_ids * n_sets)(*[rs_.ids for rs_ in sets])
+            T0 = sets[0].total_items
+            native = {}
+            for thr_ in sorted({1, n_thr}):
+                outv = (C.c_double * 8)()
+                fs, fo = np.empty(T0, dtype=np.float64), np.empty(T0, dtype=np.int32)
+                rc_ = fn(ctx.handle, booster.handle, model_name.encode(), set_ptrs, set_n, set_ids, n_sets, thr_, nb, float(args.e2e_seconds), outv,
+                         fs.ctypes.data, fo.ctypes.data, T0)
+                assert rc_ == 0 and outv[6] == 0, (rc_, outv[6], M.lib().mrk_last_error())
+                chk = ranker.prepare(model_name, sets[0].requests_with_ids())
+                chk.run(booster)
+                cs, co, _ = chk.fetch()
+                chk.close()
+                assert np.array_equal(fs, cs) and np.array_equal(fo, co), "native e2e results differ from the resident path"
+                nd = outv[1]
+                native[f"threads_{thr_}"] = {"value": nd * T0 / outv[0], "unit": "items/s", "frac_of_value": nd * T0 / outv[0] / value, "seconds": outv[0], "device_batches": int(nd),
+                                            "ms_per_batch": outv[0] / max(nd, 1) * 1e3, "batches_in_flight": nb * thr_,
+                                            "host_ms_per_batch": {k_: 1e3 * outv[2 + j_] / max(nd, 1) for j_, k_ in enumerate(("wait_results", "load", "run", "enqueue_fetch"))}}
         servers = [Server(k) for k in range(n_thr)]
         for sv in servers:
             sv.warm()
@@ -599,6 +631,8 @@ def main():
                "batches_in_flight": nb * n_thr, "host_threads": n_thr, "distinct_request_sets": n_sets,
                "host_ms_per_batch": {k: 1e3 * sum(sv.t[j] for sv in servers) / max(n_done, 1)
                                      for j, k in enumerate(("wait_results", "load", "run", "enqueue_fetch"))},
+               "driver": "python (ctypes) threads; `native_driver` = the same loop from C++ threads (tools/native/serve_driver.cpp), with 1 and with --e2e-threads host threads",
+               "native_driver": native,
                "h2d_bytes_per_batch": int(sets[0].id_bytes_total + 4 * (sets[0].total_items + 1)),
                "d2h_bytes_per_batch": int(12 * sets[0].total_items + 4 * sets[0].n_req),
                "includes": "per device batch: mrk_batch_load (user/session slots, request constants, table sizing - one host thread per batch; "
