@@ -528,7 +528,8 @@ __device__ __forceinline__ void store_f32_quad(const floatx4 &acc, int m, int n4
 }
 
 // C[M, N] = A[M, K] W[N, K]^T + bias (+ GELU | + res).  Four wavefronts in 2 x 2, each TM x TN blocks of 16 x 16
-// (TM = TN = 4: 128 x 128 tiles, 64 accumulator registers; 2: 64 x 64 tiles for grids that would not cover the chip).
+// (TM = TN = 2: 64 x 64 tiles for grids that 128 x 128 tiles would not cover the chip with; the 128 x 128 tile is
+// gemm_f32_mfma32_kernel below).
 // Operands staged through LDS in their natural layout, one 32-wide k block at a time, the next block's global loads in
 // flight during the MFMAs (at 1/16 of the f16 rate a k block is ~4 000 cycles of matrix work per wavefront: prologue and
 // barriers are noise here, unlike in gemm_kernel).  N % (32 TN) == 0, K % 32 == 0.
@@ -536,8 +537,8 @@ template <int TM, int TN, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
                                                             const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
-  __shared__ float As[BM][F32_LD];
-  __shared__ float Bs[BN][F32_LD];
+  __shared__ __align__(16) float As[BM][F32_LD];   // 16-byte fragment reads: an LDS access off its natural alignment is replayed at 64 cycles
+  __shared__ __align__(16) float Bs[BN][F32_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   // the XCD fold of gemm_kernel: one XCD's workgroups walk the N tiles of the same rows of A back to back
@@ -607,16 +608,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float *__restr
       store_f32_quad<EPI>(acc[j][i], m0 + (wr * TM + i) * 16 + fr, n0 + (wc * TN + j) * 16 + fq, M, N, bias, res, out);
 }
 
-// The 128 x 128 tile on the 32 x 32 x 2 form of the instruction (64 cycles each, half as many instructions; each wavefront 2 x 2
-// blocks of 32 x 32).  Lane (r = l & 31, g = l >> 5) holds k-slot g of row r; the canonical chain order "k = 16 t + 4 q + c, q inner"
+// The 128 x 128 tile - what packed batches run on - on the 32 x 32 x 2 form of the instruction (64 cycles each, half as many
+// instructions; each wavefront 2 x 2 blocks of 32 x 32; 152 registers = 3 workgroups per CU).  Same-box A/B against the same tile
+// on 16 x 16 x 4 (184 registers, 2 per CU): the c5 batch's forward pass 8.46 -> 8.13 ms (profiles/r05_d_*), identical bits.  Lane (r = l & 31, g = l >> 5) holds k-slot g of row r; the canonical chain order "k = 16 t + 4 q + c, q inner"
 // pairs q = 2 h, 2 h + 1 into step (c, h), so the lane's operand for that step is component c of the 16-byte piece at column
-// 16 t + 8 h + 4 g of its row - the natural LDS layout again.  Same bits as gemm_f32_mfma_kernel (tests).  MRK_ENCODER_F32_MFMA32.
+// 16 t + 8 h + 4 g of its row - the natural LDS layout again.  Same bits as gemm_f32_mfma_kernel and the <= 32-row kernel (tests).
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_mfma32_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
                                                               const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
   constexpr int BM = 128, BN = 128, TS = 4;
-  __shared__ float As[BM][F32_LD];
-  __shared__ float Bs[BN][F32_LD];
+  __shared__ __align__(16) float As[BM][F32_LD];   // 16-byte fragment reads: an LDS access off its natural alignment is replayed at 64 cycles
+  __shared__ __align__(16) float Bs[BN][F32_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int n_tiles = N / BN, m_tiles = (M + BM - 1) / BM, per_xcd = (m_tiles + 7) / 8;
@@ -811,8 +813,7 @@ void launch_gemm_f32(const float *A, const float *W, const float *bias, const fl
     // 128 x 128 tiles once the grid still covers the chip with them (two workgroups per CU), 64 x 64 tiles otherwise
     const bool big = N % 128 == 0 && (size_t)((M + 127) / 128) * (N / 128) >= 512;
     auto grid_of = [&](int bm, int bn) { return dim3((unsigned)(8 * (((M + bm - 1) / bm + 7) / 8) * (N / bn))); };
-    if (big && switches().encoder_f32_mfma32) hipLaunchKernelGGL((gemm_f32_mfma32_kernel<EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
-    else if (big) hipLaunchKernelGGL((gemm_f32_mfma_kernel<4, 4, EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    if (big) hipLaunchKernelGGL((gemm_f32_mfma32_kernel<EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, EPI>), grid_of(64, 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
     return;
   }

@@ -1,5 +1,6 @@
 // Feature registry + host half of a request.  See features.hpp.
 #include "features.hpp"
+#include "tzif.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -768,7 +769,60 @@ bool two_digits(const char *&p, int &out) {
   return true;
 }
 
-// ZonedDateTime.parse(_, ISO_DATE_TIME) for offset forms; region ids need tzdata and are rejected
+// The zone id inside "[...]" of an ISO_DATE_TIME string (ZoneId.of): "Z", a plain offset, "UTC" / "GMT" / "UT" with an optional
+// offset - fixed - or a region of the tz database, whose offset AT THE INSTANT comes from the host's zoneinfo (tzif.cpp).
+// false = not a zone id java.time knows (the feature's value is then missing, LocalDateTimeFeature.scala:47-49); a host without
+// any zoneinfo directory is an error (MRK_ERR_UNSUPPORTED), not a silently missing value.
+bool zone_offset_at(const std::string &zone, int64_t instant, int64_t &off) {
+  auto fixed = [&](const char *p, bool need_sign_only) -> bool {   // [+-]h[h][:mm[:ss]] | [+-]hhmm[ss]
+    if (*p != '+' && *p != '-') return false;
+    const int sign = *p == '-' ? -1 : 1;
+    ++p;
+    int v[3] = {0, 0, 0}, n = 0;
+    const size_t len = strlen(p);
+    const bool colon = strchr(p, ':') != nullptr;
+    if (!colon && (len == 4 || len == 6) && !need_sign_only) {   // +hhmm, +hhmmss
+      for (size_t i = 0; i < len; ++i) if (!isdigit((unsigned char)p[i])) return false;
+      for (size_t i = 0; i < len / 2; ++i) v[i] = (p[2 * i] - '0') * 10 + (p[2 * i + 1] - '0');
+      n = (int)(len / 2);
+    } else {
+      while (n < 3) {
+        if (!isdigit((unsigned char)*p)) return false;
+        int x = *p++ - '0';
+        if (isdigit((unsigned char)*p)) x = x * 10 + (*p++ - '0');
+        v[n++] = x;
+        if (*p == ':') { ++p; continue; }
+        break;
+      }
+      if (*p != 0) return false;
+    }
+    if (v[0] > 18 || v[1] > 59 || v[2] > 59) return false;
+    off = sign * (v[0] * 3600 + v[1] * 60 + v[2]);
+    return off >= -18 * 3600 && off <= 18 * 3600;
+  };
+  if (zone == "Z") { off = 0; return true; }
+  if (zone[0] == '+' || zone[0] == '-') return fixed(zone.c_str(), false);
+  for (const char *pre : {"UTC", "GMT", "UT"}) {
+    const size_t n = strlen(pre);
+    if (zone.compare(0, n, pre) == 0 && (zone.size() == n || zone[n] == '+' || zone[n] == '-')) {
+      if (zone.size() == n) { off = 0; return true; }
+      return fixed(zone.c_str() + n, false);
+    }
+  }
+  const TzRules *rules = nullptr;
+  switch (tz_lookup(zone, &rules)) {
+    case TzLookup::Ok: off = rules->offset_at(instant); return true;
+    case TzLookup::UnknownRegion: return false;
+    case TzLookup::NoTzdata:
+      throw StatusError(MRK_ERR_UNSUPPORTED, "a date-time names the time zone '" + zone + "' but this host has no zoneinfo directory (set MRK_TZDIR or TZDIR; "
+                                             "java.time would use the JVM's own tzdb)");
+  }
+  return false;
+}
+
+// ZonedDateTime.parse(_, ISO_DATE_TIME): ISO_LOCAL_DATE_TIME + offset [+ '[' zone ']'].  java.time resolves the INSTANT from the
+// written offset (Parsed.resolveInstant) and the local date-time from the zone's rules at that instant (ZonedDateTime.from ->
+// create(epochSecond, nano, zone)); without brackets the zone IS the offset.
 bool parse_iso_datetime(const char *s, Civil &out) {
   const char *p = s;
   bool neg = false;
@@ -793,6 +847,13 @@ bool parse_iso_datetime(const char *s, Civil &out) {
     if (*p == ':') { ++p; if (!two_digits(p, om)) return false; if (*p == ':') { ++p; if (!two_digits(p, os)) return false; } }
     off = sign * (oh * 3600 + om * 60 + os);
   } else return false;
+  std::string zone;
+  if (*p == '[') {
+    const char *e = strchr(p, ']');
+    if (!e || e[1] != 0 || e == p + 1) return false;
+    zone.assign(p + 1, e);
+    p = e + 1;
+  }
   if (*p != 0) return false;
   if (mo < 1 || mo > 12 || d < 1 || d > 31 || h > 23 || mi > 59 || sec > 59) return false;
   // civil -> days
@@ -803,7 +864,9 @@ bool parse_iso_datetime(const char *s, Civil &out) {
   const uint64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
   const int64_t days = era * 146097 + (int64_t)doe - 719468;
   const int64_t local = days * 86400 + h * 3600 + mi * 60 + sec;
-  out = civil_of(local - off, off);
+  int64_t zoff = off;
+  if (!zone.empty() && !zone_offset_at(zone, local - off, zoff)) return false;
+  out = civil_of(local - off, zoff);
   return true;
 }
 
@@ -1332,4 +1395,23 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
   hb.arena_entries = arena;
 }
 
+// tests (not part of include/mrk.h): LocalDateTimeFeature's parse + mapper on the host - 1 = a value, 0 = missing (java.time would
+// not parse the string), < 0 = an mrk_status
+int debug_local_time(const char *iso, int mapper, double *out) {
+  try {
+    Civil c;
+    if (!iso || !out || !parse_iso_datetime(iso, c)) return 0;
+    *out = map_datetime(mapper, c);
+    return 1;
+  } catch (const StatusError &e) {
+    set_last_error(e.what());
+    return e.status;
+  }
+}
+
 }  // namespace mrk
+
+extern "C" {
+int mrk_debug_local_time(const char *iso, int mapper, double *out) { return mrk::debug_local_time(iso, mapper, out); }
+void mrk_debug_tz_reset(void) { mrk::tz_debug_reset(); }
+}

@@ -130,7 +130,6 @@ struct Switches {
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY
   bool encoder_packed = true;  // MRK_ENCODER_PACKED=0: padded batches for pooled / logit calls too
-  bool encoder_f32_mfma32 = false;  // MRK_ENCODER_F32_MFMA32=1: the 128 x 128 f32 product on v_mfma_f32_32x32x2_f32 (experiment)
   bool encoder_f32_mfma = true;  // MRK_ENCODER_F32_MFMA=0: the f32 products / attention on the vector unit (the test instrument)
 };
 const Switches &switches();

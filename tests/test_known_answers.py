@@ -414,6 +414,35 @@ def test_local_time_errors_and_native_timestamp(mk):
     eq(b3.matrix(ranking_event(["p1"], timestamp=1661345221008)), [[(12 * 3600 + 47 * 60 + 1) / 3600.0]])  # 2022-08-24T12:47:01Z
 
 
+@pytest.mark.gpu
+def test_local_time_with_a_region_id_through_the_rank_path():
+    """"...+01:00[Europe/Paris]" (ZonedDateTime.parse resolves the local time from the REGION's rules at the written instant): the
+    host part of the request resolves it from the zoneinfo directory (csrc/tzif.cpp; here the tzdata wheel's), the matrix carries
+    it.  The C++ oracle has no tz database - the expectation is computed with Python's zoneinfo (tests/test_local_time_zones_cpu.py
+    sweeps zones and instants on the host)."""
+    import datetime as dt
+    import os
+    tzdata = pytest.importorskip("tzdata")
+    zoneinfo = pytest.importorskip("zoneinfo")
+    from metarank_amd import _native as N
+    os.environ["MRK_TZDIR"] = os.path.join(os.path.dirname(tzdata.__file__), "zoneinfo")
+    N.lib().mrk_debug_tz_reset()
+    b = make_backend("hip", single_feature_config({"name": "x", "type": "local_time", "source": "ranking.localts", "parse": "time_of_day"}), "random")
+    try:
+        for iso, instant, zone in (("2022-03-28T12:00:00+02:00[Europe/Paris]", dt.datetime(2022, 3, 28, 10, tzinfo=dt.timezone.utc), "Europe/Paris"),
+                                   ("2022-01-28T12:00:00+02:00[Europe/Paris]", dt.datetime(2022, 1, 28, 10, tzinfo=dt.timezone.utc), "Europe/Paris"),   # written offset is not the zone's: 11:00 there
+                                   ("2031-11-02T05:59:59Z[America/New_York]", dt.datetime(2031, 11, 2, 5, 59, 59, tzinfo=dt.timezone.utc), "America/New_York"),
+                                   ("2031-11-02T06:00:00Z[America/New_York]", dt.datetime(2031, 11, 2, 6, tzinfo=dt.timezone.utc), "America/New_York")):
+            z = instant.astimezone(zoneinfo.ZoneInfo(zone))
+            exp = (z.hour * 3600 + z.minute * 60 + z.second) / 3600.0
+            eq(b.matrix(ranking_event(["p1", "p2"], fields=[{"name": "localts", "value": iso}])), [[exp], [exp]])
+        eq(b.matrix(ranking_event(["p1"], fields=[{"name": "localts", "value": "2022-03-28T12:00:00+02:00[Europe/Atlantis]"}])), [[NAN]])
+    finally:
+        b.close()
+        os.environ.pop("MRK_TZDIR", None)
+        N.lib().mrk_debug_tz_reset()
+
+
 # ---- T/feature/PositionFeatureTest.scala:24-31 ------------------------------------------------------------------------
 def test_position_is_constant_online(mk):
     b = mk(single_feature_config({"name": "pos", "type": "position", "position": 5}))
