@@ -198,6 +198,15 @@ int mrk_store_delete(mrk_ctx *ctx, const char *key);
  * mrk_store_put_* (NumStats / Map / Frequency values are parsed and ignored: /rank does not read them).
  * out_records (nullable) receives the number of records decoded. */
 int mrk_store_put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int *out_records);
+/* FeatureValue.expire (FeatureValueCodec.scala:42-48,75: every record carries its feature's ttl; the Redis store drops a key that
+ * long after its LAST write, RedisKVStore.scala:40 - the other engines never do).  mrk_store_put_binary ignores it.  A host whose
+ * system of record expires keys uses mrk_store_put_binary_at instead: the same load, and every applied record is remembered
+ * with deadline = now_ms + expire (now_ms: the host's clock, Timestamp.now; pre-ttl encodings count as 90 days); a later write
+ * of the same key through ANY put replaces or clears its deadline.  mrk_store_expire(ctx, now_ms, &n) - called from a timer -
+ * deletes the values whose deadline has passed (exactly mrk_store_delete; the next flush uploads the change).  Host memory:
+ * about 40 bytes per live deadline; nothing when the _at form is never used. */
+int mrk_store_put_binary_at(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int64_t now_ms, int *out_records);
+int mrk_store_expire(mrk_ctx *ctx, int64_t now_ms, int64_t *out_expired);
 
 /* Write path: instead of a refreshed FeatureValue the host may forward the raw Writes of
  * FeatureValueFlow.commitWrite (M/flow/FeatureValueFlow.scala:44-62); the FeatureValue the read path needs is

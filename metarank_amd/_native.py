@@ -177,6 +177,8 @@ SIGNATURES = {
     "mrk_store_delete": (_I, [_V, _S]),
     "mrk_store_increment_periodic": (_I, [_V, _S, C.c_int64, C.c_int64]),
     "mrk_store_put_binary": (_I, [_V, _P, C.c_size_t, C.POINTER(C.c_int)]),
+    "mrk_store_put_binary_at": (_I, [_V, _P, C.c_size_t, C.c_int64, C.POINTER(C.c_int)]),
+    "mrk_store_expire": (_I, [_V, C.c_int64, C.POINTER(C.c_int64)]),
     "mrk_store_increment_periodic_batch": (_I, [_V, C.POINTER(_S), _P, _P, _I]),
     "mrk_store_increment": (_I, [_V, _S, C.c_int64]),
     "mrk_store_append": (_I, [_V, _S, _S, C.c_int64]),

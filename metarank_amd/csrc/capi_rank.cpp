@@ -44,7 +44,7 @@ void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev 
                        int threads, size_t lds, bool f64, void *jit_fn);
 void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                      int threads, int op_split, const QsDev &q, const QsForestDev &f, const OneOut &out, bool f64, void *jit_fn);
-int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
+int load_feature_values(Store &store, const uint8_t *bytes, size_t len, int64_t now_ms);  // codec.cpp
 void launch_resolve_ids(hipStream_t stream, const IdTableDev &tab, const uint8_t *d_bytes, const uint32_t *d_offs, uint32_t bytes_len, const ReqDev *d_reqs,
                         int n_req, int total, int32_t *d_item_slot, uint32_t *d_item_req, int32_t *d_load_status);  // resolve.hip
 
@@ -692,14 +692,31 @@ int mrk_store_put_periodic(mrk_ctx *ctx, const char *key, const int64_t *v, int 
 int mrk_store_put_bounded_list(mrk_ctx *ctx, const char *key, const char *const *v, int n) { STORE_PUT(put_bounded_list(key, v, n)); }
 int mrk_store_delete(mrk_ctx *ctx, const char *key) { STORE_PUT(erase(key)); }
 int mrk_store_increment_periodic(mrk_ctx *ctx, const char *key, int64_t ts_ms, int64_t inc) { STORE_PUT(increment_periodic(key, ts_ms, inc)); }
-int mrk_store_put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int *out_records) {
+static int put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int64_t now_ms, int *out_records) {
   return guard([&] {
     if (out_records) *out_records = 0;
     if (!bytes && len) throw StatusError(MRK_ERR_INVALID_ARG, "null blob");
     Store &st = store_of(ctx);
     std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
-    const int n = load_feature_values(st, bytes, len);
+    const int n = load_feature_values(st, bytes, len, now_ms);
     if (out_records) *out_records = n;
+  });
+}
+
+int mrk_store_put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int *out_records) { return put_binary(ctx, bytes, len, -1, out_records); }
+
+int mrk_store_put_binary_at(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int64_t now_ms, int *out_records) {
+  if (now_ms < 0) { set_last_error("mrk_store_put_binary_at: negative clock"); return MRK_ERR_INVALID_ARG; }
+  return put_binary(ctx, bytes, len, now_ms, out_records);
+}
+
+int mrk_store_expire(mrk_ctx *ctx, int64_t now_ms, int64_t *out_expired) {
+  return guard([&] {
+    if (out_expired) *out_expired = 0;
+    Store &st = store_of(ctx);
+    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    const int64_t n = st.ttl_expire(now_ms);
+    if (out_expired) *out_expired = n;
   });
 }
 

@@ -116,7 +116,8 @@ ScalarV read_scalar(In &in) {  // ScalarCodec.read
 
 // decodes every record of the blob into `store`; returns the number of records seen (records of features the
 // configuration does not use are decoded and dropped, like KVStore values nobody reads)
-int load_feature_values(Store &store, const uint8_t *bytes, size_t len) {
+// now_ms >= 0: every applied record's deadline = now_ms + its `expire` is remembered (Store::ttl_note)
+int load_feature_values(Store &store, const uint8_t *bytes, size_t len, int64_t now_ms) {
   In in{bytes, bytes + len};
   int n = 0;
   while (in.p < in.end) {
@@ -182,7 +183,9 @@ int load_feature_values(Store &store, const uint8_t *bytes, size_t len) {
         break;
       }
     }
-    if (has_ttl) (void)in.var_long();  // expire (ms)
+    int64_t expire_ms = 90ll * 86400 * 1000;   // the pre-ttl encodings decode to 90 days (FeatureValueCodec.scala:66)
+    if (has_ttl) expire_ms = in.var_long();
+    if (now_ms >= 0 && expire_ms > 0 && expire_ms < (1ll << 53)) store.ttl_note(key, now_ms + expire_ms);
     ++n;
   }
   return n;

@@ -160,6 +160,7 @@ bool Store::locate(const KeyRef &k, Cell &out) {
   out.rec = t.rows.data() + (size_t)s * t.stride;
   t.mark(s);
   ++version;
+  if (!ttl_deadline.empty()) ttl_deadline.erase(ttl_cell(k.scope, (uint32_t)it->second, s));   // a fresh write: the old deadline is void (ttl_note sets the new one)
   return true;
 }
 
@@ -434,6 +435,40 @@ bool Store::erase(const KeyRef &k) {
   t.mark(s);
   ++version;
   return true;
+}
+
+void Store::ttl_note(const KeyRef &k, int64_t deadline_ms) {
+  Table &t = tables[k.scope];
+  auto it = t.col_of.find(std::string(k.feature));
+  if (it == t.col_of.end()) return;                    // a feature this config does not use: nothing was stored
+  const uint32_t s = slot(k.scope, k.id.data() ? k.id.data() : "", k.id.size(), false);
+  if (s == NO_SLOT) return;
+  const uint64_t cell = ttl_cell(k.scope, (uint32_t)it->second, s);
+  ttl_deadline[cell] = deadline_ms;
+  ttl_heap.emplace(deadline_ms, cell);
+}
+
+int64_t Store::ttl_expire(int64_t now_ms) {
+  int64_t n = 0;
+  while (!ttl_heap.empty() && ttl_heap.top().first <= now_ms) {
+    const auto [deadline, cell] = ttl_heap.top();
+    ttl_heap.pop();
+    auto it = ttl_deadline.find(cell);
+    if (it == ttl_deadline.end() || it->second != deadline) continue;   // rewritten since (a later deadline is in the heap) or cleared
+    ttl_deadline.erase(it);
+    const ScopeId scope = (ScopeId)(cell >> 58);
+    const uint32_t col = (uint32_t)((cell >> 32) & 0x3ffffffu), s = (uint32_t)cell;
+    Table &t = tables[scope];
+    if (col >= t.cols.size() || s >= t.n_slots) continue;
+    Cell c{&t, &t.cols[col], s, t.rows.data() + (size_t)s * t.stride};
+    if (c.rec[c.c->tag_index] == TAG_MISSING) continue;
+    drop_value(c);
+    set_tag(c, TAG_MISSING);
+    t.mark(s);
+    ++version;
+    ++n;
+  }
+  return n;
 }
 
 uint32_t Store::clone_items(int copies) {

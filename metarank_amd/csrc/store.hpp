@@ -21,6 +21,7 @@
 #include <climits>
 #include <cstring>
 #include <memory>
+#include <queue>
 #include <stdexcept>
 #include <string>
 #include <string_view>
@@ -254,6 +255,9 @@ struct Store {
   DevBuf d_groups, d_updates;        // scratch of the apply kernel
   bool frozen = false;       // layout frozen after the first slot is created
   uint64_t version = 0;      // bumped on every put
+  std::unordered_map<uint64_t, int64_t> ttl_deadline;   // cell (scope | column | slot) -> deadline, ms since the epoch
+  std::priority_queue<std::pair<int64_t, uint64_t>, std::vector<std::pair<int64_t, uint64_t>>, std::greater<std::pair<int64_t, uint64_t>>> ttl_heap;  // (deadline, cell), stale entries skipped
+  static uint64_t ttl_cell(ScopeId scope, uint32_t col, uint32_t slot) { return ((uint64_t)scope << 58) | ((uint64_t)col << 32) | slot; }
 
   Store();
   // layout (called by the registry while loading the config)
@@ -282,6 +286,13 @@ struct Store {
   bool put_periodic(const KeyRef &k, const int64_t *v, int n);
   bool put_bounded_list(const KeyRef &k, const std::string_view *v, int n);
   bool erase(const KeyRef &k);
+  // ---- FeatureValue.expire (FeatureValueCodec.scala:42-48,75; the Redis store drops a key `expire` after its last write,
+  // RedisKVStore.scala:40).  Opt-in - only records applied through mrk_store_put_binary_at are tracked: 8 + 16 bytes of host
+  // memory per live deadline.  A later write of the same cell through any put replaces or clears its deadline.
+  void ttl_note(const KeyRef &k, int64_t deadline_ms);
+  void ttl_note(const char *key, int64_t deadline_ms) { ttl_note(need_key(key), deadline_ms); }
+  int64_t ttl_expire(int64_t now_ms);                  // drops every value whose deadline has passed; returns how many
+  size_t ttl_tracked() const { return ttl_deadline.size(); }
   // the same for Key.encode strings and C strings (the C ABI)
   bool put_double(const char *key, double v) { return put_double(need_key(key), v); }
   bool put_bool(const char *key, bool v) { return put_bool(need_key(key), v); }

@@ -189,10 +189,20 @@ class HipRanker:
     def append(self, key, value, ts_ms):
         N.check(N.lib().mrk_store_append(self.ctx.handle, self._k(key), str(value).encode(), int(ts_ms)))
 
-    def put_binary(self, blob: bytes) -> int:
-        """bulk load: concatenated FeatureValueCodec records (the reference's binary wire format)"""
+    def put_binary(self, blob: bytes, now_ms: int | None = None) -> int:
+        """bulk load: concatenated FeatureValueCodec records (the reference's binary wire format); now_ms: remember every
+        record's deadline now_ms + expire (mrk_store_put_binary_at) for a later expire()"""
         n = C.c_int(0)
-        N.check(N.lib().mrk_store_put_binary(self.ctx.handle, blob, len(blob), C.byref(n)))
+        if now_ms is None:
+            N.check(N.lib().mrk_store_put_binary(self.ctx.handle, blob, len(blob), C.byref(n)))
+        else:
+            N.check(N.lib().mrk_store_put_binary_at(self.ctx.handle, blob, len(blob), now_ms, C.byref(n)))
+        return n.value
+
+    def expire(self, now_ms: int) -> int:
+        """mrk_store_expire: drops the values whose deadline (FeatureValue.expire after their last write) has passed"""
+        n = C.c_int64(0)
+        N.check(N.lib().mrk_store_expire(self.ctx.handle, now_ms, C.byref(n)))
         return n.value
 
     def clone_items(self, copies: int) -> int:

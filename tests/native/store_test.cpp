@@ -134,6 +134,26 @@ int main() {
     for (size_t i = 0; i < kv.second.size(); ++i)
       if (st.slot_pool.host[(uint32_t)bits + i] != st.slot(SC_ITEM, kv.second[i], false)) { ++bad; break; }
   }
+  // ---- FeatureValue.expire (Store::ttl_note / ttl_expire): a value is dropped `expire` after its LAST write, a rewrite moves the
+  // deadline, a plain put clears it, unknown keys are no-ops
+  {
+    auto tag_of = [&](const char *id, const char *col) { uint8_t tag = 0; uint64_t bits = 0; const uint8_t *rec = nullptr; cell_of(SC_ITEM, id, col, tag, bits, rec); return tag; };
+    const int64_t T0 = 1700000000000ll;
+    st.put_double("item=ttl1/pop", 1.0); st.ttl_note("item=ttl1/pop", T0 + 1000);
+    st.put_double("item=ttl2/pop", 2.0); st.ttl_note("item=ttl2/pop", T0 + 5000);
+    st.put_double("item=ttl3/pop", 3.0); st.ttl_note("item=ttl3/pop", T0 + 1000);
+    { const char *g[1] = {"a"}; st.put_string_list("item=ttl1/genre", g, 1); st.ttl_note("item=ttl1/genre", T0 + 2000); }
+    st.ttl_note("item=nobody/pop", T0 + 1);          // no such slot
+    st.ttl_note("item=ttl1/unknown_feature", T0 + 1);
+    if (st.ttl_tracked() != 4) { printf("ttl: tracked %zu\n", st.ttl_tracked()); ++bad; }
+    if (st.ttl_expire(T0 + 999) != 0) ++bad;
+    st.put_double("item=ttl3/pop", 3.5);                          // a plain put: its deadline is void
+    st.put_double("item=ttl2/pop", 2.5); st.ttl_note("item=ttl2/pop", T0 + 9000);   // rewritten: the deadline moves
+    if (st.ttl_expire(T0 + 1000) != 1 || tag_of("ttl1", "pop") != TAG_MISSING || tag_of("ttl3", "pop") != TAG_DOUBLE || tag_of("ttl1", "genre") == TAG_MISSING) { printf("ttl: first sweep\n"); ++bad; }
+    if (st.ttl_expire(T0 + 6000) != 1 || tag_of("ttl1", "genre") != TAG_MISSING || tag_of("ttl2", "pop") != TAG_DOUBLE) { printf("ttl: second sweep\n"); ++bad; }
+    if (st.ttl_expire(T0 + 9000) != 1 || tag_of("ttl2", "pop") != TAG_MISSING || st.ttl_tracked() != 0) { printf("ttl: third sweep\n"); ++bad; }
+    if (st.ttl_expire(T0 + 99000) != 0) ++bad;
+  }
   // two thirds of the churn happened after the high-water marks were taken: a store that appended for ever would have
   // tripled; recycling keeps the growth small
   const size_t tok_end = st.tok_pool.host.size(), f64_end = st.f64_pool.host.size() + st.f32_pool.host.size(), slot_end = st.slot_pool.host.size();

@@ -95,6 +95,49 @@ def test_store_loaded_from_binary_ranks_like_typed_puts():
         b.close()
 
 
+@pytest.mark.gpu
+def test_values_expire_after_their_ttl_like_the_redis_store():
+    """FeatureValue.expire (FeatureValueCodec.scala:42-48,75; RedisKVStore.scala:40 sets the key's TTL at every write): records
+    loaded with mrk_store_put_binary_at carry deadline = now + expire; mrk_store_expire(now) drops what is overdue - exactly a
+    delete: the device sees a missing value after the next flush, the ORACLE given the surviving values only agrees bit for bit;
+    a rewrite moves the deadline; records of the plain mrk_store_put_binary never expire."""
+    from backends import HipBackend, OracleBackend
+    from workloads import ranklens
+
+    cfg = ranklens.ranklens_config()
+    b, o = HipBackend(cfg, "xgboost"), OracleBackend(cfg, "xgboost")
+    try:
+        state = list(ranklens.generate_state(400, 40))
+        T0 = 1_700_000_000_000
+        short = [(k_, key, v) for (k_, key, v) in state if key.endswith("/popularity") or key.endswith("/profile_genres")]
+        rest = [x for x in state if x not in short]
+        blob_short = b"".join(codec.feature_value(k_, key, v, ttl_ms=60_000) for k_, key, v in short)
+        blob_rest = b"".join(codec.feature_value(k_, key, v, ttl_ms=codec.DAYS_90_MS, compat=(i % 5 == 0)) for i, (k_, key, v) in enumerate(rest))
+        assert b.ranker.put_binary(blob_short, now_ms=T0) == len(short)
+        assert b.ranker.put_binary(blob_rest[: len(blob_rest)], now_ms=T0) == len(rest)
+        reqs = ranklens.generate_requests(6, 100, 400, 40, seed=17)
+        ranklens.load_state(o, iter(state))
+        same = lambda x, y: bool(((x == y) | (np.isnan(x) & np.isnan(y))).all())
+        assert all(same(b.matrix(ev), o.matrix(ev)) for ev in reqs)
+        assert b.ranker.expire(T0 + 59_999) == 0
+        # one key rewritten 30 s later: its minute starts again
+        k_, key, v = short[0]
+        b.ranker.put_binary(codec.feature_value(k_, key, v, ttl_ms=60_000), now_ms=T0 + 30_000)
+        assert b.ranker.expire(T0 + 60_000) == len(short) - 1
+        o2 = OracleBackend(cfg, "xgboost")
+        ranklens.load_state(o2, iter(rest + [short[0]]))
+        assert all(same(b.matrix(ev), o2.matrix(ev)) for ev in reqs)
+        assert not all(same(b.matrix(ev), o.matrix(ev)) for ev in reqs)      # something the requests read did expire
+        assert b.ranker.expire(T0 + 90_000) == 1
+        assert b.ranker.expire(T0 + 89 * 86_400_000) == 0                      # the 90-day values (and the pre-ttl encodings) are still there
+        n_rest = b.ranker.expire(T0 + 91 * 86_400_000)
+        assert 0.95 * len(rest) <= n_rest <= len(rest)                          # (state of a feature the stock config does not use is never stored, hence never tracked)
+        o2.close()
+    finally:
+        b.close()
+        o.close()
+
+
 def test_ranking_event_format_rejects_garbage_without_a_gpu():
     import ctypes as C
 
