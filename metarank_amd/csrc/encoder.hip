@@ -695,103 +695,6 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma32_kernel(const float *__res
       }
 }
 
-// MEASUREMENT ONLY (MRK_ENCODER_F32_DIAG=1|2|3, wrong results): the same kernel without its fragment reads (1), also without the
-// global loads and LDS stores (2), also without the barriers (3) - which part of a k step the matrix pipe waits for
-template <int EPI, int DIAG>
-__global__ __launch_bounds__(256) void gemm_f32_mfma32_diag_kernel(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-                                                              const float *__restrict__ res, float *__restrict__ out, int M, int N, int K) {
-  constexpr int BM = 128, BN = 128, TS = 4;
-  __shared__ __align__(16) float As[BM][F32_LD];   // 16-byte fragment reads: an LDS access off its natural alignment is replayed at 64 cycles
-  __shared__ __align__(16) float Bs[BN][F32_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int n_tiles = N / BN, m_tiles = (M + BM - 1) / BM, per_xcd = (m_tiles + 7) / 8;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int m_tile = xcd * per_xcd + slot / n_tiles;
-  if (m_tile >= m_tiles) return;
-  const int m0 = m_tile * BM, n0 = (slot % n_tiles) * BN;
-  const int lr = tid >> 3, lc = (tid & 7) * 4;
-  floatx4 ra[TS], rb[TS];
-  auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < TS; ++i) {
-      int m = m0 + i * 32 + lr;
-      m = m < M ? m : M - 1;
-      ra[i] = *(const floatx4 *)(A + (size_t)m * K + k0 + lc);
-    }
-#pragma unroll
-    for (int j = 0; j < TS; ++j) rb[j] = *(const floatx4 *)(W + (size_t)(n0 + j * 32 + lr) * K + k0 + lc);
-  };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int i = 0; i < TS; ++i) *(floatx4 *)&As[i * 32 + lr][lc] = ra[i];
-#pragma unroll
-    for (int j = 0; j < TS; ++j) *(floatx4 *)&Bs[j * 32 + lr][lc] = rb[j];
-  };
-  floatx16 acc[2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-  const int KT = K / F32_BK;
-  load_tiles(0);
-  store_tiles();
-  __syncthreads();
-  const int fr = lane & 31, fg = (lane >> 5) * 4;
-  floatx4 keep_a[2][2], keep_b[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      keep_a[i][h] = *(const floatx4 *)&As[(wr * 2 + i) * 32 + fr][8 * h + fg];
-      keep_b[i][h] = *(const floatx4 *)&Bs[(wc * 2 + i) * 32 + fr][8 * h + fg];
-    }
-  for (int kt = 0; kt < KT; ++kt) {
-    if (DIAG < 2 && kt + 1 < KT) load_tiles((kt + 1) * F32_BK);
-#pragma unroll
-    for (int g = 0; g < F32_BK; g += 16) {
-      floatx4 fa[2][2], fb[2][2];   // [block][h]
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (DIAG == 0) {
-            fa[i][h] = *(const floatx4 *)&As[(wr * 2 + i) * 32 + fr][g + 8 * h + fg];
-            fb[i][h] = *(const floatx4 *)&Bs[(wc * 2 + i) * 32 + fr][g + 8 * h + fg];
-          } else {   // no LDS read: the fragments read once before the loop
-            fa[i][h] = keep_a[i][h];
-            fb[i][h] = keep_b[i][h];
-          }
-        }
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][h][c], fa[i][h][c], acc[j][i], 0, 0, 0);
-    }
-    if (DIAG < 3) __syncthreads();
-    if (kt + 1 < KT) {
-      if (DIAG < 2) store_tiles();
-      if (DIAG < 3) __syncthreads();
-    }
-  }
-  // D[i = weight row][j = token]: the lane owns token fr; registers 4 v .. 4 v + 3 are weight rows 8 v + fg .. + 3 of the block
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const floatx4 quad = {acc[j][i][4 * v], acc[j][i][4 * v + 1], acc[j][i][4 * v + 2], acc[j][i][4 * v + 3]};
-        store_f32_quad<EPI>(quad, m0 + (wr * 2 + i) * 32 + fr, n0 + (wc * 2 + j) * 32 + 8 * v + fg, M, N, bias, res, out);
-      }
-}
-
 // The same product for M <= 16 MT rows - ONE request's query (MRK_ENCODER_AUTO / _F32 through mrk_rank), where the critical
 // path is what counts.  One workgroup per 16 output columns; its four wavefronts each read a quarter of the K range straight
 // from global memory into registers (every load in flight at once) and continue ONE accumulator chain in turn, handing it
@@ -910,11 +813,30 @@ void launch_gemm_f32(const float *A, const float *W, const float *bias, const fl
     // 128 x 128 tiles once the grid still covers the chip with them (two workgroups per CU), 64 x 64 tiles otherwise
     const bool big = N % 128 == 0 && (size_t)((M + 127) / 128) * (N / 128) >= 512;
     auto grid_of = [&](int bm, int bn) { return dim3((unsigned)(8 * (((M + bm - 1) / bm + 7) / 8) * (N / bn))); };
-    if (big && switches().encoder_f32_diag == 1) hipLaunchKernelGGL((gemm_f32_mfma32_diag_kernel<EPI, 1>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
-    else if (big && switches().encoder_f32_diag == 2) hipLaunchKernelGGL((gemm_f32_mfma32_diag_kernel<EPI, 2>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
-    else if (big && switches().encoder_f32_diag == 3) hipLaunchKernelGGL((gemm_f32_mfma32_diag_kernel<EPI, 3>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
-    else if (big) hipLaunchKernelGGL((gemm_f32_mfma32_kernel<EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
-    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, EPI>), grid_of(64, 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    if (big) {
+      // Workgroups per CU: the kernel fits three (152 registers, 36.9 KB of LDS), but a launch is whole ROUNDS of resident
+      // workgroups and the last round is as long as a full one: 2 322 workgroups (the c5 batch's QKV product) are 3.02 rounds of
+      // 768 - four rounds' time - but 4.54 of 512.  Measured (profiles/r05_e_*): the matrix pipe alone, no memory traffic, no
+      // barriers, needs 0.240 ms of this product's 0.270 at three per CU, i.e. the tail, not the k loop, is what is left.  So the
+      // residency is chosen per launch - rounds x residency / efficiency of a round at that residency - and imposed by
+      // padding the workgroup's LDS request.
+      const double eff[4] = {0.0, 0.70, 0.86, 0.90};
+      const long long n_wg = (long long)((M + 127) / 128) * (N / 128);
+      int best = 3;
+      double best_cost = 1e300;
+      for (int r = 1; r <= 3; ++r) {
+        const double cost = (double)((n_wg + 256LL * r - 1) / (256LL * r)) * r / eff[r];
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
+      }
+      if (switches().encoder_f32_resident >= 1 && switches().encoder_f32_resident <= 3) best = switches().encoder_f32_resident;
+      constexpr size_t STATIC_LDS = 2 * 128 * F32_LD * sizeof(float);
+      const size_t want_total = best == 3 ? 0 : best == 2 ? 56 * 1024 : 84 * 1024;
+      const size_t pad = want_total > STATIC_LDS ? want_total - STATIC_LDS : 0;
+      static std::once_flag once;
+      std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)gemm_f32_mfma32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); });
+      hipLaunchKernelGGL((gemm_f32_mfma32_kernel<EPI>), grid_of(128, 128), dim3(256), pad, s, A, W, bias, res, out, M, N, K);
+    }
+    if (!big) hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, EPI>), grid_of(64, 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
     return;
   }
   hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
