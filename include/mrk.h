@@ -29,6 +29,13 @@
  *                                 fed by FeatureValueSink.write   M/flow/FeatureValueSink.scala:10-14
  *   mrk_rank / mrk_rank_batch  <- Ranker.rerank = makeQuery + predict + sortBy(-score)
  *                                 M/ml/Ranker.scala:27-83,97-106
+ *   mrk_init(devices, n)       <- HipConfig(inner, devices: List[Int]) next to LightGBMConfig / XGBoostConfig
+ *                                 M/config/BoosterConfig.scala:96-104 (SURVEY.md 8b touch point 1): one context per device,
+ *                                 all inside the one host process (M/main/command/Serve.scala:72-128)
+ *   mrk_encoder_*              <- OnnxSession / OnnxBiEncoder / OnnxCrossEncoder  M/ml/onnx/sbert/ (OnnxSession, OnnxBiEncoder, OnnxCrossEncoder .scala)
+ *
+ * ABI 8 (round 5): mrk_init creates n contexts; mrk_device_count; mrk_comm_init_local; mrk_model_inspect; mrk_serve_stats takes
+ * the length of its output array; mrk_store_put_binary_at / mrk_store_expire; mrk_encoder_load is f32 (MRK_ENCODER_AUTO = F32).
  */
 #ifndef MRK_H
 #define MRK_H

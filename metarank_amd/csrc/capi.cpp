@@ -57,7 +57,6 @@ static Switches read_switches() {
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
   s.encoder_packed = flag("MRK_ENCODER_PACKED", true);
   s.encoder_f32_mfma = flag("MRK_ENCODER_F32_MFMA", true);
-  s.encoder_f32_resident = num("MRK_ENCODER_F32_RESIDENT", 0);
   return s;
 }
 static Switches &switches_storage() {

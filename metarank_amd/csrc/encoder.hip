@@ -813,30 +813,12 @@ void launch_gemm_f32(const float *A, const float *W, const float *bias, const fl
     // 128 x 128 tiles once the grid still covers the chip with them (two workgroups per CU), 64 x 64 tiles otherwise
     const bool big = N % 128 == 0 && (size_t)((M + 127) / 128) * (N / 128) >= 512;
     auto grid_of = [&](int bm, int bn) { return dim3((unsigned)(8 * (((M + bm - 1) / bm + 7) / 8) * (N / bn))); };
-    if (big) {
-      // Workgroups per CU: the kernel fits three (152 registers, 36.9 KB of LDS), but a launch is whole ROUNDS of resident
-      // workgroups and the last round is as long as a full one: 2 322 workgroups (the c5 batch's QKV product) are 3.02 rounds of
-      // 768 - four rounds' time - but 4.54 of 512.  Measured (profiles/r05_e_*): the matrix pipe alone, no memory traffic, no
-      // barriers, needs 0.240 ms of this product's 0.270 at three per CU, i.e. the tail, not the k loop, is what is left.  So the
-      // residency is chosen per launch - rounds x residency / efficiency of a round at that residency - and imposed by
-      // padding the workgroup's LDS request.
-      const double eff[4] = {0.0, 0.70, 0.86, 0.90};
-      const long long n_wg = (long long)((M + 127) / 128) * (N / 128);
-      int best = 3;
-      double best_cost = 1e300;
-      for (int r = 1; r <= 3; ++r) {
-        const double cost = (double)((n_wg + 256LL * r - 1) / (256LL * r)) * r / eff[r];
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
-      }
-      if (switches().encoder_f32_resident >= 1 && switches().encoder_f32_resident <= 3) best = switches().encoder_f32_resident;
-      constexpr size_t STATIC_LDS = 2 * 128 * F32_LD * sizeof(float);
-      const size_t want_total = best == 3 ? 0 : best == 2 ? 56 * 1024 : 84 * 1024;
-      const size_t pad = want_total > STATIC_LDS ? want_total - STATIC_LDS : 0;
-      static std::once_flag once;
-      std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)gemm_f32_mfma32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); });
-      hipLaunchKernelGGL((gemm_f32_mfma32_kernel<EPI>), grid_of(128, 128), dim3(256), pad, s, A, W, bias, res, out, M, N, K);
-    }
-    if (!big) hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, EPI>), grid_of(64, 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    // (Measured, profiles/r05_e / r05_f: with neither memory traffic nor barriers the 128 x 128 kernel's MFMA stream alone takes 0.240 of
+    //  the QKV product's 0.270 ms - 121 TFLOP/s is what the f32 matrix pipe sustains on the whole chip under load, the clock
+    //  following the power budget; one, two or three workgroups per CU (LDS padding): 0.307 / 0.272 / 0.270 ms.  The kernel is at
+    //  ~89 % of that ceiling; what is left is the k loop's loads, LDS round trip and barriers.)
+    if (big) hipLaunchKernelGGL((gemm_f32_mfma32_kernel<EPI>), grid_of(128, 128), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, EPI>), grid_of(64, 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);
     return;
   }
   hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, A, W, bias, res, out, M, N, K);

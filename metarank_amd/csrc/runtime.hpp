@@ -130,7 +130,6 @@ struct Switches {
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY
   bool encoder_packed = true;  // MRK_ENCODER_PACKED=0: padded batches for pooled / logit calls too
-  int encoder_f32_resident = 0;  // MRK_ENCODER_F32_RESIDENT=1|2|3: workgroups per CU of the 128 x 128 f32 product (0: chosen per launch)
   bool encoder_f32_mfma = true;  // MRK_ENCODER_F32_MFMA=0: the f32 products / attention on the vector unit (the test instrument)
 };
 const Switches &switches();

@@ -24,7 +24,7 @@
 using namespace mrk;
 
 namespace mrk {
-int load_feature_values(Store &store, const uint8_t *bytes, size_t len);  // codec.cpp
+int load_feature_values(Store &store, const uint8_t *bytes, size_t len, int64_t now_ms);  // codec.cpp
 }
 
 static unsigned long long rng_state = 0x2545f4914f6cdd1dull;
@@ -85,7 +85,7 @@ static bool load(const std::string &kind, const std::vector<uint8_t> &blob) {
     } else {
       Store st;
       std::unique_ptr<Registry> reg = load_config(CONFIG, strlen(CONFIG), st, false);
-      (void)load_feature_values(st, exact.data(), exact.size());
+      (void)load_feature_values(st, exact.data(), exact.size(), (int64_t)(exact.size() % 3 == 0 ? 1700000000000ll : -1));   // with and without ttl tracking
     }
     return true;
   } catch (const std::bad_alloc &) {
