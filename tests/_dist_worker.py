@@ -55,6 +55,16 @@ def main():
     buf[lo3:hi3] = torch.from_numpy(b.forest.predict(m[lo3:hi3]))
     all_gather_padded(buf, chunk)
     assert chunk % 128 == 0 and np.array_equal(buf[:len(m)].numpy(), b.forest.predict(m))
+    # ... and the ORDER every rank derives from the gathered scores (mrk_batch_run_sharded: all-gather, then every rank sorts) is the
+    # unsharded request's: sortBy(-score), stable, java.lang.Double.compare (ml/Ranker.scala:52-67) - on EVERY rank, ties included
+    _, full_scores, full_order = b.rerank(big)
+    gathered = buf[:len(m)].numpy()
+    bits = (-gathered).view(np.uint64).copy()               # Double.compare order of -score: sign-magnitude bits -> unsigned key
+    bits[np.isnan(gathered)] = 0x7FF8000000000000
+    neg = (bits >> np.uint64(63)) != 0
+    key = np.where(neg, ~bits, bits | np.uint64(1 << 63))
+    order = np.argsort(key, kind="stable")
+    assert np.array_equal(gathered, full_scores) and order.tolist() == full_order.tolist(), f"rank {rank}: merged order differs from the unsharded oracle"
     if rank == 0:
         full = np.concatenate([b.rerank(ev)[1] for ev in reqs])
         assert np.array_equal(merged.numpy(), full)
