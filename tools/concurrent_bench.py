@@ -12,9 +12,11 @@ sys.path.insert(0, ".")
 import metarank_amd as M
 from workloads import ranklens, synth
 
-threads = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-per_thread = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-items = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+serve = "--serve" in sys.argv          # through the serving queue (mrk_serve_rank, one slot per thread) instead of mrk_rank
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+threads = int(argv[0]) if len(argv) > 0 else 16
+per_thread = int(argv[1]) if len(argv) > 1 else 300
+items = int(argv[2]) if len(argv) > 2 else 100
 ctx = M.Context(0)
 cfg = ranklens.ranklens_config()
 ranker = M.HipRanker(cfg, ctx)
@@ -32,6 +34,11 @@ booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
 reqs = [M.Request(e) for e in events]
 for r in reqs[:16]:
     ranker.rerank("xgboost", r, booster)
+ranker.warmup_kernels("xgboost")
+srv = ranker.serve("xgboost", booster, n_slots=min(threads, 64)) if serve else None
+call = (lambda r: srv.rerank(r)) if serve else (lambda r: ranker.rerank("xgboost", r, booster))
+for r in reqs[:16]:
+    call(r)
 lat = [[] for _ in range(threads)]
 start = threading.Barrier(threads + 1)
 
@@ -41,7 +48,7 @@ def client(t):
     for k in range(per_thread):
         r = reqs[(t * 8 + k) % len(reqs)]
         t0 = time.perf_counter()
-        ranker.rerank("xgboost", r, booster)
+        call(r)
         lat[t].append(time.perf_counter() - t0)
 
 
@@ -55,6 +62,9 @@ for t in ts:
 wall = time.perf_counter() - t0
 all_lat = np.concatenate([np.asarray(l) for l in lat]) * 1e3
 n = threads * per_thread
-print(f"combine={os.environ.get('MRK_RANK_COMBINE', '1')} threads={threads} x {per_thread} requests of {items} items: "
+print(f"{'serve queue' if serve else 'mrk_rank'} combine={os.environ.get('MRK_RANK_COMBINE', '1')} threads={threads} x {per_thread} requests of {items} items: "
       f"{n / wall:.0f} requests/s, {n * items / wall / 1e6:.2f} M items/s, per-call p50 {np.percentile(all_lat, 50):.3f} ms "
       f"p99 {np.percentile(all_lat, 99):.3f} ms")
+if srv is not None:
+    print("  ", srv.stats())
+    srv.close()
