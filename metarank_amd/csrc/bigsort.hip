@@ -381,7 +381,7 @@ size_t plan_levels(int n, uint8_t *scratch, std::vector<Level> &out) {
   return off;
 }
 
-void sort_level(hipStream_t s, const std::vector<Level> &lv, size_t k, const SortSrc &src, int *out_order, int lds_cap) {
+void sort_level(mrk_ctx *ctx, hipStream_t s, const std::vector<Level> &lv, size_t k, const SortSrc &src, int *out_order, int lds_cap) {
   const Level &L = lv[k];
   if (L.samples <= BS_ONE_WG) {
     hipLaunchKernelGGL(ss_sample_sort_kernel, dim3(1), dim3(1024), 0, s, src, L.n, L.samples, L.nb, L.spl_k, L.spl_i, L.ticket);
@@ -389,12 +389,11 @@ void sort_level(hipStream_t s, const std::vector<Level> &lv, size_t k, const Sor
     hipLaunchKernelGGL(ss_sample_gather_kernel, dim3((L.samples + BS_THREADS - 1) / BS_THREADS), dim3(BS_THREADS), 0, s, src, L.n, L.samples,
                        L.smp_k, L.smp_i);
     const SortSrc child{nullptr, L.smp_k, 1, 0};
-    sort_level(s, lv, k + 1, child, L.smp_order, lds_cap);
+    sort_level(ctx, s, lv, k + 1, child, L.smp_order, lds_cap);
     hipLaunchKernelGGL(ss_pick_splitters_kernel, dim3((L.nb + BS_THREADS - 1) / BS_THREADS), dim3(BS_THREADS), 0, s, L.smp_k, L.smp_i,
                        L.smp_order, L.nb, L.spl_k, L.spl_i, L.ticket);
   }
-  static std::once_flag once;  // 4 096 buckets: 64 KB of dynamic LDS next to the kernel's static 1 KB
-  std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)ss_classify_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS_SPLITTERS * 16)); });
+  lds_optin(ctx, (const void *)ss_classify_kernel<true>, BS_LDS_SPLITTERS * 16);  // 4 096 buckets: 64 KB of dynamic LDS next to the kernel's static 1 KB
   if (L.nb <= BS_LDS_SPLITTERS)
     hipLaunchKernelGGL(ss_classify_kernel<true>, dim3(L.n_wg), dim3(BS_THREADS), (size_t)L.nb * 16, s, src, L.n, L.tile, L.nb, L.spl_k, L.spl_i,
                        L.bucket, L.table);
@@ -421,12 +420,12 @@ size_t big_sort_scratch_bytes(int n) {
 
 // out_order[0, n): the indices 0 .. n - 1 in the order of (key, index), key per `src` (sort_device.hpp); n > SORT_MAX_ITEMS.
 // Enqueued on `stream`; `scratch` (big_sort_scratch_bytes(n)) must stay untouched until the launches have run.
-void launch_big_sort(hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch) {
+void launch_big_sort(mrk_ctx *ctx, hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch) {
   std::vector<Level> lv;
   plan_levels(n, (uint8_t *)scratch, lv);
   if (lv.empty()) throw StatusError(MRK_ERR_INVALID_ARG, "launch_big_sort: a request one workgroup sorts");
   const int cap = std::min(BS_LOCAL_CAP, std::max(0, switches().big_sort_cap));
-  sort_level(stream, lv, 0, src, out_order, cap);
+  sort_level(ctx, stream, lv, 0, src, out_order, cap);
 }
 
 }  // namespace mrk

@@ -3,7 +3,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <thread>
+#include <utility>
 
 #include "runtime.hpp"
 
@@ -52,6 +55,7 @@ static Switches read_switches() {
   s.qs_split = num("MRK_QS_SPLIT", -1);
   s.qs_kernel = num("MRK_QS_KERNEL", 1);
   s.qs_r = num("MRK_QS_R", 2);
+  s.qs_pipe = num("MRK_QS_PIPE", -1);
   s.walk_tile = num("MRK_WALK_TILE", 0);
   s.encoder_graph = flag("MRK_ENCODER_GRAPH", false);
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
@@ -94,6 +98,30 @@ void drain_profile_events(mrk_ctx *ctx) {
     (void)hipEventDestroy(b);
   }
   ctx->pending_events.clear();
+}
+
+void lds_optin(mrk_ctx *ctx, const void *fn, int bytes) {
+  static thread_local const void *last_fn = nullptr;
+  static thread_local int last_dev = -1;
+  if (last_fn == fn && last_dev == ctx->device) return;
+  static std::mutex mu;
+  static std::set<std::pair<int, const void *>> done;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({ctx->device, fn}).second) {
+      int cur = -1;
+      MRK_HIP(hipGetDevice(&cur));
+      if (cur != ctx->device) MRK_HIP(hipSetDevice(ctx->device));
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (cur != ctx->device && cur >= 0) (void)hipSetDevice(cur);
+      if (e != hipSuccess) {
+        done.erase({ctx->device, fn});
+        throw StatusError(MRK_ERR_DEVICE, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+      }
+    }
+  }
+  last_fn = fn;
+  last_dev = ctx->device;
 }
 
 void ctx_retain(mrk_ctx *ctx) { ctx->refs.fetch_add(1); }

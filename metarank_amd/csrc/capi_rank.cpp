@@ -24,7 +24,7 @@ void launch_status_or(hipStream_t stream, const int32_t *all, int world, int n_r
 void launch_normalize(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int mode);
 void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int item_begin, int n, int *order, void *scratch);
 struct SortSrc { const double *vals; const unsigned long long *raw; long long stride; int negate; };  // sort_device.hpp
-void launch_big_sort(hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch);  // bigsort.hip
+void launch_big_sort(mrk_ctx *ctx, hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch);  // bigsort.hip
 size_t big_sort_scratch_bytes(int n);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
@@ -40,7 +40,7 @@ size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint3
 size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64);
 void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                              int threads, const QsDev &q, const QsForestDev &f, uint16_t *cells, bool f64, void *jit_fn);
-void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
+void launch_rank_serve(mrk_ctx *ctx, hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
                        int threads, size_t lds, bool f64, void *jit_fn);
 void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                      int threads, int op_split, const QsDev &q, const QsForestDev &f, const OneOut &out, bool f64, void *jit_fn);
@@ -350,7 +350,7 @@ static void sort_batch(mrk_batch &b) {
   ScopedKernelTimer timer(ctx, "sort");
   for (auto &br : b.big) {
     const SortSrc src{b.view.scores + br.item_begin, nullptr, 1, 1};
-    launch_big_sort(ctx->launch, src, br.n_items, b.view.order + br.item_begin, b.d_sort.p);
+    launch_big_sort(ctx, ctx->launch, src, br.n_items, b.view.order + br.item_begin, b.d_sort.p);
   }
 }
 
@@ -1256,7 +1256,7 @@ void launch_slot(mrk_server &srv, ServeSlot &sl) {  // the caller holds the stor
   d.last_seq = sl.seq - 1;  // the request just published is the first thing the workgroup sees
   d.idle_ticks = srv.idle_ticks;
   d.life_ticks = srv.life_ticks;
-  launch_rank_serve(sl.stream, ctx->store->device_view(), srv.prog->device_view(), qs_device_view(srv.model), qs_forest_view(srv.model), d,
+  launch_rank_serve(ctx, sl.stream, ctx->store->device_view(), srv.prog->device_view(), qs_device_view(srv.model), qs_forest_view(srv.model), d,
                     SERVE_THREADS, SERVE_LDS, srv.f64, srv.jit_fn);
   sl.running = true;
   srv.n_launches.fetch_add(1);

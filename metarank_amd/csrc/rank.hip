@@ -242,7 +242,7 @@ normalize_kernel(BatchDev b, int dim, int col, int mode) {
 
 }  // namespace
 
-void launch_big_sort(hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch);  // bigsort.hip
+void launch_big_sort(mrk_ctx *ctx, hipStream_t stream, const SortSrc &src, int n, int *out_order, void *scratch);  // bigsort.hip
 
 // jit_fn: mrk_jit_prepass of this program (jit.cpp), or nullptr = the kernel that interprets the program
 void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t max_req_entries, void *jit_fn) {
@@ -250,8 +250,7 @@ void launch_prepass(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, co
   // tables in LDS when the largest request's fit next to the kernel's 33 KB of static scratch (MRK_PREPASS_LDS=0: HBM arena)
   constexpr uint32_t LDS_TABLE_BUDGET = 96 * 1024;
   uint32_t lds_entries = switches().prepass_lds && (uint64_t)max_req_entries * 8 <= LDS_TABLE_BUDGET ? max_req_entries : 0;
-  static std::once_flag once;
-  std::call_once(once, [] { MRK_HIP(hipFuncSetAttribute((const void *)prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TABLE_BUDGET)); });  // static + dynamic <= 160 KB
+  lds_optin(ctx, (const void *)prepass_kernel, LDS_TABLE_BUDGET);  // static + dynamic <= 160 KB
   ScopedKernelTimer timer(ctx, "prepass");
   // (a module function keeps the default 64 KB limit on static + dynamic LDS: 33 KB are static here)
   if (jit_fn && (size_t)lds_entries * 8 <= 30 * 1024) {
@@ -335,13 +334,7 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
   if (switches().fused_lds_min > 0) lds = std::max(lds, (size_t)switches().fused_lds_min);  // experiments: cap the kernel's residency (co-residency with the scorer)
   {
     ScopedKernelTimer timer(ctx, "assemble");
-    static thread_local bool configured = false;
-    if (!configured) {
-      MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      configured = true;
-    }
+    if (!jit_fn) lds_optin(ctx, !cells ? (const void *)rank_fused_matrix_kernel : f64 ? (const void *)rank_fused_cells_kernel<true> : (const void *)rank_fused_cells_kernel<false>);
     if (!cells && jit_fn) {  // mrk_jit_rank_matrix
       StoreDev a_st = st;
       BatchDev a_b = b;
@@ -386,7 +379,7 @@ void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int
   ScopedKernelTimer timer(ctx, "normalize");
   double *colp = b.matrix + (size_t)item_begin * dim + col;
   const SortSrc src{colp, nullptr, dim, 0};
-  launch_big_sort(ctx->launch, src, n, order, scratch);
+  launch_big_sort(ctx, ctx->launch, src, n, order, scratch);
   hipLaunchKernelGGL(norm_position_apply_kernel, dim3((n + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), 0, ctx->launch, order, n, colp, dim);
   MRK_HIP(hipGetLastError());
 }
@@ -416,12 +409,7 @@ void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
     void *args[] = {&a_st, &a_b, &tab_entries, &a_vals, &a_q, &a_f, &mode, &a_out};
     MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
   } else {
-    static thread_local bool configured = false;
-    if (!configured) {
-      MRK_HIP(hipFuncSetAttribute((const void *)rank_one_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      MRK_HIP(hipFuncSetAttribute((const void *)rank_one_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      configured = true;
-    }
+    lds_optin(ctx, f64 ? (const void *)rank_one_kernel<true> : (const void *)rank_one_kernel<false>);
     if (f64) hipLaunchKernelGGL(rank_one_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, mode, out);
     else hipLaunchKernelGGL(rank_one_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, mode, out);
     MRK_HIP(hipGetLastError());
@@ -450,18 +438,14 @@ void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev 
     MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)b.n_req, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
     return;
   }
-  static std::once_flag once;
-  std::call_once(once, [] {
-    MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MRK_HIP(hipFuncSetAttribute((const void *)rank_fused_score_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  });
+  lds_optin(ctx, f64 ? (const void *)rank_fused_score_kernel<true> : (const void *)rank_fused_score_kernel<false>);
   if (f64) hipLaunchKernelGGL(rank_fused_score_kernel<true>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, cells);
   else hipLaunchKernelGGL(rank_fused_score_kernel<false>, dim3(b.n_req), dim3(threads), lds, ctx->launch, st, prog, b, tab_entries, vals_cap, q, f, cells);
   MRK_HIP(hipGetLastError());
 }
 
 // one persistent workgroup of `threads` lanes with `lds` bytes of dynamic LDS on `stream` (capi_rank.cpp mrk_serve_*)
-void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
+void launch_rank_serve(mrk_ctx *ctx, hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
                        int threads, size_t lds, bool f64, void *jit_fn) {
   if (jit_fn) {
     StoreDev a_st = st;
@@ -472,11 +456,7 @@ void launch_rank_serve(hipStream_t stream, const StoreDev &st, const ProgramDev 
     MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, 1, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, args, nullptr));
     return;
   }
-  static std::once_flag once;
-  std::call_once(once, [] {
-    MRK_HIP(hipFuncSetAttribute((const void *)rank_serve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MRK_HIP(hipFuncSetAttribute((const void *)rank_serve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  });
+  lds_optin(ctx, f64 ? (const void *)rank_serve_kernel<true> : (const void *)rank_serve_kernel<false>);
   if (f64) hipLaunchKernelGGL(rank_serve_kernel<true>, dim3(1), dim3(threads), lds, stream, st, prog, q, f, slot);
   else hipLaunchKernelGGL(rank_serve_kernel<false>, dim3(1), dim3(threads), lds, stream, st, prog, q, f, slot);
   MRK_HIP(hipGetLastError());

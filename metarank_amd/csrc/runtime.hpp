@@ -126,6 +126,7 @@ struct Switches {
   int qs_split = -1;           // MRK_QS_SPLIT
   int qs_kernel = 1;           // MRK_QS_KERNEL
   int qs_r = 2;                // MRK_QS_R
+  int qs_pipe = -1;            // MRK_QS_PIPE=0|1|2|4: never / always the pipelined scorer for forests it can hold (2, 4: with that many trees per evaluator and chunk; default: full batches, launch_shape.hpp)
   int walk_tile = 0;           // MRK_WALK_TILE=256: the tree-walk scorer's rows per workgroup (default: 512 where the tile fits)
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY
@@ -211,6 +212,11 @@ struct ScopedKernelTimer {
   ~ScopedKernelTimer();
 };
 void drain_profile_events(mrk_ctx *ctx);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a function ON A DEVICE: a process that drives several devices
+// (mrk_init with n contexts) has to opt in once per (device, function), whichever thread launches first.  Cheap on the
+// launch path: a thread-local memo of the last pair in front of a mutex-protected set.
+void lds_optin(mrk_ctx *ctx, const void *fn, int bytes = 160 * 1024);
 
 void ctx_retain(mrk_ctx *ctx);
 void ctx_release(mrk_ctx *ctx);

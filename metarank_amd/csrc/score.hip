@@ -261,11 +261,7 @@ template <bool F64, int TILE, bool ROWS_LDS>
 void launch_t(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
               int *d_flag, const uint32_t *d_row_req, uint32_t chunk_cap, uint32_t ref_cap, size_t smem) {
   auto kern = score_kernel<F64, TILE, ROWS_LDS>;
-  static thread_local const void *configured = nullptr;
-  if (configured != (const void *)kern) {
-    MRK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    configured = (const void *)kern;
-  }
+  lds_optin(ctx, (const void *)kern);
   const int grid = (rows + TILE - 1) / TILE;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), smem, ctx->launch, m->d_image.as<uint8_t>(),
                      m->d_trees.as<TreeRef>(), m->d_chunks.as<ChunkRef>(), (int)m->packed.chunks.size(),
