@@ -27,8 +27,9 @@
  *                                 M/FeatureMapping.scala:56-99
  *   mrk_store_put_*            <- KVStore[Key,FeatureValue].put  M/fstore/Persistence.scala:85-89
  *                                 fed by FeatureValueSink.write   M/flow/FeatureValueSink.scala:10-14
- *   mrk_rank / mrk_rank_batch  <- Ranker.rerank = makeQuery + predict + sortBy(-score)
- *                                 M/ml/Ranker.scala:27-83,97-106
+ *   mrk_rank, mrk_rank_binary, <- Ranker.rerank = makeQuery + predict + sortBy(-score)
+ *   mrk_batch_*                   M/ml/Ranker.scala:27-83,97-106
+ *   mrk_model_weights          <- ltrlib Booster.weights()  M/ml/rank/LambdaMARTRanker.scala:391-406
  *   mrk_init(devices, n)       <- HipConfig(inner, devices: List[Int]) next to LightGBMConfig / XGBoostConfig
  *                                 M/config/BoosterConfig.scala:96-104 (SURVEY.md 8b touch point 1): one context per device,
  *                                 all inside the one host process (M/main/command/Serve.scala:72-128)
@@ -36,6 +37,7 @@
  *
  * ABI 8 (round 5): mrk_init creates n contexts; mrk_device_count; mrk_comm_init_local; mrk_model_inspect; mrk_serve_stats takes
  * the length of its output array; mrk_store_put_binary_at / mrk_store_expire; mrk_encoder_load is f32 (MRK_ENCODER_AUTO = F32).
+ * ABI 9 (round 6): mrk_model_weights / mrk_model_inspect_weights (Booster.weights()), mrk_abi_layout.
  */
 #ifndef MRK_H
 #define MRK_H
@@ -47,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MRK_ABI_VERSION 8
+#define MRK_ABI_VERSION 9
 
 typedef enum mrk_status {
   MRK_OK = 0,
@@ -73,6 +75,16 @@ int mrk_abi_version(void);
 /* identifies the library's SOURCES (hex digest over csrc/ and this header, fixed when the library is built) */
 const char *mrk_build_id(void);
 const char *mrk_last_error(void);
+/* Layout of every struct that crosses the boundary by value or by pointer, as THIS library was compiled: what a JNA
+ * @FieldOrder Structure checks at start-up instead of trusting its own copy of this header.  Writes up to
+ * `cap` int32 into out (nullable) and returns how many there are:
+ *   [0] MRK_ABI_VERSION
+ *   [1..8]   mrk_field:      sizeof, then offsetof name, type, n, num, str, strs, nums
+ *   [9..19]  mrk_request:    sizeof, then offsetof id, timestamp_ms, user, session, fields, n_fields, n_items, item_ids,
+ *                            item_field_offsets, item_fields
+ *   [20..32] mrk_model_info: sizeof, then offsetof backend, n_trees, max_depth, n_features, is_f64, n_categorical, n_nodes,
+ *                            n_leaves, device_bytes, base_score, bitvector, tile_columns */
+int mrk_abi_layout(int32_t *out, int cap);
 
 /* One context per listed HIP ordinal, all in the calling process: out[0 .. n_devices) (HipConfig(inner, devices: List[Int]),
  * SURVEY 8b touch point 1; the reference's host is ONE JVM, M/main/command/Serve.scala:72-128).  A context owns its streams,
@@ -125,6 +137,25 @@ int mrk_model_get_info(mrk_model *model, mrk_model_info *out);
  * well-formed model the scorer does not implement (dart, multi-output, vector leaves, num_parallel_tree > 1, a non-identity
  * objective, linear trees, random-forest averaging).  What a host calls when it validates a config. */
 int mrk_model_inspect(int backend, const uint8_t *bytes, size_t len, mrk_model_info *out);
+
+/* == ltrlib Booster.weights(): Array[Double], one entry per matrix column (reference call site
+ * M/ml/rank/LambdaMARTRanker.scala:391-406: `w(offset)` / `w.slice(offset, offset + size)` per descriptor feature).  out[0 .. n_cols):
+ * n_cols = the DatasetDescriptor's dimension; columns past the model's n_features get 0.0; n_cols < n_features is
+ * MRK_ERR_DIM_MISMATCH (the JVM would throw IndexOutOfBounds).  Computed on the host from the parsed booster with the owning
+ * library's own arithmetic:
+ *   LightGBM  (LGBM_BoosterFeatureImportance, GBDT::FeatureImportance, num_iteration 0): SPLIT = number of splits on the feature
+ *             with split_gain > 0; GAIN = TOTAL_GAIN = sum of those float gains accumulated in double, tree order then node order.
+ *   XGBoost   (Booster.getScore, GBTree::FeatureScore): SPLIT = "weight" = number of splits; TOTAL_GAIN = "total_gain" = sum of
+ *             loss_chg accumulated in float; GAIN = "gain" = total_gain / weight in float; a feature never split on is absent
+ *             from the JVM's map - 0.0 here.
+ * ASSUMPTION (ltrlib 0.2.6 is not in the reference tree): its LightGBMBooster.weights() asks lightgbm4j for
+ * FeatureImportanceType.GAIN and its XGBoostBooster.weights() fills an array from getScore("", "gain"): a HipBooster passes
+ * MRK_IMPORTANCE_GAIN for both.  Unverifiable here; if ltrlib uses another type the binding changes one constant.  A model file
+ * without split gains (no `split_gain=` / "loss_changes") answers GAIN / TOTAL_GAIN with MRK_ERR_UNSUPPORTED. */
+enum { MRK_IMPORTANCE_SPLIT = 0, MRK_IMPORTANCE_GAIN = 1, MRK_IMPORTANCE_TOTAL_GAIN = 2 };
+int mrk_model_weights(mrk_model *model, int importance_type, double *out, int n_cols);
+/* the same host-only, from booster bytes (no context, no device): config validation, CPU tests */
+int mrk_model_inspect_weights(int backend, const uint8_t *bytes, size_t len, int importance_type, double *out, int n_cols);
 
 void mrk_model_retain(mrk_model *model);
 void mrk_model_free(mrk_model *model); /* drops one reference; idempotent at zero (close()/isClosed()) */

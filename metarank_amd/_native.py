@@ -157,6 +157,9 @@ SIGNATURES = {
     "mrk_model_predict_device": (_I, [_V, _P, _I, _I, _P]),
     "mrk_model_get_info": (_I, [_V, C.POINTER(mrk_model_info)]),
     "mrk_model_inspect": (_I, [_I, _P, C.c_size_t, C.POINTER(mrk_model_info)]),
+    "mrk_model_weights": (_I, [_V, _I, _P, _I]),
+    "mrk_model_inspect_weights": (_I, [_I, _P, C.c_size_t, _I, _P, _I]),
+    "mrk_abi_layout": (_I, [_P, _I]),
     "mrk_model_retain": (None, [_V]),
     "mrk_model_free": (None, [_V]),
     "mrk_config_load_json": (_I, [_V, _S, C.c_size_t]),

@@ -3,7 +3,7 @@
 Reference interface (io.github.metarank.ltrlib Booster, used at
 ml/rank/LambdaMARTRanker.scala:348,362,365,373 and constructed at :229-230):
     predictMat(values: Array[Double], rows: Int, cols: Int): Array[Double]
-    save(): Array[Byte]      close(): Unit      isClosed(): Boolean
+    save(): Array[Byte]      weights(): Array[Double] (:392)      close(): Unit      isClosed(): Boolean
 `HipBooster(bytes, backend)` is the drop-in for LightGBMBooster(bytes) / XGBoostBooster(bytes);
 all arithmetic happens in libmrk_hip.so (hand-written gfx950 kernels) — there is no CPU path.
 """
@@ -16,6 +16,13 @@ import numpy as np
 from . import _native as N
 
 LIGHTGBM, XGBOOST = 0, 1
+
+
+def inspect_weights(model_bytes: bytes, backend: int, n_cols: int, importance_type: int = 1) -> np.ndarray:
+    """mrk_model_inspect_weights: Booster.weights() from booster bytes on the host (no context, no device)"""
+    out = np.zeros(max(int(n_cols), 1), dtype=np.float64)
+    N.check(N.lib().mrk_model_inspect_weights(backend, model_bytes, len(model_bytes), importance_type, out.ctypes.data_as(C.c_void_p), int(n_cols)))
+    return out[:int(n_cols)]
 
 
 class Context:
@@ -172,6 +179,15 @@ class HipBooster:
 
     def save(self) -> bytes:
         return self._bytes
+
+    GAIN, SPLIT, TOTAL_GAIN = 1, 0, 2
+
+    def weights(self, n_cols: int | None = None, importance_type: int = 1) -> np.ndarray:
+        """Booster.weights() (LambdaMARTRanker.scala:391-392): the library's feature importance per matrix column, mrk_model_weights"""
+        n = self.info()["n_features"] if n_cols is None else int(n_cols)
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        N.check(N.lib().mrk_model_weights(self.handle, importance_type, out.ctypes.data_as(C.c_void_p), n))
+        return out[:n]
 
     def close(self):
         if self._h:

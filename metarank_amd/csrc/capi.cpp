@@ -1,6 +1,7 @@
 // C ABI (include/mrk.h): lifecycle, model handles, predictMat replacement, profiling.
 // Feature store / rank entry points live in capi_rank.cpp.
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -55,7 +56,6 @@ static Switches read_switches() {
   s.qs_split = num("MRK_QS_SPLIT", -1);
   s.qs_kernel = num("MRK_QS_KERNEL", 1);
   s.qs_r = num("MRK_QS_R", 2);
-  s.qs_pipe = num("MRK_QS_PIPE", -1);
   s.walk_tile = num("MRK_WALK_TILE", 0);
   s.encoder_graph = flag("MRK_ENCODER_GRAPH", false);
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);
@@ -382,6 +382,55 @@ int mrk_model_get_info(mrk_model *model, mrk_model_info *out) {
     out->bitvector = model->qs.ok ? 1 : 0;
     out->tile_columns = model->qs.ok ? (int32_t)model->qs.views.size() : 0;
   });
+}
+
+static void importance_checked(const Forest &f, int type, double *out, int n_cols) {
+  if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
+  if (type < MRK_IMPORTANCE_SPLIT || type > MRK_IMPORTANCE_TOTAL_GAIN) throw StatusError(MRK_ERR_INVALID_ARG, "unknown importance type " + std::to_string(type));
+  if (n_cols < f.n_features)  // the reference indexes w(offset) for every descriptor column: a shorter array would be an IndexOutOfBounds there
+    throw StatusError(MRK_ERR_DIM_MISMATCH, "weights: the model knows " + std::to_string(f.n_features) + " features, the caller's descriptor has " + std::to_string(n_cols) + " columns");
+  f.feature_importance(type, out, n_cols);
+}
+
+// == Booster.weights() (ltrlib), reference call site ml/rank/LambdaMARTRanker.scala:391-406
+int mrk_model_weights(mrk_model *model, int importance_type, double *out, int n_cols) {
+  return guard([&] {
+    if (!model) throw StatusError(MRK_ERR_INVALID_ARG, "null model");
+    importance_checked(model->forest, importance_type, out, n_cols);
+  });
+}
+
+int mrk_model_inspect_weights(int backend, const uint8_t *bytes, size_t len, int importance_type, double *out, int n_cols) {
+  return guard([&] {
+    if (!bytes && len) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
+    Forest f;
+    if (backend == MRK_BACKEND_LIGHTGBM) f = parse_lightgbm_text((const char *)bytes, len);
+    else if (backend == MRK_BACKEND_XGBOOST) f = parse_xgboost(bytes, len);
+    else throw StatusError(MRK_ERR_INVALID_ARG, "unsupported booster tag " + std::to_string(backend));
+    importance_checked(f, importance_type, out, n_cols);
+  });
+}
+
+// sizeof / offsetof of every struct that crosses the boundary, in the order mrk.h lists them
+int mrk_abi_layout(int32_t *out, int cap) {
+  const int32_t v[] = {
+      MRK_ABI_VERSION,
+      (int32_t)sizeof(mrk_field), (int32_t)offsetof(mrk_field, name), (int32_t)offsetof(mrk_field, type), (int32_t)offsetof(mrk_field, n),
+      (int32_t)offsetof(mrk_field, num), (int32_t)offsetof(mrk_field, str), (int32_t)offsetof(mrk_field, strs), (int32_t)offsetof(mrk_field, nums),
+      (int32_t)sizeof(mrk_request), (int32_t)offsetof(mrk_request, id), (int32_t)offsetof(mrk_request, timestamp_ms), (int32_t)offsetof(mrk_request, user),
+      (int32_t)offsetof(mrk_request, session), (int32_t)offsetof(mrk_request, fields), (int32_t)offsetof(mrk_request, n_fields),
+      (int32_t)offsetof(mrk_request, n_items), (int32_t)offsetof(mrk_request, item_ids), (int32_t)offsetof(mrk_request, item_field_offsets),
+      (int32_t)offsetof(mrk_request, item_fields),
+      (int32_t)sizeof(mrk_model_info), (int32_t)offsetof(mrk_model_info, backend), (int32_t)offsetof(mrk_model_info, n_trees),
+      (int32_t)offsetof(mrk_model_info, max_depth), (int32_t)offsetof(mrk_model_info, n_features), (int32_t)offsetof(mrk_model_info, is_f64),
+      (int32_t)offsetof(mrk_model_info, n_categorical), (int32_t)offsetof(mrk_model_info, n_nodes), (int32_t)offsetof(mrk_model_info, n_leaves),
+      (int32_t)offsetof(mrk_model_info, device_bytes), (int32_t)offsetof(mrk_model_info, base_score), (int32_t)offsetof(mrk_model_info, bitvector),
+      (int32_t)offsetof(mrk_model_info, tile_columns),
+  };
+  const int n = (int)(sizeof(v) / sizeof(v[0]));
+  if (out)
+    for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+  return n;
 }
 
 // Host-only: parse + validate + pack a booster exactly as mrk_model_load does, without a device (a config check, CPU tests)

@@ -19,6 +19,49 @@
 
 namespace mrk {
 
+// Booster.weights() of ltrlib (reference call site ml/rank/LambdaMARTRanker.scala:391-392) = the library's feature importance.
+// LightGBM, GBDT::FeatureImportance(num_iteration = 0, type) (src/boosting/gbdt.cpp): type 0 ("split") counts the splits with
+// split_gain > 0, type 1 ("gain") adds their float gains into a double, trees in order, nodes in order; one entry per feature up
+// to max_feature_idx.  XGBoost, GBTree::FeatureScore (src/gbm/gbtree.h): "weight" counts every split, "total_gain" adds
+// RTreeNodeStat::loss_chg in FLOAT in RegTree::WalkTree order, "gain" = total_gain / weight (float); features never split on are absent from the map the JVM
+// gets - 0 here.  Both restated from the libraries' published sources (absent from /root/reference): unpinned, like the scores.
+void Forest::feature_importance(int type, double *out, int n) const {
+  for (int i = 0; i < n; ++i) out[i] = 0.0;
+  if (type != 0)
+    for (const Tree &t : trees)
+      if (!t.feat.empty() && t.gain.size() != t.feat.size()) throw UnsupportedModel("the model file carries no split gains (split_gain / loss_changes): only the split-count importance is available");
+  if (backend == Backend::LightGBM) {
+    for (const Tree &t : trees)
+      for (size_t i = 0; i < t.feat.size(); ++i) {
+        const bool has = t.gain.size() == t.feat.size();
+        if (has && !(t.gain[i] > 0.f)) continue;           // gbdt.cpp: `if (split_gain(split_idx) > 0)`
+        out[t.feat[i]] += type == 0 ? 1.0 : (double)t.gain[i];
+      }
+    return;
+  }
+  std::vector<float> total((size_t)n, 0.f);
+  std::vector<uint64_t> count((size_t)n, 0);
+  // float sums depend on the order: RegTree::WalkTree (include/xgboost/tree_model.h) is a stack walk from the root that pushes
+  // the left child, then the right one - so it visits a node, then its RIGHT subtree, then its left subtree
+  std::vector<int32_t> stack;
+  for (const Tree &t : trees) {
+    if (t.feat.empty()) continue;
+    stack.assign(1, 0);
+    while (!stack.empty()) {
+      const int32_t i = stack.back();
+      stack.pop_back();
+      count[(size_t)t.feat[(size_t)i]] += 1;
+      if (type != 0) total[(size_t)t.feat[(size_t)i]] += t.gain[(size_t)i];
+      if (t.left[(size_t)i] >= 0) stack.push_back(t.left[(size_t)i]);
+      if (t.right[(size_t)i] >= 0) stack.push_back(t.right[(size_t)i]);
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (!count[(size_t)i]) continue;
+    out[i] = type == 0 ? (double)count[(size_t)i] : type == 2 ? (double)total[(size_t)i] : (double)(total[(size_t)i] / (float)count[(size_t)i]);
+  }
+}
+
 int64_t Forest::n_nodes() const {
   int64_t n = 0;
   for (auto &t : trees) n += (int64_t)t.feat.size();
@@ -190,6 +233,10 @@ Forest parse_lightgbm_text(const char *text, size_t len) {
       t.left = split_parse<int32_t>(need("left_child"), toi);
       t.right = split_parse<int32_t>(need("right_child"), toi);
       const size_t nn = (size_t)num_leaves - 1;
+      if (const std::string *sg = get("split_gain")) {  // Tree::split_gain_ is std::vector<float> (include/LightGBM/tree.h)
+        t.gain = split_parse<float>(*sg, [](const std::string &x) { return strtof(x.c_str(), nullptr); });
+        if (t.gain.size() != nn) throw std::runtime_error("lightgbm: split_gain length mismatch");
+      }
       if (t.feat.size() != nn || t.thr.size() != nn || dt.size() != nn || t.left.size() != nn ||
           t.right.size() != nn)
         throw std::runtime_error("lightgbm: split array length mismatch");
@@ -285,6 +332,7 @@ namespace {
 struct XgbRawTree {
   std::vector<int32_t> lc, rc, split_index;   // children (-1 = leaf), split feature
   std::vector<float> cond;                    // split condition, or the leaf value of a leaf
+  std::vector<float> loss_chg;                // RTreeNodeStat::loss_chg per node (empty: the file has none)
   std::vector<uint8_t> default_left, split_type;
   std::map<int, std::vector<int64_t>> categories;  // categorical node -> its categories
 };
@@ -334,6 +382,8 @@ void add_xgb_tree(Forest &f, const XgbRawTree &r) {
     }
   }
   const size_t nn = t.feat.size();
+  if (!r.loss_chg.empty() && r.loss_chg.size() != n) throw std::runtime_error("xgboost: loss_changes length mismatch");
+  if (!r.loss_chg.empty()) t.gain.assign(nn, 0.f);
   t.thr.assign(nn, 0.0);
   t.flags.assign(nn, 0);
   t.left.assign(nn, 0);
@@ -345,6 +395,7 @@ void add_xgb_tree(Forest &f, const XgbRawTree &r) {
     if (id < 0) continue;
     const int l = r.lc[u], rr = r.rc[u];
     t.feat[id] = r.split_index[u];
+    if (!r.loss_chg.empty()) t.gain[id] = r.loss_chg[u];
     t.left[id] = inner_id[l] >= 0 ? inner_id[l] : ~leaf_id[l];
     t.right[id] = inner_id[rr] >= 0 ? inner_id[rr] : ~leaf_id[rr];
     uint8_t fl = NF_MISS_NAN;
@@ -459,7 +510,11 @@ Forest parse_xgboost_legacy(const uint8_t *bytes, size_t len) {
       r.split_index[i] = (int32_t)(sindex & 0x7fffffffu);
       r.default_left[i] = (uint8_t)(sindex >> 31);
     }
-    in.skip((size_t)num_nodes * 16);
+    r.loss_chg.resize(num_nodes);
+    for (int i = 0; i < num_nodes; ++i) {  // RTreeNodeStat: f32 loss_chg, f32 sum_hess, f32 base_weight, i32 leaf_child_cnt
+      r.loss_chg[i] = in.get<float>();
+      in.skip(12);
+    }
     if (leaf_vec != 0) {
       const uint64_t n = in.get<uint64_t>();
       if (n > (uint64_t)(in.end - in.p) / 4) throw std::runtime_error("xgboost legacy model: bad leaf vector");
@@ -553,6 +608,11 @@ Forest parse_xgboost(const uint8_t *bytes, size_t len) {
     }
     if (const json::Value *st = jt.find("split_type"))
       for (size_t i = 0; i < n && i < st->arr.size(); ++i) r.split_type[i] = (uint8_t)st->arr[i].as_int();
+    if (const json::Value *lch = jt.find("loss_changes"))
+      if (lch->is_array() && lch->arr.size() == n) {
+        r.loss_chg.resize(n);
+        for (size_t i = 0; i < n; ++i) r.loss_chg[i] = lch->arr[i].as_float();
+      }
     // categorical side tables
     const json::Value *cats = jt.find("categories");
     if (const json::Value *cn = jt.find("categories_nodes")) {

@@ -34,6 +34,7 @@ struct Tree {
   std::vector<int32_t> left, right;
   std::vector<uint32_t> cat_begin, cat_words;  // into Forest::cat_bits (only for NF_CATEGORICAL)
   std::vector<double> leaf;                    // f64 (LightGBM) or exact widening of f32 (XGBoost)
+  std::vector<float> gain;                     // per internal node: LightGBM split_gain / XGBoost loss_chg; empty when the file has none
   int depth = 0;                               // longest root->leaf path, in internal-node visits
 };
 
@@ -46,6 +47,9 @@ struct Forest {
   std::vector<uint32_t> cat_bits;  // bitset words: bit c of word w <=> category 32*w+c is in the set
   std::string objective;
 
+  // Booster.weights(): per-feature importance, `n` >= n_features entries (the rest 0).  type: 0 split count, 1 gain, 2 total gain
+  // - each with the library's own arithmetic (forest.cpp); throws std::runtime_error when gains are asked for and the file has none
+  void feature_importance(int type, double *out, int n) const;
   int64_t n_nodes() const;
   int64_t n_leaves() const;
   int max_depth() const;

@@ -70,19 +70,4 @@ inline int scorer_waves_per_tile(long long n_tiles, int V, bool f64, int n_cus, 
   return std::max(nw, fill);
 }
 
-// The pipelined scorer (score_qs.hip qs_score_pipe_kernel: 7 evaluating wavefronts + 1 adding wavefront per 128-row tile):
-// for launches whose tiles fill the chip's wavefront slots (8 per tile, 32 per CU) at least once - below that the split
-// kernels with 8 / 16 evaluators per tile walk a tile's forest faster.
-inline bool scorer_pipelined(long long n_tiles, int n_cus) { return n_tiles * 8 >= 32LL * std::max(n_cus, 1); }
-// LDS ahead of the slab: two halves of [exit-leaf bytes CH x 128][leaf values CH x 16], CH = 7 x CT trees per chunk
-inline size_t scorer_pipe_lds(int V, int ct, int leaves, int tile_rows, bool f64) {
-  return (size_t)2 * 7 * ct * ((size_t)tile_rows + (size_t)leaves * (f64 ? 8 : 4)) + (size_t)V * 256;
-}
-// trees per evaluator and chunk: 4 where four workgroups still fit a CU's LDS, else 2; 0 = the slab is too large for this kernel
-inline int scorer_pipe_chunk(int V, bool f64, int leaves, int tile_rows) {
-  for (int ct : {4, 2})
-    if (scorer_pipe_lds(V, ct, leaves, tile_rows, f64) * 4 <= 160 * 1024) return ct;
-  return scorer_pipe_lds(V, 2, leaves, tile_rows, f64) <= 64 * 1024 ? 2 : 0;
-}
-
 }  // namespace mrk

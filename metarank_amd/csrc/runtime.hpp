@@ -126,7 +126,6 @@ struct Switches {
   int qs_split = -1;           // MRK_QS_SPLIT
   int qs_kernel = 1;           // MRK_QS_KERNEL
   int qs_r = 2;                // MRK_QS_R
-  int qs_pipe = -1;            // MRK_QS_PIPE=0|1|2|4: never / always the pipelined scorer for forests it can hold (2, 4: with that many trees per evaluator and chunk; default: full batches, launch_shape.hpp)
   int walk_tile = 0;           // MRK_WALK_TILE=256: the tree-walk scorer's rows per workgroup (default: 512 where the tile fits)
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY

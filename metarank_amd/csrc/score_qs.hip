@@ -393,170 +393,13 @@ qs_score_split_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restr
   if (tid < QS_TILE_ROWS && row < rows) out[row] = F64 ? acc64 : (double)acc32;
 }
 
-// Full batches (thousands of tiles): NE wavefronts evaluate trees, ONE more adds leaves, and the two overlap.
-// qs_score_split_kernel runs a chunk as [evaluate | barrier | two of the NW wavefronts add, the others idle | barrier]; measured
-// on c2 (profiles/r05_k): 372 cycles per tree and SIMD where the tree step alone sustains 265 at 8 wavefronts per SIMD
-// (tools/native/issue_bench.hip: a SIMD issues one VALU instruction per 4.2 cycles whatever its width; scalar instructions
-// issue beside them).  Here the exit-leaf indices of chunk k land in one half of a double buffer while the adding wavefront
-// consumes chunk k - 1 from the other half: ONE barrier per chunk, nobody idle between barriers but the adder, whose load
-// (4 VALU per tree and tile) is about half an evaluator's (52 / NE).  The adder owns rows 2 * lane, 2 * lane + 1 and adds
-// the leaf values in tree order - the additions of qs_score_wave_kernel, in its order: identical bits.  It stages the
-// next chunk's leaf values itself (nobody else reads them: no barrier for that).  Evaluator w takes trees w, w + NE,
-// w + 2 NE, ...: CT of them per chunk.
-// LDS: [exit-leaf bytes 2 x CH x 128][leaf values 2 x CH x 16][slab V x 256 at the compile-time offset SLAB_OFF - the
-// cell reads are `ds_read_addtid_b32 offset:SLAB_OFF`, M0 = view * 256].
-template <bool F64, int NE, int CT>
-struct QsPipe {
-  static constexpr int LS = F64 ? 8 : 4;
-  static constexpr int TREE_LEAF_BYTES = QS_LEAVES * LS;
-  static constexpr int CH = NE * CT;                    // trees per chunk
-  static constexpr int IDX_BYTES = CH * QS_TILE_ROWS;   // one byte per (tree, row): the leaf's byte offset inside its tree
-  static constexpr int LEAF_BYTES = CH * TREE_LEAF_BYTES;
-  static constexpr int LEAF_OFF = 2 * IDX_BYTES;
-  static constexpr int SLAB_OFF = LEAF_OFF + 2 * LEAF_BYTES;
-  static constexpr int LEAF_V4 = (LEAF_BYTES / 16 + 63) / 64;  // uint4 per lane of one chunk's leaf values
-  static_assert(SLAB_OFF % 256 == 0 && SLAB_OFF < 65536, "immediate offset of the cell reads");
-
-};
-
-template <bool F64, int NE, int CT>
-__global__ void __launch_bounds__((NE + 1) * 64)
-qs_score_pipe_kernel(const uint32_t *__restrict__ nodes, const uint8_t *__restrict__ leaves,
-                     const QsCatNode *__restrict__ cat_nodes, const uint32_t *__restrict__ cat_bits,
-                     const uint16_t *__restrict__ cells, int n_trees, int V, int rows, double base,
-                     double *__restrict__ out) {
-  using P = QsPipe<F64, NE, CT>;
-  constexpr int LS = P::LS, TREE_LEAF_BYTES = P::TREE_LEAF_BYTES, CH = P::CH;
-  extern __shared__ __align__(16) uint8_t smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long tile = blockIdx.x;
-  const int n_chunks = (n_trees + CH - 1) / CH;
-  {
-    const uint4 *src = (const uint4 *)(cells + (size_t)tile * V * QS_TILE_ROWS);
-    uint4 *dst = (uint4 *)(smem + P::SLAB_OFF);
-    for (int i = tid; i < V * 16; i += (NE + 1) * 64) dst[i] = src[i];
-  }
-  __syncthreads();  // slab staged
-  // from here on every wavefront passes exactly n_chunks barriers: the evaluators' k-th is the end of their chunk k, the
-  // adder's k-th is the start of its chunk k
-  if (wave == NE) {
-    // ------------------------------------------------------------------ the adding wavefront
-    // (named registers, not an array: behind a lambda's reference capture the array stayed in scratch memory)
-    uint4 st0 = {}, st1 = {}, st2 = {}, st3 = {};
-    static_assert(P::LEAF_V4 <= 4, "staging registers of the adding wavefront");
-    auto fetch = [&](int k) {  // chunk k's leaf values -> registers (in flight while the previous chunk is added)
-      const int n16 = min(CH, n_trees - k * CH) * (TREE_LEAF_BYTES / 16);
-      const uint4 *src = (const uint4 *)(leaves + (size_t)k * CH * TREE_LEAF_BYTES);
-      st0 = src[min(lane, n16 - 1)];
-      if constexpr (P::LEAF_V4 > 1) st1 = src[min(lane + 64, n16 - 1)];
-      if constexpr (P::LEAF_V4 > 2) st2 = src[min(lane + 128, n16 - 1)];
-      if constexpr (P::LEAF_V4 > 3) st3 = src[min(lane + 192, n16 - 1)];
-    };
-    auto put = [&](int k) {
-      const int n16 = min(CH, n_trees - k * CH) * (TREE_LEAF_BYTES / 16);
-      uint4 *dst = (uint4 *)(smem + P::LEAF_OFF + (k & 1) * P::LEAF_BYTES);
-      if (lane < n16) dst[lane] = st0;
-      if constexpr (P::LEAF_V4 > 1) if (lane + 64 < n16) dst[lane + 64] = st1;
-      if constexpr (P::LEAF_V4 > 2) if (lane + 128 < n16) dst[lane + 128] = st2;
-      if constexpr (P::LEAF_V4 > 3) if (lane + 192 < n16) dst[lane + 192] = st3;
-    };
-    fetch(0);
-    put(0);
-    double a64[2] = {0.0, 0.0};
-    float a32[2] = {(float)base, (float)base};
-    for (int k = 0; k < n_chunks; ++k) {
-      __syncthreads();  // the evaluators have written chunk k's exit leaves
-      const int nt = min(CH, n_trees - k * CH);
-      if (k + 1 < n_chunks) fetch(k + 1);
-      const uint8_t *idx = smem + (k & 1) * P::IDX_BYTES + lane * 2;
-      const uint8_t *lv = smem + P::LEAF_OFF + (k & 1) * P::LEAF_BYTES;
-#pragma unroll 4
-      for (int tt = 0; tt < nt; ++tt) {
-        const uint32_t pair = *(const uint16_t *)(idx + tt * QS_TILE_ROWS);  // byte offsets of rows 2 * lane, 2 * lane + 1
-        const uint8_t *tl = lv + tt * TREE_LEAF_BYTES;
-        if constexpr (F64) {
-          a64[0] += *(const double *)(tl + (pair & 0xffu));
-          a64[1] += *(const double *)(tl + (pair >> 8));
-        } else {
-          a32[0] += *(const float *)(tl + (pair & 0xffu));
-          a32[1] += *(const float *)(tl + (pair >> 8));
-        }
-      }
-      if (k + 1 < n_chunks) put(k + 1);
-    }
-    const long long row0 = tile * QS_TILE_ROWS + (long long)lane * 2;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (row0 + j < rows) out[row0 + j] = F64 ? a64[j] : (double)a32[j];
-    return;
-  }
-  // -------------------------------------------------------------------- an evaluating wavefront
-  // one tree.  Its node constants are fetched here, not a tree ahead: two sets of them (64 scalar registers) would cost the
-  // eighth wavefront per SIMD, and with eight the scalar-load latency hides behind the other seven's VALU blocks.
-  auto step = [&](int t, uint8_t *idx_dst) {
-    QsNodeRegs cur;
-    qs_load_nodes(cur, nodes + (size_t)t * QS_TREE_WORDS);
-    // the 15 cell reads in two asm blocks (30 operands is the limit of one): the compiler pads every block it cannot see
-    // into with an s_nop, and one per node was 15 of the tree's ~60 scalar issue slots
-    uint32_t c[QS_SLOTS - 1], mm[QS_SLOTS - 1];
-#define MRK_RD(i, o, m, v) "s_lshr_b32 m0, %" #v ", 16\n\ts_pack_ll_b32_b16 %" #m ", %" #v ", %" #v "\n\tds_read_addtid_b32 %" #o " offset:%" #i "\n\t"
-    asm volatile(MRK_RD(24, 0, 8, 16) MRK_RD(24, 1, 9, 17) MRK_RD(24, 2, 10, 18) MRK_RD(24, 3, 11, 19) MRK_RD(24, 4, 12, 20)
-                 MRK_RD(24, 5, 13, 21) MRK_RD(24, 6, 14, 22) MRK_RD(24, 7, 15, 23)
-                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]),
-                   "=&s"(mm[0]), "=&s"(mm[1]), "=&s"(mm[2]), "=&s"(mm[3]), "=&s"(mm[4]), "=&s"(mm[5]), "=&s"(mm[6]), "=&s"(mm[7])
-                 : "s"(cur.mv[0]), "s"(cur.mv[1]), "s"(cur.mv[2]), "s"(cur.mv[3]), "s"(cur.mv[4]), "s"(cur.mv[5]), "s"(cur.mv[6]), "s"(cur.mv[7]),
-                   "n"(P::SLAB_OFF)
-                 : "memory", "scc");
-    asm volatile(MRK_RD(21, 0, 7, 14) MRK_RD(21, 1, 8, 15) MRK_RD(21, 2, 9, 16) MRK_RD(21, 3, 10, 17) MRK_RD(21, 4, 11, 18)
-                 MRK_RD(21, 5, 12, 19) MRK_RD(21, 6, 13, 20)
-                 : "=&v"(c[8]), "=&v"(c[9]), "=&v"(c[10]), "=&v"(c[11]), "=&v"(c[12]), "=&v"(c[13]), "=&v"(c[14]),
-                   "=&s"(mm[8]), "=&s"(mm[9]), "=&s"(mm[10]), "=&s"(mm[11]), "=&s"(mm[12]), "=&s"(mm[13]), "=&s"(mm[14])
-                 : "s"(cur.mv[8]), "s"(cur.mv[9]), "s"(cur.mv[10]), "s"(cur.mv[11]), "s"(cur.mv[12]), "s"(cur.mv[13]), "s"(cur.mv[14]),
-                   "n"(P::SLAB_OFF)
-                 : "memory", "scc");
-#undef MRK_RD
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads above are invisible to the compiler
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < QS_SLOTS - 1; ++s)
-      c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, cur.kk[s]) - __builtin_bit_cast(short2v, c[s]));  // < 0 <=> cell > k
-#pragma unroll
-    for (int s = 0; s < QS_SLOTS - 1; ++s)
-      c[s] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, c[s]) >> 15);  // 0xFFFF where the test is false
-    uint32_t acc_a = 0, acc_b = 0;
-#pragma unroll
-    for (int s = 0; s < QS_SLOTS - 1; s += 2) {
-      asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_a) : "v"(c[s]), "s"(mm[s]));
-      if (s + 1 < QS_SLOTS - 1) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc_b) : "v"(c[s + 1]), "s"(mm[s + 1]));
-    }
-    uint32_t accn = acc_a | acc_b;
-    const uint32_t catw = cur.kk[QS_SLOTS - 1];
-    if (catw >> 24) {
-      const QsCatNode *cn = cat_nodes + (catw & 0xffffffu);
-      for (uint32_t j = 0; j < (catw >> 24); ++j) {
-        const QsCatNode cnode = cn[j];
-        accn |= qs_cat_pair<F64>(cnode, *(const uint32_t *)(smem + P::SLAB_OFF + ((cnode.view_dl & 0xffffu) << 8) + lane * 4), cat_bits);
-      }
-    }
-    // exit leaf = lowest position not removed (position nl - 1 is in no left subtree: a zero bit exists); stored as the
-    // leaf's byte offset, rows 2 * lane and 2 * lane + 1 in one 16-bit store
-    const uint32_t inv = ~accn;
-    const uint32_t pair = ((uint32_t)__builtin_ctz(inv) | ((uint32_t)__builtin_ctz(inv >> 16) << 8)) * (uint32_t)LS;
-    *(uint16_t *)(idx_dst + lane * 2) = (uint16_t)pair;
-  };
-  int t = wave;  // this wavefront's next tree
-  for (int k = 0; k < n_chunks; ++k) {
-    uint8_t *idx = smem + (k & 1) * P::IDX_BYTES + wave * QS_TILE_ROWS;
-#pragma unroll 1
-    for (int j = 0; j < CT; ++j, t += NE)
-      if (t < n_trees) step(t, idx + j * NE * QS_TILE_ROWS);
-    __syncthreads();  // chunk k written; the adder is done with chunk k - 1, whose half chunk k + 1 overwrites
-  }
-}
-
+// (Measured and removed, round 6 - commit 4ad2903 has the code: a PIPELINED form of the split kernel - 7 evaluating wavefronts + 1
+// adding wavefront per tile, the exit leaves of chunk k double-buffered against the adds of chunk k - 1, one barrier per chunk,
+// nobody idle.  Same box: 0.226 vs 0.223 ms at 384 000 rows, 1.966 vs 1.908 ms at 4 M rows, bench 1 041 vs 1 142 M items/s
+// (profiles/r06_b_score_pipe_ab.txt).  The idle adders were never the loss: at 4 M rows the split kernel runs a tree step in 300
+// cycles per SIMD where the bare step - no scalar loads, no leaves - sustains 265 at 8 wavefronts per SIMD and its 58 VALU
+// instructions alone take 244 (tools/native/issue_bench.hip, profiles/r06_a_issue_bench.txt); what a 3 000-tile launch loses
+// on top is the DRAIN: the last workgroups run on an emptying chip, where one wavefront per SIMD needs 723 cycles per tree.)
 template <bool F64>
 void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, double *d_out) {
   const PackedForestQS &q = m->qs;
@@ -565,30 +408,6 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
   // wavefronts per tile: by residency and fill (launch_shape.hpp has the rule and the measurements behind it)
   const int split_env = switches().qs_split;
   const int nw = split_env >= 0 ? split_env : scorer_waves_per_tile(n_tiles, V, F64, ctx->n_cus, QS_LEAVES, QS_TILE_ROWS);
-  // full batches: the pipelined kernel (7 evaluating wavefronts + 1 adding one per tile, four workgroups per CU)
-  const int pipe = switches().qs_pipe;
-  if (split_env < 0 && pipe != 0 && V > 0 && (pipe > 0 || scorer_pipelined(n_tiles, ctx->n_cus))) {
-    int ct = scorer_pipe_chunk(V, F64, QS_LEAVES, QS_TILE_ROWS);
-    if ((pipe == 2 || pipe == 4) && scorer_pipe_lds(V, pipe, QS_LEAVES, QS_TILE_ROWS, F64) <= 160 * 1024) ct = pipe;  // tests: both chunk sizes
-    if (ct) {
-      ScopedKernelTimer timer(ctx, "score");
-#define MRK_PIPE(CT_)                                                                                                       \
-      {                                                                                                                       \
-        auto pk = qs_score_pipe_kernel<F64, 7, CT_>;                                                                          \
-        using PipeShape = QsPipe<F64, 7, CT_>;                                                                                \
-        const size_t pipe_lds = (size_t)PipeShape::SLAB_OFF + (size_t)V * 256;                                               \
-        lds_optin(ctx, (const void *)pk);                                                                                     \
-        hipLaunchKernelGGL(pk, dim3((unsigned)n_tiles), dim3(8 * 64), pipe_lds,                                              \
-                           ctx->launch, m->d_qs_nodes.as<uint32_t>(), m->d_qs_leaves.as<uint8_t>(),                           \
-                           m->d_qs_catnodes.as<QsCatNode>(), m->d_qs_cat.as<uint32_t>(), d_cells, q.n_trees, V, rows,         \
-                           m->forest.base_score, d_out);                                                                      \
-      }
-      if (ct == 4) MRK_PIPE(4) else MRK_PIPE(2)
-#undef MRK_PIPE
-      MRK_HIP(hipGetLastError());
-      return;
-    }
-  }
   if (nw == 2 || nw == 4 || nw == 8 || nw == 16) {
     const size_t lds = (size_t)V * 256 + (size_t)8 * nw * (QS_LEAVES * (F64 ? 8 : 4) + QS_TILE_ROWS);
     if (lds <= 160 * 1024) {

@@ -28,7 +28,8 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_abi_version_and_error_paths_without_gpu():
     L = _native.lib()
-    assert L.mrk_abi_version() == 8
+    assert L.mrk_abi_version() == 9
+    assert L.mrk_model_weights(None, 1, None, 0) == _native.ERR_INVALID_ARG   # ABI 9
     # null arguments are rejected before any device work
     assert L.mrk_model_predict_f64(None, None, 1, 1, None) == _native.ERR_INVALID_ARG
     assert b"null model" in L.mrk_last_error()
@@ -51,6 +52,44 @@ def test_abi_version_and_error_paths_without_gpu():
     assert L.mrk_config_kernel_keys(None, b"m", None, 0, C.byref(need)) == _native.ERR_INVALID_ARG
     assert L.mrk_config_precompile_for_model(None, 0, b"m", 0, None, 0, 1, b"/tmp", None) == _native.ERR_INVALID_ARG
     assert L.mrk_config_specialize_for_model(b"{}", 2, b"m", 0, None, 0, 0, None, 0, C.byref(need)) == _native.ERR_INVALID_ARG   # no model bytes
+
+
+def test_abi_layout_matches_the_header_and_the_ctypes_structures(tmp_path):
+    """mrk_abi_layout(): what a JNA @FieldOrder binding checks at start-up.  Three independent views of the same
+    structs must agree: the library's own numbers, the ctypes Structures of the Python harness, and a C99 program compiled from
+    include/mrk.h by gcc."""
+    import ctypes as C
+    import subprocess
+
+    L = _native.lib()
+    n = L.mrk_abi_layout(None, 0)
+    v = (C.c_int32 * n)()
+    assert L.mrk_abi_layout(v, n) == n and n == 33 and v[0] == L.mrk_abi_version()
+    short = (C.c_int32 * 3)(-1, -1, -1)
+    assert L.mrk_abi_layout(short, 2) == n and short[2] == -1   # never writes past cap
+    def view(st, fields):
+        return [C.sizeof(st)] + [getattr(st, f).offset for f in fields]
+    fields = {"mrk_field": ["name", "type", "n", "num", "str", "strs", "nums"],
+              "mrk_request": ["id", "timestamp_ms", "user", "session", "fields", "n_fields", "n_items", "item_ids", "item_field_offsets", "item_fields"],
+              "mrk_model_info": ["backend", "n_trees", "max_depth", "n_features", "is_f64", "n_categorical", "n_nodes", "n_leaves", "device_bytes",
+                                 "base_score", "bitvector", "tile_columns"]}
+    got = list(v)
+    want = [L.mrk_abi_version()] + view(_native.mrk_field, fields["mrk_field"]) + view(_native.mrk_request, fields["mrk_request"]) + \
+        view(_native.mrk_model_info, fields["mrk_model_info"])
+    assert got == want
+    # every field of the three structs is covered (a field added to the header without a layout entry fails here)
+    for name, fs in fields.items():
+        assert [f for f, _ in getattr(_native, name)._fields_] == fs
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mrk.h"', 'int main(void) {', '  printf("%d", MRK_ABI_VERSION);']
+    for name, fs in fields.items():
+        lines.append(f'  printf(" %zu", sizeof({name}));')
+        lines += [f'  printf(" %zu", offsetof({name}, {f}));' for f in fs]
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    assert [int(x) for x in subprocess.check_output([str(exe)]).split()] == got
 
 
 def test_build_id_follows_the_sources(tmp_path):

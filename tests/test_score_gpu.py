@@ -174,7 +174,7 @@ def test_full_size_properties_100k(ctx):
 # test that pins a kernel re-reads them (M.reload_switches).
 @pytest.fixture
 def scorer_env():
-    saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT", "MRK_QS_PIPE", "MRK_WALK_TILE")}
+    saved = {k: os.environ.get(k) for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT", "MRK_WALK_TILE")}
     yield
     for k, v in saved.items():
         if v is None:
@@ -185,7 +185,7 @@ def scorer_env():
 
 
 def _predict_with(b, X, **env):
-    for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT", "MRK_QS_PIPE", "MRK_WALK_TILE"):
+    for k in ("MRK_SCORER", "MRK_QS_KERNEL", "MRK_QS_R", "MRK_QS_SPLIT", "MRK_WALK_TILE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     M.reload_switches()
@@ -197,8 +197,6 @@ def _all_kernels(b, X):
     for nw in ("1", "2", "4", "8", "16"):  # 1 = one wavefront per tile; 2/4/8/16 = wavefronts splitting the trees of a tile
         out[f"bitvector-wave-split{nw}"] = _predict_with(b, X, MRK_QS_KERNEL="1", MRK_QS_SPLIT=nw)
     out["bitvector-wave-auto"] = _predict_with(b, X, MRK_QS_KERNEL="1")
-    for ct in ("2", "4"):  # 7 evaluating wavefronts + 1 adding one per tile, 2 / 4 trees per evaluator and chunk (full batches' kernel)
-        out[f"bitvector-pipelined-{ct}"] = _predict_with(b, X, MRK_QS_KERNEL="1", MRK_QS_PIPE=ct)
     for r in ("2", "4", "8"):
         out[f"bitvector-generic-r{r}"] = _predict_with(b, X, MRK_QS_KERNEL="0", MRK_QS_R=r)
     out["walk"] = _predict_with(b, X, MRK_SCORER="walk")
