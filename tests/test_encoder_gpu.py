@@ -494,8 +494,9 @@ def test_precision_is_a_property_of_the_handle_not_of_the_call():
 
 def test_c5_against_the_fp32_embedding_not_against_itself():
     """BASELINE config 5 with the oracle fed an INDEPENDENT embedding - numpy's fp32 run of the graph - instead of the device's
-    own: with the encoder in f32 mode the device's cosine column is within 1e-6 of the oracle's, and every score the
-    500-tree forest produces is the oracle's except where a cosine sits within that distance of a split threshold; the same
+    own: with the encoder in f32 mode the device's cosine column is within 2e-6 of the oracle's, and every score the
+    500-tree forest produces is the oracle's except where the two cosines STRADDLE one of the forest's split thresholds on that
+    column (asserted per moved score, the count printed); the same
     comparison for the default fp16 mode is reported (how many of the scores move by more than 1e-5 at 3e-3 cosine error)."""
     w = synth.synthetic_bert(**MINILM, classifier=False)
     tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
@@ -519,6 +520,18 @@ def test_c5_against_the_fp32_embedding_not_against_itself():
     model = synth.synthetic_lgbm_model(n_trees=500, n_features=25, quantiles=ranklens.column_quantiles(np.concatenate(mats)), missing="per_feature")
     orc.load_model(model, 0)
     want = [orc.rerank(ev) for ev in emb_reqs]
+    # the forest's split thresholds on the cosine column (24), read from the model text itself
+    cos_thr = []
+    feats = None
+    for line in model.decode().split("\n"):
+        if line.startswith("split_feature="):
+            feats = [int(x) for x in line.split("=", 1)[1].split()]
+        elif line.startswith("threshold=") and feats is not None:
+            cos_thr += [float(t) for f, t in zip(feats, line.split("=", 1)[1].split()) if f == 24]
+            feats = None
+    cos_thr = np.unique(np.array(cos_thr))
+    assert len(cos_thr) > 20
+    straddled = []
     report = {}
     for mode in ("f32", "fp16"):
         enc = HipEncoder(blob_w, tj, precision="f32" if mode == "f32" else "f16")
@@ -540,7 +553,15 @@ def test_c5_against_the_fp32_embedding_not_against_itself():
                 assert bool(((a[:, other] == b[:, other]) | (np.isnan(a[:, other]) & np.isnan(b[:, other]))).all()), (mode, r)
                 ok = np.isfinite(b[:, 24])
                 cos_err = max(cos_err, float(np.abs(a[ok, 24] - b[ok, 24]).max()))
-                moved += int((np.abs(scores[lo:hi] - want[r][1]) > 1e-5).sum())
+                mv = np.flatnonzero(np.abs(scores[lo:hi] - want[r][1]) > 1e-5)
+                moved += len(mv)
+                if mode == "f32":   # every moved score is EXPLAINED: the two cosines of that candidate straddle a split threshold of the column
+                    for i in mv:
+                        x, y = sorted((float(a[i, 24]), float(b[i, 24])))
+                        k = np.searchsorted(cos_thr, x, side="left")   # LightGBM: v <= threshold goes left
+                        assert k < len(cos_thr) and x <= cos_thr[k] < y, (r, int(i), x, y)
+                        assert y - x < 2e-6, (r, int(i), x, y)
+                        straddled.append(y - x)
                 total += hi - lo
                 reordered += int(order[lo:hi].tolist() != want[r][2].tolist())
             report[mode] = {"cosine_err": cos_err, "scores_moved": moved, "of": total, "requests_reordered": reordered}
@@ -559,6 +580,10 @@ def test_c5_against_the_fp32_embedding_not_against_itself():
         finally:
             hip.close()
             enc.close()
+    report["f32"]["straddled_thresholds"] = len(straddled)
+    report["f32"]["widest_straddle"] = max(straddled) if straddled else 0.0
     print("\nC5 against the fp32 embedding:", report)
-    assert report["f32"]["cosine_err"] < 1e-5 and report["f32"]["scores_moved"] <= report["f32"]["of"] // 200, report
+    # the tolerance is explained, not blanket: each of the f32 mode's moved scores (printed above) belongs to a candidate whose
+    # cosine - 1e-6 apart between two f32 orderings of the same graph - has one of the forest's thresholds between the two values
+    assert report["f32"]["cosine_err"] < 2e-6 and report["f32"]["scores_moved"] <= report["f32"]["of"] // 200, report
     assert report["fp16"]["cosine_err"] < ATOL_COS, report

@@ -32,6 +32,23 @@ def test_oracle_reproduces_the_library(case):
 
 
 @needs_fixtures
+@pytest.mark.parametrize("case", CASES or ["none"])
+def test_weights_reproduce_the_library_importances(case):
+    """mrk_model_inspect_weights (== Booster.weights(), include/mrk.h) against the library's own feature importances, bit for bit
+    (fixtures written before round 6 carry none: skipped per case)."""
+    from metarank_amd.booster import inspect_weights
+
+    z = np.load(case + ".npz", allow_pickle=False)
+    if "importance_gain" not in z.files:
+        pytest.skip("fixture without importances: re-run tools/make_real_goldens.py")
+    blob, backend = open(case + ".model", "rb").read(), int(z["backend"])
+    n = len(z["importance_gain"])
+    for kind, key in ((0, "importance_split"), (1, "importance_gain"), (2, "importance_total_gain")):
+        if key in z.files:
+            assert np.array_equal(inspect_weights(blob, backend, n, kind), z[key]), key
+
+
+@needs_fixtures
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES or ["none"])
 def test_hip_reproduces_the_library(case):

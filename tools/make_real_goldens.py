@@ -11,6 +11,8 @@ environment has neither, nor a network.  Writes into tests/golden/real/:
                    - the calls ltrlib makes: LightGBMBooster.predictMat -> LGBM_BoosterPredictForMat(PREDICT_NORMAL; lambdarank
                    has no output transform), XGBoostBooster.predictMat -> DMatrix(float[], rows, cols, NaN) + predict
                    (ml/rank/LambdaMARTRanker.scala:347-359)
+                   + importance_split / importance_gain (/ importance_total_gain): the library's feature importances
+                   (LightGBM feature_importance, XGBoost get_score) = what ltrlib's Booster.weights() returns -> mrk_model_weights
     minilm.npz     (with --minilm-dir) the embeddings and cosines of OnnxBiencoderTest.scala:13-25 (0.539 / 0.738)
 
 tests/test_real_goldens.py consumes whatever is there: the oracle (oracle/forest_oracle.cpp behind oracle/forest.py) and
@@ -89,7 +91,10 @@ def make_lightgbm(out, rng):
         P[250:252, 5] = [np.inf, -np.inf]
         pred = bst.predict(P, raw_score=True, num_threads=1)
         open(os.path.join(out, name + ".model"), "w").write(model)
-        np.savez_compressed(os.path.join(out, name + ".npz"), X=P, pred=pred.astype(np.float64), backend=0, library=f"lightgbm {lgb.__version__}")
+        # Booster.weights() of ltrlib = LGBM_BoosterFeatureImportance: both types, for mrk_model_weights (include/mrk.h)
+        np.savez_compressed(os.path.join(out, name + ".npz"), X=P, pred=pred.astype(np.float64), backend=0, library=f"lightgbm {lgb.__version__}",
+                            importance_split=bst.feature_importance("split").astype(np.float64),
+                            importance_gain=bst.feature_importance("gain").astype(np.float64))
         print(name, len(model), "bytes,", len(P), "rows")
 
 
@@ -123,10 +128,14 @@ def make_xgboost(out, rng):
                 forms["legacy"] = bytes(bst.save_raw(raw_format="deprecated"))   # xgboost < 3: the pre-1.0 binary layout
             except Exception as e:  # noqa: BLE001
                 print("  (no legacy binary from this xgboost version:", e, ")")
+        def score(kind):   # Booster.getScore(featureMap, kind): features never split on are absent -> 0
+            got = bst.get_score(importance_type=kind)
+            return np.array([float(got.get(f"f{j}", 0.0)) for j in range(X.shape[1])], dtype=np.float64)
+        imp = {"importance_split": score("weight"), "importance_gain": score("gain"), "importance_total_gain": score("total_gain")}
         for fmt, blob in forms.items():
             open(os.path.join(out, f"{name}.{fmt}.model"), "wb").write(blob)
             np.savez_compressed(os.path.join(out, f"{name}.{fmt}.npz"), X=P, pred=pred.astype(np.float32), backend=1,
-                                library=f"xgboost {xgb.__version__}")
+                                library=f"xgboost {xgb.__version__}", **imp)
             print(name, fmt, len(blob), "bytes,", len(P), "rows")
 
 
