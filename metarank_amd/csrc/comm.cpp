@@ -132,14 +132,29 @@ int mrk_comm_init_local(mrk_ctx *const *ctxs, int n) {
       for (ncclComm_t c : comms) if (c) (void)ncclCommAbort(c);
       throw StatusError(MRK_ERR_DEVICE, std::string("mrk_comm_init_local: ") + ncclGetErrorString(rc != ncclSuccess ? rc : end));
     }
-    for (int i = 0; i < n; ++i) {
-      std::lock_guard<std::mutex> lk(ctxs[i]->mu);
-      MRK_HIP(hipSetDevice(ctxs[i]->device));
-      ctxs[i]->comm = comms[(size_t)i];
-      ctxs[i]->comm_rank = i;
-      ctxs[i]->comm_world = n;
-      ctxs[i]->d_comm.reserve(256);
+    // all or nothing: a failure while the contexts take their communicators (hipSetDevice, the scratch allocation) aborts every
+    // communicator and clears the contexts already assigned - no half-initialised world, and a retry is not refused
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
+    try {
+      for (int i = 0; i < n; ++i) {
+        std::lock_guard<std::mutex> lk(ctxs[i]->mu);
+        MRK_HIP(hipSetDevice(ctxs[i]->device));
+        ctxs[i]->d_comm.reserve(256);
+        ctxs[i]->comm = comms[(size_t)i];
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_world = n;
+      }
+    } catch (...) {
+      for (int i = 0; i < n; ++i) {
+        std::lock_guard<std::mutex> lk(ctxs[i]->mu);
+        if (ctxs[i]->comm == comms[(size_t)i]) { ctxs[i]->comm = nullptr; ctxs[i]->comm_rank = 0; ctxs[i]->comm_world = 1; }
+      }
+      for (ncclComm_t c : comms) if (c) (void)ncclCommAbort(c);
+      if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+      throw;
     }
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
   });
 }
 

@@ -871,12 +871,17 @@ __global__ __launch_bounds__(64 * ATT_HEADS) void attention_f32_mfma_kernel(cons
     }
     bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    // a block of dead keys (liveness does not depend on the query: the branch is uniform) leaves the state untouched - also
+    // while no live key has been seen yet (m_run = -inf), where exp(p - m_new) would have been exp(0) for every dead key; and a
+    // non-finite V at a dead key never meets a zero probability.  A sequence without any live key ends as 0 / 0 = NaN, like
+    // attention_f32_kernel's and the fp32 oracle's.
+    if (bm == -FLT_MAX) continue;
     const float m_new = fmaxf(m_run, bm);
     const float alpha = expf(m_run - m_new);
     float ls = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      p[e] = p[e] == -FLT_MAX && m_new != -FLT_MAX ? 0.f : expf(p[e] - m_new);
+      p[e] = p[e] == -FLT_MAX ? 0.f : expf(p[e] - m_new);
       ls += p[e];
     }
     ls += __shfl_xor(ls, 16, 64);
@@ -896,7 +901,7 @@ __global__ __launch_bounds__(64 * ATT_HEADS) void attention_f32_mfma_kernel(cons
     }
   }
   if (q0 + r >= seq) return;
-  const float inv = 1.0f / l_run;
+  const float inv = 1.0f / l_run;   // (l_run == 0: no live key at all -> 0 * inf = NaN, as in attention_f32_kernel)
   float *dst = ctx + (first + q0 + r) * H + head * DH;
 #pragma unroll
   for (int d = 0; d < KG; ++d) {

@@ -446,6 +446,14 @@ void Store::ttl_note(const KeyRef &k, int64_t deadline_ms) {
   const uint64_t cell = ttl_cell(k.scope, (uint32_t)it->second, s);
   ttl_deadline[cell] = deadline_ms;
   ttl_heap.emplace(deadline_ms, cell);
+  // a rewrite leaves the cell's previous pair in the heap until ITS deadline passes (90 days by default): a hot cell rewritten
+  // a hundred times a second would grow the heap by 8 * 10^8 pairs.  Rebuild from the live deadlines once stale pairs outnumber them.
+  if (ttl_heap.size() > 2 * ttl_deadline.size() + 1024) {
+    std::vector<std::pair<int64_t, uint64_t>> live;
+    live.reserve(ttl_deadline.size());
+    for (const auto &kv : ttl_deadline) live.emplace_back(kv.second, kv.first);
+    ttl_heap = decltype(ttl_heap)(std::greater<std::pair<int64_t, uint64_t>>(), std::move(live));
+  }
 }
 
 int64_t Store::ttl_expire(int64_t now_ms) {

@@ -183,6 +183,32 @@ def test_head_size_64(minilm):
     enc.close()
 
 
+def test_f32_attention_with_dead_key_blocks_before_the_first_live_key():
+    """Masks that are not a prefix of ones: whole 16-key blocks of dead keys BEFORE the first live key (the online softmax
+    of attention_f32_mfma_kernel gave such keys weight exp(0) while its running maximum was still -inf), in the middle and at the end.
+    Live positions must match the numpy fp32 graph; the vector-unit twin must agree with the matrix-core kernel."""
+    w = synth.synthetic_bert(**MINILM, classifier=False)
+    tj = synth.wordpiece_tokenizer_json(vocab_size=2000, max_length=256)
+    enc = HipEncoder(synth.bert_safetensors(w, 12), tj, precision="f32")
+    try:
+        rng = np.random.default_rng(77)
+        n, seq = 5, 80
+        ids = rng.integers(5, 2000, size=(n, seq)); types = np.zeros_like(ids)
+        mask = np.zeros((n, seq), dtype=np.int32)
+        mask[0, 40:52] = 1                 # two dead blocks, then live keys, then dead to the end
+        mask[1, 16:] = 1                   # exactly one dead block first
+        mask[2, :20] = 1; mask[2, 64:70] = 1   # dead blocks in the middle
+        mask[3, 79] = 1                    # one live key, the last
+        mask[4, :] = 1
+        fp32 = bert.last_hidden_state(w, ids, types, mask, heads=12)
+        h = enc.hidden_ids(ids, types, mask)
+        live = mask.astype(bool)
+        assert np.isfinite(h[live]).all()
+        np.testing.assert_allclose(h[live], fp32[live], rtol=0, atol=ATOL_F32_HIDDEN)
+    finally:
+        enc.close()
+
+
 def test_load_errors():
     w = synth.synthetic_bert(layers=1, hidden=96, heads=2, inter=128, vocab=50, max_pos=16)  # head size 48
     with pytest.raises(N.MrkError) as e:
