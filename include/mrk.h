@@ -416,6 +416,11 @@ void mrk_batch_free(mrk_batch *batch);
  * (more than 128 candidates, per-item field overrides, a model with a request-normalised column, all slots busy) go
  * through mrk_rank transparently.  A workgroup that has seen no request for a while (2 ms; MRK_SERVE_IDLE_US) leaves
  * its CU and is relaunched by the next request; store flushes stop the workgroups for their duration.
+ * n_slots (1 .. 64) is a wish: every resident workgroup is a kernel on a stream of its own and occupies that stream's hardware
+ * queue while it stays, so no more slots are created than the process has hardware queues to spare (GPU_MAX_HW_QUEUES minus 4;
+ * the library sets the variable to 24 before its first HIP call unless the host has set it - ROCm's default of 4 made the fifth
+ * slot wait behind another slot's kernel for up to its 20 ms residency).  Callers beyond the slots are combined by mrk_rank's
+ * front.
  * mrk_serve_stats: the first min(n_out, MRK_SERVE_STATS) of {requests through the queue, requests through mrk_rank, workgroup launches; then, summed over the
  * queue's requests, in ns: host resolve + pack, host publish -> acknowledgement, host copy-out, device input copy + cache drops,
  * device ranking, device result write-back; last: the SHADER CYCLES of the device ranking summed the same way - cycles / ns = the

@@ -34,6 +34,7 @@ static Switches read_switches() {
   s.serve_idle_us = std::max(1, num("MRK_SERVE_IDLE_US", 2000));
   s.serve_life_us = std::max(1, num("MRK_SERVE_LIFE_US", 20000));
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
+  s.rank_lanes = std::max(1, std::min((int)mrk_ctx::RANK_LANES_MAX, num("MRK_RANK_LANES", 3)));
   s.table_load_pct = std::max(10, std::min(90, num("MRK_TABLE_LOAD_PCT", 75)));
   s.host_threads = std::max(0, std::min(256, num("MRK_HOST_THREADS", 0)));
   if (const char *e = getenv("MRK_RANK_JIT")) s.jit_mode = !strcmp(e, "require") ? 2 : !strcmp(e, "async") ? 3 : !strcmp(e, "auto") ? 4 : atoi(e) != 0 ? 1 : 0;
@@ -98,6 +99,19 @@ void drain_profile_events(mrk_ctx *ctx) {
     (void)hipEventDestroy(b);
   }
   ctx->pending_events.clear();
+}
+
+int hw_queue_budget() {
+  // Persistent serving workgroups (mrk_serve_*) each hold a stream's hardware queue for as long as they stay; with the runtime's
+  // default of 4 queues the fifth slot already waits behind another slot's kernel.  The variable is read when HIP initialises:
+  // setting it here works when this library makes the process's first HIP call (a JVM host: always), and never overrides the host.
+  static const int budget = [] {
+    (void)setenv("GPU_MAX_HW_QUEUES", "24", 0);
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? atoi(e) : 4;
+    return v >= 1 ? v : 4;
+  }();
+  return budget;
 }
 
 void lds_optin(mrk_ctx *ctx, const void *fn, int bytes) {
@@ -222,6 +236,7 @@ void mrk_debug_reload_switches(void) { mrk::reload_switches(); }
 const char *mrk_last_error(void) { return g_last_error.c_str(); }
 
 int mrk_device_count(void) {
+  (void)hw_queue_budget();
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) {
     (void)hipGetLastError();
@@ -252,6 +267,7 @@ int mrk_init(const int *device_ids, int n_devices, mrk_ctx **out) {
     if (!out) throw StatusError(MRK_ERR_INVALID_ARG, "out is null");
     for (int i = 0; i < std::max(n_devices, 1); ++i) out[i] = nullptr;
     if (n_devices < 1 || !device_ids) throw StatusError(MRK_ERR_INVALID_ARG, "need at least one device id");
+    (void)hw_queue_budget();   // before the process's first HIP call
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)

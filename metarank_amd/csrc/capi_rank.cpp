@@ -6,6 +6,10 @@
 #include <cstring>
 #include <thread>
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <cstdlib>
 
 #include "features.hpp"
@@ -129,10 +133,16 @@ struct mrk_batch {
 namespace mrk {
 
 void free_rank_state(mrk_ctx *ctx) {
-  if (ctx->rank_scratch) {
+  for (int i = 0; i < mrk_ctx::RANK_LANES_MAX; ++i) {
+    mrk_batch *b = (mrk_batch *)ctx->rank_lane[i];
+    if (!b) continue;
     (void)hipSetDevice(ctx->device);
-    delete (mrk_batch *)ctx->rank_scratch;
-    ctx->rank_scratch = nullptr;
+    if (b->stream) {
+      (void)hipStreamSynchronize(b->stream);
+      (void)hipStreamDestroy(b->stream);
+    }
+    delete b;
+    ctx->rank_lane[i] = nullptr;
   }
   delete ctx->registry;
   delete ctx->store;
@@ -154,19 +164,36 @@ struct StoreAccess {
   StoreAccess(mrk_ctx *c, bool exclusive = false, bool flush = true) : ctx(c) {
     if (!ctx->store) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_load_json must be called first");
     if (exclusive) {
+      ctx->store_writers.fetch_add(1);
       unique = std::unique_lock<std::shared_mutex>(ctx->store_mu);
+      ctx->store_writers.fetch_sub(1);
       if (flush) do_flush();
       return;
     }
-    shared = std::shared_lock<std::shared_mutex>(ctx->store_mu);
+    lock_shared();
     while (flush && ctx->store->dirty()) {
       shared.unlock();
       {
-        std::unique_lock<std::shared_mutex> x(ctx->store_mu);
+        StoreWriteLock x(ctx);
         do_flush();
       }
-      shared.lock();
+      lock_shared();
     }
+  }
+  // readers that have not started wait for announced writers (puts from the feedback stream must not starve behind the
+  // overlapping leaders of mrk_rank's front); a reader never holds anything while it waits here
+  void lock_shared() {
+    if (ctx->store_writers.load(std::memory_order_acquire) > 0) {
+      // ... for at most a millisecond: a stream of puts that never pauses must not starve the readers either
+      const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(1);
+      while (ctx->store_writers.load(std::memory_order_acquire) > 0 && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+    }
+    shared = std::shared_lock<std::shared_mutex>(ctx->store_mu);
+  }
+  // the device work is enqueued: what follows (waiting for it, copying results) needs no store - a flush synchronises the device itself
+  void release() {
+    if (shared.owns_lock()) shared.unlock();
+    if (unique.owns_lock()) unique.unlock();
   }
   void do_flush() {
     MRK_HIP(hipSetDevice(ctx->device));
@@ -249,7 +276,8 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
     const size_t o_bytes = align_up(off_bytes, 256);
     b.d_ids.reserve(o_bytes + std::max<size_t>(id_bytes, 1));
     const void *src_off = ids->offsets, *src_bytes = ids->bytes;
-    if (!is_pinned_host(ids->offsets) || !is_pinned_host(ids->bytes)) {
+    const bool own_staging = (const void *)ids->offsets == (const void *)b.h_ids.p;   // mrk_rank's front flattens straight into this batch's pinned staging
+    if (!own_staging && (!is_pinned_host(ids->offsets) || !is_pinned_host(ids->bytes))) {
       b.h_ids.reserve(o_bytes + std::max<size_t>(id_bytes, 1));
       memcpy(b.h_ids.p, ids->offsets, off_bytes);
       memcpy(b.h_ids.as<uint8_t>() + o_bytes, ids->bytes, id_bytes);
@@ -499,6 +527,8 @@ static void fetch_batch(mrk_batch &b, double *scores, int32_t *order, double *ma
   if (!b.fetch_enqueued) enqueue_fetch(b, scores != nullptr, order != nullptr);
   b.fetch_enqueued = false;
   if (matrix && T && b.prog->dim) MRK_HIP(hipMemcpyAsync(matrix, b.d_matrix.p, T * b.prog->dim * 8, hipMemcpyDeviceToHost, b.s()));
+  // (Measured and removed, round 6: a leader of mrk_rank's front sleeping on a hipEventBlockingSync event instead of this polling
+  // wait when several lanes are in flight - 183 k vs 183 k requests/s at 64 callers, 289 k vs 301 k at 128, profiles/r06_e_callers.txt.)
   MRK_HIP(hipStreamSynchronize(b.s()));
   const uint8_t *h = b.h_out.as<uint8_t>();
   if (scores && T) memcpy(scores, h, T * 8);
@@ -518,7 +548,7 @@ extern "C" {
 int mrk_config_load_json(mrk_ctx *ctx, const char *json, size_t len) {
   return guard([&] {
     if (!ctx || !json) throw StatusError(MRK_ERR_INVALID_ARG, "null argument");
-    std::unique_lock<std::shared_mutex> sl(ctx->store_mu);
+    StoreWriteLock sl(ctx);
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "this context already has a configuration");
     MRK_HIP(hipSetDevice(ctx->device));
@@ -678,7 +708,7 @@ int mrk_model_dim(mrk_ctx *ctx, const char *model_name) {
   return guard([&] {                                      \
     if (!key) throw StatusError(MRK_ERR_INVALID_ARG, "null key"); \
     Store &st = store_of(ctx);                            \
-    std::unique_lock<std::shared_mutex> lk(ctx->store_mu); \
+    StoreWriteLock lk(ctx); \
     (void)st.call;                                        \
   })
 
@@ -697,7 +727,7 @@ static int put_binary(mrk_ctx *ctx, const uint8_t *bytes, size_t len, int64_t no
     if (out_records) *out_records = 0;
     if (!bytes && len) throw StatusError(MRK_ERR_INVALID_ARG, "null blob");
     Store &st = store_of(ctx);
-    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    StoreWriteLock lk(ctx);
     const int n = load_feature_values(st, bytes, len, now_ms);
     if (out_records) *out_records = n;
   });
@@ -714,7 +744,7 @@ int mrk_store_expire(mrk_ctx *ctx, int64_t now_ms, int64_t *out_expired) {
   return guard([&] {
     if (out_expired) *out_expired = 0;
     Store &st = store_of(ctx);
-    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    StoreWriteLock lk(ctx);
     const int64_t n = st.ttl_expire(now_ms);
     if (out_expired) *out_expired = n;
   });
@@ -724,7 +754,7 @@ int mrk_store_increment_periodic_batch(mrk_ctx *ctx, const char *const *keys, co
   return guard([&] {
     if (n < 0 || (n > 0 && (!keys || !ts_ms || !inc))) throw StatusError(MRK_ERR_INVALID_ARG, "bad increment batch");
     Store &st = store_of(ctx);
-    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    StoreWriteLock lk(ctx);
     for (int i = 0; i < n; ++i) {
       if (!keys[i]) throw StatusError(MRK_ERR_INVALID_ARG, "null key");
       (void)st.increment_periodic(keys[i], ts_ms[i], inc[i]);
@@ -750,7 +780,7 @@ int mrk_debug_scorer_split(int rows, int views, int f64, int n_cus) {
 int mrk_debug_clone_items(mrk_ctx *ctx, int copies, int64_t *out_items) {
   return guard([&] {
     Store &st = store_of(ctx);
-    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    StoreWriteLock lk(ctx);
     const uint32_t n = st.clone_items(copies);
     if (out_items) *out_items = n;
   });
@@ -772,7 +802,7 @@ int mrk_debug_store_info(mrk_ctx *ctx, int scope, int64_t *out) {
 int mrk_store_flush(mrk_ctx *ctx) {
   return guard([&] {
     Store &st = store_of(ctx);
-    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    StoreWriteLock lk(ctx);
     MRK_HIP(hipSetDevice(ctx->device));
     st.flush(ctx->stream);
   });
@@ -787,12 +817,25 @@ static const Program &program_of(mrk_ctx *ctx, const char *model_name) {
 }
 
 // ---- mrk_rank with a batching front.  The reference serves every request on its own thread
-// (cats-effect compute pool, one rerank per fiber); here concurrent callers of mrk_rank are combined: whoever
-// arrives while nobody is ranking becomes the leader, takes every compatible request queued so far (same model
-// handle, same model name, same wish for the explain matrix; up to MRK_RANK_COMBINE_MAX), runs them as ONE
-// device batch (one upload, three launches, one download) and hands every caller its slice.  A single caller
-// sees exactly the old behaviour (a batch of one).  MRK_RANK_COMBINE=0 turns the front off.
+// (cats-effect compute pool, one rerank per fiber: api/routes/RankApi.scala:25-41, ml/Ranker.scala:27-83); here concurrent
+// callers of mrk_rank are combined.  A context has MRK_RANK_LANES scratch batches ("lanes", default 3), each with its own
+// stream, pinned staging and grow-only device buffers.  A caller queues its ticket; whoever is waiting when a lane is free
+// takes the lane and every compatible ticket queued so far (same model handle, same model name, same wish for the explain
+// matrix; up to MRK_RANK_COMBINE_MAX; FIFO), ranks them as ONE device batch - one upload, the id bytes resolved by a kernel,
+// one to three launches, results straight from the lane's pinned buffer into every caller's arrays - and gives the lane
+// back.  While that batch is on the device the next leader builds and uploads the next one on another lane: host work and
+// device work of consecutive batches overlap (round 5's front had one lane and one leader: 37 k requests/s at 32 callers).
+// A single caller sees the old behaviour: a batch of one, lane 0 = the context stream, ids resolved on the host.
+// MRK_RANK_COMBINE=0: no combining - every caller ranks alone on whichever lane is free.
 namespace {
+// A waiting caller sleeps on its OWN ticket's state word (futex): woken by exactly one system call from the leader that
+// finished its batch or from whoever freed a lane, and it does not have to take the front's mutex to find out that it is done.
+enum : uint32_t { TK_WAITING = 0, TK_LEAD = 1, TK_DONE = 2 };
+inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
+  (void)syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake(std::atomic<uint32_t> *w) { (void)syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
+
 struct RankTicket {
   mrk_model *model;
   std::string model_name;
@@ -802,17 +845,25 @@ struct RankTicket {
   double *matrix;
   int status = MRK_OK;
   std::string err;
-  bool done = false;
+  std::atomic<uint32_t> state{TK_WAITING};   // TK_*: set under ctx->qmu; TK_DONE is the LAST access of anybody else to this (stack) object
+  bool taken = false;                        // travels in somebody's batch (ctx->qmu)
+  RankTicket(mrk_model *m, const char *name, const mrk_request *r, double *s, int32_t *o, double *mat)
+      : model(m), model_name(name), req(r), scores(s), order(o), matrix(mat) {}
 };
 
-// ranks tickets [0, n) as one batch; fills status / err of each.  The scratch batch of the context is owned by the
-// leader of the batching front (one at a time); the store is held shared, the launch lock only while launching.
-void rank_tickets(mrk_ctx *ctx, RankTicket **tk, int n) {
+// measurement aid (MRK_FRONT_TRACE=1; not part of include/mrk.h): per batch of the front [n, lane-wait-free build us, run us, fetch us, total us]
+struct FrontTrace { int n; float build_us, run_us, fetch_us, copy_us; };
+std::mutex g_trace_mu;
+std::vector<FrontTrace> g_trace;
+bool g_trace_on = getenv("MRK_FRONT_TRACE") != nullptr;
+
+// ranks tickets [0, n) as one batch on the lane's scratch batch (owned by the calling leader); fills status / err of each.
+// The store is held shared (several leaders build at once), the launch lock only while launching.
+void rank_tickets(mrk_ctx *ctx, mrk_batch &b, RankTicket **tk, int n) {
   auto fail_all = [&](int code, const std::string &msg) {
     for (int i = 0; i < n; ++i) { tk[i]->status = code; tk[i]->err = msg; }
   };
   try {
-    std::lock_guard<std::mutex> rl(ctx->rank_mu);
     const Program *progp;
     {
       std::shared_lock<std::shared_mutex> sl(ctx->store_mu);
@@ -820,38 +871,81 @@ void rank_tickets(mrk_ctx *ctx, RankTicket **tk, int n) {
     }
     const Program &prog = *progp;
     StoreAccess access(ctx, program_mutates_store(prog));
-    if (!ctx->rank_scratch) ctx->rank_scratch = new mrk_batch();  // grow-only: no hipMalloc / hipFree per request
-    mrk_batch &b = *(mrk_batch *)ctx->rank_scratch;
-    if (b.ctx) {  // a previous call that failed before its fetch may have left an upload from h_in in flight
-      MRK_HIP(hipSetDevice(ctx->device));
-      MRK_HIP(hipStreamSynchronize(b.s()));
-    }
+    MRK_HIP(hipSetDevice(ctx->device));
+    if (b.ctx) MRK_HIP(hipStreamSynchronize(b.s()));  // a previous call that failed before its fetch may have left an upload from h_in in flight
     std::vector<mrk_request> reqs(n);
     for (int i = 0; i < n; ++i) reqs[i] = *tk[i]->req;
-    build_batch(ctx, prog, reqs.data(), n, nullptr, b);
-    b.want_matrix = tk[0]->matrix != nullptr;
-    run_batch(b, tk[0]->model, 0, b.total_items, true, /*direct=*/true);
-    if (n == 1) {
-      fetch_batch(b, tk[0]->scores, tk[0]->order, tk[0]->matrix);
-    } else {
-      std::vector<double> sc((size_t)b.total_items), mat;
-      std::vector<int32_t> od((size_t)b.total_items);
-      if (b.want_matrix) mat.resize((size_t)b.total_items * prog.dim);
-      fetch_batch(b, sc.data(), od.data(), b.want_matrix ? mat.data() : nullptr);
-      size_t off = 0;
-      for (int i = 0; i < n; ++i) {
-        const size_t m = (size_t)std::max(tk[i]->req->n_items, 0);
-        if (tk[i]->scores) memcpy(tk[i]->scores, sc.data() + off, m * 8);
-        if (tk[i]->order) memcpy(tk[i]->order, od.data() + off, m * 4);
-        if (tk[i]->matrix) memcpy(tk[i]->matrix, mat.data() + off * prog.dim, m * prog.dim * 8);
-        off += m;
+    // Combined batches hand the candidates' ids to the device as they arrived (resolve.hip: one lane per candidate hashes and
+    // probes the mirrored id map) instead of hashing them one after the other on the leader's thread: 7 us of host work per
+    // 100-candidate request becomes a copy of its id bytes into the lane's pinned staging.  A lone request keeps the host path.
+    mrk_item_ids flat{};
+    bool use_flat = n > 1;
+    size_t total = 0, id_bytes = 0;
+    if (use_flat) {
+      for (int i = 0; i < n && use_flat; ++i) {
+        const mrk_request &rq = reqs[i];
+        if (rq.n_items < 0 || (rq.n_items > 0 && !rq.item_ids)) { use_flat = false; break; }
+        for (int k = 0; k < rq.n_items; ++k) id_bytes += rq.item_ids[k] ? strlen(rq.item_ids[k]) : 0;
+        total += (size_t)rq.n_items;
       }
+      if (total == 0 || id_bytes > 0x7fffffffull) use_flat = false;
+    }
+    if (use_flat) {
+      const size_t off_bytes = align_up((total + 1) * 4, 256);
+      b.h_ids.reserve(off_bytes + std::max<size_t>(id_bytes, 1));
+      uint32_t *offs = b.h_ids.as<uint32_t>();
+      uint8_t *bytes = b.h_ids.as<uint8_t>() + off_bytes;
+      size_t at = 0, k_all = 0;
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < reqs[i].n_items; ++k) {
+          offs[k_all++] = (uint32_t)at;
+          if (const char *id = reqs[i].item_ids[k]) {
+            const size_t len = strlen(id);
+            memcpy(bytes + at, id, len);
+            at += len;
+          }
+        }
+      offs[k_all] = (uint32_t)at;
+      flat.bytes = bytes;
+      flat.offsets = offs;
+      flat.bytes_len = at;
+    }
+    const auto c0 = std::chrono::steady_clock::now();
+    build_batch(ctx, prog, reqs.data(), n, use_flat ? &flat : nullptr, b);
+    b.want_matrix = tk[0]->matrix != nullptr;
+    const auto c1 = std::chrono::steady_clock::now();
+    run_batch(b, tk[0]->model, 0, b.total_items, true, /*direct=*/true);
+    const auto c2 = std::chrono::steady_clock::now();
+    std::vector<double> mat;   // the explain matrix of a combined batch is the one thing still staged (rare path)
+    if (b.want_matrix && n > 1) mat.resize((size_t)b.total_items * prog.dim);
+    enqueue_fetch(b, true, true);
+    b.fetch_enqueued = true;
+    access.release();   // (want_matrix was set before the run: the matrix, if asked for, is already assembled)
+    fetch_batch(b, nullptr, nullptr, !b.want_matrix ? nullptr : n == 1 ? tk[0]->matrix : mat.data());
+    const auto c3 = std::chrono::steady_clock::now();
+    // every caller's slice straight out of the lane's pinned result buffer
+    const uint8_t *h = b.h_out.as<uint8_t>();
+    const double *sc = (const double *)h;
+    const int32_t *od = (const int32_t *)(h + b.out_order_off);
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+      const size_t m = (size_t)std::max(tk[i]->req->n_items, 0);
+      if (tk[i]->scores && m) memcpy(tk[i]->scores, sc + off, m * 8);
+      if (tk[i]->order && m) memcpy(tk[i]->order, od + off, m * 4);
+      if (tk[i]->matrix && n > 1 && m) memcpy(tk[i]->matrix, mat.data() + off * prog.dim, m * prog.dim * 8);
+      off += m;
     }
     for (int i = 0; i < n; ++i) tk[i]->status = status_to_code(b.h_status[i], tk[i]->err);
+    if (g_trace_on) {
+      const auto c4 = std::chrono::steady_clock::now();
+      auto us = [](auto a, auto b2) { return (float)std::chrono::duration<double, std::micro>(b2 - a).count(); };
+      std::lock_guard<std::mutex> tl(g_trace_mu);
+      g_trace.push_back({n, us(c0, c1), us(c1, c2), us(c2, c3), us(c3, c4)});
+    }
   } catch (const StatusError &e) {
     if (n == 1) fail_all(e.status, e.what());
     else {  // a request the host rejects (bad arguments, dim mismatch) must not fail its neighbours: one by one
-      for (int i = 0; i < n; ++i) rank_tickets(ctx, tk + i, 1);
+      for (int i = 0; i < n; ++i) rank_tickets(ctx, b, tk + i, 1);
     }
   } catch (const std::bad_alloc &) {
     fail_all(MRK_ERR_DEVICE, "out of host memory");
@@ -859,58 +953,115 @@ void rank_tickets(mrk_ctx *ctx, RankTicket **tk, int n) {
     fail_all(MRK_ERR_PARSE, e.what());
   }
 }
+
+// the lane's scratch batch, created on first use (caller holds the lane); lane 0 runs on the context stream
+mrk_batch *lane_batch(mrk_ctx *ctx, int lane) {
+  if (!ctx->rank_lane[lane]) {
+    std::unique_ptr<mrk_batch> nb(new mrk_batch());
+    if (lane > 0) {
+      MRK_HIP(hipSetDevice(ctx->device));
+      MRK_HIP(hipStreamCreateWithFlags(&nb->stream, hipStreamNonBlocking));
+    }
+    ctx->rank_lane[lane] = nb.release();
+  }
+  return (mrk_batch *)ctx->rank_lane[lane];
+}
 }  // namespace
 
 int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
              int32_t *out_order, double *out_matrix) {
   if (!req || !ctx || !model_name) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
   if (model && model->ctx != ctx) { set_last_error("model belongs to another context"); return MRK_ERR_INVALID_ARG; }
-  RankTicket t{model, model_name, req, out_scores, out_order, out_matrix};
+  RankTicket t(model, model_name, req, out_scores, out_order, out_matrix);
   const Switches &sw = switches();
-  if (!sw.rank_combine) {
-    RankTicket *one = &t;
-    rank_tickets(ctx, &one, 1);
-  } else {
-    // Whoever finds no leader becomes one, serves ONE batch (its own ticket is in it: the queue is FIFO and the leader's
-    // ticket is its oldest compatible entry or was taken by the previous leader) and hands leadership to a waiter - a
-    // caller never serves other callers' batches after its own result is ready.
-    std::unique_lock<std::mutex> lk(ctx->qmu);
-    ctx->rank_queue.push_back(&t);
-    while (!t.done) {
-      if (ctx->rank_leader) {
-        ctx->qcv.wait(lk, [&] { return t.done || !ctx->rank_leader; });
-        continue;
+  const int n_lanes = sw.rank_lanes;
+  // Wake-ups are targeted: a finished batch wakes the callers of ITS tickets, a freed lane elects the OLDEST waiting ticket as
+  // the next leader - nobody else.  (One condition variable and notify_all - round 6's first version - woke every waiting caller
+  // on every batch: at 64 callers x 4 lanes 1.4 M wake-ups a second queued up on this mutex, profiles/r06_d.)
+  auto free_lane = [&]() {
+    for (int i = 0; i < n_lanes; ++i)
+      if (!ctx->lane_busy[i]) return i;
+    return -1;
+  };
+  auto elect = [&]() {  // (qmu held) a lane is free: the oldest waiting ticket leads
+    if (ctx->rank_queue.empty() || free_lane() < 0) return;
+    RankTicket *q = (RankTicket *)ctx->rank_queue.front();
+    if (q->state.exchange(TK_LEAD, std::memory_order_acq_rel) == TK_WAITING) futex_wake(&q->state);
+  };
+  std::unique_lock<std::mutex> lk(ctx->qmu);
+  bool queued = false;
+  for (;;) {
+    const int lane = t.taken ? -1 : free_lane();
+    if (lane < 0) {
+      // my ticket travels in somebody else's batch, or every lane is busy: wait for TK_DONE or for my election
+      if (!queued && !t.taken) { ctx->rank_queue.push_back(&t); queued = true; }
+      {  // an election that found the lane gone again (or the ticket taken meanwhile): back to waiting - unless it is done already
+        uint32_t was = TK_LEAD;
+        (void)t.state.compare_exchange_strong(was, TK_WAITING, std::memory_order_acq_rel);
       }
-      ctx->rank_leader = true;
-      struct Resign {  // leadership is given up whatever happens in the batch
-        mrk_ctx *c;
-        std::unique_lock<std::mutex> &l;
-        ~Resign() {
-          if (!l.owns_lock()) l.lock();
-          c->rank_leader = false;
-          c->qcv.notify_all();
-        }
-      } resign{ctx, lk};
-      // this caller's ticket plus everything queued that is compatible with it
-      std::vector<RankTicket *> take;
-      std::vector<void *> rest;
-      take.push_back(&t);
-      for (void *p : ctx->rank_queue) {
-        RankTicket *q = (RankTicket *)p;
-        if (q == &t) continue;
-        const bool ok = (int)take.size() < sw.combine_max && q->model == t.model && q->model_name == t.model_name &&
-                        (q->matrix != nullptr) == (t.matrix != nullptr);
-        if (ok) take.push_back(q); else rest.push_back(p);
-      }
-      ctx->rank_queue.swap(rest);
       lk.unlock();
-      rank_tickets(ctx, take.data(), (int)take.size());
+      uint32_t st = t.state.load(std::memory_order_acquire);
+      // (Measured and removed: up to four waiting callers polling their ticket for a batch's duration before sleeping - no gain
+      //  at 4 / 16 callers, -3 % at 64 ... 256 on a box with a 16-CPU quota, profiles/r06_e_callers.txt.)
+      while (st == TK_WAITING) {
+        futex_wait(&t.state, TK_WAITING);
+        st = t.state.load(std::memory_order_acquire);
+      }
+      if (st == TK_DONE) break;   // (without the mutex: whoever set it does not touch the ticket again)
       lk.lock();
-      for (RankTicket *q : take) q->done = true;
+      if (t.state.load(std::memory_order_acquire) == TK_DONE) { lk.unlock(); break; }
+      continue;
     }
+    // Lead ONE batch on this lane: my ticket plus everything queued that is compatible with it, in arrival order.  A caller
+    // never serves other callers' batches after its own result is ready.
+    ctx->lane_busy[lane] = true;
+    std::vector<RankTicket *> take;
+    std::vector<void *> rest;
+    take.push_back(&t);
+    for (void *p : ctx->rank_queue) {
+      RankTicket *q = (RankTicket *)p;
+      if (q == &t) continue;
+      const bool ok = sw.rank_combine && (int)take.size() < sw.combine_max && q->model == t.model && q->model_name == t.model_name &&
+                      (q->matrix != nullptr) == (t.matrix != nullptr);
+      if (ok) take.push_back(q); else rest.push_back(p);
+    }
+    ctx->rank_queue.swap(rest);
+    for (RankTicket *q : take) q->taken = true;
+    elect();   // tickets this batch does not take (another model, an explain request) need not wait for it: another lane may be free
+    lk.unlock();
+    try {
+      rank_tickets(ctx, *lane_batch(ctx, lane), take.data(), (int)take.size());
+    } catch (const std::exception &e) {  // (lane creation: rank_tickets itself reports through the tickets)
+      for (RankTicket *q : take) { q->status = MRK_ERR_DEVICE; q->err = e.what(); }
+    }
+    lk.lock();
+    ctx->lane_busy[lane] = false;
+    elect();
+    lk.unlock();
+    // results are in the callers' arrays: release them - outside the mutex, one system call each; TK_DONE is the last access
+    // to a ticket (its caller may return, and the object is gone, the moment it is visible)
+    for (RankTicket *q : take) {
+      if (q == &t) continue;
+      std::atomic<uint32_t> *w = &q->state;
+      if (w->exchange(TK_DONE, std::memory_order_acq_rel) == TK_WAITING) futex_wake(w);
+    }
+    break;
   }
   if (t.status != MRK_OK) set_last_error(t.err);
   return t.status;
+}
+
+/* not part of include/mrk.h: the front's per-batch phase times since the last call (MRK_FRONT_TRACE=1); out = rows of 5 floats */
+int mrk_debug_front_trace(float *out, int cap_rows) {
+  std::lock_guard<std::mutex> tl(g_trace_mu);
+  const int n = (int)std::min<size_t>(g_trace.size(), (size_t)std::max(cap_rows, 0));
+  for (int i = 0; i < n; ++i) {
+    out[5 * i] = (float)g_trace[i].n; out[5 * i + 1] = g_trace[i].build_us; out[5 * i + 2] = g_trace[i].run_us;
+    out[5 * i + 3] = g_trace[i].fetch_us; out[5 * i + 4] = g_trace[i].copy_us;
+  }
+  const int total = (int)g_trace.size();
+  g_trace.clear();
+  return total;
 }
 
 int mrk_rank_binary(mrk_ctx *ctx, mrk_model *model, const char *model_name, const uint8_t *event, size_t len,
@@ -1415,6 +1566,13 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
     srv->idle_ticks = (uint64_t)std::max(1, switches().serve_idle_us) * 100ull;  // wall_clock64: 100 MHz
     srv->life_ticks = (uint64_t)std::max(1, switches().serve_life_us) * 100ull;
     srv->jit_fn = jit_serve_function(prog, srv->f64, switches().thr_stage ? &model->qs_sig : nullptr);  // warm-up: the compile happens here, not under the first request
+    // Every slot's workgroup is a kernel of its own on a stream of its own, and it STAYS (up to MRK_SERVE_LIFE_US): streams that
+    // share a hardware queue wait for each other, so a slot whose stream landed behind another slot's resident kernel answered
+    // 20 ... 200 ms late - round 5's "collapse at 32 callers" (p99 76 ms; ROCm maps a process's streams onto GPU_MAX_HW_QUEUES = 4
+    // hardware queues by default; with 32 of them 16 callers hold p99 0.16 ms at 112 k requests/s, profiles/r06_d_callers_serve.txt).
+    // mrk_init asks for more hardware queues (hw_queue_budget, capi.cpp); the slots beyond what those can hold are not created:
+    // their callers go through mrk_rank's front, which combines them.
+    n_slots = std::max(1, std::min(n_slots, hw_queue_budget() - 4));   // 4: the context stream, the lanes of mrk_rank's front, a batch
     for (int i = 0; i < n_slots; ++i) {
       std::unique_ptr<ServeSlot> sl(new ServeSlot());
       MRK_HIP(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));

@@ -611,7 +611,7 @@ Registry::~Registry() {
 void unbind_encoders(mrk_ctx *ctx) {
   std::vector<mrk_encoder *> drop;
   {
-    std::unique_lock<std::shared_mutex> lk(ctx->store_mu);
+    StoreWriteLock lk(ctx);
     if (ctx->registry)
       for (auto &f : ctx->registry->features)
         if (f->encoder) { drop.push_back(f->encoder); f->encoder = nullptr; }
@@ -620,7 +620,7 @@ void unbind_encoders(mrk_ctx *ctx) {
 }
 
 void bind_encoder(mrk_ctx *ctx, const char *feature, mrk_encoder *enc) {
-  std::unique_lock<std::shared_mutex> lk(ctx->store_mu);  // resolve_requests reads FeatureDef::encoder under the shared lock
+  StoreWriteLock lk(ctx);  // resolve_requests reads FeatureDef::encoder under the shared lock
   if (!ctx->registry) throw StatusError(MRK_ERR_INVALID_ARG, "mrk_config_bind_encoder: load a config first");
   for (auto &f : ctx->registry->features)
     if (f->name == feature) {
@@ -1036,7 +1036,6 @@ void resolve_requests(const Program &prog, Store &store, const mrk_request *reqs
     if (rows.empty()) continue;
     std::vector<float> logits(rows.size());
     encoder_score_rows(f.encoder, rows, logits.data());
-    size_t at = 0;
     // raw logits (SingleValue(name, score: Float) widens); schema.norm.scale runs on the device over the request's whole
     // column - these, the scores the caller already had, NaN for the rest (FieldMatchCrossEncoderFeature.scala:104-111)
     for (size_t k = 0; k < where.size(); ++k) cross_values.push_back({where[k].first, where[k].second, ho.dst, (double)logits[k]});

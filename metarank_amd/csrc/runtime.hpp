@@ -50,10 +50,16 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+  // The first allocation is exact; a buffer that has to GROW is one whose size follows the traffic (the scratch batches of
+  // mrk_rank's front: the combined batch is whatever was queued), and every regrowth is a hipFree - a device-wide
+  // synchronisation - plus a hipMalloc: milliseconds, seen as 40-90 ms p99 by 64 callers while eight lanes found their sizes
+  // (profiles/r06_c).  So regrowth at least doubles (x 1.25 beyond 256 MB).
   void reserve(size_t bytes) {
     if (bytes <= cap) return;
+    const size_t grown = cap >= (256u << 20) ? cap + cap / 4 : cap * 2;
     release();
     size_t want = bytes < 256 ? 256 : bytes;
+    if (grown > want) want = grown;
     MRK_HIP(hipMalloc(&p, want));
     cap = want;
   }
@@ -69,11 +75,14 @@ struct PinBuf {
   PinBuf(const PinBuf &) = delete;
   PinBuf &operator=(const PinBuf &) = delete;
   ~PinBuf() { if (p) (void)hipHostFree(p); }
-  void reserve(size_t bytes) {
+  void reserve(size_t bytes) {  // (regrowth doubles, like DevBuf's)
     if (bytes <= cap) return;
+    const size_t grown = cap >= (256u << 20) ? cap + cap / 4 : cap * 2;
     if (p) (void)hipHostFree(p);
     p = nullptr;
+    cap = 0;
     size_t want = bytes < 4096 ? 4096 : bytes;
+    if (grown > want) want = grown;
     MRK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
     cap = want;
   }
@@ -107,6 +116,7 @@ struct Switches {
   bool rank_fused_score = false; // MRK_RANK_FUSED_SCORE=1: full batches of small requests in ONE launch (assembly, forest, ordering per request workgroup) - measured slower than the three launches, kept for A/B
   bool rank_one = true;        // MRK_RANK_ONE=0: mrk_rank's small batches take the three-launch path instead of the one-launch kernel
   int combine_max = 256;       // MRK_RANK_COMBINE_MAX
+  int rank_lanes = 3;          // MRK_RANK_LANES: batches of mrk_rank's front in flight at once (1 ... 8)
   int table_load_pct = 75;     // MRK_TABLE_LOAD_PCT
   int host_threads = 0;        // MRK_HOST_THREADS (0: min(8, hardware threads))
   int jit_mode = 4;            // MRK_RANK_JIT: 0 off, 1 on (wait for the compiler), 2 require, 3 async, 4 auto (default: disk cache at once, else async)
@@ -135,6 +145,7 @@ struct Switches {
 const Switches &switches();
 void reload_switches();
 
+
 }  // namespace mrk
 
 struct mrk_ctx {
@@ -153,6 +164,10 @@ struct mrk_ctx {
   // that read the device tables takes it shared (a flush may reallocate the tables; it waits for the device first).
   // Lock order: store_mu before mu.
   std::shared_mutex store_mu;
+  // libstdc++'s shared_mutex prefers readers; since round 6 several leaders of mrk_rank's front hold the store shared at
+  // overlapping times, so a put could wait for ever.  Writers announce themselves (StoreWriteLock) and new readers
+  // (StoreAccess, capi_rank.cpp) let them pass first.
+  std::atomic<int> store_writers{0};
   // scratch for predict_f64
   mrk::DevBuf d_x, d_out, d_flag;
   mrk::DevBuf d_cells;  // binned tile of the bit-vector scorer (score_qs.hip), grow-only
@@ -164,7 +179,11 @@ struct mrk_ctx {
   // feature side (created by mrk_config_load_json)
   mrk::Registry *registry = nullptr;  // owned; freed by mrk::free_rank_state
   mrk::Store *store = nullptr;
-  void *rank_scratch = nullptr;       // mrk_batch reused by mrk_rank (owned; freed by mrk::free_rank_state)
+  // mrk_rank's scratch batches ("lanes": grow-only mrk_batch objects, lane 0 on the context stream, the others on streams of
+  // their own; owned, freed by mrk::free_rank_state).  A lane is held by one leader of the batching front at a time (qmu).
+  static constexpr int RANK_LANES_MAX = 8;
+  void *rank_lane[RANK_LANES_MAX] = {};
+  bool lane_busy[RANK_LANES_MAX] = {};
   // multi-GPU (comm.cpp): the RCCL communicator this context's device belongs to (ncclComm_t), nullptr = a world of one
   void *comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -174,15 +193,24 @@ struct mrk_ctx {
   std::mutex comm_mu;
   std::mutex servers_mu;              // the serving queues of this context (capi_rank.cpp mrk_serve_*): a store flush stops their workgroups
   std::vector<void *> servers;        // mrk_server*
-  std::mutex rank_mu;                 // owner of rank_scratch (the leader of the batching front, or a caller with the front off)
-  // batching front of mrk_rank: concurrent callers are combined into one device batch by whichever caller
-  // finds no leader active (capi_rank.cpp)
+  // batching front of mrk_rank: concurrent callers are combined into device batches by whichever waiting caller finds a
+  // free lane (capi_rank.cpp); several batches are in flight at once - one per lane
   std::mutex qmu;
   std::condition_variable qcv;
   std::vector<void *> rank_queue;     // RankTicket*
-  bool rank_leader = false;
   mrk_ctx();
   ~mrk_ctx();
+};
+
+// exclusive access to a context's feature store, with precedence over readers that have not started yet
+struct StoreWriteLock {
+  mrk_ctx *ctx;
+  std::unique_lock<std::shared_mutex> lk;
+  explicit StoreWriteLock(mrk_ctx *c) : ctx(c) {
+    ctx->store_writers.fetch_add(1);
+    lk = std::unique_lock<std::shared_mutex>(ctx->store_mu);
+    ctx->store_writers.fetch_sub(1);
+  }
 };
 
 struct mrk_model {
@@ -216,6 +244,10 @@ void drain_profile_events(mrk_ctx *ctx);
 // (mrk_init with n contexts) has to opt in once per (device, function), whichever thread launches first.  Cheap on the
 // launch path: a thread-local memo of the last pair in front of a mutex-protected set.
 void lds_optin(mrk_ctx *ctx, const void *fn, int bytes = 160 * 1024);
+
+// Hardware queues the HIP runtime may spread this process's streams over (GPU_MAX_HW_QUEUES; ROCm's default is 4).  The first
+// mrk_* call that touches HIP sets it to 24 unless the host has set it; returns what is in force as far as the library can tell.
+int hw_queue_budget();
 
 void ctx_retain(mrk_ctx *ctx);
 void ctx_release(mrk_ctx *ctx);

@@ -3,6 +3,7 @@ mrk_batch_enqueue_fetch / mrk_batch_host_outputs): item ids travel as UTF-8 byte
 kernel (csrc/resolve.hip), pre-pass tables are sized from bounds, results land in pinned memory.  Everything must equal
 the oracle - and the pointer-style path (host lookups, exact table sizes) - bit for bit."""
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -477,4 +478,98 @@ def test_item_id_offsets_from_the_wire_are_checked(oracle_c2):
         batch.close()
         rs.close()
     finally:
+        hip.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["mrk_rank", "mrk_serve_rank"])
+def test_native_callers_stress_the_front_while_a_writer_puts(oracle_c2, tmp_path, entry):
+    """64 NATIVE threads (tools/native/callers_driver.cpp: C++ against include/mrk.h, no interpreter between the calls) x 150
+    requests each through mrk_rank's pipelined front - several lanes in flight, ids of combined batches resolved on the device -
+    and through the serving queue, while a writer keeps putting values (the id table grows; every put needs the store
+    exclusively, and must not starve behind the overlapping leaders).  Every result equals the oracle's bit for bit; the
+    writer makes progress; no call takes seconds."""
+    import ctypes as C
+    import os
+    import subprocess
+
+    from metarank_amd import _native as N
+    from metarank_amd.request import request_array
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libcallers_driver.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-I", os.path.join(repo, "include"),
+                           os.path.join(repo, "tools", "native", "callers_driver.cpp"), "-o", so, "-L", os.path.dirname(N.LIB_PATH), "-lmrk_hip",
+                           "-Wl,-rpath," + os.path.dirname(N.LIB_PATH), "-pthread"])
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    srv = None
+    try:
+        ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
+        events = ranklens.generate_requests(120, 100, N_ITEMS, N_SESS, seed=91) + ranklens.generate_requests(8, 7, N_ITEMS, N_SESS, seed=92)
+        events.append({"id": "odd", "timestamp": ranklens.TS, "user": None, "session": events[0]["session"], "fields": [],
+                       "items": [{"id": "nobody"}, {"id": "12"}, {"id": "1"}, {"id": "123456789"}, {"id": ""}, {"id": "фильм-7"}, {"id": "12"}]})
+        q = ranklens.column_quantiles(np.concatenate([oracle_c2.matrix(ev) for ev in events[:16]]))
+        blob = synth.synthetic_lgbm_model(n_trees=150, n_features=24, quantiles=q, cat_features=[7], cat_prob=0.02)
+        oracle_c2.load_model(blob, 0)
+        hip.load_model(blob, 0)
+        items = 100
+        sc = np.zeros((len(events), items), dtype=np.float64)
+        od = np.zeros((len(events), items), dtype=np.int32)
+        for i, ev in enumerate(events):
+            _, es, eo = oracle_c2.rerank(ev)
+            sc[i, :len(es)] = es
+            od[i, :len(eo)] = eo
+        reqs = [M.Request(e) for e in events]
+        arr = request_array(reqs)
+        for r in reqs[:4]:
+            hip.ranker.rerank("xgboost", r, hip.booster)
+        hip.ranker.warmup_kernels("xgboost")
+        if entry == "mrk_serve_rank":
+            srv = hip.ranker.serve("xgboost", hip.booster, n_slots=32)
+            for r in reqs[:4]:
+                srv.rerank(r)
+        N.lib()
+        d = C.CDLL(so)
+        d.mrk_bench_callers.restype = C.c_int
+        d.mrk_bench_callers.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        def drive(threads, per_thread):
+            lat = np.zeros(threads * per_thread, dtype=np.float64)
+            out = np.zeros(8, dtype=np.float64)
+            rc = d.mrk_bench_callers(hip.ranker.ctx.handle, hip.booster.handle, b"xgboost", srv._h if srv is not None else None, C.addressof(arr), len(reqs),
+                                     items, threads, per_thread, lat.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                     od.ctypes.data_as(C.c_void_p))
+            return rc, lat, out
+
+        # warm-up: combined batches of every size class reach kernels single requests never use (under MRK_RANK_JIT=1 - what the
+        # suite runs with - the first use of each waits ~4 s for the compiler); their results are checked too
+        for warm_threads in (3, 12, 40):
+            rc, _, out = drive(warm_threads, 6)
+            assert rc == 0 and out[1] == 0 and out[3] == 0, (warm_threads, rc, out[1], out[3])
+        stop = threading.Event()
+        puts = [0]
+
+        def writer():   # ~5 000 puts a second: above what the reference's import path sustains (doc/performance.md:7: 1 000 - 3 000 events/s)
+            i = 0
+            while not stop.is_set():
+                hip.put_double(f"item=stress-{i % 500}/popularity", float(i))  # items no request names
+                i += 1
+                puts[0] = i
+                time.sleep(0.0002)
+
+        w = threading.Thread(target=writer)
+        w.start()
+        threads, per_thread = 64, 150
+        rc, lat, out = drive(threads, per_thread)
+        stop.set()
+        w.join()
+        print(f"\n{entry}: {threads * per_thread / out[0]:.0f} requests/s with a writer ({puts[0]} puts), p50 {np.percentile(lat, 50):.3f} ms, "
+              f"p99 {np.percentile(lat, 99):.3f} ms, max {lat.max():.1f} ms")
+        assert rc == 0 and out[1] == 0, (rc, out[1])
+        assert out[3] == 0, f"{int(out[3])} of {threads * per_thread} concurrent results differ from the oracle"
+        assert puts[0] > 20, "the writer starved behind the readers"
+        assert lat.max() < 2000.0
+    finally:
+        if srv is not None:
+            srv.close()
         hip.close()
