@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--depth", type=int, default=6, help="xgboost: tree depth (Metarank's XGBoost default maxDepth is 8)")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="requests timed on the CPU oracle (0 = skip)")
     ap.add_argument("--latency-requests", type=int, default=300, help="single-request latency samples (0 = skip, also skips the sweep)")
+    ap.add_argument("--concurrent-callers", default=None, help="caller counts of the concurrent-callers leg of `latency` ('' = skip)")
+    ap.add_argument("--concurrent-requests", type=int, default=400, help="... requests per caller")
     ap.add_argument("--latency-sweep", type=int, default=None,
                     help="sequential requests per size of the reference's latency protocol (sizes 25..300; default 5000 for the default c2 run, 0 = skip)")
     args = ap.parse_args()
@@ -108,6 +110,8 @@ def main():
     sharded = wl in ("c4", "c4x")
     if args.latency_sweep is None:
         args.latency_sweep = 5000 if (wl == "c2" and args.gpus == 1) else 0
+    if args.concurrent_callers is None:
+        args.concurrent_callers = "1,16,64,128,256" if (wl == "c2" and args.gpus == 1) else ""
     if wl == "c4x":
         args.cpu_sample, args.latency_requests = 0, 0
     if args.trees is None:
@@ -862,6 +866,60 @@ def main():
                 latency["sweep"] = sw
             except Exception as e:  # noqa: BLE001
                 latency["sweep"] = {"error": str(e)}
+
+        # ---- concurrent callers of the per-request entry point: how `Ranker.rerank` is driven by the reference's host (one fiber
+        #      per request, api/routes/RankApi.scala:25-41).  NATIVE threads (tools/native/callers_driver.cpp: C++ against include/mrk.h,
+        #      nothing between the calls), closed loop, each result compared bit for bit with the sequential pass above.
+        if enc is None and not sharded and args.concurrent_callers:
+            try:
+                import ctypes as C
+                from metarank_amd.request import request_array
+                drv_c = os.path.join(REPO, "tools", "native", "libcallers_driver.so")
+                if not os.path.exists(drv_c):
+                    raise RuntimeError("tools/native/libcallers_driver.so is not built (__graft_entry__.build)")
+                dc = C.CDLL(drv_c)
+                dc.mrk_bench_callers.restype = C.c_int
+                dc.mrk_bench_callers.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                counts = [int(x) for x in args.concurrent_callers.split(",")]
+                c_events = ranklens.generate_requests(max(counts) * 8, args.items, args.catalogue, args.sessions, seed=ranklens.SEED + 9100)
+                c_reqs = [M.Request(e) for e in c_events]
+                c_arr = request_array(c_reqs)
+                c_sc = np.zeros((len(c_reqs), args.items), dtype=np.float64)
+                c_od = np.zeros((len(c_reqs), args.items), dtype=np.int32)
+                for i_, r in enumerate(c_reqs):
+                    _, s_, o_ = ranker.rerank(model_name, r, booster)
+                    c_sc[i_, :len(s_)] = s_
+                    c_od[i_, :len(o_)] = o_
+
+                def callers(threads, per_thread, srv_handle=None):
+                    lat_ = np.zeros(threads * per_thread, dtype=np.float64)
+                    out_ = np.zeros(8, dtype=np.float64)
+                    rc_ = dc.mrk_bench_callers(ctx.handle, booster.handle, model_name.encode(), srv_handle, C.addressof(c_arr), len(c_reqs), args.items, threads,
+                                               per_thread, lat_.ctypes.data_as(C.c_void_p), out_.ctypes.data_as(C.c_void_p), c_sc.ctypes.data_as(C.c_void_p),
+                                               c_od.ctypes.data_as(C.c_void_p))
+                    assert rc_ == 0 and out_[1] == 0, (rc_, out_[1])
+                    n_ = threads * per_thread
+                    return {"callers": threads, "requests_per_s": n_ / out_[0], "items_per_s": n_ * args.items / out_[0],
+                            "p50_ms": float(np.percentile(lat_, 50, method="weibull")), "p99_ms": float(np.percentile(lat_, 99, method="weibull")),
+                            "max_ms": float(lat_.max()), "results_differing_from_sequential": int(out_[3])}
+
+                for warm_n in (4, 16, 48):   # batch kernels of every size class, the lanes' buffers
+                    callers(warm_n, 40)
+                conc = {"driver": "native threads (tools/native/callers_driver.cpp), closed loop, every result checked against a sequential pass",
+                        "host_cpus": os.cpu_count(), "cpu_quota": (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
+                        "requests_per_caller": args.concurrent_requests,
+                        "mrk_rank": [callers(t_, args.concurrent_requests) for t_ in counts]}
+                if info["bitvector"] and args.items <= 128:
+                    srv = ranker.serve(model_name, booster, n_slots=32)
+                    for r in c_reqs[:8]:
+                        srv.rerank(r)
+                    conc["mrk_serve_rank"] = [callers(t_, args.concurrent_requests, srv._h) for t_ in counts if t_ <= 64]
+                    conc["mrk_serve_rank_stats"] = srv.stats()
+                    srv.close()
+                latency["concurrent"] = conc
+            except Exception as e:  # noqa: BLE001
+                latency["concurrent"] = {"error": str(e)}
 
     # ---- CPU baseline: the oracle (scalar C++ port of the reference read path + forest walk), 1 thread
     cpu = None
