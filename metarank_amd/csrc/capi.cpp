@@ -57,7 +57,6 @@ static Switches read_switches() {
   s.qs_split = num("MRK_QS_SPLIT", -1);
   s.qs_kernel = num("MRK_QS_KERNEL", 1);
   s.qs_r = num("MRK_QS_R", 2);
-  s.qs_lds_min = std::max(0, num("MRK_QS_LDS_MIN", 0));
   s.walk_tile = num("MRK_WALK_TILE", 0);
   s.encoder_graph = flag("MRK_ENCODER_GRAPH", false);
   s.encoder_skinny = num("MRK_ENCODER_SKINNY", 15);

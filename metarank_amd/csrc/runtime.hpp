@@ -136,7 +136,6 @@ struct Switches {
   int qs_split = -1;           // MRK_QS_SPLIT
   int qs_kernel = 1;           // MRK_QS_KERNEL
   int qs_r = 2;                // MRK_QS_R
-  int qs_lds_min = 0;          // MRK_QS_LDS_MIN: least dynamic LDS the bit-vector scorer's workgroups ask for (experiments: caps its residency per CU - co-residency with the assembly kernel of the other stream)
   int walk_tile = 0;           // MRK_WALK_TILE=256: the tree-walk scorer's rows per workgroup (default: 512 where the tile fits)
   bool encoder_graph = false;  // MRK_ENCODER_GRAPH
   int encoder_skinny = 15;     // MRK_ENCODER_SKINNY

@@ -409,8 +409,7 @@ void launch_wave(mrk_ctx *ctx, mrk_model *m, const uint16_t *d_cells, int rows, 
   const int split_env = switches().qs_split;
   const int nw = split_env >= 0 ? split_env : scorer_waves_per_tile(n_tiles, V, F64, ctx->n_cus, QS_LEAVES, QS_TILE_ROWS);
   if (nw == 2 || nw == 4 || nw == 8 || nw == 16) {
-    size_t lds = (size_t)V * 256 + (size_t)8 * nw * (QS_LEAVES * (F64 ? 8 : 4) + QS_TILE_ROWS);
-    if (lds <= 160 * 1024 && switches().qs_lds_min > 0) lds = std::min<size_t>(160 * 1024, std::max<size_t>(lds, (size_t)switches().qs_lds_min));
+    const size_t lds = (size_t)V * 256 + (size_t)8 * nw * (QS_LEAVES * (F64 ? 8 : 4) + QS_TILE_ROWS);
     if (lds <= 160 * 1024) {
       ScopedKernelTimer timer(ctx, "score");
 #define MRK_SPLIT(NW_)                                                                                                      \

@@ -24,6 +24,7 @@ flags = [a for a in sys.argv[1:] if a.startswith("--")]
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 if "--lanes" in flags:   # (must be set before the library reads its switches)
     os.environ["MRK_RANK_LANES"] = argv.pop(0)
+slots_wish = int(argv.pop(0)) if "--slots" in flags else 64
 import metarank_amd as M
 from metarank_amd import _native as N
 from metarank_amd.request import request_array
@@ -128,7 +129,7 @@ def main():
     d = driver()
     rows = []
     for threads in thread_counts:
-        srv = ranker.serve("xgboost", booster, n_slots=min(threads, 64)) if serve else None
+        srv = ranker.serve("xgboost", booster, n_slots=min(threads, slots_wish)) if serve else None
         if srv is not None:
             for r in reqs[:16]:
                 srv.rerank(r)
