@@ -379,6 +379,19 @@ def main():
         if n:
             kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / prof_steps}
     ctx.profile_enable(False)
+    if os.environ.get("MRK_BENCH_PHASE"):   # measurement builds (MRK_DEFINES=MRK_PHASE_CLOCKS): where the specialised kernel's cycles go
+        import ctypes as C
+        lib_ = M.lib()
+        lib_.mrk_debug_phase.restype = C.c_int
+        lib_.mrk_debug_phase.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        out_ = (C.c_uint64 * 64)()
+        rc_ = lib_.mrk_debug_phase(ctx._h, model_name.encode(), out_)
+        v_ = [float(x) for x in out_]
+        wg_ = max(v_[6], 1.0)
+        log(f"phase clocks rc={rc_} workgroups={int(wg_)} per workgroup (thread 0): " +
+            ", ".join(f"[{i}] {v_[i] / wg_:.0f}" for i in (0, 1, 2, 3, 4, 5, 7)))
+        feats_ = cfg["models"][model_name]["features"]
+        log("per op: " + ", ".join(f"{n} {v_[16 + i] / wg_:.0f}" for i, n in enumerate(feats_)))
     for k in kernels:
         kernels[k]["launches_per_batch"] = kernels[k].pop("launches_per_step")
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_batch"])

@@ -88,7 +88,7 @@ def build(force: bool = False) -> str:
     defines = [f"-D{d}" for d in os.environ.get("MRK_DEFINES", "").split()]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-ffp-contract=off"] + defines  # the JVM never fuses a*b+c; parity with the reference is bit-exact
-    objdir = os.path.join(HERE, "build")
+    objdir = os.environ.get("MRK_BUILD_DIR") or os.path.join(HERE, "build")  # MRK_BUILD_DIR + MRK_LIB: a second build (other defines) beside the default one
     os.makedirs(objdir, exist_ok=True)
     stamp = os.path.join(objdir, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):

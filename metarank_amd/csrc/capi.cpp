@@ -42,6 +42,8 @@ static Switches read_switches() {
   s.jit_record_regs = flag("MRK_JIT_REGS", true);
   s.jit_sig = flag("MRK_JIT_SIG", true);
   s.items_lds = flag("MRK_ITEMS_LDS", true);
+  s.items_rt = flag("MRK_ITEMS_RT", true);
+  s.items_rt_threads = num("MRK_ITEMS_RT_THREADS", 0);
   s.jit_shipped = flag("MRK_JIT_SHIPPED", true);
   if (const char *d = getenv("MRK_JIT_DEFINES")) s.jit_defines = d; else s.jit_defines.clear();
   s.thr_stage = flag("MRK_THR_STAGE", true);

@@ -33,7 +33,7 @@ size_t big_sort_scratch_bytes(int n);
 void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows, int cols, double *d_out,
                         int *d_status, const uint32_t *d_row_req);
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
-                           uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries);
+                           uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries, void *jit_rt_fn = nullptr, uint32_t thr_total = 0);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, int op_split, int slices, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
 size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap);
@@ -432,6 +432,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
                         : fused_score ? jit_fused_score_function(*b.prog, f64, sig)
                         : !b.fused_ok ? jit_items_function(*b.prog, f64, sig)
                         : b.fused_split > 1 || b.fused_slices > 1 ? jit_split_function(*b.prog, f64, sig) : jit_rank_function(*b.prog, f64, sig);
+  void *jit_rt_fn = cells && !one && !fused_score && !b.fused_ok ? jit_items_rt_function(*b.prog, f64, sig) : nullptr;   // the resident-table form of the item-parallel kernel
   void *jit_prep_fn = cells && !one && !fused_score && !b.fused_ok && b.prog->prep.size() && sw.jit_prepass ? jit_prepass_function(*b.prog) : nullptr;   // (before LaunchOn: a first use may compile)
   LaunchOn on(ctx, b.s());
   const StoreDev st = ctx->store->device_view();
@@ -474,7 +475,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
       launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, b.fused_slices, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
     } else {
       launch_prepass(ctx, st, pd, b.view, b.fused_entries, jit_prep_fn);
-      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn, b.fused_entries);
+      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn, b.fused_entries, jit_rt_fn, jit_rt_fn ? model->qs_sig.thr_total : 0u);
     }
     b.matrix_valid = false;
     // lo is a multiple of the tile size: the scorer sees rows [lo, hi) as its rows [0, hi - lo)

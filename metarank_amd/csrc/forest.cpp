@@ -954,6 +954,7 @@ QsSignature qs_signature(const PackedForestQS &pf, uint32_t thr_cap) {
     off += chunks * QS_STAGE_CHUNK;
   }
   if ((size_t)off != pf.thr.size()) return QsSignature{};
+  sg.thr_total = off;
   sg.text = "/*cap " + std::to_string(thr_cap) + " views " + std::to_string(sg.n_views) + "*/" + sg.text;
   sg.ok = true;
   return sg;

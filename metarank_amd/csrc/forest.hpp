@@ -183,6 +183,7 @@ struct QsSignature {
   bool ok = false;             // false: the image does not have the layout the signature assumes - kernels read descriptors
   uint32_t thr_cap = 0;        // doubles per LDS staging buffer (QsDev::thr_cap)
   int n_views = 0;
+  uint32_t thr_total = 0;      // doubles of all threshold tables together (whole chunks per column)
   std::vector<QsSig> cols;     // n_features
   std::string text;            // the rows as a C++ initialiser list: part of the specialised translation unit, and the key
 };

@@ -106,6 +106,7 @@ std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignat
     table("JitSigRows", "QsSig", sig->cols.size(), sig->text);
     s += "struct JitQs {\n  static constexpr bool is_static = true;\n  static constexpr int n_feats = " + std::to_string(sig->cols.size()) +
          ", n_views = " + std::to_string(sig->n_views) + ";\n  static constexpr uint32_t thr_cap = " + std::to_string(sig->thr_cap) +
+         "u, thr_total = " + std::to_string(sig->thr_total) +
          "u;\n  __device__ __forceinline__ constexpr QsSig operator[](int i) const { return JitSigRows{}[i]; }\n};\n";
     qs = "mrk::JitQs";
   }
@@ -144,6 +145,11 @@ std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignat
     s += "extern \"C\" __global__ void __launch_bounds__(256)" + attr + "\nmrk_jit_assemble_cells"
          "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells, uint32_t lds_entries) {\n"
          "  mrk::assemble_cells_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, q, cells, lds_entries);\n}\n";
+  // ... and its persistent form with every threshold table resident in LDS (rank_device.hpp assemble_cells_rt_body): only with a signature
+  if ((kernel == JIT_ALL || kernel == JIT_ITEMS_RT) && qs != "mrk::QsDyn" && jit_items_rt_applies(sig))
+    s += "extern \"C\" __global__ void __launch_bounds__(512)" + attr + "\nmrk_jit_assemble_cells_rt"
+         "(mrk::StoreDev st, mrk::BatchDev b, mrk::QsDev q, uint16_t *cells, uint32_t lds_entries) {\n"
+         "  mrk::assemble_cells_rt_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, b, q, cells, lds_entries);\n}\n";
   // pre-pass + assembly + forest + ordering of a small request in one launch (rank_device.hpp rank_one_body)
   if (kernel == JIT_ALL || kernel == JIT_ONE)
     // (a request's workgroup is 8 wavefronts = 2 per SIMD and a handful of them run at a time: nothing to gain from the
@@ -221,7 +227,11 @@ struct JitKernels {
   std::map<std::string, std::unique_ptr<JitSlotSet>> by_sig;
 };
 
-const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve", "mrk_jit_rank_fused_score", "mrk_jit_prepass"};
+const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit_rank_cells_split", "mrk_jit_rank_matrix", "mrk_jit_assemble_cells", "mrk_jit_rank_one", "mrk_jit_rank_serve", "mrk_jit_rank_fused_score", "mrk_jit_prepass", "mrk_jit_assemble_cells_rt"};
+// a kernel that exists only with a forest signature: no program-only stand-in (the caller falls back to another KERNEL meanwhile)
+static inline bool jit_needs_sig(int kernel) { return kernel == JIT_ITEMS_RT; }
+// the resident-table kernel: every table in LDS (<= 64 KB of thresholds leaves room for a request's hash tables and a second workgroup)
+bool jit_items_rt_applies(const QsSignature *sig) { return sig && sig->ok && sig->thr_total > 0 && (size_t)sig->thr_total * 8 <= 64 * 1024 && switches().jit_sig && switches().items_rt; }
 // kernels that neither write the scorer's tile nor depend on the scorer's precision: one per program, kept in slot [kernel][1]
 static inline bool jit_program_only(int kernel) { return kernel == JIT_MATRIX || kernel == JIT_PREPASS; }
 
@@ -308,6 +318,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
   JitKernels *k = (JitKernels *)prog.jit;
   if (jit_program_only(kernel)) f64 = true;
   const bool keyed = sig && sig->ok && !jit_program_only(kernel) && switches().jit_sig;
+  if (jit_needs_sig(kernel) && (!keyed || !jit_items_rt_applies(sig))) return nullptr;
   std::unique_ptr<JitSlotSet> &set = k->by_sig[keyed ? sig->text : std::string()];
   if (!set) set.reset(new JitSlotSet());
   JitSlot &sl = set->slot[kernel][f64 ? 1 : 0];
@@ -315,7 +326,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
   if (no_compile && sl.not_on_disk) return nullptr;   // O(1) after the first miss: no translation unit rebuilt, no file probed per request
   // while this signature's kernel is not there (compiling, failed, its file unloadable): the program's signature-less
   // kernel, if it is loaded or on disk - never the interpreting kernel when a specialised one exists
-  auto stand_in = [&]() -> void * { return keyed && !no_compile ? jit_function_locked(prog, kernel, f64, false, nullptr, true) : nullptr; };
+  auto stand_in = [&]() -> void * { return keyed && !no_compile && !jit_needs_sig(kernel) ? jit_function_locked(prog, kernel, f64, false, nullptr, true) : nullptr; };
   if (sl.failed && mode != 2) return stand_in();
   // the lambdas run on a background thread too: they own a copy of the signature (the model may be freed meanwhile)
   const std::shared_ptr<const QsSignature> sg = keyed ? std::make_shared<const QsSignature>(*sig) : nullptr;
@@ -359,6 +370,7 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
         void *fallback = nullptr;
         if (keyed && !no_compile) {
           for (int kn = 0; kn < JIT_KERNELS; ++kn) {
+            if (jit_needs_sig(kn)) continue;
             void *f = jit_function_locked(prog, kn, jit_program_only(kn) ? true : f64, false, nullptr, true);
             if (kn == kernel) fallback = f;
           }
@@ -420,6 +432,7 @@ int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const st
   for (int k = 0; k < JIT_KERNELS; ++k) {
     if (!(kernel_mask & (1u << k))) continue;
     const bool kf64 = jit_program_only(k) ? true : f64;
+    if (jit_needs_sig(k) && !jit_items_rt_applies(sig)) continue;
     const std::string src = jit_source(prog, kf64, k, switches().jit_sig ? sig : nullptr);
     const std::string user = cache_path(src);
     const std::string name = user.empty() ? shipped_path(src) : user;
@@ -440,6 +453,7 @@ int jit_precompile(const Program &prog, bool f64, unsigned kernel_mask, const st
 void *jit_rank_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_RANK, f64, sig); }
 // the item-parallel kernel (nullptr under the same conditions)
 void *jit_items_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_ITEMS, f64, sig); }
+void *jit_items_rt_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_ITEMS_RT, f64, sig); }
 // the op-split / sliced form of the fused kernel (small batches, few large requests)
 void *jit_split_function(const Program &prog, bool f64, const QsSignature *sig) { return jit_function(prog, JIT_SPLIT, f64, sig); }
 // the f64-matrix form of the fused kernel
@@ -480,9 +494,14 @@ extern "C" int mrk_debug_phase_clocks(const Program *prog, unsigned long long *o
   if (!prog || !prog->jit) return -1;
   JitKernels *k = (JitKernels *)prog->jit;
   hipModule_t mod = nullptr;
-  for (auto &set : k->by_sig)   // the fused kernel that was compiled last (a measurement build ranks one model)
-    for (int f = 1; f >= 0; --f)
-      if (set.second->slot[JIT_RANK][f].mod) mod = set.second->slot[JIT_RANK][f].mod;
+  const char *want = getenv("MRK_PHASE_KERNEL");   // "items": the item-parallel kernel's clocks (c4 / c4x)
+  const bool items = want && !strcmp(want, "items");
+  for (auto &set : k->by_sig)   // the kernel that was compiled last (a measurement build ranks one model)
+    for (int f = 1; f >= 0; --f) {
+      if (!items && set.second->slot[JIT_RANK][f].mod) mod = set.second->slot[JIT_RANK][f].mod;
+      if (items && set.second->slot[JIT_ITEMS][f].mod && !(mod && switches().items_rt)) mod = set.second->slot[JIT_ITEMS][f].mod;
+      if (items && switches().items_rt && set.second->slot[JIT_ITEMS_RT][f].mod) mod = set.second->slot[JIT_ITEMS_RT][f].mod;
+    }
   hipDeviceptr_t p = nullptr;
   size_t bytes = 0;
   if (!mod || hipModuleGetGlobal(&p, &bytes, mod, "mrk_phase_clocks") != hipSuccess || bytes < 64 * 8) return -2;

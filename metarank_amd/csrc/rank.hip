@@ -293,8 +293,31 @@ static void launch_override_cells(mrk_ctx *ctx, const BatchDev &b, const QsDev &
 // max_req_entries: the largest request's table entries (the pre-pass launch's figure): when they fit ITEMS_LDS_TABLE_BYTES,
 // single-request workgroups copy their request's tables into LDS (rank_device.hpp assemble_cells_body); MRK_ITEMS_LDS=0: never
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
-                           uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries) {
+                           uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries, void *jit_rt_fn, uint32_t thr_total) {
   if (b.item_hi <= b.item_lo) return;
+  if (jit_rt_fn) {
+    // the resident-table form (rank_device.hpp assemble_cells_rt_body): persistent workgroups, all threshold tables in LDS
+    ScopedKernelTimer timer(ctx, "assemble");
+    const int n_items = b.item_hi - b.item_lo;
+    constexpr uint32_t RT_LDS_TABLE_BYTES = 16 * 1024;   // 64 KB of thresholds + 16 KB of hash tables: two 512-lane workgroups per CU
+    uint32_t lds_entries = switches().items_lds && prog.n_prep > 0 && (uint64_t)max_req_entries * 8 <= RT_LDS_TABLE_BYTES ? max_req_entries : 0u;
+    const size_t lds = (size_t)thr_total * 8 + (size_t)lds_entries * 8;
+    // lanes per workgroup: 512 (8 wavefronts share one copy of the tables) when that still gives every CU two workgroups' worth
+    // of blocks, else 256 (a 100 000-candidate request is 391 blocks of 256)
+    int threads = (long long)n_items >= 2ll * 512 * ctx->n_cus ? 512 : 256;
+    if (switches().items_rt_threads == 256 || switches().items_rt_threads == 512) threads = switches().items_rt_threads;
+    const int n_blocks = (n_items + threads - 1) / threads;
+    // resident workgroups per CU: by LDS (160 KB) and by wavefronts (16 at 128 VGPRs)
+    const int per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 16 / (threads / 64)));
+    const unsigned grid = (unsigned)std::min(n_blocks, per_cu * ctx->n_cus);
+    StoreDev a_st = st;
+    BatchDev a_b = b;
+    QsDev a_q = q;
+    void *args[] = {&a_st, &a_b, &a_q, &cells, &lds_entries};
+    MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_rt_fn, grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, ctx->launch, args, nullptr));
+    launch_override_cells(ctx, b, q, cells, f64);
+    return;
+  }
   {
     ScopedKernelTimer timer(ctx, "assemble");
     const dim3 grid((b.item_hi - b.item_lo + ASM_THREADS - 1) / ASM_THREADS);

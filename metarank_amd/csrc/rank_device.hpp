@@ -88,7 +88,9 @@ constexpr int PREP_THREADS = 256;
 constexpr int FUSED_MAX_PREP = 32;  // pre-pass entries of one model (PrepOut copies + `first` slots kept in LDS)
 constexpr int PREP_GROUP = 4;       // entries handled by one merged pass (their loads are issued together)
 constexpr int PREP_WAVES = 8;       // most wavefronts of a workgroup that runs a pre-pass (512 lanes: a single request split over op groups)
-constexpr int PREP_INTS = 96;       // ints of LDS scratch: wave_tot[PREP_WAVES][PREP_GROUP] | first[FUSED_MAX_PREP] | misc[4] | tokens[PREP_GROUP]
+constexpr int DIV_GROUP = 8;        // diversity entries the wave-local section handles in one pass (the five of the Ranklens model: one pass, not two)
+constexpr int DIV_PRE_TOK = 6;      // tokens per list fetched ahead of the inserts in the wave-local sections
+constexpr int PREP_INTS = 96;       // ints of LDS scratch: wave_tot[PREP_WAVES][PREP_GROUP] | first[FUSED_MAX_PREP] | misc[4] | tokens[DIV_GROUP]
 
 struct PrepScratch {   // LDS scratch of one workgroup
   double *vals;        // vals_cap doubles: diversity median
@@ -99,7 +101,7 @@ struct PrepScratch {   // LDS scratch of one workgroup
   __device__ __forceinline__ int *wave_tot() const { return ints; }                              // [PREP_WAVES][PREP_GROUP]
   __device__ __forceinline__ int *first() const { return ints + PREP_WAVES * PREP_GROUP; }       // [FUSED_MAX_PREP]
   __device__ __forceinline__ int *misc() const { return ints + PREP_WAVES * PREP_GROUP + FUSED_MAX_PREP; }   // [4]
-  __device__ __forceinline__ int *tokens() const { return misc() + 4; }                          // [PREP_GROUP]
+  __device__ __forceinline__ int *tokens() const { return misc() + 4; }                          // [DIV_GROUP]
 };
 
 // exclusive prefix sum of a 0/1 flag over the workgroup + total (blockDim.x <= 64 * PREP_WAVES)
@@ -264,11 +266,23 @@ __device__ __forceinline__ void prepass_interacted_with(const StoreDev &st, cons
           ic[u].bits = 0;
           if (u < n) ic[u] = load_cell(irec, col[u]);
         }
+        // the first tokens of every field's list, requested together (one trip for the group, not one per field)
+        uint32_t ptk[PREP_GROUP][DIV_PRE_TOK];
+#pragma unroll
+        for (int u = 0; u < PREP_GROUP; ++u) {
+          const uint32_t plen = u < n && ic[u].tag == TAG_STRING_LIST ? ic[u].hi() : 0u;
+          const uint32_t *toks = list_tokens(st, irec, ic[u].lo());
+#pragma unroll
+          for (int t = 0; t < DIV_PRE_TOK; ++t) ptk[u][t] = (uint32_t)t < plen ? toks[t] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < PREP_GROUP; ++u) {
           if (u < n) {  // uniform
-            const bool list = ic[u].tag == TAG_STRING_LIST;
-            if (table_add_list(list_tokens(st, irec, ic[u].lo()), tab[u], cap[u], list ? ic[u].hi() : 0u)) atomicOr(&b.status[r], ST_TABLE_FULL);
+            const uint32_t tlen = ic[u].tag == TAG_STRING_LIST ? ic[u].hi() : 0u;
+            uint32_t failed = table_add_tokens<DIV_PRE_TOK>(tab[u], cap[u], ptk[u], tlen);
+            if (wave_any(tlen > (uint32_t)DIV_PRE_TOK))
+              failed += table_add_list(list_tokens(st, irec, ic[u].lo()) + DIV_PRE_TOK, tab[u], cap[u], tlen > (uint32_t)DIV_PRE_TOK ? tlen - DIV_PRE_TOK : 0u);
+            if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
           }
         }
       }
@@ -287,22 +301,25 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
   const int n_prep = prog.n_prep;
   int *s_first = sc.first();
   int *s_tokens = sc.tokens();
+#ifdef MRK_PHASE_CLOCKS
+  unsigned long long dv_t = clock64(), dv_acc[3] = {0, 0, 0};
+#endif
   for (int e0 = 0; e0 < n_prep;) {
     if (prog.prep[e0].kind != PREP_DIVERSITY || po_out[e0].preset) { ++e0; continue; }
-    int ent[PREP_GROUP];
+    int ent[DIV_GROUP];
     int n = 0, e1 = e0;
-    for (; e1 < n_prep && n < PREP_GROUP; ++e1) {
+    for (; e1 < n_prep && n < DIV_GROUP; ++e1) {
       if (prog.prep[e1].kind != PREP_DIVERSITY || po_out[e1].preset) continue;
 #pragma unroll
-      for (int u = 0; u < PREP_GROUP; ++u) if (u == n) ent[u] = e1;
+      for (int u = 0; u < DIV_GROUP; ++u) if (u == n) ent[u] = e1;
       ++n;
     }
-    ColRef col[PREP_GROUP];
-    unsigned long long *tab[PREP_GROUP];
-    uint32_t cap[PREP_GROUP];
-    int top[PREP_GROUP];
+    ColRef col[DIV_GROUP];
+    unsigned long long *tab[DIV_GROUP];
+    uint32_t cap[DIV_GROUP];
+    int top[DIV_GROUP];
 #pragma unroll
-    for (int u = 0; u < PREP_GROUP; ++u) {
+    for (int u = 0; u < DIV_GROUP; ++u) {
       if (u >= n) ent[u] = e0;
       col[u] = prog.prep[ent[u]].item_col;
       top[u] = prog.prep[ent[u]].top;
@@ -311,22 +328,22 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
     }
     // (a) first candidate with state, per entry; the cells of the first 64 candidates stay in registers for (b) and (c)
     const uint8_t *keep_rec = nullptr;
-    Cell keep[PREP_GROUP];
+    Cell keep[DIV_GROUP];
 #pragma unroll
-    for (int u = 0; u < PREP_GROUP; ++u) { keep[u].tag = TAG_MISSING; keep[u].bits = 0; }
+    for (int u = 0; u < DIV_GROUP; ++u) { keep[u].tag = TAG_MISSING; keep[u].bits = 0; }
     for (int base = 0; base < rq.n_items; base += 64) {
       const int i = base + lane;
       if (i < rq.n_items) {
         const uint8_t *irec = record(st, SC_ITEM, b.item_slot[rq.item_begin + i]);
-        Cell c[PREP_GROUP];
+        Cell c[DIV_GROUP];
 #pragma unroll
-        for (int u = 0; u < PREP_GROUP; ++u) {
+        for (int u = 0; u < DIV_GROUP; ++u) {
           c[u].tag = TAG_MISSING;
           c[u].bits = 0;
           if (u < n) c[u] = load_cell(irec, col[u]);
         }
 #pragma unroll
-        for (int u = 0; u < PREP_GROUP; ++u) {
+        for (int u = 0; u < DIV_GROUP; ++u) {
           if (u < n && c[u].tag != TAG_MISSING) atomicMin(&s_first[ent[u]], (i << 8) | (int)c[u].tag);
           if (base == 0) keep[u] = c[u];
         }
@@ -335,45 +352,55 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
       wave_lds_sync();
       bool all = true;
 #pragma unroll
-      for (int u = 0; u < PREP_GROUP; ++u) all = all && (u >= n || s_first[ent[u]] != 0x7fffffff);
+      for (int u = 0; u < DIV_GROUP; ++u) all = all && (u >= n || s_first[ent[u]] != 0x7fffffff);
       wave_lds_sync();
       if (all) break;
     }
-    int mode[PREP_GROUP];
+    int mode[DIV_GROUP];
 #pragma unroll
-    for (int u = 0; u < PREP_GROUP; ++u) {
+    for (int u = 0; u < DIV_GROUP; ++u) {
       const int first = u < n ? s_first[ent[u]] : 0x7fffffff;
       const int htag = first != 0x7fffffff ? (first & 255) : (int)TAG_MISSING;
       mode[u] = (htag == TAG_STRING || htag == TAG_STRING_LIST) ? DIV_STRING : (htag == TAG_DOUBLE ? DIV_DOUBLE : DIV_EMPTY);
     }
+    MRK_PHASE(dv_t, dv_acc[0]);
     // (b) string entries: the first `top` candidates of that type, in request order
     bool any_string = false;
 #pragma unroll
-    for (int u = 0; u < PREP_GROUP; ++u) any_string = any_string || (u < n && mode[u] == DIV_STRING);
-    if (lane < PREP_GROUP) s_tokens[lane] = 0;
+    for (int u = 0; u < DIV_GROUP; ++u) any_string = any_string || (u < n && mode[u] == DIV_STRING);
+    if (lane < DIV_GROUP) s_tokens[lane] = 0;
     wave_lds_sync();
     if (any_string) {
-      int running[PREP_GROUP];
+      int running[DIV_GROUP];
 #pragma unroll
-      for (int u = 0; u < PREP_GROUP; ++u) running[u] = 0;
+      for (int u = 0; u < DIV_GROUP; ++u) running[u] = 0;
       for (int base = 0; base < rq.n_items; base += 64) {
         bool more = false;
 #pragma unroll
-        for (int u = 0; u < PREP_GROUP; ++u) more = more || (u < n && mode[u] == DIV_STRING && running[u] < top[u]);
+        for (int u = 0; u < DIV_GROUP; ++u) more = more || (u < n && mode[u] == DIV_STRING && running[u] < top[u]);
         if (!more) break;
         const int i = base + lane;
-        Cell c[PREP_GROUP];
-        bool cand[PREP_GROUP];
+        Cell c[DIV_GROUP];
+        bool cand[DIV_GROUP];
         const uint8_t *irec = base == 0 ? keep_rec : (i < rq.n_items ? record(st, SC_ITEM, b.item_slot[rq.item_begin + i]) : nullptr);
 #pragma unroll
-        for (int u = 0; u < PREP_GROUP; ++u) {
+        for (int u = 0; u < DIV_GROUP; ++u) {
           c[u].tag = TAG_MISSING;
           c[u].bits = 0;
           if (u < n && mode[u] == DIV_STRING) c[u] = base == 0 ? keep[u] : load_cell(irec, col[u]);
           cand[u] = c[u].tag == TAG_STRING || c[u].tag == TAG_STRING_LIST;
         }
+        // the first tokens of every entry's list, requested together: one trip to memory for the group instead of one per entry
+        uint32_t ptk[DIV_GROUP][DIV_PRE_TOK];
 #pragma unroll
-        for (int u = 0; u < PREP_GROUP; ++u) {
+        for (int u = 0; u < DIV_GROUP; ++u) {
+          const uint32_t plen = u < n && mode[u] == DIV_STRING && c[u].tag == TAG_STRING_LIST ? c[u].hi() : 0u;
+          const uint32_t *toks = list_tokens(st, irec, c[u].lo());
+#pragma unroll
+          for (int t = 0; t < DIV_PRE_TOK; ++t) ptk[u][t] = (uint32_t)t < plen ? toks[t] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < DIV_GROUP; ++u) {
           int total = 0;
           const int excl = wave_scan_flag(u < n && cand[u], total);
           if (u < n && mode[u] == DIV_STRING) {  // uniform
@@ -381,7 +408,9 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
             const bool one = take && c[u].tag == TAG_STRING;
             const uint32_t tlen = take && !one ? c[u].hi() : 0u;
             uint32_t failed = table_add(tab[u], cap[u], c[u].lo(), one) ? 0u : 1u;
-            failed += table_add_list(list_tokens(st, irec, c[u].lo()), tab[u], cap[u], tlen);
+            failed += table_add_tokens<DIV_PRE_TOK>(tab[u], cap[u], ptk[u], tlen);
+            if (wave_any(tlen > (uint32_t)DIV_PRE_TOK))
+              failed += table_add_list(list_tokens(st, irec, c[u].lo()) + DIV_PRE_TOK, tab[u], cap[u], tlen > (uint32_t)DIV_PRE_TOK ? tlen - DIV_PRE_TOK : 0u);
             if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
             if (take) atomicAdd(&s_tokens[u], one ? 1 : (int)tlen);
           }
@@ -392,16 +421,17 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
     }
     if (lane == 0) {
 #pragma unroll
-      for (int u = 0; u < PREP_GROUP; ++u)
+      for (int u = 0; u < DIV_GROUP; ++u)
         if (u < n && mode[u] != DIV_DOUBLE) {
           po_out[ent[u]].mode = mode[u];
           po_out[ent[u]].scalar = mode[u] == DIV_STRING ? (double)s_tokens[u] : 0.0;
         }
     }
     wave_lds_sync();   // (the next group zeroes s_tokens)
+    MRK_PHASE(dv_t, dv_acc[1]);
     // (c) numeric entries: the first `top` (<= 64) present values in request order, then their median
 #pragma unroll
-    for (int u = 0; u < PREP_GROUP; ++u) {
+    for (int u = 0; u < DIV_GROUP; ++u) {
       if (u >= n || mode[u] != DIV_DOUBLE) continue;
       int running = 0;
       for (int base = 0; base < rq.n_items && running < top[u]; base += 64) {
@@ -428,8 +458,13 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
       }
       wave_lds_sync();
     }
+    MRK_PHASE(dv_t, dv_acc[2]);
     e0 = e1;
   }
+#ifdef MRK_PHASE_CLOCKS
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 3; ++i) atomicAdd(&mrk_phase_clocks[8 + i], dv_acc[i]);
+#endif
 }
 
 // The pre-pass of request r, run by one whole workgroup.  Tables live at tab_base + (po.tab_off - tab_sub)
@@ -470,6 +505,10 @@ __device__ __forceinline__ void prepass_request(const StoreDev &st, const Prog &
     const int wave = tid >> 6;
     if (lone || wave != 0) prepass_interacted_with(st, prog, b, r, rq, tab_base, tab_sub, po_out, lone ? tid : tid - 64, lone ? nthr : nthr - 64);
     if (wave == 0) prepass_diversity_wave(st, prog, b, r, rq, tab_base, tab_sub, po_out, sc);
+#ifdef MRK_PHASE_CLOCKS
+    if (tid == 64) atomicAdd(&mrk_phase_clocks[2], clock64() - sc.clk);   // the interacted_with section alone (wavefront 1)
+    if (tid == 0) atomicAdd(&mrk_phase_clocks[3], clock64() - sc.clk);    // the diversity section alone (wavefront 0)
+#endif
     __syncthreads();
     MRK_PHASE(sc.clk, sc.acc[1]);
     return;
@@ -742,6 +781,7 @@ struct MatrixSink {   // row-major f64 matrix, ClickthroughQuery's layout
   double *row;
   bool active;
   __device__ __forceinline__ void begin() const {}
+  __device__ __forceinline__ void finish() const {}
   __device__ __forceinline__ void put(int col, double v) const {
     if (active) row[col] = v;
   }
@@ -839,8 +879,9 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
                                          (__attribute__((address_space(3))) void *)(buf + k0), 16, 0, 0);
     }
   }
-  // before the first put of an item
+  // before the first put of an item / after its last
   __device__ __forceinline__ void begin() const { restart(0); }
+  __device__ __forceinline__ void finish() const {}
   __device__ __forceinline__ void restart(int col) const {
     ft_cur = feature(col);
     if constexpr (!QS::is_static) ft_next = feature(col + 1);
@@ -904,6 +945,125 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
       qs_emit_views_sig<F64>(x, pos, QS{}[col], [&]() -> uint32_t { return f->zero_bin; }, emit);
     else
       qs_emit_views<F64>(x, pos, ft, q.views, emit);
+  }
+};
+
+// ---- the same tile written by a workgroup that holds EVERY threshold table of the forest in LDS (the item-parallel kernel
+// of a model whose signature is known at compile time and whose tables fit: assemble_cells_rt_body).  Nothing is staged per
+// column, so nothing is waited for, and a value need not be binned the moment it is produced: the sink keeps up to RT_Q
+// values back and bins them TOGETHER - RT_Q independent lower-bound searches whose LDS reads are in flight at the same
+// time.  The staging sink's search is a chain of 7-8 dependent LDS trips per column, 24 columns one after the other; here
+// the chain of a group is as long as ONE search.  Same lower bound, same cells.
+// (The queue is three named slots and a count, all of which fold in a compile-time program: every put happens at a fixed
+// point of straight-line code.  Were the count not to fold, the switch below would be a uniform branch - never a run-time
+// index into registers.)
+constexpr int RT_Q = 4;
+template <bool F64, typename QS>
+struct CellSinkRT {
+  static_assert(QS::is_static, "the resident-table sink needs the forest's signature at compile time");
+  QsDev q;
+  uint16_t *dst;           // &cells[tile][0][row]
+  int32_t *status;
+  qs_lds_double *thr_all;  // the forest's threshold tables, laid out as in global memory (QsSig::thr_off)
+  bool active;
+  mutable double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+  mutable int c0 = 0, c1 = 0, c2 = 0, qn = 0;
+
+  __device__ __forceinline__ void begin() const { qn = 0; }
+  __device__ __forceinline__ QsFeatureK desc(int col) const { return (QsFeatureK)(unsigned long long)q.feats + col; }
+  static __device__ __forceinline__ constexpr bool resident(const QsSig &s) { return (uint32_t)s.chunks * QS_STAGE_CHUNK <= QS_LDS_THR; }
+
+  template <int N>
+  __device__ __forceinline__ void bin_group(const int (&col)[RT_Q], const double (&val)[RT_Q]) const {
+    double x[N];
+    qs_lds_double *T[N], *p[N];
+    uint32_t pos[N];
+    auto below = [](double t, double xx) { return F64 ? (t < xx) : (t <= xx); };
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      bool ok;
+      x[i] = qs_prep<F64>(val[i], ok);
+      if (!ok && active) atomicOr(status, ST_XGB_INF);
+      T[i] = thr_all + QS{}[col[i]].thr_off;
+      p[i] = T[i];
+    }
+    // (tables of <= 128 entries take 7 steps, the others 8; lengths are whole chunks: the +inf padding answers like the table's end)
+    // (the scheduler, short of registers, would run the N chains one after the other again: the barriers keep a step's N reads
+    //  together, ahead of the step's N compares)
+    double t[N];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = QS{}[col[i]].chunks > 1 && resident(QS{}[col[i]]) ? T[i][127] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (QS{}[col[i]].chunks > 1 && resident(QS{}[col[i]])) p[i] += below(t[i], x[i]) ? 128 : 0;
+#pragma unroll
+    for (int h = 64; h >= 1; h >>= 1) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < N; ++i) t[i] = QS{}[col[i]].chunks > 0 && resident(QS{}[col[i]]) ? p[i][h - 1] : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (QS{}[col[i]].chunks > 0 && resident(QS{}[col[i]])) p[i] += below(t[i], x[i]) ? h : 0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = QS{}[col[i]].chunks > 0 && resident(QS{}[col[i]]) ? p[i][0] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const QsSig sg = QS{}[col[i]];
+      const QsFeatureK f = desc(col[i]);
+      if (sg.chunks == 0) pos[i] = 0u;
+      else if (resident(sg)) {
+        pos[i] = (uint32_t)(p[i] - T[i]) + (below(t[i], x[i]) ? 1u : 0u);
+        if constexpr (!F64) pos[i] = min(pos[i], (uint32_t)f->thr_len);   // x = +inf walks through the +inf padding
+      } else {
+        pos[i] = qs_bin_search<F64>(q.thr + sg.thr_off, f->thr_len, x[i]);  // a table too long for LDS: searched where it lies
+      }
+    }
+    uint16_t *d = dst;
+    const bool act = active;
+    auto emit = [d, act](uint32_t view, uint32_t cell) { if (act) d[view * QS_TILE_ROWS] = (uint16_t)cell; };
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const QsFeatureK f = desc(col[i]);
+      qs_emit_views_sig<F64>(x[i], pos[i], QS{}[col[i]], [&]() -> uint32_t { return f->zero_bin; }, emit);
+    }
+  }
+
+  __device__ __forceinline__ void put(int col, double v) const {
+    bool splits = false;
+    if (col < QS::n_feats) splits = QS{}[col].view_begin != QS{}[col].view_end;
+    if (!splits) {  // a column the forest does not know or never splits on: nothing to bin, but still part of XGBoost's DMatrix row
+      if constexpr (!F64) {
+        bool fin;
+        (void)qs_prep<F64>(v, fin);
+        if (!fin && active) atomicOr(status, ST_XGB_INF);
+      }
+      return;
+    }
+    switch (qn) {
+      case 0: v0 = v; c0 = col; qn = 1; break;
+      case 1: v1 = v; c1 = col; qn = 2; break;
+      case 2: v2 = v; c2 = col; qn = 3; break;
+      default: {
+        const int cols[RT_Q] = {c0, c1, c2, col};
+        const double vals[RT_Q] = {v0, v1, v2, v};
+        bin_group<4>(cols, vals);
+        qn = 0;
+      }
+    }
+  }
+  __device__ __forceinline__ void finish() const {
+    const int cols[RT_Q] = {c0, c1, c2, 0};
+    const double vals[RT_Q] = {v0, v1, v2, 0.0};
+    if (qn == 1) bin_group<1>(cols, vals);
+    else if (qn == 2) bin_group<2>(cols, vals);
+    else if (qn == 3) bin_group<3>(cols, vals);
+    qn = 0;
   }
 };
 
@@ -1372,12 +1532,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
             const PrepOut po = pos[op.i1 + f0 + u];
             const unsigned long long *tab = tab_base + (po.tab_off - tab_sub);
             const uint32_t len = fc[u].tag == TAG_STRING_LIST ? fc[u].hi() : 0u;
-            double cnt = 0.0;
-#pragma unroll
-            for (int t = 0; t < IW_TOK; ++t) {
-              if (!wave_any((uint32_t)t < len)) break;
-              cnt = cnt + (double)table_get(tab, po.tab_cap, tk[u][t], (uint32_t)t < len);
-            }
+            double cnt = table_sum_tokens<IW_TOK>(tab, po.tab_cap, tk[u], len, 0.0);
             if (wave_any(len > (uint32_t)IW_TOK))  // the rest of longer lists, in list order
               cnt = table_sum_list(list_tokens(st, irec, fc[u].lo()) + IW_TOK, tab, po.tab_cap, len > (uint32_t)IW_TOK ? len - IW_TOK : 0u, cnt);
             sink.put(dst + f0 + u, cnt);
@@ -1399,12 +1554,10 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
           const double w1 = 0.0 + (double)table_get(tab, po.tab_cap, c.lo(), one);
           // the list's first TOK_BATCH tokens were fetched ahead; longer lists continue from memory, in list order
           const uint32_t len = list ? c.hi() : 0u;
-          double wl = 0.0;
+          uint32_t dtk[TOK_BATCH];
 #pragma unroll
-          for (int t = 0; t < TOK_BATCH; ++t) {
-            if (!wave_any((uint32_t)t < len)) break;
-            wl = wl + (double)table_get(tab, po.tab_cap, pre.tok[t], (uint32_t)t < len);
-          }
+          for (int t = 0; t < TOK_BATCH; ++t) dtk[t] = pre.tok[t];
+          double wl = table_sum_tokens<TOK_BATCH>(tab, po.tab_cap, dtk, len, 0.0);
           if (wave_any(len > (uint32_t)TOK_BATCH))
             wl = table_sum_list(list_tokens(st, irec, c.lo()) + TOK_BATCH, tab, po.tab_cap, len > (uint32_t)TOK_BATCH ? len - TOK_BATCH : 0u, wl);
           if (one || list) v = (one ? w1 : wl) / po.scalar;
@@ -1487,7 +1640,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
     Cell pc[Prog::n_ops > 0 ? Prog::n_ops : 1];
     OpPre pre[Prog::n_ops > 0 ? Prog::n_ops : 1];
 #ifdef MRK_PHASE_CLOCKS
-    unsigned long long t_op = clock64(), op_acc[Prog::n_ops > 0 ? Prog::n_ops : 1] = {};
+    unsigned long long t_op = clock64(), op_acc[Prog::n_ops > 0 ? Prog::n_ops : 1] = {}, pre_acc = 0;
 #endif
     // Ops run in groups whose fetched-ahead state fits the register file: a group's primary cells (register reads when the
     // record is held in registers, else its first trip to memory), then its second trip, then its arithmetic.
@@ -1506,6 +1659,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
         constexpr int own = op_owner<Prog>(oi);
         if (G == 1 || (own & (G - 1)) == og) prefetch_op(op, pc[oi], pre[oi]);
       });
+      MRK_PHASE(t_op, pre_acc);
       static_for<lo, hi>([&](auto ic) __attribute__((always_inline)) {
         constexpr int oi = decltype(ic)::value;
         constexpr Op op = Prog{}.ops[oi];
@@ -1517,6 +1671,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
 #ifdef MRK_PHASE_CLOCKS
     if (threadIdx.x == 0)
       for (int i = 0; i < Prog::n_ops && i < 48; ++i) atomicAdd(&mrk_phase_clocks[16 + i], op_acc[i]);
+    if (threadIdx.x == 0) atomicAdd(&mrk_phase_clocks[7], pre_acc);   // issuing the groups' primary cells + second trips
 #endif
   } else {
     for (int oi = 0; oi < prog.n_ops; ++oi) {
@@ -1528,6 +1683,7 @@ __device__ __forceinline__ void assemble_item_rec(const StoreDev &st, const Prog
       run_op(op, pc, pre);
     }
   }
+  sink.finish();
 }
 
 // the record pieces the specialised kernel keeps in registers: the whole fixed part of the candidate's record when the
@@ -1627,6 +1783,9 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
   extern __shared__ __align__(16) unsigned long long s_tab_copy[];
   const int wg_lo = b.item_lo + (int)blockIdx.x * ASM_THREADS;
   if (wg_lo >= b.item_hi) return;                  // (uniform)
+#ifdef MRK_PHASE_CLOCKS
+  unsigned long long clk_t = clock64(), clk_acc[2] = {0, 0};
+#endif
   const int wg_hi = min(wg_lo + ASM_THREADS, b.item_hi) - 1;
   const int r_lo = (int)b.item_req[wg_lo], r_hi = (int)b.item_req[wg_hi];
   bool in_lds = false;
@@ -1653,8 +1812,89 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
   CellSink<F64, QS> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * qs_n_views<QS>(q) * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r],
                      (qs_lds_double *)s_thr[threadIdx.x >> 6], active};
   // (two instantiations: through a selected pointer the table accesses would be flat instead of ds / global operations)
+  MRK_PHASE(clk_t, clk_acc[0]);
   if (in_lds) assemble_item(st, prog, b, gi, r, rq, s_tab_copy, tab_sub, &b.prep_out[(size_t)r * prog.n_prep], sink);
   else assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
+  MRK_PHASE(clk_t, clk_acc[1]);
+#ifdef MRK_PHASE_CLOCKS
+  if (threadIdx.x == 0) {
+    atomicAdd(&mrk_phase_clocks[0], clk_acc[0]);   // table copy + request lookup
+    atomicAdd(&mrk_phase_clocks[5], clk_acc[1]);   // per-item assembly
+    atomicAdd(&mrk_phase_clocks[6], 1ull);
+  }
+#endif
+}
+
+// The item-parallel kernel of a model whose forest signature is a compile-time constant and whose threshold tables fit in LDS
+// next to a request's hash tables: PERSISTENT workgroups (the grid is what the chip holds at once; each walks blocks of blockDim.x
+// candidates) that load ALL threshold tables once - 48 KB for the 24 Ranklens columns - instead of every wavefront staging every
+// column's table for every 64 candidates (750 B of L2 -> LDS traffic per candidate: twice the record itself), and bin through
+// CellSinkRT.  A workgroup whose block belongs to one request keeps that request's finished hash tables in LDS as before, and
+// keeps them across blocks of the same request (config 4: one copy per workgroup for the whole launch).
+// Dynamic LDS: [threshold tables: QS::thr_total x 8 B][hash tables: lds_entries x 8 B].
+template <bool F64, typename QS, typename Prog>
+__device__ __forceinline__ void assemble_cells_rt_body(const StoreDev &st, const Prog &prog, const BatchDev &b, const QsDev &q, uint16_t *cells,
+                                                       uint32_t lds_entries) {
+  extern __shared__ __align__(16) uint8_t smem_rt[];
+  constexpr uint32_t THR = QS::thr_total;   // doubles; a whole number of 128-entry chunks
+  qs_lds_double *s_thr = (qs_lds_double *)smem_rt;
+  unsigned long long *s_tab_copy = (unsigned long long *)(smem_rt + (size_t)THR * 8);
+  const int nthr = (int)blockDim.x;
+  {
+    const uint4 *src = (const uint4 *)q.thr;
+    uint4 *dst = (uint4 *)smem_rt;
+    for (uint32_t i = threadIdx.x; i < THR / 2; i += (uint32_t)nthr) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int n_blocks = (b.item_hi - b.item_lo + nthr - 1) / nthr;
+  int have_req = -1;   // the request whose tables s_tab_copy holds
+#ifdef MRK_PHASE_CLOCKS
+  unsigned long long clk_t = clock64(), clk_acc[2] = {0, 0};
+#endif
+  for (int blk = (int)blockIdx.x; blk < n_blocks; blk += (int)gridDim.x) {
+    const int wg_lo = b.item_lo + blk * nthr;
+    const int wg_hi = min(wg_lo + nthr, b.item_hi) - 1;
+    const int r_lo = (int)b.item_req[wg_lo], r_hi = (int)b.item_req[wg_hi];
+    bool in_lds = false;
+    uint32_t tab_sub = 0;
+    if (lds_entries > 0u && r_lo == r_hi && prog.n_prep > 0) {
+      const PrepOut *po = &b.prep_out[(size_t)r_lo * prog.n_prep];
+      const uint32_t a0 = b.reqs[r_lo].arena_begin;
+      uint32_t n_ent = 0;
+      for (int e = 0; e < prog.n_prep; ++e) n_ent = max(n_ent, po[e].tab_off - a0 + po[e].tab_cap);
+      in_lds = n_ent <= lds_entries;                 // (uniform: the whole workgroup takes one branch)
+      if (in_lds) {
+        if (have_req != r_lo) {
+          __syncthreads();                           // the previous block's lookups are over
+          const unsigned long long *src = b.arena + (size_t)a0;
+          for (uint32_t i = threadIdx.x; i < n_ent; i += (uint32_t)nthr) s_tab_copy[i] = src[i];
+          __syncthreads();
+          have_req = r_lo;
+        }
+        tab_sub = a0;
+      }
+    }
+    const int gi0 = wg_lo + (int)threadIdx.x;
+    const bool active = gi0 < b.item_hi;
+    MRK_PHASE(clk_t, clk_acc[0]);
+    if (__any(active)) {                             // (else: a whole wavefront past the end)
+      const int gi = active ? gi0 : b.item_hi - 1;   // lanes without an item ride along on a missing record
+      const int r = (int)b.item_req[gi];
+      const ReqDev rq = b.reqs[r];
+      CellSinkRT<F64, QS> sink{q, cells + (size_t)(gi / QS_TILE_ROWS) * QS::n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
+      // (two instantiations: through a selected pointer the table accesses would be flat instead of ds / global operations)
+      if (in_lds) assemble_item(st, prog, b, gi, r, rq, s_tab_copy, tab_sub, &b.prep_out[(size_t)r * prog.n_prep], sink);
+      else assemble_item(st, prog, b, gi, r, rq, b.arena, 0u, &b.prep_out[(size_t)r * prog.n_prep], sink);
+    }
+    MRK_PHASE(clk_t, clk_acc[1]);
+  }
+#ifdef MRK_PHASE_CLOCKS
+  if (threadIdx.x == 0) {
+    atomicAdd(&mrk_phase_clocks[0], clk_acc[0]);
+    atomicAdd(&mrk_phase_clocks[5], clk_acc[1]);
+    atomicAdd(&mrk_phase_clocks[6], 1ull);
+  }
+#endif
 }
 
 // rank_fused_body writing ClickthroughQuery's row-major f64 matrix

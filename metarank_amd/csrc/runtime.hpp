@@ -126,6 +126,8 @@ struct Switches {
   bool thr_stage = true;       // MRK_THR_STAGE=0: the assembly kernels search threshold tables in global memory instead of staging them in LDS (experiments)
   bool jit_shipped = true;     // MRK_JIT_SHIPPED=0: ignore the code objects shipped next to the library (tests of the compile paths)
   bool items_lds = true;       // MRK_ITEMS_LDS=0: the item-parallel assembly kernel probes the pre-pass tables in the HBM arena even where a workgroup's request's tables fit its LDS
+  bool items_rt = true;        // MRK_ITEMS_RT=0: the item-parallel kernel stages threshold tables per wavefront and column even where all of them fit in LDS (A/B of the resident-table kernel)
+  int items_rt_threads = 0;    // MRK_ITEMS_RT_THREADS=256|512: lanes of the resident-table kernel's workgroups (default: by launch size)
   bool jit_sig = true;         // MRK_JIT_SIG=0: the specialised kernels are keyed by the program only and read the forest's column descriptors from memory (A/B of the view-signature folding)
   bool jit_record_regs = true; // MRK_JIT_REGS=0: the specialised kernel reads the candidate's record cell by cell instead of keeping it in registers
   std::string jit_cache_dir;   // MRK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mrk_jit, else ~/.cache/mrk_jit; "" / "off": none

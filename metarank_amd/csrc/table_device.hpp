@@ -19,6 +19,16 @@ namespace {
 // request live in LDS and their size sets the occupancy; features.cpp table_capacity sizes them tokens / 0.75 + 2, and
 // cap / PROBE_W * PROBE_W still holds those tokens for PROBE_W <= 4); the home bucket is the multiply-high range reduction
 // of a multiplicative hash.
+// Round 6: bit 63 of a bucket's FIRST entry says "an insert walked past this bucket" (it was full of other keys then).  A key
+// lives in the first bucket of its probe sequence that had room when it came, and every bucket before that one was walked
+// past - so a lookup ends at the first bucket without the mark, found or not.  Without it a miss ends only at a bucket with an
+// empty entry: at load 0.75 four of ten buckets are full, a miss walks 1.6 buckets on average - and a wavefront's lookup loop
+// runs as long as its SLOWEST lane: 4 - 5 trips for 64 lanes, where the mark leaves ~2 (tools/phase_clocks.py: the lookups
+// were 55 % of an unloaded request's assembly phase).  Counts are < 2^31 (bits 32..62).
+constexpr unsigned long long TABLE_WALKED = 1ull << 63;
+#ifndef MRK_TABLE_WALKED
+#define MRK_TABLE_WALKED 1   // 0 (A/B through MRK_JIT_DEFINES): nothing is marked, a miss ends at an empty entry only
+#endif
 __device__ __forceinline__ uint32_t tok_home(uint32_t tok, uint32_t span) { return __umulhi(tok * 2654435761u, span); }
 
 // Both primitives are written for the wavefront, not for the lane: the probe loop runs while ANY active lane is
@@ -69,6 +79,7 @@ __device__ __forceinline__ bool table_add_from(unsigned long long *tab, uint32_t
     // not done: the bucket holds other keys only (on to the next one), or its empty entry went to another key (the SAME
     // bucket once more: it may have another empty entry)
     const bool next = open && !here;
+    if (MRK_TABLE_WALKED && next && !(e[0] & TABLE_WALKED)) atomicOr(bp, TABLE_WALKED);   // (the first entry of a full bucket is never empty)
     seen += next ? 1u : 0u;
     bkt = next ? (bkt + 1u == nb ? 0u : bkt + 1u) : bkt;
     full = full || (open && !done && seen >= nb);
@@ -89,11 +100,12 @@ __device__ __forceinline__ uint32_t table_get_from(const unsigned long long *tab
 #pragma unroll
     for (int k = 0; k < PROBE_W; ++k) {
       const uint32_t key = (uint32_t)e[k];
-      r2 = key == tok ? (uint32_t)(e[k] >> 32) : r2;
+      r2 = key == tok ? (uint32_t)(e[k] >> 32) & 0x7fffffffu : r2;
       lo = min(lo, key);
     }
     res = open ? r2 : res;
-    open = open && r2 == 0u && lo != 0u && seen + 1u < nb;   // found, or an empty entry, or every bucket seen: done
+    // found, or an empty entry, or no insert ever walked past this bucket, or every bucket seen: done
+    open = open && r2 == 0u && lo != 0u && (!MRK_TABLE_WALKED || (e[0] & TABLE_WALKED) != 0ull) && seen + 1u < nb;
     bkt = bkt + 1u == nb ? 0u : bkt + 1u;
   }
   return res;
@@ -110,12 +122,29 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
   return table_get_from(tab, nb, tok, want, tok_home(tok, nb), 0u, 0u);
 }
 
+// (Measured and removed, round 6 - profiles/r06_l_get_k_ab.txt: K lookups of one table sharing their trips - the K buckets of a trip read
+// together, one loop for all K.  K = 2 / 4 against one at a time, same box: c2 assembly 0.212 / 0.221 vs 0.206 ms, c4x 0.828 / 0.907 vs
+// 0.775 ms - K buckets in registers spill (6 -> 17 -> 53 VGPRs spilled in the c2 kernel), and with the walked-past mark a lookup
+// is 1 - 2 trips anyway.)
 // The tokens of a list are fetched TOK_BATCH at a time (independent loads in flight together) before the
 // probes start: one trip to memory per batch instead of one per token.
 #ifndef MRK_TOK_BATCH
 #define MRK_TOK_BATCH 8
 #endif
 constexpr int TOK_BATCH = MRK_TOK_BATCH;
+
+// tk[0, min(len, N)) -> table: tokens already in registers (the caller fetched them with its other loads).  Returns the number
+// this lane could not insert.
+template <int N>
+__device__ __forceinline__ uint32_t table_add_tokens(unsigned long long *tab, uint32_t cap, const uint32_t (&tk)[N], uint32_t len) {
+  uint32_t failed = 0;
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    if (!wave_any((uint32_t)t < len)) break;
+    failed += table_add(tab, cap, tk[t], (uint32_t)t < len) ? 0u : 1u;
+  }
+  return failed;
+}
 
 // every token of toks[0, len) -> table (pre-pass); len = 0 for lanes without a list.  Returns the
 // number of tokens this lane could not insert (table full).
@@ -134,6 +163,17 @@ __device__ __forceinline__ uint32_t table_add_list(const uint32_t *toks, unsigne
   return failed;
 }
 
+// cnt + the table counts of tk[0, min(len, N)), added as doubles in token order (lanes past their list add 0.0)
+template <int N>
+__device__ __forceinline__ double table_sum_tokens(const unsigned long long *tab, uint32_t cap, const uint32_t (&tk)[N], uint32_t len, double cnt) {
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    if (!wave_any((uint32_t)t < len)) break;
+    cnt = cnt + (double)table_get(tab, cap, tk[t], (uint32_t)t < len);
+  }
+  return cnt;
+}
+
 // sum over the tokens toks[0, len) of their table counts, added as doubles in list order
 // (InteractedWithFeature.scala:150-160 / DiversityFeature.scala:112-122: integers, exact)
 __device__ __forceinline__ double table_sum_list(const uint32_t *toks, const unsigned long long *tab, uint32_t cap, uint32_t len,
@@ -142,11 +182,7 @@ __device__ __forceinline__ double table_sum_list(const uint32_t *toks, const uns
     uint32_t tk[TOK_BATCH];
 #pragma unroll
     for (int t = 0; t < TOK_BATCH; ++t) tk[t] = j0 + t < len ? toks[j0 + t] : 0u;
-#pragma unroll
-    for (int t = 0; t < TOK_BATCH; ++t) {
-      if (!wave_any(j0 + t < len)) break;
-      cnt = cnt + (double)table_get(tab, cap, tk[t], j0 + t < len);  // riding lanes add 0.0
-    }
+    cnt = table_sum_tokens<TOK_BATCH>(tab, cap, tk, len > j0 ? len - j0 : 0u, cnt);
   }
   return cnt;
 }

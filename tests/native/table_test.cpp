@@ -16,6 +16,7 @@
 static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long c, unsigned long long v) {
   __atomic_compare_exchange_n(p, &c, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
   return c;   // the value found there (== the expected one on success), like the device's atomicCAS
@@ -60,7 +61,7 @@ static void run(long long &checks, long long &bad) {
         (void)A::add(tab.data(), cap, 12345u, false);   // a lane that rides along inserts nothing
         size_t used = 0;   // every entry is a key of the reference with its count, once
         for (unsigned long long e : tab)
-          if ((uint32_t)e) { ++used; if (!ref.count((uint32_t)e) || ref[(uint32_t)e] != (uint32_t)(e >> 32)) { ++bad; printf("%s: entry mismatch\n", A::name); } }
+          if ((uint32_t)e) { ++used; if (!ref.count((uint32_t)e) || ref[(uint32_t)e] != ((uint32_t)(e >> 32) & 0x7fffffffu /* bit 63: the bucket's walked-past mark */)) { ++bad; printf("%s: entry mismatch\n", A::name); } }
         if (used != ref.size()) { ++bad; printf("%s: cap %u: %zu entries for %zu keys\n", A::name, cap, used, ref.size()); }
         std::vector<uint32_t> q;   // lookups: present keys, absent keys, riding lanes
         for (auto &kv : ref) q.push_back(kv.first);

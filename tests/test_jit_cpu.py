@@ -45,7 +45,10 @@ def test_source_carries_the_program_as_constants():
         rc, one = specialize(cfg, 0 | ((k + 1) << 8))
         one = one.decode().replace("\n", "")
         assert rc == 0 and name in one and not any(o in one for o in names if o != name), name
-    assert specialize(cfg, 0 | (9 << 8))[0] == _native.ERR_INVALID_ARG
+    # the resident-table form of the item-parallel kernel (jit.hpp JIT_ITEMS_RT) exists only with a forest signature
+    rc, rt = specialize(cfg, 0 | (9 << 8))
+    assert rc == 0 and b"mrk_jit_assemble_cells_rt(" not in rt.replace(b"\n", b"")
+    assert specialize(cfg, 0 | (10 << 8))[0] == _native.ERR_INVALID_ARG
 
 
 def specialize_for_model(cfg, backend, blob, what, model=b"xgboost"):
@@ -75,6 +78,11 @@ def test_source_carries_the_forests_view_signature():
     assert "struct JitQs" in text and "rank_fused_cells_body<true, false, mrk::JitQs>" in text and "n_feats = 24" in text
     rows = re.search(r"struct JitSigRows \{.*?= \{(.*?)\};", text, re.S).group(1)
     assert rows.count("{") == 24
+    # the resident-table item-parallel kernel: every threshold table in LDS, their total size a constant of the signature
+    rc, rsrc = specialize_for_model(cfg, 0, blob, 0 | (9 << 8))
+    assert rc == 0 and b"mrk_jit_assemble_cells_rt(" in rsrc.replace(b"\n", b"") and b"assemble_cells_rt_body<true, mrk::JitQs>" in rsrc
+    total = int(re.search(r"thr_total = (\d+)u", rsrc.decode()).group(1))
+    assert total % 128 == 0 and 0 < total * 8 <= 64 * 1024
     # the f64-matrix kernel bins nothing: no signature in its translation unit
     rc, msrc = specialize_for_model(cfg, 0, blob, 0 | (3 << 8))
     assert rc == 0 and b"JitQs" not in msrc
@@ -99,7 +107,7 @@ def test_hiprtc_compiles_the_signature_keyed_kernels(backend):
     cfg = ranklens.ranklens_config()
     blob = (synth.synthetic_lgbm_model(n_trees=40, n_features=24, missing="per_feature", cat_features=[7], cat_prob=0.05) if backend == 0
             else synth.synthetic_xgb_model(n_trees=10, n_features=24, depth=3))
-    for kernel in (1, 5):   # the kernel of full batches, mrk_rank's one-launch kernel
+    for kernel in (1, 5, 9):   # the kernel of full batches, mrk_rank's one-launch kernel, the resident-table item-parallel kernel
         rc, code = specialize_for_model(cfg, backend, blob, 1 | (kernel << 8))
         assert rc == 0, _native.lib().mrk_last_error()
         assert code[:4] == b"\x7fELF" and b"gfx950" in code

@@ -47,11 +47,15 @@ batch.sync()
 assert lib.mrk_debug_phase(ctx._h, b"xgboost", out) == 0
 v = np.array(list(out), dtype=np.float64)
 wg = v[6]
-names = ["table sweep", "interacted_with histograms", "diversity find-first/type", "diversity strings", "diversity medians", "per-item assembly"]
+# (round 6, wave-per-section pre-pass: [1] = both sections + their barrier, [2] / [3] = the interacted_with section on wavefront 1 and
+#  the diversity section on wavefront 0, each by itself; [7] = issuing the op groups' primary cells and second trips, part of [5])
+names = ["table sweep", "pre-pass sections + barrier", "  interacted_with alone (wave 1)", "  diversity alone (wave 0)", "diversity medians (workgroup-wide path)", "per-item assembly"]
 print(f"workgroups {int(wg)}; cycles per workgroup (thread 0):")
-tot = v[:6].sum() / wg
+tot = (v[0] + v[1] + v[5]) / wg
 for i, n in enumerate(names):
     print(f"  {n:28s} {v[i] / wg:10.0f}  {100 * v[i] / wg / tot:5.1f} %")
+print(f"  {'  of which issuing trips':28s} {v[7] / wg:10.0f}")
+print(f"  diversity section: find-first {v[8] / wg:.0f}, strings {v[9] / wg:.0f}, numeric medians {v[10] / wg:.0f}")
 print(f"  {'total':28s} {tot:10.0f}")
 model_feats = cfg["models"]["xgboost"]["features"]
 ops = v[16:16 + len(model_feats)]
