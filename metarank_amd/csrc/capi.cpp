@@ -191,6 +191,8 @@ static void upload_model(mrk_ctx *ctx, mrk_model *m) {
     {  // the assembly kernel stages tables with 1 KiB wave-loads that may run past a table's end: slack after the last one
       std::vector<double> padded(m->qs.thr);
       padded.resize(padded.size() + 2 * QS_STAGE_CHUNK, 0.0);
+      // ... and behind the slack the compact tables of the resident-table sinks (score_qs.hip qs_device_view: QsDev::thr_rt)
+      padded.insert(padded.end(), m->qs.thr_rt.begin(), m->qs.thr_rt.end());
       up(m->d_qs_thr, padded.data(), padded.size() * 8);
     }
     up(m->d_qs_feats, m->qs.feats.data(), m->qs.feats.size() * sizeof(QsFeature));

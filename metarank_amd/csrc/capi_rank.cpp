@@ -35,8 +35,9 @@ void launch_score_batch(mrk_ctx *ctx, mrk_model *m, const double *d_x, int rows,
 void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, const QsDev &q,
                            uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries, void *jit_rt_fn = nullptr, uint32_t thr_total = 0);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
-                       int vals_cap, int threads, int op_split, int slices, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn);
-size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap);
+                       int vals_cap, int threads, int op_split, int slices, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn, size_t rt_bytes = 0);
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, size_t rt_bytes);
+size_t fused_rt_max_bytes();
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 QsForestDev qs_forest_view(const mrk_model *m);  // score_qs.hip
@@ -332,7 +333,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.fused_slices = shape.slices;
   b.fused_threads = shape.threads();
   b.fused_ok = sw.rank_fused && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
-               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR) <= 64 * 1024;
+               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR, fused_rt_max_bytes()) <= 64 * 1024;
 }
 
 static void check_model_fits(mrk_model *model, const Program &prog) {
@@ -472,10 +473,11 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
     if (hi % QS_TILE_ROWS && tile_bytes)  // rows past the last item of the last tile of this range
       MRK_HIP(hipMemsetAsync(b.d_cells.as<uint8_t>() + (size_t)(hi / QS_TILE_ROWS) * tile_bytes, 0, tile_bytes, b.s()));
     if (b.fused_ok) {
-      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, b.fused_slices, &q, b.d_cells.as<uint16_t>(), f64, jit_fn);
+      launch_rank_fused(ctx, st, pd, b.view, b.fused_entries, b.fused_vals, b.fused_threads, b.fused_split, b.fused_slices, &q, b.d_cells.as<uint16_t>(), f64, jit_fn,
+                        sig && sig->ok ? (size_t)sig->rt_total * 8 : 0);
     } else {
       launch_prepass(ctx, st, pd, b.view, b.fused_entries, jit_prep_fn);
-      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn, b.fused_entries, jit_rt_fn, jit_rt_fn ? model->qs_sig.thr_total : 0u);
+      launch_assemble_cells(ctx, st, pd, b.view, q, b.d_cells.as<uint16_t>(), f64, jit_fn, b.fused_entries, jit_rt_fn, jit_rt_fn ? model->qs_sig.rt_total : 0u);
     }
     b.matrix_valid = false;
     // lo is a multiple of the tile size: the scorer sees rows [lo, hi) as its rows [0, hi - lo)

@@ -132,6 +132,11 @@ struct QsSig {
   uint16_t chunks;                 // ceil(thr_len / QS_STAGE_CHUNK)
   uint8_t view_begin, view_end;
   uint32_t view_kinds;
+  // the column's table in the COMPACT layout the resident-table sinks search (forest.hpp PackedForestQS::thr_rt): offset and
+  // EXACT length in doubles (0: no thresholds; QS_RT_NONE: not resident - more than 256 thresholds, searched in global memory)
+  uint32_t rt_off;
+  uint32_t rt_len;
 };
+constexpr uint32_t QS_RT_NONE = 0xffffffffu;
 
 }  // namespace mrk

@@ -839,7 +839,15 @@ PackedForestQS pack_forest_qs(const Forest &f, int n_cols) {
     // staged copy in a FIXED number of steps (qs_device.hpp qs_bin_search_staged) - an entry past the table compares as
     // "not below" for every value
     while (pf.thr.size() % QS_STAGE_CHUNK) pf.thr.push_back(std::numeric_limits<double>::infinity());
+    // the compact copy (resident-table sinks): exact length - their search halves a compile-time length, every read inside the table
+    pf.rt_off.push_back((uint32_t)pf.thr_rt.size());
+    if (v.size() > 256) pf.rt_len.push_back(QS_RT_NONE);
+    else {
+      pf.rt_len.push_back((uint32_t)v.size());
+      pf.thr_rt.insert(pf.thr_rt.end(), v.begin(), v.end());
+    }
   }
+  if (pf.thr_rt.size() % 2) pf.thr_rt.push_back(std::numeric_limits<double>::infinity());   // copied 16 bytes at a time
   {
     int id = 0, cur = -1;
     for (auto &kv : view_ids) {
@@ -948,13 +956,19 @@ QsSignature qs_signature(const PackedForestQS &pf, uint32_t thr_cap) {
     // pack_forest_qs lays the tables out in column order, each padded to whole chunks: a column's offset follows from the
     // chunk counts before it (a different layout: no signature, the kernels keep reading descriptors)
     if (f.thr_off != off || f.view_end - f.view_begin > 6 || f.view_end < f.view_begin) return QsSignature{};
-    sg.cols.push_back(QsSig{off, (uint16_t)chunks, f.view_begin, f.view_end, f.view_kinds});
+    const size_t fi = sg.cols.size();
+    if (fi >= pf.rt_off.size() || fi >= pf.rt_len.size()) return QsSignature{};
+    // (a column the forest never splits on is never searched: its compact table's place is not part of the key)
+    const bool used = f.view_begin != f.view_end;
+    const uint32_t rt_off = used ? pf.rt_off[fi] : 0u, rt_len = used ? pf.rt_len[fi] : 0u;
+    sg.cols.push_back(QsSig{off, (uint16_t)chunks, f.view_begin, f.view_end, f.view_kinds, rt_off, rt_len});
     sg.text += "{" + std::to_string(off) + "u," + std::to_string(chunks) + "," + std::to_string(f.view_begin) + "," + std::to_string(f.view_end) + "," +
-               std::to_string(f.view_kinds) + "u},";
+               std::to_string(f.view_kinds) + "u," + std::to_string(rt_off) + "u," + std::to_string(rt_len) + "u},";
     off += chunks * QS_STAGE_CHUNK;
   }
   if ((size_t)off != pf.thr.size()) return QsSignature{};
   sg.thr_total = off;
+  sg.rt_total = (uint32_t)pf.thr_rt.size();
   sg.text = "/*cap " + std::to_string(thr_cap) + " views " + std::to_string(sg.n_views) + "*/" + sg.text;
   sg.ok = true;
   return sg;

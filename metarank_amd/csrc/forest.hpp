@@ -164,12 +164,17 @@ struct PackedForestQS {
   std::vector<uint32_t> nodes;   // (n_trees + 1) * QS_SLOTS * 2
   std::vector<uint8_t> leaves;   // n_trees * QS_LEAVES * (8 | 4)
   std::vector<double> thr;
+  // the same tables once more, COMPACT: back to back at their exact lengths (no 128-entry chunks, no padding) - a model with
+  // 50 distinct thresholds per column is 9 KB here and 24 KB in `thr`; what the resident-table sinks keep in LDS.
+  // Columns with more than 256 thresholds take no room (rt_len = QS_RT_NONE).
+  std::vector<double> thr_rt;
+  std::vector<uint32_t> rt_off, rt_len;   // per feature
   std::vector<QsFeature> feats;  // n_features
   std::vector<QsView> views;
   std::vector<QsCatNode> cat_nodes;
   std::vector<uint32_t> cat_bits;
   size_t device_bytes() const {
-    return nodes.size() * 4 + leaves.size() + thr.size() * 8 + feats.size() * 16 + views.size() * 4 + cat_nodes.size() * 16 + cat_bits.size() * 4;
+    return nodes.size() * 4 + leaves.size() + (thr.size() + thr_rt.size()) * 8 + feats.size() * 16 + views.size() * 4 + cat_nodes.size() * 16 + cat_bits.size() * 4;
   }
 };
 
@@ -184,6 +189,7 @@ struct QsSignature {
   uint32_t thr_cap = 0;        // doubles per LDS staging buffer (QsDev::thr_cap)
   int n_views = 0;
   uint32_t thr_total = 0;      // doubles of all threshold tables together (whole chunks per column)
+  uint32_t rt_total = 0;       // doubles of the compact tables (PackedForestQS::thr_rt)
   std::vector<QsSig> cols;     // n_features
   std::string text;            // the rows as a C++ initialiser list: part of the specialised translation unit, and the key
 };

@@ -106,7 +106,7 @@ std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignat
     table("JitSigRows", "QsSig", sig->cols.size(), sig->text);
     s += "struct JitQs {\n  static constexpr bool is_static = true;\n  static constexpr int n_feats = " + std::to_string(sig->cols.size()) +
          ", n_views = " + std::to_string(sig->n_views) + ";\n  static constexpr uint32_t thr_cap = " + std::to_string(sig->thr_cap) +
-         "u, thr_total = " + std::to_string(sig->thr_total) +
+         "u, thr_total = " + std::to_string(sig->thr_total) + "u, rt_total = " + std::to_string(sig->rt_total) +
          "u;\n  __device__ __forceinline__ constexpr QsSig operator[](int i) const { return JitSigRows{}[i]; }\n};\n";
     qs = "mrk::JitQs";
   }
@@ -231,7 +231,7 @@ const char *const JIT_KERNEL_NAME[JIT_KERNELS] = {"mrk_jit_rank_cells", "mrk_jit
 // a kernel that exists only with a forest signature: no program-only stand-in (the caller falls back to another KERNEL meanwhile)
 static inline bool jit_needs_sig(int kernel) { return kernel == JIT_ITEMS_RT; }
 // the resident-table kernel: every table in LDS (<= 64 KB of thresholds leaves room for a request's hash tables and a second workgroup)
-bool jit_items_rt_applies(const QsSignature *sig) { return sig && sig->ok && sig->thr_total > 0 && (size_t)sig->thr_total * 8 <= 64 * 1024 && switches().jit_sig && switches().items_rt; }
+bool jit_items_rt_applies(const QsSignature *sig) { return sig && sig->ok && sig->rt_total > 0 && (size_t)sig->rt_total * 8 <= 64 * 1024 && switches().jit_sig && switches().items_rt; }
 // kernels that neither write the scorer's tile nor depend on the scorer's precision: one per program, kept in slot [kernel][1]
 static inline bool jit_program_only(int kernel) { return kernel == JIT_MATRIX || kernel == JIT_PREPASS; }
 

@@ -13,6 +13,7 @@ struct QsDev {             // what a kernel needs to bin a value of any matrix c
   const QsFeature *feats;  // n_feats
   const QsView *views;
   const double *thr;
+  const double *thr_rt;    // the compact tables (QsSig::rt_off): what a resident-table sink copies into LDS
   int32_t n_feats;
   int32_t n_views;
   uint32_t thr_cap;        // doubles per LDS staging buffer: the longest staged table rounded up to QS_STAGE_CHUNK

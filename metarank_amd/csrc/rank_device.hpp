@@ -88,8 +88,13 @@ constexpr int PREP_THREADS = 256;
 constexpr int FUSED_MAX_PREP = 32;  // pre-pass entries of one model (PrepOut copies + `first` slots kept in LDS)
 constexpr int PREP_GROUP = 4;       // entries handled by one merged pass (their loads are issued together)
 constexpr int PREP_WAVES = 8;       // most wavefronts of a workgroup that runs a pre-pass (512 lanes: a single request split over op groups)
-constexpr int DIV_GROUP = 8;        // diversity entries the wave-local section handles in one pass (the five of the Ranklens model: one pass, not two)
-constexpr int DIV_PRE_TOK = 6;      // tokens per list fetched ahead of the inserts in the wave-local sections
+#ifndef MRK_DIV_GROUP
+#define MRK_DIV_GROUP 4
+#endif
+constexpr int DIV_GROUP = MRK_DIV_GROUP;   // diversity entries the wave-local section handles in one pass (8 - the five of the Ranklens model in one pass - measured no faster under load and 12 k cycles slower unloaded: profiles/r06_m_prepass_ab.txt)
+// (Round 6, measured and removed: the first 6 tokens of every entry's / field's list fetched together ahead of the inserts - one
+//  trip per group instead of one per entry.  No gain under load (c2 assembly 0.206 vs 0.208 ms), the diversity section 12 k cycles
+//  SLOWER on an unloaded request, +25 KB of unrolled insert loops: profiles/r06_m_prepass_ab.txt.)
 constexpr int PREP_INTS = 96;       // ints of LDS scratch: wave_tot[PREP_WAVES][PREP_GROUP] | first[FUSED_MAX_PREP] | misc[4] | tokens[DIV_GROUP]
 
 struct PrepScratch {   // LDS scratch of one workgroup
@@ -266,23 +271,11 @@ __device__ __forceinline__ void prepass_interacted_with(const StoreDev &st, cons
           ic[u].bits = 0;
           if (u < n) ic[u] = load_cell(irec, col[u]);
         }
-        // the first tokens of every field's list, requested together (one trip for the group, not one per field)
-        uint32_t ptk[PREP_GROUP][DIV_PRE_TOK];
-#pragma unroll
-        for (int u = 0; u < PREP_GROUP; ++u) {
-          const uint32_t plen = u < n && ic[u].tag == TAG_STRING_LIST ? ic[u].hi() : 0u;
-          const uint32_t *toks = list_tokens(st, irec, ic[u].lo());
-#pragma unroll
-          for (int t = 0; t < DIV_PRE_TOK; ++t) ptk[u][t] = (uint32_t)t < plen ? toks[t] : 0u;
-        }
 #pragma unroll
         for (int u = 0; u < PREP_GROUP; ++u) {
           if (u < n) {  // uniform
-            const uint32_t tlen = ic[u].tag == TAG_STRING_LIST ? ic[u].hi() : 0u;
-            uint32_t failed = table_add_tokens<DIV_PRE_TOK>(tab[u], cap[u], ptk[u], tlen);
-            if (wave_any(tlen > (uint32_t)DIV_PRE_TOK))
-              failed += table_add_list(list_tokens(st, irec, ic[u].lo()) + DIV_PRE_TOK, tab[u], cap[u], tlen > (uint32_t)DIV_PRE_TOK ? tlen - DIV_PRE_TOK : 0u);
-            if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
+            const bool list = ic[u].tag == TAG_STRING_LIST;
+            if (table_add_list(list_tokens(st, irec, ic[u].lo()), tab[u], cap[u], list ? ic[u].hi() : 0u)) atomicOr(&b.status[r], ST_TABLE_FULL);
           }
         }
       }
@@ -390,15 +383,6 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
           if (u < n && mode[u] == DIV_STRING) c[u] = base == 0 ? keep[u] : load_cell(irec, col[u]);
           cand[u] = c[u].tag == TAG_STRING || c[u].tag == TAG_STRING_LIST;
         }
-        // the first tokens of every entry's list, requested together: one trip to memory for the group instead of one per entry
-        uint32_t ptk[DIV_GROUP][DIV_PRE_TOK];
-#pragma unroll
-        for (int u = 0; u < DIV_GROUP; ++u) {
-          const uint32_t plen = u < n && mode[u] == DIV_STRING && c[u].tag == TAG_STRING_LIST ? c[u].hi() : 0u;
-          const uint32_t *toks = list_tokens(st, irec, c[u].lo());
-#pragma unroll
-          for (int t = 0; t < DIV_PRE_TOK; ++t) ptk[u][t] = (uint32_t)t < plen ? toks[t] : 0u;
-        }
 #pragma unroll
         for (int u = 0; u < DIV_GROUP; ++u) {
           int total = 0;
@@ -408,9 +392,7 @@ __device__ __forceinline__ void prepass_diversity_wave(const StoreDev &st, const
             const bool one = take && c[u].tag == TAG_STRING;
             const uint32_t tlen = take && !one ? c[u].hi() : 0u;
             uint32_t failed = table_add(tab[u], cap[u], c[u].lo(), one) ? 0u : 1u;
-            failed += table_add_tokens<DIV_PRE_TOK>(tab[u], cap[u], ptk[u], tlen);
-            if (wave_any(tlen > (uint32_t)DIV_PRE_TOK))
-              failed += table_add_list(list_tokens(st, irec, c[u].lo()) + DIV_PRE_TOK, tab[u], cap[u], tlen > (uint32_t)DIV_PRE_TOK ? tlen - DIV_PRE_TOK : 0u);
+            failed += table_add_list(list_tokens(st, irec, c[u].lo()), tab[u], cap[u], tlen);
             if (failed) atomicOr(&b.status[r], ST_TABLE_FULL);
             if (take) atomicAdd(&s_tokens[u], one ? 1 : (int)tlen);
           }
@@ -958,20 +940,27 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
 // point of straight-line code.  Were the count not to fold, the switch below would be a uniform branch - never a run-time
 // index into registers.)
 constexpr int RT_Q = 4;
+// The workgroup-per-request kernels keep the compact tables resident too when they are no bigger than this (the benchmark's
+// Ranklens model - ~50 distinct thresholds on its continuous columns, 740 in all: 6 KB - where two wavefronts' staging buffers take
+// 4 - 8 KB): the same LDS class, so the same residency, no staging traffic (every wavefront staged every column's table for every 64 candidates), no counted waits, 4 searches at a time.
+constexpr size_t FUSED_RT_MAX_BYTES = 8 * 1024;
+template <typename QS> __device__ __forceinline__ constexpr bool qs_fused_rt() {
+  if constexpr (QS::is_static) return QS::rt_total > 0u && (size_t)QS::rt_total * 8 <= FUSED_RT_MAX_BYTES;
+  else return false;
+}
 template <bool F64, typename QS>
 struct CellSinkRT {
   static_assert(QS::is_static, "the resident-table sink needs the forest's signature at compile time");
   QsDev q;
   uint16_t *dst;           // &cells[tile][0][row]
   int32_t *status;
-  qs_lds_double *thr_all;  // the forest's threshold tables, laid out as in global memory (QsSig::thr_off)
+  qs_lds_double *thr_all;  // the forest's COMPACT threshold tables (QsDev::thr_rt, QsSig::rt_off / rt_len)
   bool active;
   mutable double v0 = 0.0, v1 = 0.0, v2 = 0.0;
   mutable int c0 = 0, c1 = 0, c2 = 0, qn = 0;
 
   __device__ __forceinline__ void begin() const { qn = 0; }
   __device__ __forceinline__ QsFeatureK desc(int col) const { return (QsFeatureK)(unsigned long long)q.feats + col; }
-  static __device__ __forceinline__ constexpr bool resident(const QsSig &s) { return (uint32_t)s.chunks * QS_STAGE_CHUNK <= QS_LDS_THR; }
 
   template <int N>
   __device__ __forceinline__ void bin_group(const int (&col)[RT_Q], const double (&val)[RT_Q]) const {
@@ -979,50 +968,50 @@ struct CellSinkRT {
     qs_lds_double *T[N], *p[N];
     uint32_t pos[N];
     auto below = [](double t, double xx) { return F64 ? (t < xx) : (t <= xx); };
+    // entries of column c's compact table in LDS (0: none there)
+    auto span = [](int c) -> uint32_t { return QS{}[c].rt_len <= 256u ? QS{}[c].rt_len : 0u; };
+    uint32_t n[N];   // what is left of each column's range (compile time: the lengths are constants of the signature)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       bool ok;
       x[i] = qs_prep<F64>(val[i], ok);
       if (!ok && active) atomicOr(status, ST_XGB_INF);
-      T[i] = thr_all + QS{}[col[i]].thr_off;
+      T[i] = thr_all + QS{}[col[i]].rt_off;
       p[i] = T[i];
+      n[i] = span(col[i]);
     }
-    // (tables of <= 128 entries take 7 steps, the others 8; lengths are whole chunks: the +inf padding answers like the table's end)
-    // (the scheduler, short of registers, would run the N chains one after the other again: the barriers keep a step's N reads
-    //  together, ahead of the step's N compares)
+    // the branch-free lower bound of qs_bin_search - halve the range, keep the half the value lies in - for every column of the
+    // group TOGETHER, step by step: a step's N reads are in flight at the same time.  (The scheduler, short of registers, would
+    // run the N chains one after the other again: the barriers keep a step's reads together, ahead of the step's compares.)
     double t[N];
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = QS{}[col[i]].chunks > 1 && resident(QS{}[col[i]]) ? T[i][127] : 0.0;
-    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < 8; ++s) {   // 256 entries: 8 halvings
+      bool any = false;
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-      if (QS{}[col[i]].chunks > 1 && resident(QS{}[col[i]])) p[i] += below(t[i], x[i]) ? 128 : 0;
-#pragma unroll
-    for (int h = 64; h >= 1; h >>= 1) {
+      for (int i = 0; i < N; ++i) any = any || n[i] > 1u;
+      if (!any) break;   // (compile time)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < N; ++i) t[i] = QS{}[col[i]].chunks > 0 && resident(QS{}[col[i]]) ? p[i][h - 1] : 0.0;
+      for (int i = 0; i < N; ++i) t[i] = n[i] > 1u ? p[i][(n[i] >> 1) - 1u] : 0.0;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < N; ++i)
-        if (QS{}[col[i]].chunks > 0 && resident(QS{}[col[i]])) p[i] += below(t[i], x[i]) ? h : 0;
+        if (n[i] > 1u) {
+          const uint32_t half = n[i] >> 1;
+          p[i] += below(t[i], x[i]) ? half : 0u;
+          n[i] -= half;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = QS{}[col[i]].chunks > 0 && resident(QS{}[col[i]]) ? p[i][0] : 0.0;
+    for (int i = 0; i < N; ++i) t[i] = span(col[i]) > 0u ? p[i][0] : 0.0;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const QsSig sg = QS{}[col[i]];
-      const QsFeatureK f = desc(col[i]);
-      if (sg.chunks == 0) pos[i] = 0u;
-      else if (resident(sg)) {
-        pos[i] = (uint32_t)(p[i] - T[i]) + (below(t[i], x[i]) ? 1u : 0u);
-        if constexpr (!F64) pos[i] = min(pos[i], (uint32_t)f->thr_len);   // x = +inf walks through the +inf padding
-      } else {
-        pos[i] = qs_bin_search<F64>(q.thr + sg.thr_off, f->thr_len, x[i]);  // a table too long for LDS: searched where it lies
-      }
+      if (sg.rt_len == 0u) pos[i] = 0u;
+      else if (sg.rt_len <= 256u) pos[i] = (uint32_t)(p[i] - T[i]) + (below(t[i], x[i]) ? 1u : 0u);   // (no padding to walk through: pos <= the table's length)
+      else pos[i] = qs_bin_search<F64>(q.thr + sg.thr_off, desc(col[i])->thr_len, x[i]);  // a table too long for LDS: searched where it lies
     }
     uint16_t *d = dst;
     const bool act = active;
@@ -1722,9 +1711,12 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 //     finished tables from the arena: c3 assembly 0.306 -> 0.278 ms but + 0.045 ms of pre-pass launch, 869 -> 814 M items/s same
 //     box, profiles/r04_d_ab.txt.  Not kept.)
 // lds_skip: bytes at the start of the dynamic LDS that belong to the caller (the one-launch kernel keeps the scorer's slab there).
+// rt_src / rt_doubles: compact threshold tables the workgroup copies into the threshold region before its pre-pass (0: none - the
+// region is per-wavefront staging buffers); make_sink gets both views of the region.
 template <bool SPLIT, typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
-                                                int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink, uint32_t lds_skip = 0) {
+                                                int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink, uint32_t lds_skip = 0,
+                                                const double *rt_src = nullptr, uint32_t rt_doubles = 0) {
   const int op_split = SPLIT ? ((mode & 255) > 1 ? (mode & 255) : 1) : 1;
   const int slices = SPLIT ? (((mode >> 8) & 255) > 1 ? ((mode >> 8) & 255) : 1) : 1;   // (the plain kernel keeps its registers for the ops)
   extern __shared__ __align__(16) uint8_t smem_base[];
@@ -1734,7 +1726,8 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
   PrepOut *s_po = (PrepOut *)(smem + (size_t)tab_entries * 8 + (size_t)vals_cap * 8);
   int *s_int = (int *)(s_po + FUSED_MAX_PREP);
   const size_t thr_at = ((size_t)((uint8_t *)(s_int + PREP_INTS) - smem) + 15) & ~(size_t)15;  // LDS-DMA writes 16 B per lane
-  qs_lds_double *s_thr = (qs_lds_double *)(smem + thr_at) + (size_t)(threadIdx.x >> 6) * 2 * thr_cap;
+  qs_lds_double *s_thr_all = (qs_lds_double *)(smem + thr_at);
+  qs_lds_double *s_thr = s_thr_all + (size_t)(threadIdx.x >> 6) * 2 * thr_cap;
   const int r = (int)blockIdx.x / slices, sl = (int)blockIdx.x % slices;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
@@ -1744,6 +1737,11 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
   const int slice_lo = sl * per, slice_hi = min(rq.n_items, slice_lo + per);
   if (sl > 0 && slice_lo >= rq.n_items) return;            // a shorter request than the batch's longest: nothing left for this slice
   for (int e = threadIdx.x; e < prog.n_prep; e += blockDim.x) s_po[e] = b.prep_out[(size_t)r * prog.n_prep + e];
+  if (rt_doubles) {   // (uniform) the forest's compact tables: on their way while the pre-pass runs; its last barrier publishes them
+    const uint4 *src = (const uint4 *)rt_src;
+    uint4 *dst = (uint4 *)(smem + thr_at);
+    for (uint32_t i = threadIdx.x; i < rt_doubles / 2; i += blockDim.x) dst[i] = src[i];
+  }
   __syncthreads();
   PrepScratch sc{s_vals, vals_cap, s_int, 0ull, {0, 0, 0, 0, 0, 0}};
 #ifdef MRK_PHASE_CLOCKS
@@ -1757,7 +1755,7 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
     const bool active = i < slice_hi && gi0 >= b.item_lo && gi0 < b.item_hi;
     if (!__any(active)) continue;  // wavefront-uniform
     const int gi = active ? gi0 : rq.item_begin;
-    assemble_item<SPLIT>(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr), og, op_split);
+    assemble_item<SPLIT>(st, prog, b, gi, r, rq, s_tab, (uint32_t)rq.arena_begin, s_po, make_sink(gi, r, active, s_thr, s_thr_all), og, op_split);
   }
   MRK_PHASE(sc.clk, sc.acc[5]);
 #ifdef MRK_PHASE_CLOCKS
@@ -1831,17 +1829,17 @@ __device__ __forceinline__ void assemble_cells_body(const StoreDev &st, const Pr
 // column's table for every 64 candidates (750 B of L2 -> LDS traffic per candidate: twice the record itself), and bin through
 // CellSinkRT.  A workgroup whose block belongs to one request keeps that request's finished hash tables in LDS as before, and
 // keeps them across blocks of the same request (config 4: one copy per workgroup for the whole launch).
-// Dynamic LDS: [threshold tables: QS::thr_total x 8 B][hash tables: lds_entries x 8 B].
+// Dynamic LDS: [compact threshold tables: QS::rt_total x 8 B][hash tables: lds_entries x 8 B].
 template <bool F64, typename QS, typename Prog>
 __device__ __forceinline__ void assemble_cells_rt_body(const StoreDev &st, const Prog &prog, const BatchDev &b, const QsDev &q, uint16_t *cells,
                                                        uint32_t lds_entries) {
   extern __shared__ __align__(16) uint8_t smem_rt[];
-  constexpr uint32_t THR = QS::thr_total;   // doubles; a whole number of 128-entry chunks
+  constexpr uint32_t THR = QS::rt_total;   // doubles of the compact tables (an even number)
   qs_lds_double *s_thr = (qs_lds_double *)smem_rt;
   unsigned long long *s_tab_copy = (unsigned long long *)(smem_rt + (size_t)THR * 8);
   const int nthr = (int)blockDim.x;
   {
-    const uint4 *src = (const uint4 *)q.thr;
+    const uint4 *src = (const uint4 *)q.thr_rt;
     uint4 *dst = (uint4 *)smem_rt;
     for (uint32_t i = threadIdx.x; i < THR / 2; i += (uint32_t)nthr) dst[i] = src[i];
   }
@@ -1901,16 +1899,22 @@ __device__ __forceinline__ void assemble_cells_rt_body(const StoreDev &st, const
 template <bool SPLIT = false, typename Prog>
 __device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap, int mode = 1) {
   rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, 0u, mode,
-                  [&](int gi, int, bool active, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
+                  [&](int gi, int, bool active, qs_lds_double *, qs_lds_double *) { return MatrixSink{b.matrix + (size_t)gi * prog.dim, active}; });
 }
 
 // the hot-path instance of rank_fused_body: straight into the scorer's binned tile
 template <bool F64, bool SPLIT = false, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
                                                       int vals_cap, const QsDev &q, uint16_t *cells, int mode = 1) {
-  rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode, [&](int gi, int r, bool active, qs_lds_double *s_thr) {
-    return CellSink<F64, QS>{q, cells + (size_t)(gi / QS_TILE_ROWS) * qs_n_views<QS>(q) * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
-  });
+  if constexpr (qs_fused_rt<QS>()) {   // the forest's compact tables fit: resident, searched four columns at a time (CellSinkRT)
+    rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode, [&](int gi, int r, bool active, qs_lds_double *, qs_lds_double *s_all) {
+      return CellSinkRT<F64, QS>{q, cells + (size_t)(gi / QS_TILE_ROWS) * QS::n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_all, active};
+    }, 0u, q.thr_rt, QS::rt_total);
+  } else {
+    rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode, [&](int gi, int r, bool active, qs_lds_double *s_thr, qs_lds_double *) {
+      return CellSink<F64, QS>{q, cells + (size_t)(gi / QS_TILE_ROWS) * qs_n_views<QS>(q) * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_thr, active};
+    });
+  }
 }
 
 // ---- ONE launch for a handful of small requests (mrk_rank, the serving queue): pre-pass + assembly + forest + ordering in
@@ -1935,7 +1939,7 @@ __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &pr
   BatchDev bl = b;
   bl.status = s_status - r;   // &bl.status[r] is the LDS word
   __syncthreads();
-  rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
+  rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr, qs_lds_double *) {
     return CellSink<F64, QS>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active, /*vm_stores=*/false};
   }, slab_bytes + 16);
   // (qs_score_tile_split starts with a barrier: the slab is complete, the assembly's LDS regions are free)
@@ -1985,7 +1989,7 @@ __device__ __forceinline__ void rank_fused_score_body(const StoreDev &st, const 
   // rows past the request's last candidate (their cells only have to be harmless)
   for (uint32_t i = tid; i < (uint32_t)qs_n_views<QS>(q) * QS_TILE_ROWS; i += nthr)
     if ((int)(i % QS_TILE_ROWS) >= rq.n_items) tile[i] = 0;
-  rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), 1, [&](int gi, int rr, bool active, qs_lds_double *s_thr) {
+  rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), 1, [&](int gi, int rr, bool active, qs_lds_double *s_thr, qs_lds_double *) {
     return CellSink<F64, QS>{q, tile + (gi - rq.item_begin), &b.status[rr], s_thr, active};
   });
   // the tile has reached L2 (this CU's L1 holds none of its lines: nothing has read them), every table is dead

@@ -498,6 +498,7 @@ QsDev qs_device_view(const mrk_model *m) {
   q.feats = m->d_qs_feats.as<QsFeature>();
   q.views = m->d_qs_views.as<QsView>();
   q.thr = m->d_qs_thr.as<double>();
+  q.thr_rt = q.thr + m->qs.thr.size() + 2 * QS_STAGE_CHUNK;   // (capi.cpp upload_model: tables, slack, compact tables)
   q.n_feats = (int32_t)m->qs.feats.size();
   q.n_views = (int32_t)m->qs.views.size();
   static_assert(QS_LDS_THR == 256u, "qs_stage_cap (forest.cpp) stages tables of up to QS_LDS_THR entries");

@@ -133,19 +133,6 @@ __device__ __forceinline__ uint32_t table_get(const unsigned long long *tab, uin
 #endif
 constexpr int TOK_BATCH = MRK_TOK_BATCH;
 
-// tk[0, min(len, N)) -> table: tokens already in registers (the caller fetched them with its other loads).  Returns the number
-// this lane could not insert.
-template <int N>
-__device__ __forceinline__ uint32_t table_add_tokens(unsigned long long *tab, uint32_t cap, const uint32_t (&tk)[N], uint32_t len) {
-  uint32_t failed = 0;
-#pragma unroll
-  for (int t = 0; t < N; ++t) {
-    if (!wave_any((uint32_t)t < len)) break;
-    failed += table_add(tab, cap, tk[t], (uint32_t)t < len) ? 0u : 1u;
-  }
-  return failed;
-}
-
 // every token of toks[0, len) -> table (pre-pass); len = 0 for lanes without a list.  Returns the
 // number of tokens this lane could not insert (table full).
 __device__ __forceinline__ uint32_t table_add_list(const uint32_t *toks, unsigned long long *tab, uint32_t cap, uint32_t len) {

@@ -82,7 +82,8 @@ def test_source_carries_the_forests_view_signature():
     rc, rsrc = specialize_for_model(cfg, 0, blob, 0 | (9 << 8))
     assert rc == 0 and b"mrk_jit_assemble_cells_rt(" in rsrc.replace(b"\n", b"") and b"assemble_cells_rt_body<true, mrk::JitQs>" in rsrc
     total = int(re.search(r"thr_total = (\d+)u", rsrc.decode()).group(1))
-    assert total % 128 == 0 and 0 < total * 8 <= 64 * 1024
+    compact = int(re.search(r"rt_total = (\d+)u", rsrc.decode()).group(1))   # the same tables padded to powers of two instead of 128-entry chunks
+    assert total % 128 == 0 and compact % 2 == 0 and 0 < compact <= total and compact * 8 <= 64 * 1024
     # the f64-matrix kernel bins nothing: no signature in its translation unit
     rc, msrc = specialize_for_model(cfg, 0, blob, 0 | (3 << 8))
     assert rc == 0 and b"JitQs" not in msrc
