@@ -36,7 +36,7 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
                            uint16_t *cells, bool f64, void *jit_fn, uint32_t max_req_entries, void *jit_rt_fn = nullptr, uint32_t thr_total = 0);
 void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries,
                        int vals_cap, int threads, int op_split, int slices, const QsDev *q, uint16_t *cells, bool f64, void *jit_fn, size_t rt_bytes = 0);
-size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, size_t rt_bytes);
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, size_t rt_bytes, bool split);
 size_t fused_rt_max_bytes();
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
@@ -333,7 +333,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.fused_slices = shape.slices;
   b.fused_threads = shape.threads();
   b.fused_ok = sw.rank_fused && (int)prog.prep.size() <= fused_max_prep() && hb.max_items <= 1024 &&
-               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR, fused_rt_max_bytes()) <= 64 * 1024;
+               hb.max_req_entries <= (1u << 20) && fused_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, QS_LDS_THR, fused_rt_max_bytes(), true) <= 64 * 1024;
 }
 
 static void check_model_fits(mrk_model *model, const Program &prog) {

@@ -341,12 +341,12 @@ void launch_assemble_cells(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &p
 // thr_cap: doubles per threshold staging buffer (QsDev::thr_cap; QS_LDS_THR = the largest any model needs)
 // rt_bytes: the forest's compact threshold tables when the kernel that runs may keep them resident (rank_device.hpp FUSED_RT_MAX_BYTES;
 // the region then holds whichever the kernel's sink uses - staging buffers or the resident copy - so it is sized for both)
-size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, size_t rt_bytes) {
+size_t fused_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, size_t rt_bytes, bool split) {
   const size_t staging = (size_t)((threads + 63) / 64) * 2 * thr_cap * 8;  // two buffers per wavefront
   return (size_t)tab_entries * 8 + (size_t)vals_cap * 8 + FUSED_MAX_PREP * sizeof(PrepOut) + PREP_INTS * sizeof(int) +
-         16 + std::max(staging, rt_bytes <= FUSED_RT_MAX_BYTES ? rt_bytes : 0);  // (16-B aligned)
+         16 + std::max(staging, rt_bytes <= (split ? FUSED_RT_MAX_BYTES_SPLIT : FUSED_RT_MAX_BYTES) ? rt_bytes : 0);  // (16-B aligned)
 }
-size_t fused_rt_max_bytes() { return FUSED_RT_MAX_BYTES; }
+size_t fused_rt_max_bytes() { return FUSED_RT_MAX_BYTES_SPLIT; }
 int fused_max_prep() { return FUSED_MAX_PREP; }
 
 // pre-pass + assembly of every request in one launch (one workgroup per request, tables in LDS).
@@ -357,7 +357,7 @@ void launch_rank_fused(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog,
   if (b.n_req <= 0) return;
   int mode = (op_split > 1 ? op_split : 1) | ((slices > 1 ? slices : 1) << 8);  // rank_device.hpp rank_fused_body
   const unsigned grid = (unsigned)b.n_req * (unsigned)(slices > 1 ? slices : 1);
-  size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u, q && cells ? rt_bytes : 0);
+  size_t lds = fused_lds_bytes(tab_entries, vals_cap, threads, q ? q->thr_cap : 0u, q && cells ? rt_bytes : 0, op_split > 1 || slices > 1);
   if (switches().fused_lds_min > 0) lds = std::max(lds, (size_t)switches().fused_lds_min);  // experiments: cap the kernel's residency (co-residency with the scorer)
   {
     ScopedKernelTimer timer(ctx, "assemble");
@@ -415,7 +415,7 @@ void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int
 size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64) {
   const size_t nw = (size_t)threads / 64;
   const size_t scoring = 8 * nw * (QS_LEAVES * (f64 ? 8 : 4) + QS_TILE_ROWS) + QS_TILE_ROWS * 8;
-  return (size_t)n_views * QS_TILE_ROWS * 2 + 16 + std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, 0), scoring);
+  return (size_t)n_views * QS_TILE_ROWS * 2 + 16 + std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, 0, false), scoring);
 }
 
 // One workgroup per request (requests of <= QS_TILE_ROWS candidates, `threads` = item lanes x op split, <= 512);
@@ -446,7 +446,7 @@ void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
 size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64) {
   const size_t nw = (size_t)threads / 64;
   const size_t scoring = (size_t)n_views * QS_TILE_ROWS * 2 + 16 + 8 * nw * (QS_LEAVES * (f64 ? 8 : 4) + QS_TILE_ROWS) + QS_TILE_ROWS * 8;
-  return std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, 0), scoring);
+  return std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, 0, false), scoring);
 }
 
 // One workgroup per request of a full batch (requests of <= QS_TILE_ROWS candidates, 128 or 64 lanes); `cells`: one tile per request.

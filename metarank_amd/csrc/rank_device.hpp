@@ -939,16 +939,30 @@ struct CellSink {     // the scorer's binned tile: [tile of 128 rows][view][row]
 // (The queue is three named slots and a count, all of which fold in a compile-time program: every put happens at a fixed
 // point of straight-line code.  Were the count not to fold, the switch below would be a uniform branch - never a run-time
 // index into registers.)
-constexpr int RT_Q = 4;
+#ifndef MRK_RT_Q
+#define MRK_RT_Q 4
+#endif
+constexpr int RT_Q = MRK_RT_Q;   // 2 .. 4
+static_assert(RT_Q >= 2 && RT_Q <= 4, "the resident-table sink holds 1 - 3 values back");
 // The workgroup-per-request kernels keep the compact tables resident too when they are no bigger than this (the benchmark's
 // Ranklens model - ~50 distinct thresholds on its continuous columns, 740 in all: 6 KB - where two wavefronts' staging buffers take
 // 4 - 8 KB): the same LDS class, so the same residency, no staging traffic (every wavefront staged every column's table for every 64 candidates), no counted waits, 4 searches at a time.
-constexpr size_t FUSED_RT_MAX_BYTES = 8 * 1024;
-template <typename QS> __device__ __forceinline__ constexpr bool qs_fused_rt() {
-  if constexpr (QS::is_static) return QS::rt_total > 0u && (size_t)QS::rt_total * 8 <= FUSED_RT_MAX_BYTES;
+// (the split / sliced kernel's workgroups are up to 8 wavefronts - 16 KB of staging buffers at 128-entry tables: its cap is 20 KB: the 64-column c3 model is 16.4 KB)
+#ifndef MRK_FUSED_RT_MAX
+#define MRK_FUSED_RT_MAX 8192
+#endif
+#ifndef MRK_FUSED_RT_MAX_SPLIT
+#define MRK_FUSED_RT_MAX_SPLIT 20480
+#endif
+// (A/B through MRK_JIT_DEFINES: 0 = the staging sink; never above the library's own values - the host sizes the region by those)
+constexpr size_t FUSED_RT_MAX_BYTES = MRK_FUSED_RT_MAX, FUSED_RT_MAX_BYTES_SPLIT = MRK_FUSED_RT_MAX_SPLIT;
+template <typename QS, bool SPLIT> __device__ __forceinline__ constexpr bool qs_fused_rt() {
+  if constexpr (QS::is_static) return QS::rt_total > 0u && (size_t)QS::rt_total * 8 <= (SPLIT ? FUSED_RT_MAX_BYTES_SPLIT : FUSED_RT_MAX_BYTES);
   else return false;
 }
-template <bool F64, typename QS>
+// QUEUE = false: every value is binned at once (the kernels whose workgroups share out the ops at RUN time - op split - reach a
+// put under a run-time condition: the count of values held back would not fold, and every put would carry every group shape).
+template <bool F64, typename QS, bool QUEUE = true>
 struct CellSinkRT {
   static_assert(QS::is_static, "the resident-table sink needs the forest's signature at compile time");
   QsDev q;
@@ -963,7 +977,7 @@ struct CellSinkRT {
   __device__ __forceinline__ QsFeatureK desc(int col) const { return (QsFeatureK)(unsigned long long)q.feats + col; }
 
   template <int N>
-  __device__ __forceinline__ void bin_group(const int (&col)[RT_Q], const double (&val)[RT_Q]) const {
+  __device__ __forceinline__ void bin_group(const int (&col)[4], const double (&val)[4]) const {
     double x[N];
     qs_lds_double *T[N], *p[N];
     uint32_t pos[N];
@@ -1034,21 +1048,30 @@ struct CellSinkRT {
       }
       return;
     }
+    if constexpr (!QUEUE) {
+      const int cols[4] = {col, 0, 0, 0};
+      const double vals[4] = {v, 0.0, 0.0, 0.0};
+      bin_group<1>(cols, vals);
+      return;
+    }
+    if (qn == RT_Q - 1) {   // the group is complete
+      int cols[4] = {c0, c1, c2, 0};
+      double vals[4] = {v0, v1, v2, 0.0};
+      cols[RT_Q - 1] = col;
+      vals[RT_Q - 1] = v;
+      bin_group<RT_Q>(cols, vals);
+      qn = 0;
+      return;
+    }
     switch (qn) {
       case 0: v0 = v; c0 = col; qn = 1; break;
       case 1: v1 = v; c1 = col; qn = 2; break;
-      case 2: v2 = v; c2 = col; qn = 3; break;
-      default: {
-        const int cols[RT_Q] = {c0, c1, c2, col};
-        const double vals[RT_Q] = {v0, v1, v2, v};
-        bin_group<4>(cols, vals);
-        qn = 0;
-      }
+      default: v2 = v; c2 = col; qn = 3; break;
     }
   }
   __device__ __forceinline__ void finish() const {
-    const int cols[RT_Q] = {c0, c1, c2, 0};
-    const double vals[RT_Q] = {v0, v1, v2, 0.0};
+    const int cols[4] = {c0, c1, c2, 0};
+    const double vals[4] = {v0, v1, v2, 0.0};
     if (qn == 1) bin_group<1>(cols, vals);
     else if (qn == 2) bin_group<2>(cols, vals);
     else if (qn == 3) bin_group<3>(cols, vals);
@@ -1138,7 +1161,7 @@ __device__ __forceinline__ constexpr bool op_primary_in_item(const Op &op) {
 }
 
 #ifndef MRK_IW_TOK
-#define MRK_IW_TOK 4
+#define MRK_IW_TOK 5   // (round 6: 4 -> 5, the benchmark's tag lists have 5 tokens - the sixth-token path is a trip to memory inside the op; c2 assembly -1.5 %, c4x -2 %, r06_p)
 #endif
 constexpr int IW_BATCH = 4, IW_TOK = MRK_IW_TOK;   // interacted_with: fields handled together, tokens per field fetched ahead
 constexpr int RATE_BATCH = 4;             // rate: periods fetched together
@@ -1170,7 +1193,7 @@ __device__ __forceinline__ constexpr int op_pre_weight(const Op &op) {
   }
 }
 #ifndef MRK_PRE_GROUP_BUDGET
-#define MRK_PRE_GROUP_BUDGET 72
+#define MRK_PRE_GROUP_BUDGET 48   // (round 6: 72 -> 48 - c2's 18 ops in 3 groups instead of 2: neutral on c2, the item-parallel kernel -5.7 % (fewer spills), 96: +10 %; r06_p)
 #endif
 constexpr int PRE_GROUP_BUDGET = MRK_PRE_GROUP_BUDGET;  // registers of fetched-ahead state per group (c2's 19 ops: 2 groups)
 // end of the group of ops that starts at `lo` (in_regs: the candidate's record is held in registers, so a primary cell
@@ -1906,9 +1929,9 @@ __device__ __forceinline__ void rank_fused_matrix_body(const StoreDev &st, const
 template <bool F64, bool SPLIT = false, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
                                                       int vals_cap, const QsDev &q, uint16_t *cells, int mode = 1) {
-  if constexpr (qs_fused_rt<QS>()) {   // the forest's compact tables fit: resident, searched four columns at a time (CellSinkRT)
+  if constexpr (qs_fused_rt<QS, SPLIT>()) {   // the forest's compact tables fit: resident, searched four columns at a time (CellSinkRT)
     rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode, [&](int gi, int r, bool active, qs_lds_double *, qs_lds_double *s_all) {
-      return CellSinkRT<F64, QS>{q, cells + (size_t)(gi / QS_TILE_ROWS) * QS::n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_all, active};
+      return CellSinkRT<F64, QS, !SPLIT>{q, cells + (size_t)(gi / QS_TILE_ROWS) * QS::n_views * QS_TILE_ROWS + (gi % QS_TILE_ROWS), &b.status[r], s_all, active};
     }, 0u, q.thr_rt, QS::rt_total);
   } else {
     rank_fused_body<SPLIT>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode, [&](int gi, int r, bool active, qs_lds_double *s_thr, qs_lds_double *) {
