@@ -41,8 +41,8 @@ size_t fused_rt_max_bytes();
 int fused_max_prep();
 QsDev qs_device_view(const mrk_model *m);
 QsForestDev qs_forest_view(const mrk_model *m);  // score_qs.hip
-size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64);
-size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64);
+size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64, size_t rt_bytes);
+size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64, size_t rt_bytes);
 void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                              int threads, const QsDev &q, const QsForestDev &f, uint16_t *cells, bool f64, void *jit_fn);
 void launch_rank_serve(mrk_ctx *ctx, hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
@@ -398,7 +398,7 @@ static bool rank_one_applies(const mrk_batch &b, const mrk_model *model, bool ce
   if (!sw.rank_one || !cells || !b.fused_ok || b.n_req < 1 || b.n_req > 16 || b.hb.max_items > QS_TILE_ROWS || b.view.n_overrides > 0) return false;
   if (b.fused_slices != 1 || b.fused_threads > 512) return false;
   const QsDev q = qs_device_view(model);
-  return rank_one_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, q.thr_cap, q.n_views, model->forest.backend == Backend::LightGBM) <= 96 * 1024;
+  return rank_one_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, q.thr_cap, q.n_views, model->forest.backend == Backend::LightGBM, (size_t)q.rt_doubles * 8) <= 96 * 1024;
 }
 
 // enqueue the pipeline on the batch's stream for batch items [lo, hi); the caller holds the store (StoreAccess)
@@ -425,7 +425,7 @@ static void run_batch(mrk_batch &b, mrk_model *model, int lo, int hi, bool sort,
   // kinds side by side on every CU)
   const bool fused_score = !one && sort && lo == 0 && hi == b.total_items && cells && sw.rank_fused_score && b.fused_ok && b.fused_split == 1 &&
                            b.fused_slices == 1 && b.hb.max_items <= QS_TILE_ROWS && b.view.n_overrides == 0 && b.big.empty() && b.fused_threads <= 256 &&
-                           rank_fused_score_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, qs_device_view(model).thr_cap, qs_device_view(model).n_views, f64) <= 64 * 1024;
+                           rank_fused_score_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, qs_device_view(model).thr_cap, qs_device_view(model).n_views, f64, (size_t)qs_device_view(model).rt_doubles * 8) <= 64 * 1024;
   // (the kernels that write the scorer's tile are keyed by the forest's view signature too: their sinks hold it as constants)
   const QsSignature *sig = cells && sw.thr_stage ? &model->qs_sig : nullptr;
   void *jit_fn = !cells ? (b.fused_ok && model && b.fused_split == 1 && b.fused_slices == 1 ? jit_matrix_function(*b.prog) : nullptr)  // a model scored from the f64 matrix: the hot path too
@@ -1455,7 +1455,7 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   const uint32_t entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
   const QsDev q = qs_device_view(srv.model);
   if (!hb.overrides.empty() || (int)prog.prep.size() > fused_max_prep() || hb.max_req_entries > (1u << 20) ||
-      rank_one_lds_bytes(entries, (int)vals, SERVE_THREADS, q.thr_cap, q.n_views, srv.f64) > SERVE_LDS)
+      rank_one_lds_bytes(entries, (int)vals, SERVE_THREADS, q.thr_cap, q.n_views, srv.f64, (size_t)q.rt_doubles * 8) > SERVE_LDS)
     return false;
   // the request's input block: build_batch's arrays, 16-byte aligned
   size_t off = 0;

@@ -17,6 +17,7 @@ struct QsDev {             // what a kernel needs to bin a value of any matrix c
   int32_t n_feats;
   int32_t n_views;
   uint32_t thr_cap;        // doubles per LDS staging buffer: the longest staged table rounded up to QS_STAGE_CHUNK
+  uint32_t rt_doubles;     // doubles of the compact tables (0: no signature): what the launchers size a resident region by
 };
 
 typedef __attribute__((address_space(3))) double qs_lds_double;  // forces ds_read for tables staged in LDS

@@ -412,10 +412,10 @@ void launch_normalize_big(mrk_ctx *ctx, const BatchDev &b, int dim, int col, int
 }
 
 // LDS of the one-launch kernel: [slab][status word][max(assembly regions, scoring regions)]
-size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64) {
+size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64, size_t rt_bytes) {
   const size_t nw = (size_t)threads / 64;
   const size_t scoring = 8 * nw * (QS_LEAVES * (f64 ? 8 : 4) + QS_TILE_ROWS) + QS_TILE_ROWS * 8;
-  return (size_t)n_views * QS_TILE_ROWS * 2 + 16 + std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, 0, false), scoring);
+  return (size_t)n_views * QS_TILE_ROWS * 2 + 16 + std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, rt_bytes, true), scoring);
 }
 
 // One workgroup per request (requests of <= QS_TILE_ROWS candidates, `threads` = item lanes x op split, <= 512);
@@ -424,7 +424,7 @@ void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
                      int threads, int op_split, const QsDev &q, const QsForestDev &f, const OneOut &out, bool f64, void *jit_fn) {
   if (b.n_req <= 0) return;
   int mode = op_split > 1 ? op_split : 1;
-  const size_t lds = rank_one_lds_bytes(tab_entries, vals_cap, threads, q.thr_cap, f.n_views, f64);
+  const size_t lds = rank_one_lds_bytes(tab_entries, vals_cap, threads, q.thr_cap, f.n_views, f64, (size_t)q.rt_doubles * 8);
   ScopedKernelTimer timer(ctx, "rank_one");
   if (jit_fn) {
     StoreDev a_st = st;
@@ -443,17 +443,17 @@ void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, c
   }
 }
 
-size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64) {
+size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64, size_t rt_bytes) {
   const size_t nw = (size_t)threads / 64;
   const size_t scoring = (size_t)n_views * QS_TILE_ROWS * 2 + 16 + 8 * nw * (QS_LEAVES * (f64 ? 8 : 4) + QS_TILE_ROWS) + QS_TILE_ROWS * 8;
-  return std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, 0, false), scoring);
+  return std::max(fused_lds_bytes(tab_entries, vals_cap, threads, thr_cap, rt_bytes, false), scoring);
 }
 
 // One workgroup per request of a full batch (requests of <= QS_TILE_ROWS candidates, 128 or 64 lanes); `cells`: one tile per request.
 void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                              int threads, const QsDev &q, const QsForestDev &f, uint16_t *cells, bool f64, void *jit_fn) {
   if (b.n_req <= 0) return;
-  const size_t lds = rank_fused_score_lds_bytes(tab_entries, vals_cap, threads, q.thr_cap, f.n_views, f64);
+  const size_t lds = rank_fused_score_lds_bytes(tab_entries, vals_cap, threads, q.thr_cap, f.n_views, f64, (size_t)q.rt_doubles * 8);
   ScopedKernelTimer timer(ctx, "rank_fused");
   if (jit_fn) {
     StoreDev a_st = st;

@@ -1962,9 +1962,15 @@ __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &pr
   BatchDev bl = b;
   bl.status = s_status - r;   // &bl.status[r] is the LDS word
   __syncthreads();
-  rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr, qs_lds_double *) {
-    return CellSink<F64, QS>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active, /*vm_stores=*/false};
-  }, slab_bytes + 16);
+  if constexpr (qs_fused_rt<QS, true>()) {   // the compact tables resident (no queue: the ops are shared out at run time)
+    rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *, qs_lds_double *s_all) {
+      return CellSinkRT<F64, QS, false>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_all, active};
+    }, slab_bytes + 16, q.thr_rt, QS::rt_total);
+  } else {
+    rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr, qs_lds_double *) {
+      return CellSink<F64, QS>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active, /*vm_stores=*/false};
+    }, slab_bytes + 16);
+  }
   // (qs_score_tile_split starts with a barrier: the slab is complete, the assembly's LDS regions are free)
   constexpr int TREE_LEAF_BYTES = QS_LEAVES * (F64 ? 8 : 4);
   const int nw = nthr >> 6;
@@ -2012,9 +2018,15 @@ __device__ __forceinline__ void rank_fused_score_body(const StoreDev &st, const 
   // rows past the request's last candidate (their cells only have to be harmless)
   for (uint32_t i = tid; i < (uint32_t)qs_n_views<QS>(q) * QS_TILE_ROWS; i += nthr)
     if ((int)(i % QS_TILE_ROWS) >= rq.n_items) tile[i] = 0;
-  rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), 1, [&](int gi, int rr, bool active, qs_lds_double *s_thr, qs_lds_double *) {
-    return CellSink<F64, QS>{q, tile + (gi - rq.item_begin), &b.status[rr], s_thr, active};
-  });
+  if constexpr (qs_fused_rt<QS, false>()) {
+    rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), 1, [&](int gi, int rr, bool active, qs_lds_double *, qs_lds_double *s_all) {
+      return CellSinkRT<F64, QS>{q, tile + (gi - rq.item_begin), &b.status[rr], s_all, active};
+    }, 0u, q.thr_rt, QS::rt_total);
+  } else {
+    rank_fused_body<false>(st, prog, b, tab_entries, vals_cap, qs_thr_cap<QS>(q), 1, [&](int gi, int rr, bool active, qs_lds_double *s_thr, qs_lds_double *) {
+      return CellSink<F64, QS>{q, tile + (gi - rq.item_begin), &b.status[rr], s_thr, active};
+    });
+  }
   // the tile has reached L2 (this CU's L1 holds none of its lines: nothing has read them), every table is dead
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

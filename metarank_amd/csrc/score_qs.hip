@@ -503,6 +503,7 @@ QsDev qs_device_view(const mrk_model *m) {
   q.n_views = (int32_t)m->qs.views.size();
   static_assert(QS_LDS_THR == 256u, "qs_stage_cap (forest.cpp) stages tables of up to QS_LDS_THR entries");
   q.thr_cap = switches().thr_stage ? qs_stage_cap(m->qs) : 0u;
+  q.rt_doubles = switches().thr_stage && switches().jit_sig && m->qs_sig.ok ? m->qs_sig.rt_total : 0u;
   return q;
 }
 
