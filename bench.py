@@ -74,8 +74,9 @@ def main():
     ap.add_argument("--items", type=int, default=None, help="candidate items per request (c2: 100, c3: 1000, c4: 100000)")
     ap.add_argument("--streams", type=int, default=None,
                     help="batches in flight per GPU (each on its own HIP stream; steps alternate between them). "
-                         "Default 2 for c2 / c3 (the assembly kernels wait on memory while the scorer is VALU-bound: consecutive "
-                         "batches overlap), 1 for c4")
+                         "Default 3 for c2 / c3 (the assembly kernels wait on memory while the scorer is VALU-bound: consecutive "
+                         "batches overlap; round 6, same box: 2 / 3 / 4 in flight = 1 168 / 1 191 / 1 198 M items/s on c2, 875 / 952 M on c3 - "
+                         "profiles/r06_t_streams.txt; round 5's kernels lost with 3), 1 for c4")
     ap.add_argument("--batches-per-step", type=int, default=None,
                     help="device batches one step runs (default: c2 / c3 96, c4 128, c5 8: a step is about 50 ms of device work)")
     ap.add_argument("--e2e-seconds", type=float, default=1.5, help="timed length of the end-to-end serving loop (0 = skip)")
@@ -117,7 +118,7 @@ def main():
     if args.trees is None:
         args.trees = 500 if args.backend == "lightgbm" else 100
     if args.streams is None:
-        args.streams = 1 if sharded else 2
+        args.streams = 1 if sharded else 3
     n_streams = max(1, args.streams)
     if args.batches_per_step is None:
         args.batches_per_step = {"c2": 96, "c3": 96, "c4": 128, "c4x": 4, "c5": 8}[wl]
