@@ -319,7 +319,8 @@ static void *jit_function_locked(const Program &prog, int kernel, bool f64, bool
   if (jit_program_only(kernel)) f64 = true;
   const bool keyed = sig && sig->ok && !jit_program_only(kernel) && switches().jit_sig;
   if (jit_needs_sig(kernel) && (!keyed || !jit_items_rt_applies(sig))) return nullptr;
-  std::unique_ptr<JitSlotSet> &set = k->by_sig[keyed ? sig->text : std::string()];
+  // (MRK_JIT_DEFINES is part of the translation unit: a process that flips it - tests, A/B scripts - gets the kernels of the text it asked for)
+  std::unique_ptr<JitSlotSet> &set = k->by_sig[(keyed ? sig->text : std::string()) + (switches().jit_defines.empty() ? std::string() : "\n#" + switches().jit_defines)];
   if (!set) set.reset(new JitSlotSet());
   JitSlot &sl = set->slot[kernel][f64 ? 1 : 0];
   if (sl.fn) return (void *)sl.fn;
@@ -473,7 +474,7 @@ std::string jit_loaded_keys(const Program &prog) {
   for (auto &set : k->by_sig)
     for (int kn = 0; kn < JIT_KERNELS; ++kn)
       for (JitSlot &sl : set.second->slot[kn])
-        if (sl.fn) out += std::string(JIT_KERNEL_NAME[kn]) + " " + sl.key + (set.first.empty() ? " program" : " program+forest") + "\n";
+        if (sl.fn) out += std::string(JIT_KERNEL_NAME[kn]) + " " + sl.key + ((set.first.empty() || set.first[0] == '\n') ? " program" : " program+forest") + "\n";
   return out;
 }
 

@@ -84,6 +84,17 @@ def test_source_carries_the_forests_view_signature():
     total = int(re.search(r"thr_total = (\d+)u", rsrc.decode()).group(1))
     compact = int(re.search(r"rt_total = (\d+)u", rsrc.decode()).group(1))   # the same tables padded to powers of two instead of 128-entry chunks
     assert total % 128 == 0 and compact % 2 == 0 and 0 < compact <= total and compact * 8 <= 64 * 1024
+    # ... and every column's place in the compact layout: exact lengths, back to back in column order (columns the forest never
+    # splits on take no room), at most 256 entries resident
+    sig_rows = [tuple(int(x.rstrip("u")) for x in r.split(",")) for r in re.findall(r"\{([0-9u,]+)\}", re.search(r"struct JitSigRows \{.*?= \{(.*?)\};", rsrc.decode(), re.S).group(1))]
+    assert len(sig_rows) == 24 and all(len(r) == 7 for r in sig_rows)
+    at = 0
+    for thr_off, chunks, vb, ve, kinds, rt_off, rt_len in sig_rows:
+        assert thr_off % 128 == 0 and rt_len <= min(256, chunks * 128)
+        if vb != ve:
+            assert rt_off >= at
+            at = rt_off + rt_len
+    assert at <= compact <= at + 1
     # the f64-matrix kernel bins nothing: no signature in its translation unit
     rc, msrc = specialize_for_model(cfg, 0, blob, 0 | (3 << 8))
     assert rc == 0 and b"JitQs" not in msrc

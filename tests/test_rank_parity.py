@@ -228,6 +228,32 @@ def test_assembly_paths_agree(oracle_c2, kind):
                 assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), ("items, arena tables", jit, r)
             batch.close()
         os.environ.pop("MRK_ITEMS_LDS", None)
+        # round 6: the two sinks of the signature-keyed kernels - compact tables RESIDENT in LDS, several searches at a time (the default
+        # where they fit) vs a table STAGED per wavefront and column - in the workgroup-per-request kernel, its split form and the
+        # item-parallel kernel (persistent resident-table form vs the staging form): identical bytes
+        saved_defs = os.environ.get("MRK_JIT_DEFINES")
+        for fused, split, defs, items_rt in (("1", None, "MRK_FUSED_RT_MAX=0 MRK_FUSED_RT_MAX_SPLIT=0", "1"), ("1", "2", "MRK_FUSED_RT_MAX=0 MRK_FUSED_RT_MAX_SPLIT=0", "1"),
+                                             ("1", "2", None, "1"), ("0", None, None, "0"), ("0", None, "MRK_RT_Q=2", "1")):
+            os.environ.update(MRK_RANK_FUSED=fused, MRK_RANK_CELLS="1", MRK_RANK_JIT="require", MRK_JIT_SIG="1", MRK_ITEMS_RT=items_rt)
+            for k, v in (("MRK_FUSED_SPLIT", split), ("MRK_JIT_DEFINES", defs)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            M.reload_switches()
+            batch = hip.ranker.prepare("xgboost", reqs)
+            batch.run(hip.booster)
+            scores, order, _ = batch.fetch()
+            assert (batch.status() == 0).all()
+            for r, (_, es, eo) in enumerate(expected):
+                lo, hi = batch.offsets[r], batch.offsets[r + 1]
+                assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), ("sinks", fused, split, defs, items_rt, r)
+            batch.close()
+        for k, v in (("MRK_JIT_DEFINES", saved_defs), ("MRK_ITEMS_RT", None), ("MRK_FUSED_SPLIT", None)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         # op split (what a handful of requests gets by itself): the item lanes in 2 / 4 copies that share the ops,
         # specialised kernel (tile), interpreting kernels (tile and f64 matrix)
         for split in ("2", "4"):
