@@ -88,6 +88,44 @@ def test_c2_ranklens_100_items(oracle_c2, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["lgbm", "xgb"])
+def test_forests_with_long_threshold_tables(oracle_c2, kind):
+    """Round 6: the assembly kernels keep a forest's threshold tables resident in LDS when they are small (the benchmark's model:
+    ~50 distinct thresholds per column).  Forests that are not: ~250 thresholds per column (the tables no longer fit the
+    workgroup-per-request kernels' budget: the staging sinks run; the item-parallel kernel still holds them - 40 KB) and columns
+    with MORE than 256 thresholds (never resident, never staged: searched in global memory) next to short ones.  Scores and
+    order equal the oracle's through the one-launch kernel, the batch kernels and the item-parallel kernel (300-item requests)."""
+    hip = HipBackend(ranklens.ranklens_config(), "xgboost")
+    try:
+        load(hip)
+        reqs = ranklens.generate_requests(24, 100, N_ITEMS, N_SESS, seed=31) + ranklens.generate_requests(3, 300, N_ITEMS, N_SESS, seed=32)
+        mats = [oracle_c2.matrix(ev) for ev in reqs]
+        q = ranklens.column_quantiles(np.concatenate(mats), n=900)
+        assert max(len(c) for c in q) > 300
+        if kind == "lgbm":   # 7 500 splits over 24 columns: up to ~250 distinct thresholds on the continuous columns
+            blob, be = synth.synthetic_lgbm_model(n_trees=500, n_features=24, quantiles=q, cat_features=[7], cat_prob=0.02, missing="per_feature"), 0
+        else:                # 12 000 splits (16-leaf trees: the bit-vector scorer): the continuous columns beyond 256
+            blob, be = synth.synthetic_xgb_model(n_trees=800, n_features=24, depth=4, quantiles=q), 1
+        oracle_c2.load_model(blob, be)
+        hip.load_model(blob, be)
+        assert hip.booster.info()["bitvector"] == 1
+        expected = [oracle_c2.rerank(ev) for ev in reqs]
+        for ev, (_, es, eo) in list(zip(reqs, expected))[:6] + [(reqs[-1], expected[-1])]:
+            _, hs, ho = hip.rerank(ev)
+            assert same(hs, es) and ho.tolist() == eo.tolist()
+        batch = hip.ranker.prepare("xgboost", reqs)
+        batch.run(hip.booster)
+        scores, order, _ = batch.fetch()
+        assert (batch.status() == 0).all()
+        for r, (_, es, eo) in enumerate(expected):
+            lo, hi = batch.offsets[r], batch.offsets[r + 1]
+            assert same(scores[lo:hi], es) and order[lo:hi].tolist() == eo.tolist(), r
+        batch.close()
+    finally:
+        hip.close()
+
+
+@pytest.mark.gpu
 def test_c3_1000_items_64_columns():
     cfg = ranklens.c3_config()
     orc = OracleBackend(cfg, "xgboost")
