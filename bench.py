@@ -95,6 +95,11 @@ def main():
                     help="booster format of the synthetic forest.  lightgbm (default): 500 leaf-wise 16-leaf trees, f64 - the Ranklens "
                          "stock model's backend.  xgboost: complete depth-`--depth` trees, f32 - BASELINE config #2 as written is "
                          "`--backend xgboost --trees 100 --depth 6`")
+    ap.add_argument("--quantiles", type=int, default=49,
+                    help="split candidates per column of the synthetic forest (empirical quantiles of a sample matrix).  49 (default, rounds 1-6): "
+                         "the forest ends up with ~50 distinct thresholds on a continuous column - 6 KB of threshold tables, which the assembly "
+                         "kernels keep resident in LDS (round 6); 254 = a LightGBM model trained with max_bin 255 whose 7 500 splits use most "
+                         "bins: ~40 KB of tables - the workgroup-per-request kernels stage them per column, the item-parallel kernel still holds them")
     ap.add_argument("--depth", type=int, default=6, help="xgboost: tree depth (Metarank's XGBoost default maxDepth is 8)")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="requests timed on the CPU oracle (0 = skip)")
     ap.add_argument("--latency-requests", type=int, default=300, help="single-request latency samples (0 = skip, also skips the sweep)")
@@ -282,11 +287,11 @@ def main():
     sample.close()
     if args.backend == "lightgbm":
         blob = synth.synthetic_lgbm_model(n_trees=args.trees, n_features=dim, num_leaves=16, max_depth=8,
-                                          quantiles=ranklens.column_quantiles(sm), cat_features=[7] if not args.drop_features else None, cat_prob=0.007,  # ~ one categorical split per 10 trees
+                                          quantiles=ranklens.column_quantiles(sm, n=args.quantiles), cat_features=[7] if not args.drop_features else None, cat_prob=0.007,  # ~ one categorical split per 10 trees
                                           missing="per_feature")  # one missing type per column, as LightGBM's bin mappers produce
         booster = M.HipBooster(blob, M.LIGHTGBM, ctx)
     else:  # complete depth-d trees, f32 thresholds / leaves, one categorical split per ~10 trees
-        blob = synth.synthetic_xgb_model(n_trees=args.trees, n_features=dim, depth=args.depth, quantiles=ranklens.column_quantiles(sm),
+        blob = synth.synthetic_xgb_model(n_trees=args.trees, n_features=dim, depth=args.depth, quantiles=ranklens.column_quantiles(sm, n=args.quantiles),
                                          cat_features=[7] if not args.drop_features else None, cat_prob=0.1 / max(1, 2 ** args.depth - 1))
         booster = M.HipBooster(blob, M.XGBOOST, ctx)
     info = booster.info()
@@ -441,7 +446,7 @@ def main():
     pmc_kernel = None
     try:
         import glob
-        shape_ok = n_gpus == 1 and args.backend == "lightgbm" and (
+        shape_ok = n_gpus == 1 and args.backend == "lightgbm" and args.quantiles == 49 and (
             (wl == "c2" and args.requests == 3840) or (wl == "c3" and args.requests == 384) or (wl == "c4x" and args.items == 4_000_000 and args.clones == 79))
         files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_{wl}_summary.json")), reverse=True)
         summary = json.load(open(files[0])) if files and shape_ok else None
@@ -1003,7 +1008,7 @@ def main():
             "dtype": "f64" if args.backend == "lightgbm" else "f32", "data": "synthetic",
             "config": {"workload": f"ranklens-{args.items}item-{dim}col-{args.trees}tree-" + (args.backend if args.backend == "lightgbm" else f"xgboost-depth{args.depth}"), "requests_per_step_per_gpu": args.requests,
                        "items_per_request": args.items, "device_batches_per_step": bps, "items_per_device_batch": total_items, "items_per_step_per_gpu": total_items * bps, "catalogue_items": n_catalogue, "item_table_bytes": int(n_catalogue) * ranker.item_stride(),
-                       "sessions": args.sessions, "columns": dim, "trees": info["n_trees"], "leaves_per_tree": 16 if args.backend == "lightgbm" else 2 ** args.depth, "backend": args.backend,
+                       "sessions": args.sessions, "columns": dim, "split_candidates_per_column": args.quantiles, "trees": info["n_trees"], "leaves_per_tree": 16 if args.backend == "lightgbm" else 2 ** args.depth, "backend": args.backend,
                        "scorer": "bit-vector" if info["bitvector"] else "tree walk",
                        "tile_columns": V, "batches_in_flight": n_streams,
                        "parallelism": (f"item-sharded x{n_gpus}" if sharded else f"request-sharded x{n_gpus}") +
