@@ -43,6 +43,8 @@ static Switches read_switches() {
   s.jit_sig = flag("MRK_JIT_SIG", true);
   s.items_lds = flag("MRK_ITEMS_LDS", true);
   s.items_rt = flag("MRK_ITEMS_RT", true);
+  s.rank_one_max = std::max(1, std::min(256, num("MRK_RANK_ONE_MAX", 128)));
+  s.split_max_req = std::max(0, std::min(256, num("MRK_SPLIT_MAX_REQ", 64)));
   s.items_rt_threads = num("MRK_ITEMS_RT_THREADS", 0);
   s.jit_shipped = flag("MRK_JIT_SHIPPED", true);
   if (const char *d = getenv("MRK_JIT_DEFINES")) s.jit_defines = d; else s.jit_defines.clear();

@@ -328,7 +328,7 @@ static void build_batch(mrk_ctx *ctx, const Program &prog, const mrk_request *re
   b.fused_entries = (uint32_t)std::max<uint64_t>(hb.max_req_entries, 1);
   b.fused_vals = (int)vals;
   const Switches &sw = switches();
-  const FusedShape shape = fused_launch_shape(n_req, hb.max_items, sw.fused_threads, sw.fused_split, sw.fused_slices);  // launch_shape.hpp
+  const FusedShape shape = fused_launch_shape(n_req, hb.max_items, sw.fused_threads, sw.fused_split, sw.fused_slices, sw.split_max_req);  // launch_shape.hpp
   b.fused_split = shape.split;
   b.fused_slices = shape.slices;
   b.fused_threads = shape.threads();
@@ -395,7 +395,7 @@ struct LaunchOn {
 // batch's pinned buffer (rank_device.hpp rank_one_body).  Only for callers that read the results through h_out.
 static bool rank_one_applies(const mrk_batch &b, const mrk_model *model, bool cells) {
   const Switches &sw = switches();
-  if (!sw.rank_one || !cells || !b.fused_ok || b.n_req < 1 || b.n_req > 16 || b.hb.max_items > QS_TILE_ROWS || b.view.n_overrides > 0) return false;
+  if (!sw.rank_one || !cells || !b.fused_ok || b.n_req < 1 || b.n_req > sw.rank_one_max || b.hb.max_items > QS_TILE_ROWS || b.view.n_overrides > 0) return false;
   if (b.fused_slices != 1 || b.fused_threads > 512) return false;
   const QsDev q = qs_device_view(model);
   return rank_one_lds_bytes(b.fused_entries, b.fused_vals, b.fused_threads, q.thr_cap, q.n_views, model->forest.backend == Backend::LightGBM, (size_t)q.rt_doubles * 8) <= 96 * 1024;

@@ -14,7 +14,7 @@ struct FusedShape {
 };
 
 // force_* = the MRK_FUSED_THREADS / MRK_FUSED_SPLIT / MRK_FUSED_SLICES switches (0 = by batch shape)
-inline FusedShape fused_launch_shape(int n_req, int max_items, int force_threads = 0, int force_split = 0, int force_slices = 0) {
+inline FusedShape fused_launch_shape(int n_req, int max_items, int force_threads = 0, int force_split = 0, int force_slices = 0, int split_max_req = 64) {
   FusedShape s;
   // the largest request rounded up to whole wavefronts, at most 256 lanes (100-item requests: 128 lanes measure 0.288 ms
   // on c2, 64 lanes - one wavefront running two serial rounds - 0.421)
@@ -25,7 +25,9 @@ inline FusedShape fused_launch_shape(int n_req, int max_items, int force_threads
   if (s.item_lanes <= 256) {
     const int fit = s.item_lanes <= 128 ? 4 : 2;
     if (force_split) s.split = std::min(fit, force_split);
-    else if (n_req <= 16) s.split = fit;
+    // (round 6: up to 64 requests when they are small - mrk_rank's combined batches, r06_x; batches of 17 ... 64 LARGE requests keep
+    //  their slices: 96 x 1 000 candidates 0.52 -> 0.21 ms with 4)
+    else if (n_req <= 16 || (n_req <= split_max_req && s.item_lanes <= 128)) s.split = fit;
   }
   // Few LARGE requests (c3: 384 x 1 000 candidates = 1.5 workgroups per CU, each looping 4 times over its 256 lanes): cover
   // a request with several workgroups as long as the launch stays within ONE residency of the chip (4 096 wavefronts at

@@ -126,6 +126,11 @@ struct Switches {
   bool thr_stage = true;       // MRK_THR_STAGE=0: the assembly kernels search threshold tables in global memory instead of staging them in LDS (experiments)
   bool jit_shipped = true;     // MRK_JIT_SHIPPED=0: ignore the code objects shipped next to the library (tests of the compile paths)
   bool items_lds = true;       // MRK_ITEMS_LDS=0: the item-parallel assembly kernel probes the pre-pass tables in the HBM arena even where a workgroup's request's tables fit its LDS
+  // Round 6 (r06_x, native closed-loop callers of mrk_rank, same box): the one-launch kernel for combined batches of up to 128
+  // requests (was 16: bigger ones took three launches + a copy) and op-split workgroups for up to 64: 188 k -> 228 k requests/s at
+  // 64 callers, 315 k -> 339 k at 128, 351 k -> 397 k at 256 (the last measured with 128 / 32).
+  int rank_one_max = 128;      // MRK_RANK_ONE_MAX: most requests of a batch the one-launch kernel takes (mrk_rank's combined batches)
+  int split_max_req = 64;      // MRK_SPLIT_MAX_REQ: batches of up to this many small requests get op-split workgroups (launch_shape.hpp)
   bool items_rt = true;        // MRK_ITEMS_RT=0: the item-parallel kernel stages threshold tables per wavefront and column even where all of them fit in LDS (A/B of the resident-table kernel)
   int items_rt_threads = 0;    // MRK_ITEMS_RT_THREADS=256|512: lanes of the resident-table kernel's workgroups (default: by launch size)
   bool jit_sig = true;         // MRK_JIT_SIG=0: the specialised kernels are keyed by the program only and read the forest's column descriptors from memory (A/B of the view-signature folding)

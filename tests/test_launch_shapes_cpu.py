@@ -32,7 +32,9 @@ def fused(lib, n_req, max_items):
     (96, 1000, (256, 1, 4), "96 large requests: one workgroup per round of the lanes (0.52 -> 0.21 ms)"),
     (1, 100, (512, 4, 1), "a single /rank request: four copies of the item lanes share the ops (p50 0.19 -> 0.158 ms)"),
     (16, 100, (512, 4, 1), "... up to 16 requests"),
-    (17, 100, (128, 1, 1), "... and not beyond"),
+    (64, 100, (512, 4, 1), "... and up to 64 when they are small (mrk_rank's combined batches: 188 k -> 228 k requests/s at 64 callers, r06_x)"),
+    (65, 100, (128, 1, 1), "... and not beyond"),
+    (17, 1000, (256, 1, 4), "17 large requests keep their slices"),
     (1, 1000, (512, 2, 1), "a single 1 000-item request: 256 item lanes leave room for two copies; no slices on top of a split"),
     (1, 1, (256, 4, 1), "one candidate: one wavefront of item lanes, four copies"),
     (3840, 300, (256, 1, 1), "a full batch of 300-item requests: 2 rounds, but 3 840 x 4 wavefronts already exceed a residency"),

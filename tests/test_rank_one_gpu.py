@@ -319,7 +319,7 @@ def test_kernel_keys_say_which_specialised_kernels_ran():
         try:
             ranklens.load_state(hip, ranklens.generate_state(N_ITEMS, N_SESS))
             hip.load_model(synth.synthetic_lgbm_model(n_trees=50, n_features=24, missing="per_feature"), 0)
-            batch = hip.ranker.prepare("xgboost", ranklens.generate_requests(40, 100, N_ITEMS, N_SESS, seed=7))
+            batch = hip.ranker.prepare("xgboost", ranklens.generate_requests(80, 100, N_ITEMS, N_SESS, seed=7))   # (more than 64 small requests: the unsplit kernel)
             batch.run(hip.booster)
             batch.fetch()
             batch.close()

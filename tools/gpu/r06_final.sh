@@ -1,7 +1,7 @@
 # Round 6, measurement pass (same recipe as round 5's, tools/gpu/r04_c.sh): the whole GPU suite, the bench line of every workload,
 # config 2 as written, kernel stats of the default bench command, PMC passes of c2 / c3 / c4x; then the callers table.
 #   gpurun --timeout 3000 -- 'TAG=r06_g bash tools/gpu/r06_final.sh'
-export TAG=${TAG:-r06_v} XGB=1
+export TAG=${TAG:-r06_y} XGB=1
 bash tools/gpu/r04_c.sh
 O=gpurun_out/$TAG
 F='^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl\|slow batch'
