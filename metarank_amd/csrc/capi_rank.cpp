@@ -7,7 +7,9 @@
 #include <thread>
 
 #include <linux/futex.h>
+#include <sys/prctl.h>
 #include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <cstdlib>
@@ -45,8 +47,8 @@ size_t rank_one_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint3
 size_t rank_fused_score_lds_bytes(uint32_t tab_entries, int vals_cap, int threads, uint32_t thr_cap, int n_views, bool f64, size_t rt_bytes);
 void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                              int threads, const QsDev &q, const QsForestDev &f, uint16_t *cells, bool f64, void *jit_fn);
-void launch_rank_serve(mrk_ctx *ctx, hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
-                       int threads, size_t lds, bool f64, void *jit_fn);
+void launch_rank_serve(mrk_ctx *ctx, hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeGangDev &gang,
+                       int n_slots, int threads, size_t lds, bool f64, void *jit_fn);
 void launch_rank_one(mrk_ctx *ctx, const StoreDev &st, const ProgramDev &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
                      int threads, int op_split, const QsDev &q, const QsForestDev &f, const OneOut &out, bool f64, void *jit_fn);
 int load_feature_values(Store &store, const uint8_t *bytes, size_t len, int64_t now_ms);  // codec.cpp
@@ -971,10 +973,28 @@ mrk_batch *lane_batch(mrk_ctx *ctx, int lane) {
 }
 }  // namespace
 
+static int rank_through_server(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
+                               int32_t *out_order, bool &done);
+static int rank_front(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
+                      int32_t *out_order, double *out_matrix);
+
 int mrk_rank(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
              int32_t *out_order, double *out_matrix) {
   if (!req || !ctx || !model_name) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
   if (model && model->ctx != ctx) { set_last_error("model belongs to another context"); return MRK_ERR_INVALID_ARG; }
+  // A host that started a serving queue for this model (mrk_serve_start: Serve.scala's warm-up) has its per-request calls
+  // answered by the queue's resident workgroups - no launch, no copy command -, whatever entry point its fibers use; what the
+  // queue does not take (every slot busy, more than 128 candidates, a matrix asked for) goes through the batching front below.
+  if (model && !out_matrix && ctx->n_servers.load(std::memory_order_acquire) != 0) {
+    bool done = false;
+    const int rc = rank_through_server(ctx, model, model_name, req, out_scores, out_order, done);
+    if (done || rc != MRK_OK) return rc;
+  }
+  return rank_front(ctx, model, model_name, req, out_scores, out_order, out_matrix);
+}
+
+static int rank_front(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
+                      int32_t *out_order, double *out_matrix) {
   RankTicket t(model, model_name, req, out_scores, out_order, out_matrix);
   const Switches &sw = switches();
   const int n_lanes = sw.rank_lanes;
@@ -1350,15 +1370,25 @@ int mrk_batch_status(mrk_batch *batch, int32_t *out_status) {
 namespace {
 
 struct ServeSlot {
-  hipStream_t stream = nullptr;
+  int gang = 0;                 // index into mrk_server::gangs; this slot is workgroup `index - gang.first` of the gang's kernel
   void *pinned = nullptr;       // [ServeCtl 128 B][output block][input block], coherent host memory
   ServeCtl *ctl = nullptr;
   uint8_t *h_out = nullptr, *h_in = nullptr;
   DevBuf d_in;
   HostBatch hb;
-  uint32_t seq = 0, launch_id = 0;
-  bool running = false;         // a workgroup was launched and has not been seen to leave (owner: whoever holds the slot + the store shared, or the store exclusively)
-  bool dead = false;            // its workgroup did not answer in time: never handed out again (a late answer would land in the next request's buffers)
+  uint32_t seq = 0;
+};
+
+// One kernel launch = one gang of up to SERVE_GANG slots on one stream.  `mu` orders launches and stops of the gang; `launch_id`
+// names the launch whose workgroups are (or were last) resident - a slot whose `ctl->exited` equals it has been left.
+struct ServeGang {
+  hipStream_t stream = nullptr;
+  int first = 0, n = 0;
+  DevBuf d_slots, d_clock;      // ServeSlotDev[n]; the gang's last-activity word
+  std::mutex mu;
+  std::atomic<uint32_t> launch_id{0};
+  bool running = false;         // (mu) a kernel was launched and has not been waited for
+  std::atomic<bool> dead{false};   // a workgroup of it did not answer in time: none of its slots is handed out again (a late answer would land in the next request's buffers)
   bool stuck = false;           // ... and was still resident after a flush waited 2 s for it: later flushes ask once, without waiting again
 };
 
@@ -1378,6 +1408,10 @@ struct mrk_server {
   void *jit_fn = nullptr;
   uint64_t idle_ticks = 0, life_ticks = 0;
   std::vector<std::unique_ptr<ServeSlot>> slots;
+  std::vector<std::unique_ptr<ServeGang>> gangs;
+  std::atomic<int> users{0};   // callers of mrk_rank that are inside serve_fast through the context's server list
+  std::atomic<int> waiting{0};          // callers between publish and acknowledgement
+  std::atomic<uint64_t> est_dev_ns{0};  // what a request takes on the device (input copy + ranking + write-back), smoothed
   std::mutex mu;
   std::condition_variable cv;
   std::vector<int> free_slots;  // a stack: the most recently used slot is the one whose workgroup is still resident
@@ -1390,30 +1424,57 @@ struct mrk_server {
 
 namespace {
 
-void stop_slot(ServeSlot &sl) {  // the caller owns the slot and no request is in flight in it
-  if (!sl.running || sl.dead) return;  // (a retired slot's stream is not waited for: its workgroup may never leave)
-  __atomic_store_n(&sl.ctl->stop, 1u, __ATOMIC_SEQ_CST);
-  (void)hipStreamSynchronize(sl.stream);
-  __atomic_store_n(&sl.ctl->stop, 0u, __ATOMIC_SEQ_CST);
-  sl.running = false;
+void tell_gang(mrk_server &srv, ServeGang &g, uint32_t v) {
+  for (int i = g.first; i < g.first + g.n; ++i) __atomic_store_n(&srv.slots[(size_t)i]->ctl->stop, v, __ATOMIC_SEQ_CST);
 }
 
-void launch_slot(mrk_server &srv, ServeSlot &sl) {  // the caller holds the store (shared): the device views are current
+// (g.mu held) waits until every workgroup of the gang has left: they serve what is published in their slots first.  Bounded: a
+// gang that is still resident after `seconds` is retired (false).
+bool drain_gang(mrk_server &srv, ServeGang &g, int seconds) {
+  if (!g.running) return true;
+  tell_gang(srv, g, 1u);
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(seconds);
+  hipError_t q = hipStreamQuery(g.stream);
+  for (uint32_t spin = 1; q == hipErrorNotReady; ++spin) {
+    if ((spin & 0xffu) == 0u && std::chrono::steady_clock::now() > deadline) break;
+    __builtin_ia32_pause();
+    q = hipStreamQuery(g.stream);
+  }
+  if (q == hipErrorNotReady) {
+    g.dead.store(true);
+    return false;
+  }
+  tell_gang(srv, g, 0u);
+  g.running = false;   // it left (or its launch failed): nothing of this gang touches the device any more
+  return true;
+}
+
+// (g.mu held; the caller holds the store shared: the device views are current)
+void launch_gang(mrk_server &srv, ServeGang &g) {
   mrk_ctx *ctx = srv.ctx;
-  sl.launch_id += 1;
-  ServeSlotDev d;
-  d.ctl = sl.ctl;
-  d.in_host = sl.h_in;
-  d.in_dev = sl.d_in.as<uint8_t>();
-  d.out = OneOut{(double *)sl.h_out, (int32_t *)(sl.h_out + 1024), (int32_t *)(sl.h_out + 1536), nullptr, 1};
-  d.launch_id = sl.launch_id;
-  d.last_seq = sl.seq - 1;  // the request just published is the first thing the workgroup sees
+  ServeGangDev d;
+  d.slots = g.d_slots.as<ServeSlotDev>();
+  d.clock = g.d_clock.as<unsigned long long>();
+  d.launch_id = g.launch_id.load() + 1;
+  d.pad = 0;
   d.idle_ticks = srv.idle_ticks;
   d.life_ticks = srv.life_ticks;
-  launch_rank_serve(ctx, sl.stream, ctx->store->device_view(), srv.prog->device_view(), qs_device_view(srv.model), qs_forest_view(srv.model), d,
-                    SERVE_THREADS, SERVE_LDS, srv.f64, srv.jit_fn);
-  sl.running = true;
+  launch_rank_serve(ctx, g.stream, ctx->store->device_view(), srv.prog->device_view(), qs_device_view(srv.model), qs_forest_view(srv.model), d,
+                    g.n, SERVE_THREADS, SERVE_LDS, srv.f64, srv.jit_fn);
+  g.launch_id.store(d.launch_id);
+  g.running = true;
   srv.n_launches.fetch_add(1);
+}
+
+// The caller has published a request in a slot of `g` and saw (or assumes) that no workgroup of launch `seen` will serve it:
+// the gang is drained and launched again as a whole, unless somebody else did meanwhile.  Returns the launch now resident.
+uint32_t revive_gang(mrk_server &srv, ServeGang &g, uint32_t seen) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.dead.load()) throw StatusError(MRK_ERR_DEVICE, "the slot's serving gang was retired");
+  if (g.running && g.launch_id.load() != seen) return g.launch_id.load();
+  if (!drain_gang(srv, g, 5)) throw StatusError(MRK_ERR_DEVICE, "a serving gang did not leave within 5 s (its slots are retired)");
+  launch_gang(srv, g);
+  return g.launch_id.load();
 }
 
 // true: ranked through the queue (status = the request's device status word); false: not a request the queue takes
@@ -1423,9 +1484,15 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   int si = -1;
   {
     std::lock_guard<std::mutex> lk(srv.mu);
-    if (srv.closing || srv.free_slots.empty()) return false;  // every slot busy: the batching front of mrk_rank combines the overflow
-    si = srv.free_slots.back();
-    srv.free_slots.pop_back();
+    if (srv.closing) return false;
+    while (!srv.free_slots.empty()) {
+      const int c = srv.free_slots.back();
+      srv.free_slots.pop_back();
+      if (srv.gangs[(size_t)srv.slots[(size_t)c]->gang]->dead.load()) { srv.dead_slots += 1; continue; }   // retired with its gang
+      si = c;
+      break;
+    }
+    if (si < 0) return false;  // every slot busy: the batching front of mrk_rank combines the overflow
   }
   struct Release {
     mrk_server &s;
@@ -1434,7 +1501,7 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
     ~Release() {
       {
         std::lock_guard<std::mutex> lk(s.mu);
-        if (dead) s.dead_slots += 1;
+        if (dead || s.gangs[(size_t)s.slots[(size_t)i]->gang]->dead.load()) s.dead_slots += 1;
         else s.free_slots.push_back(i);
       }
       s.cv.notify_one();
@@ -1479,22 +1546,45 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   if (seq == 0xffffffffu) sl.seq = 0;  // (never: 4 G requests through one slot)
   const auto h1 = std::chrono::steady_clock::now();
   __atomic_store_n(&ctl.seq, seq, __ATOMIC_SEQ_CST);  // publishes the block and the header
-  auto gone = [&] { return __atomic_load_n(&ctl.exited, __ATOMIC_SEQ_CST) == sl.launch_id; };
+  ServeGang &g = *srv.gangs[(size_t)sl.gang];
+  uint32_t seen = g.launch_id.load();   // (0: never launched - no slot's `exited` word holds it)
+  auto gone = [&] { return seen == 0u || __atomic_load_n(&ctl.exited, __ATOMIC_SEQ_CST) == seen; };
   auto acked = [&] { return __atomic_load_n(&ctl.ack, __ATOMIC_ACQUIRE) == seq; };
-  if (!sl.running) launch_slot(srv, sl);
+  if (gone()) seen = revive_gang(srv, g, seen);
+  // Waiting: the first few callers spin on the acknowledgement (nothing is faster); the callers beyond them sleep through
+  // the time the device is known to need and spin for the rest.  64 callers spinning for 0.1 ms each are 64 busy CPUs: on a
+  // host whose CPU quota is smaller (the measurement boxes: profiles/r06_ad) the scheduler parks them for whole periods -
+  // p50 0.15 ms, maximum 77 ... 400 ms, and the closed-loop rate FELL from 32 to 64 callers.
+  struct Waiting {
+    std::atomic<int> &n;
+    int mine;
+    explicit Waiting(std::atomic<int> &c) : n(c), mine(c.fetch_add(1) + 1) {}
+    ~Waiting() { n.fetch_sub(1); }
+  } waiting(srv.waiting);
+  if (waiting.mine > switches().serve_spin_callers) {
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); slack_set = true; }   // this thread's timers: 1 us instead of 50
+    const uint64_t est = srv.est_dev_ns.load(std::memory_order_relaxed);
+    if (est > 20000 && !acked()) {
+      struct timespec ts = {0, (long)std::min<uint64_t>(est, 2000000)};
+      (void)nanosleep(&ts, nullptr);
+    }
+  }
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(5);
   for (uint32_t spin = 1; !acked(); ++spin) {
     if ((spin & 31u) == 0u) {
-      if (gone()) {  // the workgroup left (idle / told to stop) - possibly after serving this request
-        MRK_HIP(hipStreamSynchronize(sl.stream));
-        sl.running = false;
+      if (gone()) {  // the workgroup left (idle / old / told to stop) - possibly after serving this request
         if (acked()) break;
-        launch_slot(srv, sl);
+        seen = revive_gang(srv, g, seen);
       } else if ((spin & 0xffffu) == 0u && std::chrono::steady_clock::now() > deadline) {
-        __atomic_store_n(&ctl.stop, 1u, __ATOMIC_SEQ_CST);  // should it still be alive: leave
-        sl.dead = true;
+        tell_gang(srv, g, 1u);  // should they still be alive: leave
+        g.dead.store(true);
         release.dead = true;
-        throw StatusError(MRK_ERR_DEVICE, "the serving workgroup did not answer within 5 s (the slot is retired)");
+        char why[256];
+        snprintf(why, sizeof why, "the serving workgroup did not answer within 5 s (its gang is retired; slot %d: seq %u ack %u exited %u stop %u, gang launch %u seen %u)",
+                 si, __atomic_load_n(&ctl.seq, __ATOMIC_SEQ_CST), __atomic_load_n(&ctl.ack, __ATOMIC_SEQ_CST), __atomic_load_n(&ctl.exited, __ATOMIC_SEQ_CST),
+                 __atomic_load_n(&ctl.stop, __ATOMIC_SEQ_CST), g.launch_id.load(), seen);
+        throw StatusError(MRK_ERR_DEVICE, why);
       }
     }
     __builtin_ia32_pause();
@@ -1506,6 +1596,10 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   status = hs[0] | hs[1];
   const unsigned long long *clk = (const unsigned long long *)(hs + 16);
   for (int k = 0; k < 4; ++k) srv.dev_ticks[k].fetch_add(clk[k]);
+  {
+    const uint64_t sample = (clk[0] + clk[1] + clk[2]) * 10, old = srv.est_dev_ns.load(std::memory_order_relaxed);   // 100 MHz ticks -> ns
+    if (sample < 10000000) srv.est_dev_ns.store(old ? (old * 7 + sample) / 8 : sample, std::memory_order_relaxed);
+  }
   const auto h3 = std::chrono::steady_clock::now();
   srv.host_ns[0].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(h1 - h0).count());
   srv.host_ns[1].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(h2 - h1).count());
@@ -1521,28 +1615,33 @@ static void quiesce_servers(mrk_ctx *ctx) {  // the caller holds the store exclu
   std::lock_guard<std::mutex> lk(ctx->servers_mu);
   for (void *p : ctx->servers) {
     mrk_server *srv = (mrk_server *)p;
-    for (auto &sl : srv->slots)
-      if (sl->running && !sl->dead) __atomic_store_n(&sl->ctl->stop, 1u, __ATOMIC_SEQ_CST);
-    for (auto &sl : srv->slots) stop_slot(*sl);
-    // A retired slot (its workgroup missed the 5 s deadline) was told to stop when it was retired.  Slow is not hung: if
-    // its kernel is still on the device it still reads the store views it was launched with, and the caller is about to
-    // reallocate them - wait for it a while, and refuse the flush rather than free memory under a live kernel.
-    for (auto &sl : srv->slots) {
-      if (!sl->dead || !sl->running) continue;
-      // (the 2 s are spent ONCE per stuck slot: while it stays resident every later flush fails at once instead of holding
+    for (auto &g : srv->gangs) {   // tell all of them first: they leave side by side
+      std::lock_guard<std::mutex> gl(g->mu);
+      if (g->running && !g->dead.load()) tell_gang(*srv, *g, 1u);
+    }
+    for (auto &g : srv->gangs) {
+      std::lock_guard<std::mutex> gl(g->mu);
+      if (!g->running) continue;
+      if (!g->dead.load()) {
+        if (drain_gang(*srv, *g, 5)) continue;
+      }
+      // A retired gang (a workgroup of it missed the 5 s deadline) was told to stop when it was retired.  Slow is not hung: if
+      // its kernel is still on the device it still reads the store views it was launched with, and the caller is about to
+      // reallocate them - wait for it a while, and refuse the flush rather than free memory under a live kernel.
+      // (the 2 s are spent ONCE per stuck gang: while it stays resident every later flush fails at once instead of holding
       //  the store exclusively for another 2 s per request - one stuck workgroup is an error state, not a stall of the service)
-      const auto deadline = std::chrono::steady_clock::now() + (sl->stuck ? std::chrono::seconds(0) : std::chrono::seconds(2));
-      hipError_t q = hipStreamQuery(sl->stream);
+      const auto deadline = std::chrono::steady_clock::now() + (g->stuck ? std::chrono::seconds(0) : std::chrono::seconds(2));
+      hipError_t q = hipStreamQuery(g->stream);
       while (q == hipErrorNotReady && std::chrono::steady_clock::now() < deadline) {
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        q = hipStreamQuery(sl->stream);
+        q = hipStreamQuery(g->stream);
       }
       if (q == hipErrorNotReady) {
-        sl->stuck = true;
+        g->stuck = true;
         throw StatusError(MRK_ERR_DEVICE, "a retired serving workgroup is still resident: the store is not reallocated under it");
       }
-      sl->stuck = false;
-      sl->running = false;   // it left (or its launch failed): nothing of this slot touches the device any more
+      g->stuck = false;
+      g->running = false;   // it left (or its launch failed): nothing of this gang touches the device any more
     }
   }
 }
@@ -1569,16 +1668,17 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
     srv->idle_ticks = (uint64_t)std::max(1, switches().serve_idle_us) * 100ull;  // wall_clock64: 100 MHz
     srv->life_ticks = (uint64_t)std::max(1, switches().serve_life_us) * 100ull;
     srv->jit_fn = jit_serve_function(prog, srv->f64, switches().thr_stage ? &model->qs_sig : nullptr);  // warm-up: the compile happens here, not under the first request
-    // Every slot's workgroup is a kernel of its own on a stream of its own, and it STAYS (up to MRK_SERVE_LIFE_US): streams that
-    // share a hardware queue wait for each other, so a slot whose stream landed behind another slot's resident kernel answered
-    // 20 ... 200 ms late - round 5's "collapse at 32 callers" (p99 76 ms; ROCm maps a process's streams onto GPU_MAX_HW_QUEUES = 4
-    // hardware queues by default; with 32 of them 16 callers hold p99 0.16 ms at 112 k requests/s, profiles/r06_d_callers_serve.txt).
-    // mrk_init asks for more hardware queues (hw_queue_budget, capi.cpp); the slots beyond what those can hold are not created:
-    // their callers go through mrk_rank's front, which combines them.
-    n_slots = std::max(1, std::min(n_slots, hw_queue_budget() - 4));   // 4: the context stream, the lanes of mrk_rank's front, a batch
+    // A resident kernel holds its stream's hardware queue for as long as it stays, and streams that share a hardware queue wait
+    // for each other: round 5's "collapse at 32 callers" (p99 76 ms) was a slot whose stream had landed behind another slot's
+    // resident kernel (ROCm maps a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default; mrk_init asks for
+    // 24, hw_queue_budget in capi.cpp).  One kernel per slot (round 6's first form) therefore capped the slots at the queues, and
+    // the callers beyond them - sent through mrk_rank's front, whose lanes share the same queues - still met 150 ... 230 ms stalls.
+    // Slots are launched in GANGS instead: SERVE_GANG workgroups per kernel, one stream per gang - 64 slots on 8 streams.
+    const int n_gangs = std::min((n_slots + SERVE_GANG - 1) / SERVE_GANG, std::max(1, hw_queue_budget() - 4));   // 4: the context stream, the lanes of mrk_rank's front, a batch
+    n_slots = std::min(n_slots, n_gangs * SERVE_GANG);
     for (int i = 0; i < n_slots; ++i) {
       std::unique_ptr<ServeSlot> sl(new ServeSlot());
-      MRK_HIP(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
+      sl->gang = i / SERVE_GANG;
       MRK_HIP(hipHostMalloc(&sl->pinned, 128 + SERVE_OUT_BYTES + SERVE_IN_CAP, hipHostMallocCoherent | hipHostMallocMapped));
       memset(sl->pinned, 0, 128 + SERVE_OUT_BYTES + SERVE_IN_CAP);
       static_assert(sizeof(ServeCtl) == 128, "ServeCtl is one 128-byte line");
@@ -1589,30 +1689,76 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
       srv->slots.push_back(std::move(sl));
       srv->free_slots.push_back(n_slots - 1 - i);  // slot 0 on top
     }
+    for (int k = 0; k < n_gangs; ++k) {
+      std::unique_ptr<ServeGang> g(new ServeGang());
+      g->first = k * SERVE_GANG;
+      g->n = std::min(SERVE_GANG, n_slots - g->first);
+      MRK_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+      std::vector<ServeSlotDev> view((size_t)g->n);
+      for (int i = 0; i < g->n; ++i) {
+        ServeSlot &sl = *srv->slots[(size_t)(g->first + i)];
+        view[(size_t)i].ctl = sl.ctl;
+        view[(size_t)i].in_host = sl.h_in;
+        view[(size_t)i].in_dev = sl.d_in.as<uint8_t>();
+        view[(size_t)i].out = OneOut{(double *)sl.h_out, (int32_t *)(sl.h_out + 1024), (int32_t *)(sl.h_out + 1536), nullptr, 1};
+      }
+      g->d_slots.reserve(view.size() * sizeof(ServeSlotDev));
+      g->d_clock.reserve(8);
+      MRK_HIP(hipMemcpy(g->d_slots.p, view.data(), view.size() * sizeof(ServeSlotDev), hipMemcpyHostToDevice));
+      MRK_HIP(hipMemset(g->d_clock.p, 0, 8));
+      srv->gangs.push_back(std::move(g));
+    }
     mrk_model_retain(model);
     ctx_retain(ctx);
     {
       std::lock_guard<std::mutex> lk(ctx->servers_mu);
       ctx->servers.push_back(srv.get());
+      ctx->n_servers.store((int)ctx->servers.size(), std::memory_order_release);
     }
     *out = srv.release();
   });
 }
 
-int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, int32_t *out_order) {
-  if (!srv || !req) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
-  bool done = false;
+static int serve_one(mrk_server *srv, const mrk_request *req, double *out_scores, int32_t *out_order, bool &done) {
   int status = 0;
+  done = false;
   const int rc = guard([&] { done = serve_fast(*srv, req, out_scores, out_order, status); });
-  if (rc != MRK_OK) return rc;
-  if (!done) {
-    srv->n_fallback.fetch_add(1);
-    return mrk_rank(srv->ctx, srv->model, srv->model_name.c_str(), req, out_scores, out_order, nullptr);
-  }
+  if (rc != MRK_OK || !done) return rc;
   std::string msg;
   const int code = status_to_code(status, msg);
   if (code != MRK_OK) set_last_error(msg);
   return code;
+}
+
+int mrk_serve_rank(mrk_server *srv, const mrk_request *req, double *out_scores, int32_t *out_order) {
+  if (!srv || !req) { set_last_error("null argument"); return MRK_ERR_INVALID_ARG; }
+  bool done = false;
+  const int rc = serve_one(srv, req, out_scores, out_order, done);
+  if (done || rc != MRK_OK) return rc;
+  srv->n_fallback.fetch_add(1);
+  return rank_front(srv->ctx, srv->model, srv->model_name.c_str(), req, out_scores, out_order, nullptr);
+}
+
+// mrk_rank's way into the queue: the context's server for (model, model_name), if one was started.  `users` keeps
+// mrk_serve_stop from freeing it between the lookup and the slot.
+static int rank_through_server(mrk_ctx *ctx, mrk_model *model, const char *model_name, const mrk_request *req, double *out_scores,
+                               int32_t *out_order, bool &done) {
+  done = false;
+  if (req->n_items > QS_TILE_ROWS) return MRK_OK;
+  mrk_server *srv = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->servers_mu);
+    for (void *p : ctx->servers) {
+      mrk_server *c = (mrk_server *)p;
+      if (c->model == model && c->model_name == model_name) { srv = c; break; }
+    }
+    if (srv) srv->users.fetch_add(1);
+  }
+  if (!srv) return MRK_OK;
+  const int rc = serve_one(srv, req, out_scores, out_order, done);
+  if (!done && rc == MRK_OK) srv->n_fallback.fetch_add(1);
+  srv->users.fetch_sub(1);
+  return rc;
 }
 
 int mrk_serve_stats(mrk_server *srv, int64_t *out, int n_out) {
@@ -1641,13 +1787,26 @@ void mrk_serve_stop(mrk_server *srv) {
   {
     std::lock_guard<std::mutex> lk(ctx->servers_mu);
     ctx->servers.erase(std::remove(ctx->servers.begin(), ctx->servers.end(), (void *)srv), ctx->servers.end());
+    ctx->n_servers.store((int)ctx->servers.size(), std::memory_order_release);
   }
+  while (srv->users.load() != 0) std::this_thread::yield();   // callers of mrk_rank that found this server before it left the list
   (void)hipSetDevice(ctx->device);
-  for (auto &sl : srv->slots) {
-    stop_slot(*sl);
-    if (sl->dead) continue;  // its workgroup may still be polling the slot's pinned block: leaked on purpose
-    if (sl->stream) (void)hipStreamDestroy(sl->stream);
-    if (sl->pinned) (void)hipHostFree(sl->pinned);
+  for (auto &g : srv->gangs) {
+    std::lock_guard<std::mutex> gl(g->mu);
+    if (!g->dead.load()) (void)drain_gang(*srv, *g, 5);
+    if (g->dead.load() && g->running) {
+      // its workgroups may still be resident, polling their slots' pinned blocks: stream, blocks and device buffers are leaked
+      // on purpose (a hipFree would wait for the resident kernel - for ever, if it hangs)
+      g->d_slots.p = nullptr; g->d_slots.cap = 0;
+      g->d_clock.p = nullptr; g->d_clock.cap = 0;
+      for (int i = g->first; i < g->first + g->n; ++i) { srv->slots[(size_t)i]->d_in.p = nullptr; srv->slots[(size_t)i]->d_in.cap = 0; }
+      continue;
+    }
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    for (int i = g->first; i < g->first + g->n; ++i) {
+      ServeSlot &sl = *srv->slots[(size_t)i];
+      if (sl.pinned) (void)hipHostFree(sl.pinned);
+    }
   }
   mrk_model_free(srv->model);
   delete srv;

@@ -171,8 +171,8 @@ std::string jit_source(const Program &prog, bool f64, int kernel, const QsSignat
   // ... and its persistent form (rank_device.hpp rank_serve_body)
   if (kernel == JIT_ALL || kernel == JIT_SERVE)
     s += "extern \"C\" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nmrk_jit_rank_serve"
-         "(mrk::StoreDev st, mrk::QsDev q, mrk::QsForestDev f, mrk::ServeSlotDev slot) {\n"
-         "  mrk::rank_serve_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, q, f, slot);\n}\n";
+         "(mrk::StoreDev st, mrk::QsDev q, mrk::QsForestDev f, mrk::ServeGangDev gang) {\n"
+         "  mrk::rank_serve_body<" + b64 + ", " + qs + ">(st, mrk::JitProg{}, q, f, gang);\n}\n";
   return s;
 }
 

@@ -84,8 +84,8 @@ rank_fused_score_kernel(StoreDev st, ProgramDev prog, BatchDev b, uint32_t tab_e
 // the persistent form: one workgroup serves the requests published in its slot (rank_device.hpp rank_serve_body)
 template <bool F64>
 __global__ void __launch_bounds__(512)
-rank_serve_kernel(StoreDev st, ProgramDev prog, QsDev q, QsForestDev f, ServeSlotDev slot) {
-  rank_serve_body<F64>(st, prog, q, f, slot);
+rank_serve_kernel(StoreDev st, ProgramDev prog, QsDev q, QsForestDev f, ServeGangDev gang) {
+  rank_serve_body<F64>(st, prog, q, f, gang);
 }
 
 __global__ void override_kernel(BatchDev b, int dim) {
@@ -471,21 +471,22 @@ void launch_rank_fused_score(mrk_ctx *ctx, const StoreDev &st, const ProgramDev 
   MRK_HIP(hipGetLastError());
 }
 
-// one persistent workgroup of `threads` lanes with `lds` bytes of dynamic LDS on `stream` (capi_rank.cpp mrk_serve_*)
-void launch_rank_serve(mrk_ctx *ctx, hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &slot,
-                       int threads, size_t lds, bool f64, void *jit_fn) {
+// a gang of `n_slots` persistent workgroups of `threads` lanes with `lds` bytes of dynamic LDS each, one kernel on `stream`
+// (capi_rank.cpp mrk_serve_*)
+void launch_rank_serve(mrk_ctx *ctx, hipStream_t stream, const StoreDev &st, const ProgramDev &prog, const QsDev &q, const QsForestDev &f, const ServeGangDev &gang,
+                       int n_slots, int threads, size_t lds, bool f64, void *jit_fn) {
   if (jit_fn) {
     StoreDev a_st = st;
     QsDev a_q = q;
     QsForestDev a_f = f;
-    ServeSlotDev a_s = slot;
+    ServeGangDev a_s = gang;
     void *args[] = {&a_st, &a_q, &a_f, &a_s};
-    MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, 1, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, args, nullptr));
+    MRK_HIP(hipModuleLaunchKernel((hipFunction_t)jit_fn, (unsigned)n_slots, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, args, nullptr));
     return;
   }
   lds_optin(ctx, f64 ? (const void *)rank_serve_kernel<true> : (const void *)rank_serve_kernel<false>);
-  if (f64) hipLaunchKernelGGL(rank_serve_kernel<true>, dim3(1), dim3(threads), lds, stream, st, prog, q, f, slot);
-  else hipLaunchKernelGGL(rank_serve_kernel<false>, dim3(1), dim3(threads), lds, stream, st, prog, q, f, slot);
+  if (f64) hipLaunchKernelGGL(rank_serve_kernel<true>, dim3(n_slots), dim3(threads), lds, stream, st, prog, q, f, gang);
+  else hipLaunchKernelGGL(rank_serve_kernel<false>, dim3(n_slots), dim3(threads), lds, stream, st, prog, q, f, gang);
   MRK_HIP(hipGetLastError());
 }
 

@@ -128,28 +128,35 @@ struct OneOut {
   int32_t n_req_pad;     // max(n_req, 1)
 };
 
-// ---- the serving queue (rank_device.hpp rank_serve_body, capi_rank.cpp mrk_serve_*): one persistent workgroup per slot.
+// ---- the serving queue (rank_device.hpp rank_serve_body, capi_rank.cpp mrk_serve_*): one persistent workgroup per slot,
+// launched in GANGS - one kernel of up to SERVE_GANG workgroups on one stream, workgroup i serving slot i of the gang - so
+// that 64 slots take 8 streams (a resident kernel holds its stream's hardware queue, and a process has few of those).
 // ServeCtl lives in pinned host memory: the host writes `seq` / `stop` and the request header, the device `ack` /
 // `exited`.  No word is written from both sides.
 struct ServeCtl {
   uint32_t seq;       // host: number of the request in the slot's input block (published last, after the block and this header)
   uint32_t stop;      // host: 1 = leave at the next poll
   uint32_t ack;       // device: last request whose results are in the slot's output block
-  uint32_t exited;    // device: the launch id of the workgroup that has left (idle for `idle_ticks`, or told to stop)
+  uint32_t exited;    // device: the launch id of the gang whose workgroup has left this slot (idle, old, or told to stop)
   // the request's header
   uint32_t in_bytes;  // bytes of the input block
   uint32_t o_reqs, o_consts, o_irf, o_prep, o_slot, o_ireq;   // where the arrays of BatchDev start inside it
   uint32_t total_items, tab_entries, vals_cap, mode;
   uint32_t pad[17];   // 128 B
 };
-struct ServeSlotDev {
+struct ServeSlotDev {        // one per slot, in device memory, written once (mrk_serve_start)
   ServeCtl *ctl;             // pinned
   const uint8_t *in_host;    // pinned input block (the host side's packing of one request: build_batch's layout)
   uint8_t *in_dev;           // its device copy, made by the workgroup itself
   OneOut out;                // pinned output block
-  uint32_t launch_id, last_seq;
-  unsigned long long idle_ticks;   // wall_clock64 ticks (100 MHz) without a request after which the workgroup leaves
-  unsigned long long life_ticks;   // ... and the age at which it leaves after the request it is serving, however busy the slot is:
+};
+constexpr int SERVE_GANG = 8;
+struct ServeGangDev {        // kernel argument of one gang launch
+  const ServeSlotDev *slots; // [gridDim.x]
+  unsigned long long *clock; // device word: wall_clock64 of the gang's last served request (idleness is the gang's, not a slot's)
+  uint32_t launch_id, pad;
+  unsigned long long idle_ticks;   // wall_clock64 ticks (100 MHz) without a request in the GANG after which its workgroups leave
+  unsigned long long life_ticks;   // ... and the age at which each leaves after the request it is serving, however busy the slot is:
                                    // hipFree / hipHostFree / a device-wide sync on ANY thread wait for every resident kernel
 };
 

@@ -1739,7 +1739,7 @@ __device__ __forceinline__ void assemble_item(const StoreDev &st, const Prog &pr
 template <bool SPLIT, typename Prog, typename SinkMaker>
 __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries,
                                                 int vals_cap, uint32_t thr_cap, int mode, const SinkMaker &make_sink, uint32_t lds_skip = 0,
-                                                const double *rt_src = nullptr, uint32_t rt_doubles = 0) {
+                                                const double *rt_src = nullptr, uint32_t rt_doubles = 0, int blk = -1) {
   const int op_split = SPLIT ? ((mode & 255) > 1 ? (mode & 255) : 1) : 1;
   const int slices = SPLIT ? (((mode >> 8) & 255) > 1 ? ((mode >> 8) & 255) : 1) : 1;   // (the plain kernel keeps its registers for the ops)
   extern __shared__ __align__(16) uint8_t smem_base[];
@@ -1751,7 +1751,8 @@ __device__ __forceinline__ void rank_fused_body(const StoreDev &st, const Prog &
   const size_t thr_at = ((size_t)((uint8_t *)(s_int + PREP_INTS) - smem) + 15) & ~(size_t)15;  // LDS-DMA writes 16 B per lane
   qs_lds_double *s_thr_all = (qs_lds_double *)(smem + thr_at);
   qs_lds_double *s_thr = s_thr_all + (size_t)(threadIdx.x >> 6) * 2 * thr_cap;
-  const int r = (int)blockIdx.x / slices, sl = (int)blockIdx.x % slices;
+  const int bid = blk < 0 ? (int)blockIdx.x : blk;   // (a serving gang's workgroup i ranks request 0 of ITS slot's batch)
+  const int r = bid / slices, sl = bid % slices;
   const ReqDev rq = b.reqs[r];
   if (rq.item_begin >= b.item_hi || rq.item_begin + rq.n_items <= b.item_lo) return;  // not in this shard
   const int item_lanes = (int)blockDim.x / op_split;       // a whole number of wavefronts (the host sizes the workgroup)
@@ -1951,10 +1952,10 @@ __device__ __forceinline__ void rank_fused_cells_body(const StoreDev &st, const 
 // assembly sees has its `status` pointer bent there): no global atomic, nothing to wait for before it is copied out.
 template <bool F64, typename QS = QsDyn, typename Prog>
 __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &prog, const BatchDev &b, uint32_t tab_entries, int vals_cap,
-                                              const QsDev &q, const QsForestDev &f, int mode, const OneOut &out) {
+                                              const QsDev &q, const QsForestDev &f, int mode, const OneOut &out, int blk = -1) {
   extern __shared__ __align__(16) uint8_t smem_base[];
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int r = blockIdx.x;
+  const int r = blk < 0 ? (int)blockIdx.x : blk;
   const ReqDev rq = b.reqs[r];
   const uint32_t slab_bytes = (uint32_t)qs_n_views<QS>(q) * (QS_TILE_ROWS * 2);
   for (uint32_t i = tid; i < slab_bytes / 4 + 4; i += nthr) ((uint32_t *)smem_base)[i] = 0u;  // rows past the request's last candidate; the status word
@@ -1965,11 +1966,11 @@ __device__ __forceinline__ void rank_one_body(const StoreDev &st, const Prog &pr
   if constexpr (qs_fused_rt<QS, true>()) {   // the compact tables resident (no queue: the ops are shared out at run time)
     rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *, qs_lds_double *s_all) {
       return CellSinkRT<F64, QS, false>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_all, active};
-    }, slab_bytes + 16, q.thr_rt, QS::rt_total);
+    }, slab_bytes + 16, q.thr_rt, QS::rt_total, r);
   } else {
     rank_fused_body<true>(st, prog, bl, tab_entries, vals_cap, qs_thr_cap<QS>(q), mode & 255, [&](int gi, int rr, bool active, qs_lds_double *s_thr, qs_lds_double *) {
       return CellSink<F64, QS>{q, (uint16_t *)smem_base + (gi - rq.item_begin), &bl.status[rr], s_thr, active, /*vm_stores=*/false};
-    }, slab_bytes + 16);
+    }, slab_bytes + 16, nullptr, 0, r);
   }
   // (qs_score_tile_split starts with a barrier: the slab is complete, the assembly's LDS regions are free)
   constexpr int TREE_LEAF_BYTES = QS_LEAVES * (F64 ? 8 : 4);
@@ -2069,28 +2070,40 @@ __device__ __forceinline__ void rank_fused_score_body(const StoreDev &st, const 
 // relaunches it with the next request.  If a request slips in between the announcement and the exit it is still served
 // (device: store exited, fence, read seq; host: store seq, fence, read exited - one side sees the other).
 template <bool F64, typename QS = QsDyn, typename Prog>
-__device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &prog, const QsDev &q, const QsForestDev &f, const ServeSlotDev &s) {
+__device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &prog, const QsDev &q, const QsForestDev &f, const ServeGangDev &g) {
   extern __shared__ __align__(16) uint8_t smem_base[];
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const ServeSlotDev s = g.slots[blockIdx.x];
   const uint32_t slab_bytes = (uint32_t)qs_n_views<QS>(q) * (QS_TILE_ROWS * 2);
   volatile uint32_t *s_word = (volatile uint32_t *)(smem_base + slab_bytes + 8);   // [0] seq | STOP, [1] leave after this request
-  uint32_t last = s.last_seq;
+  // the slot's last ANSWERED request: whatever the host has published beyond it is this workgroup's first request (a gang is
+  // launched as a whole: most of its slots have nothing pending, the one that asked for the launch has)
+  uint32_t last = __hip_atomic_load(&s.ctl->ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   unsigned long long idle_since = wall_clock64();
   const unsigned long long born = idle_since;
   for (;;) {
-    if (tid == 0) {
+    // The poller's test must not be provably the test of any `tid == 0` block further down: the compiler then threads the
+    // back edge of the lanes that fail both straight to the barrier below - an inner loop the poller's lane never re-enters,
+    // in which lanes 1 .. 63 of its wavefront rank the same request for ever (measured: round 6, the first gang build).
+    int poller = tid;
+    asm volatile("" : "+v"(poller));
+    if (poller == 0) {
       uint32_t seq = last, leave = 0, stop = 0;
       for (;;) {
         // A slot under sustained traffic never idles (the host hands out the most recently used slot first), and a
         // resident kernel stalls every hipFree / reallocation / device-wide sync of the process: past `life_ticks` the
         // workgroup takes its leave exactly as if it had been told to (a request already published is served first).
         const unsigned long long now = wall_clock64();
-        const bool old = now - born > s.life_ticks;
+        const bool old = now - born > g.life_ticks;
         seq = __hip_atomic_load(&s.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (seq != last && !old) break;
         const bool told = old || __hip_atomic_load(&s.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-        if (told || now - idle_since > s.idle_ticks) {
-          __hip_atomic_store(&s.ctl->exited, s.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!told && now - idle_since > g.idle_ticks) {   // this slot is idle - is the gang?  (its workgroups leave together)
+          const unsigned long long seen = __hip_atomic_load(g.clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (seen > idle_since && now - seen <= g.idle_ticks) idle_since = seen;
+        }
+        if (told || now - idle_since > g.idle_ticks) {
+          __hip_atomic_store(&s.ctl->exited, g.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __threadfence_system();
           seq = __hip_atomic_load(&s.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           if (seq != last) leave = 1;   // a request slipped in: serve it, then leave
@@ -2134,7 +2147,7 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long t_in = wall_clock64();
     const unsigned long long c_in = clock64();   // shader cycles next to the 100 MHz wall clock: the clock the request actually ran at
-    rank_one_body<F64, QS>(st, prog, b, tab_entries, (int)vals_cap, q, f, (int)mode, s.out);
+    rank_one_body<F64, QS>(st, prog, b, tab_entries, (int)vals_cap, q, f, (int)mode, s.out, 0);
     const unsigned long long c_ranked = clock64();
     const unsigned long long t_ranked = wall_clock64();
     __threadfence_system();   // every lane's results are in host memory before the acknowledgement
@@ -2147,6 +2160,7 @@ __device__ __forceinline__ void rank_serve_body(const StoreDev &st, const Prog &
       clk[1] = t_ranked - t_in;
       clk[2] = wall_clock64() - t_ranked;
       clk[3] = c_ranked - c_in;
+      __hip_atomic_store(g.clock, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the gang's last activity
       __threadfence_system();
       __hip_atomic_store(&s.ctl->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

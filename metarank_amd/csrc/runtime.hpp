@@ -112,6 +112,8 @@ struct Switches {
   bool rank_combine = true;    // MRK_RANK_COMBINE=0: no batching front in mrk_rank
   bool rank_serve = true;      // MRK_RANK_SERVE=0: mrk_serve_rank never takes the persistent-workgroup queue (everything through mrk_rank)
   int serve_life_us = 20000;   // MRK_SERVE_LIFE_US: ... and leaves after the request it is serving once it is this old, idle or not (bounds what a hipFree on another thread waits for)
+  int serve_spin_callers = 8;  // MRK_SERVE_SPIN_CALLERS: up to this many callers of the serving queue wait for their answer spinning; the ones beyond
+                               // sleep through most of the device's time first (a host with a CPU quota throttles 64 spinning threads)
   int serve_idle_us = 2000;    // MRK_SERVE_IDLE_US: a serving workgroup without a request for this long leaves its CU (relaunched by the next request)
   bool rank_fused_score = false; // MRK_RANK_FUSED_SCORE=1: full batches of small requests in ONE launch (assembly, forest, ordering per request workgroup) - measured slower than the three launches, kept for A/B
   bool rank_one = true;        // MRK_RANK_ONE=0: mrk_rank's small batches take the three-launch path instead of the one-launch kernel
@@ -200,6 +202,7 @@ struct mrk_ctx {
   std::mutex comm_mu;
   std::mutex servers_mu;              // the serving queues of this context (capi_rank.cpp mrk_serve_*): a store flush stops their workgroups
   std::vector<void *> servers;        // mrk_server*
+  std::atomic<int> n_servers{0};      // its size, for mrk_rank's lock-free "is there a queue at all"
   // batching front of mrk_rank: concurrent callers are combined into device batches by whichever waiting caller finds a
   // free lane (capi_rank.cpp); several batches are in flight at once - one per lane
   std::mutex qmu;

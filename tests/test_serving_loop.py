@@ -482,9 +482,11 @@ def test_item_id_offsets_from_the_wire_are_checked(oracle_c2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("entry", ["mrk_rank", "mrk_serve_rank"])
+@pytest.mark.parametrize("entry", ["mrk_rank", "mrk_serve_rank", "mrk_rank_with_a_queue"])
 def test_native_callers_stress_the_front_while_a_writer_puts(oracle_c2, tmp_path, entry):
-    """64 NATIVE threads (tools/native/callers_driver.cpp: C++ against include/mrk.h, no interpreter between the calls) x 150
+    """(`mrk_rank_with_a_queue`: the callers use mrk_rank while a serving queue of the model is started - the library routes
+    them through the queue's 64 slots, 8 gangs of 8 resident workgroups, and the overflow through the front.)
+    64 NATIVE threads (tools/native/callers_driver.cpp: C++ against include/mrk.h, no interpreter between the calls) x 150
     requests each through mrk_rank's pipelined front - several lanes in flight, ids of combined batches resolved on the device -
     and through the serving queue, while a writer keeps putting values (the id table grows; every put needs the store
     exclusively, and must not starve behind the overlapping leaders).  Every result equals the oracle's bit for bit; the
@@ -524,8 +526,8 @@ def test_native_callers_stress_the_front_while_a_writer_puts(oracle_c2, tmp_path
         for r in reqs[:4]:
             hip.ranker.rerank("xgboost", r, hip.booster)
         hip.ranker.warmup_kernels("xgboost")
-        if entry == "mrk_serve_rank":
-            srv = hip.ranker.serve("xgboost", hip.booster, n_slots=32)
+        if entry != "mrk_rank":
+            srv = hip.ranker.serve("xgboost", hip.booster, n_slots=64)
             for r in reqs[:4]:
                 srv.rerank(r)
         N.lib()
@@ -536,7 +538,7 @@ def test_native_callers_stress_the_front_while_a_writer_puts(oracle_c2, tmp_path
         def drive(threads, per_thread):
             lat = np.zeros(threads * per_thread, dtype=np.float64)
             out = np.zeros(8, dtype=np.float64)
-            rc = d.mrk_bench_callers(hip.ranker.ctx.handle, hip.booster.handle, b"xgboost", srv._h if srv is not None else None, C.addressof(arr), len(reqs),
+            rc = d.mrk_bench_callers(hip.ranker.ctx.handle, hip.booster.handle, b"xgboost", srv._h if entry == "mrk_serve_rank" else None, C.addressof(arr), len(reqs),
                                      items, threads, per_thread, lat.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
                                      od.ctypes.data_as(C.c_void_p))
             return rc, lat, out
@@ -569,6 +571,10 @@ def test_native_callers_stress_the_front_while_a_writer_puts(oracle_c2, tmp_path
         assert out[3] == 0, f"{int(out[3])} of {threads * per_thread} concurrent results differ from the oracle"
         assert puts[0] > 20, "the writer starved behind the readers"
         assert lat.max() < 2000.0
+        if srv is not None:
+            st = srv.stats()
+            print(f"   queue: {st}")
+            assert st["queue"] > threads * per_thread // 4, st   # the queue, not its fallback, did the work
     finally:
         if srv is not None:
             srv.close()

@@ -3,7 +3,10 @@ fiber, api/routes/RankApi.scala:25-41): T NATIVE threads x N sequential requests
 with --serve - through the serving queue (mrk_serve_rank).  The threads are C++ (tools/native/callers_driver.cpp, against
 include/mrk.h only); every concurrent result is compared bit for bit with a sequential pass over the same requests.
 
-    python tools/concurrent_bench.py [--serve] [--json] [--lanes N] [threads,threads,... [requests_per_thread [items]]]
+    python tools/concurrent_bench.py [--serve | --queue] [--json] [--lanes N] [threads,threads,... [requests_per_thread [items]]]
+
+--queue: the callers use mrk_rank while a serving queue of the model is started (mrk_serve_start once, as a host does at warm-up):
+the library answers them through the queue's resident workgroups and sends the overflow through the batching front.
 
 Prints one line per thread count: requests/s, items/s, per-call p50 / p99 (R-6 percentiles) and the number of results that
 differed from the sequential pass (must be 0).  (Until round 5 this tool drove Python threads: at 16+ callers it measured the
@@ -31,6 +34,7 @@ from metarank_amd.request import request_array
 from workloads import ranklens, synth
 
 serve = "--serve" in flags
+queue = "--queue" in flags   # mrk_rank while a serving queue of this model is started: the library routes the calls through it
 thread_counts = [int(x) for x in (argv[0] if argv else "1,4,16,32,64,128,256").split(",")]
 per_thread = int(argv[1]) if len(argv) > 1 else 400
 items = int(argv[2]) if len(argv) > 2 else 100
@@ -129,16 +133,17 @@ def main():
     d = driver()
     rows = []
     for threads in thread_counts:
-        srv = ranker.serve("xgboost", booster, n_slots=min(threads, slots_wish)) if serve else None
+        srv = ranker.serve("xgboost", booster, n_slots=min(threads, slots_wish)) if (serve or queue) else None
         if srv is not None:
             for r in reqs[:16]:
                 srv.rerank(r)
         if "--python" in flags:
             row = run_python(ranker, booster, srv, reqs, threads)
         else:
-            run_native(d, ctx, booster, srv._h if srv is not None else None, arr, len(reqs), threads if '--warm-full' in flags else min(threads, 8), sc, od)   # warm: lanes, streams, pinned buffers
-            row = run_native(d, ctx, booster, srv._h if srv is not None else None, arr, len(reqs), threads, sc, od)
-        row["path"] = "mrk_serve_rank" if serve else "mrk_rank"
+            h = srv._h if (srv is not None and serve) else None
+            run_native(d, ctx, booster, h, arr, len(reqs), threads if '--warm-full' in flags else min(threads, 8), sc, od)   # warm: lanes, streams, pinned buffers
+            row = run_native(d, ctx, booster, h, arr, len(reqs), threads, sc, od)
+        row["path"] = "mrk_serve_rank" if serve else ("mrk_rank+queue" if queue else "mrk_rank")
         if srv is not None:
             row["serve_stats"] = srv.stats()
             srv.close()
