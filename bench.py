@@ -930,10 +930,13 @@ def main():
                         "requests_per_caller": args.concurrent_requests,
                         "mrk_rank": [callers(t_, args.concurrent_requests) for t_ in counts]}
                 if info["bitvector"] and args.items <= 128:
-                    srv = ranker.serve(model_name, booster, n_slots=32)
+                    # the serving queue started (mrk_serve_start at warm-up: 64 slots = 8 gangs of 8 resident workgroups): first
+                    # its own entry point, then mrk_rank again - the library now answers it through the queue, overflow through the front
+                    srv = ranker.serve(model_name, booster, n_slots=64)
                     for r in c_reqs[:8]:
                         srv.rerank(r)
-                    conc["mrk_serve_rank"] = [callers(t_, args.concurrent_requests, srv._h) for t_ in counts if t_ <= 64]
+                    conc["mrk_serve_rank"] = [callers(t_, args.concurrent_requests, srv._h) for t_ in counts if t_ <= 128]
+                    conc["mrk_rank_with_the_queue_started"] = [callers(t_, args.concurrent_requests) for t_ in counts]
                     conc["mrk_serve_rank_stats"] = srv.stats()
                     srv.close()
                 latency["concurrent"] = conc

@@ -37,7 +37,8 @@
  *
  * ABI 8 (round 5): mrk_init creates n contexts; mrk_device_count; mrk_comm_init_local; mrk_model_inspect; mrk_serve_stats takes
  * the length of its output array; mrk_store_put_binary_at / mrk_store_expire; mrk_encoder_load is f32 (MRK_ENCODER_AUTO = F32).
- * ABI 9 (round 6): mrk_model_weights / mrk_model_inspect_weights (Booster.weights()), mrk_abi_layout.
+ * ABI 9 (round 6): mrk_model_weights / mrk_model_inspect_weights (Booster.weights()), mrk_abi_layout.  Same ABI, new behaviour:
+ * the serving queue's slots are launched in gangs (64 slots on 8 streams) and mrk_rank answers through a started queue.
  */
 #ifndef MRK_H
 #define MRK_H
@@ -416,11 +417,17 @@ void mrk_batch_free(mrk_batch *batch);
  * (more than 128 candidates, per-item field overrides, a model with a request-normalised column, all slots busy) go
  * through mrk_rank transparently.  A workgroup that has seen no request for a while (2 ms; MRK_SERVE_IDLE_US) leaves
  * its CU and is relaunched by the next request; store flushes stop the workgroups for their duration.
- * n_slots (1 .. 64) is a wish: every resident workgroup is a kernel on a stream of its own and occupies that stream's hardware
- * queue while it stays, so no more slots are created than the process has hardware queues to spare (GPU_MAX_HW_QUEUES minus 4;
- * the library sets the variable to 24 before its first HIP call unless the host has set it - ROCm's default of 4 made the fifth
- * slot wait behind another slot's kernel for up to its 20 ms residency).  Callers beyond the slots are combined by mrk_rank's
- * front.
+ * n_slots (1 .. 64): the slots are launched in GANGS - one kernel of up to 8 workgroups per stream, workgroup i serving slot i of
+ * its gang - because a resident kernel occupies its stream's hardware queue while it stays and a process has few of those
+ * (GPU_MAX_HW_QUEUES; the library sets it to 24 before its first HIP call unless the host has set it): 64 slots take 8 streams.
+ * A gang leaves as a whole (idle: no request in any of its slots for MRK_SERVE_IDLE_US; old: MRK_SERVE_LIFE_US; told: a store
+ * flush) and is launched again as a whole by the next request that finds its slot left.  Up to MRK_SERVE_SPIN_CALLERS (8)
+ * callers wait for their answer spinning; the callers beyond them sleep through the time the device is known to need
+ * (+ MRK_SERVE_SLEEP_EXTRA_US) and spin for the rest - 64 spinning threads are 64 busy CPUs, which a host with a CPU quota does
+ * not have.  Callers beyond the slots are combined by mrk_rank's front.
+ * While a queue is started, mrk_rank itself answers through it (same model handle and model name, no matrix asked for, at most
+ * 128 candidates) and sends the rest through its batching front: a host calls mrk_serve_start once at warm-up and keeps calling
+ * mrk_rank from its request fibers.
  * mrk_serve_stats: the first min(n_out, MRK_SERVE_STATS) of {requests through the queue, requests through mrk_rank, workgroup launches; then, summed over the
  * queue's requests, in ns: host resolve + pack, host publish -> acknowledgement, host copy-out, device input copy + cache drops,
  * device ranking, device result write-back; last: the SHADER CYCLES of the device ranking summed the same way - cycles / ns = the

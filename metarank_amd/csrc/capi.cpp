@@ -33,6 +33,7 @@ static Switches read_switches() {
   s.rank_serve = flag("MRK_RANK_SERVE", true);
   s.serve_idle_us = std::max(1, num("MRK_SERVE_IDLE_US", 2000));
   s.serve_spin_callers = std::max(0, num("MRK_SERVE_SPIN_CALLERS", 8));
+  s.serve_sleep_extra_us = std::max(0, num("MRK_SERVE_SLEEP_EXTRA_US", 8));
   s.serve_life_us = std::max(1, num("MRK_SERVE_LIFE_US", 20000));
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
   s.rank_lanes = std::max(1, std::min((int)mrk_ctx::RANK_LANES_MAX, num("MRK_RANK_LANES", 3)));

@@ -1564,9 +1564,10 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   if (waiting.mine > switches().serve_spin_callers) {
     static thread_local bool slack_set = false;
     if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); slack_set = true; }   // this thread's timers: 1 us instead of 50
+    // (publish -> acknowledgement is the device's total + 15 ... 20 us of PCIe round trips: profiles/r06_ad, 96 against 77 us)
     const uint64_t est = srv.est_dev_ns.load(std::memory_order_relaxed);
     if (est > 20000 && !acked()) {
-      struct timespec ts = {0, (long)std::min<uint64_t>(est, 2000000)};
+      struct timespec ts = {0, (long)std::min<uint64_t>(est + (uint64_t)switches().serve_sleep_extra_us * 1000, 2000000)};
       (void)nanosleep(&ts, nullptr);
     }
   }
@@ -1714,6 +1715,7 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
       std::lock_guard<std::mutex> lk(ctx->servers_mu);
       ctx->servers.push_back(srv.get());
       ctx->n_servers.store((int)ctx->servers.size(), std::memory_order_release);
+      ctx->hot_server.store(srv.get(), std::memory_order_seq_cst);
     }
     *out = srv.release();
   });
@@ -1745,6 +1747,28 @@ static int rank_through_server(mrk_ctx *ctx, mrk_model *model, const char *model
                                int32_t *out_order, bool &done) {
   done = false;
   if (req->n_items > QS_TILE_ROWS) return MRK_OK;
+  // The context's most recently started queue, without a lock (64 callers a few hundred thousand times a second on one mutex
+  // are a queue of their own, and a holder the scheduler parks stops them all).  Readers count themselves into the current
+  // epoch's cell BEFORE they load the pointer; mrk_serve_stop withdraws the pointer, turns the epoch and waits for the old
+  // cell to drain - whoever could still hold the withdrawn pointer is in it.
+  {
+    int cell = -1;
+    for (;;) {
+      const uint32_t e = ctx->hot_epoch.load(std::memory_order_seq_cst);
+      ctx->hot_readers[e & 1].fetch_add(1, std::memory_order_seq_cst);
+      if (ctx->hot_epoch.load(std::memory_order_seq_cst) == e) { cell = (int)(e & 1); break; }
+      ctx->hot_readers[e & 1].fetch_sub(1, std::memory_order_seq_cst);
+    }
+    mrk_server *hot = (mrk_server *)ctx->hot_server.load(std::memory_order_seq_cst);
+    int rc = MRK_OK;
+    const bool mine = hot && hot->model == model && hot->model_name == model_name;
+    if (mine) {
+      rc = serve_one(hot, req, out_scores, out_order, done);
+      if (!done && rc == MRK_OK) hot->n_fallback.fetch_add(1);
+    }
+    ctx->hot_readers[cell].fetch_sub(1, std::memory_order_seq_cst);
+    if (mine) return rc;
+  }
   mrk_server *srv = nullptr;
   {
     std::lock_guard<std::mutex> lk(ctx->servers_mu);
@@ -1788,6 +1812,12 @@ void mrk_serve_stop(mrk_server *srv) {
     std::lock_guard<std::mutex> lk(ctx->servers_mu);
     ctx->servers.erase(std::remove(ctx->servers.begin(), ctx->servers.end(), (void *)srv), ctx->servers.end());
     ctx->n_servers.store((int)ctx->servers.size(), std::memory_order_release);
+    if (ctx->hot_server.load() == (void *)srv) ctx->hot_server.store(ctx->servers.empty() ? nullptr : ctx->servers.back(), std::memory_order_seq_cst);
+  }
+  {  // mrk_rank's lock-free readers that may still hold the withdrawn pointer (rank_through_server)
+    std::lock_guard<std::mutex> lk(ctx->hot_stop_mu);
+    const uint32_t e = ctx->hot_epoch.fetch_add(1, std::memory_order_seq_cst);
+    while (ctx->hot_readers[e & 1].load(std::memory_order_seq_cst) != 0) std::this_thread::yield();
   }
   while (srv->users.load() != 0) std::this_thread::yield();   // callers of mrk_rank that found this server before it left the list
   (void)hipSetDevice(ctx->device);

@@ -114,6 +114,7 @@ struct Switches {
   int serve_life_us = 20000;   // MRK_SERVE_LIFE_US: ... and leaves after the request it is serving once it is this old, idle or not (bounds what a hipFree on another thread waits for)
   int serve_spin_callers = 8;  // MRK_SERVE_SPIN_CALLERS: up to this many callers of the serving queue wait for their answer spinning; the ones beyond
                                // sleep through most of the device's time first (a host with a CPU quota throttles 64 spinning threads)
+  int serve_sleep_extra_us = 8;   // MRK_SERVE_SLEEP_EXTRA_US: ... that sleep = the device's smoothed time per request + this
   int serve_idle_us = 2000;    // MRK_SERVE_IDLE_US: a serving workgroup without a request for this long leaves its CU (relaunched by the next request)
   bool rank_fused_score = false; // MRK_RANK_FUSED_SCORE=1: full batches of small requests in ONE launch (assembly, forest, ordering per request workgroup) - measured slower than the three launches, kept for A/B
   bool rank_one = true;        // MRK_RANK_ONE=0: mrk_rank's small batches take the three-launch path instead of the one-launch kernel
@@ -203,6 +204,10 @@ struct mrk_ctx {
   std::mutex servers_mu;              // the serving queues of this context (capi_rank.cpp mrk_serve_*): a store flush stops their workgroups
   std::vector<void *> servers;        // mrk_server*
   std::atomic<int> n_servers{0};      // its size, for mrk_rank's lock-free "is there a queue at all"
+  std::atomic<void *> hot_server{nullptr};   // the most recently started one: mrk_rank's way in without the mutex ...
+  std::atomic<uint32_t> hot_epoch{0};        // ... guarded by reader counts per epoch parity (capi_rank.cpp rank_through_server)
+  std::atomic<int> hot_readers[2] = {{0}, {0}};
+  std::mutex hot_stop_mu;
   // batching front of mrk_rank: concurrent callers are combined into device batches by whichever waiting caller finds a
   // free lane (capi_rank.cpp); several batches are in flight at once - one per lane
   std::mutex qmu;
