@@ -1361,7 +1361,8 @@ int mrk_batch_status(mrk_batch *batch, int32_t *out_status) {
 // ---------------------------------------------------------------- the serving queue
 // main/command/Serve.scala:130-150 (warm-up, then the port opens) and api/routes/RankApi.scala:25-41 (one rerank per
 // request thread): mrk_serve_start compiles what the model needs and prepares `n_slots` slots, each a persistent workgroup
-// (rank_device.hpp rank_serve_body) with its request / result blocks in pinned memory; mrk_serve_rank is then the whole
+// (rank_device.hpp rank_serve_body; launched in gangs of SERVE_GANG per kernel and stream) with its request / result blocks in
+// pinned memory; mrk_serve_rank is then the whole
 // request path: resolve the request on the calling thread, write it into a free slot, publish, spin on the acknowledgement -
 // no HIP call, no launch, no copy command.  Whatever the one-workgroup path does not cover (more than 128 candidates,
 // per-item overrides, tables beyond the slot's LDS, explain) goes through mrk_rank.
@@ -1499,12 +1500,10 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
     int i;
     bool dead = false;
     ~Release() {
-      {
-        std::lock_guard<std::mutex> lk(s.mu);
-        if (dead || s.gangs[(size_t)s.slots[(size_t)i]->gang]->dead.load()) s.dead_slots += 1;
-        else s.free_slots.push_back(i);
-      }
-      s.cv.notify_one();
+      std::lock_guard<std::mutex> lk(s.mu);
+      if (dead || s.gangs[(size_t)s.slots[(size_t)i]->gang]->dead.load()) s.dead_slots += 1;
+      else s.free_slots.push_back(i);
+      s.cv.notify_one();   // under the mutex: mrk_serve_stop deletes the server as soon as it sees the last slot back
     }
   } release{srv, si};
   ServeSlot &sl = *srv.slots[(size_t)si];
