@@ -34,6 +34,8 @@ static Switches read_switches() {
   s.serve_idle_us = std::max(1, num("MRK_SERVE_IDLE_US", 2000));
   s.serve_spin_callers = std::max(0, num("MRK_SERVE_SPIN_CALLERS", 8));
   s.serve_sleep_extra_us = std::max(0, num("MRK_SERVE_SLEEP_EXTRA_US", 8));
+  s.serve_overload_ms = std::max(0, num("MRK_SERVE_OVERLOAD_MS", 200));
+  s.serve_poll_us = std::max(0, num("MRK_SERVE_POLL_US", 4));
   s.serve_life_us = std::max(1, num("MRK_SERVE_LIFE_US", 20000));
   s.combine_max = std::max(1, num("MRK_RANK_COMBINE_MAX", 256));
   s.rank_lanes = std::max(1, std::min((int)mrk_ctx::RANK_LANES_MAX, num("MRK_RANK_LANES", 3)));
@@ -105,6 +107,46 @@ void drain_profile_events(mrk_ctx *ctx) {
     (void)hipEventDestroy(b);
   }
   ctx->pending_events.clear();
+}
+
+std::atomic<int> &resident_gangs() {
+  static std::atomic<int> n{0};
+  return n;
+}
+
+namespace {
+std::mutex &deferred_mu() { static std::mutex m; return m; }
+std::vector<std::pair<void *, bool>> &deferred() { static std::vector<std::pair<void *, bool>> v; return v; }   // (pointer, pinned)
+}  // namespace
+
+void release_device(void *p) {
+  if (resident_gangs().load(std::memory_order_acquire) > 0) {
+    std::lock_guard<std::mutex> lk(deferred_mu());
+    deferred().emplace_back(p, false);
+    return;
+  }
+  (void)hipFree(p);
+}
+
+void release_pinned(void *p) {
+  if (resident_gangs().load(std::memory_order_acquire) > 0) {
+    std::lock_guard<std::mutex> lk(deferred_mu());
+    deferred().emplace_back(p, true);
+    return;
+  }
+  (void)hipHostFree(p);
+}
+
+void flush_deferred_releases() {
+  std::vector<std::pair<void *, bool>> mine;
+  {
+    std::lock_guard<std::mutex> lk(deferred_mu());
+    mine.swap(deferred());
+  }
+  for (auto &e : mine) {
+    if (e.second) (void)hipHostFree(e.first);
+    else (void)hipFree(e.first);
+  }
 }
 
 int hw_queue_budget() {

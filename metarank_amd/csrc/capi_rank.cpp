@@ -7,6 +7,7 @@
 #include <thread>
 
 #include <linux/futex.h>
+#include <sched.h>
 #include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <time.h>
@@ -1389,6 +1390,7 @@ struct ServeGang {
   std::mutex mu;
   std::atomic<uint32_t> launch_id{0};
   bool running = false;         // (mu) a kernel was launched and has not been waited for
+  bool counted = false;         // (mu) ... and is counted in resident_gangs() (runtime.hpp: memory is not given back meanwhile)
   std::atomic<bool> dead{false};   // a workgroup of it did not answer in time: none of its slots is handed out again (a late answer would land in the next request's buffers)
   bool stuck = false;           // ... and was still resident after a flush waited 2 s for it: later flushes ask once, without waiting again
 };
@@ -1412,6 +1414,13 @@ struct mrk_server {
   std::vector<std::unique_ptr<ServeGang>> gangs;
   std::atomic<int> users{0};   // callers of mrk_rank that are inside serve_fast through the context's server list
   std::atomic<int> waiting{0};          // callers between publish and acknowledgement
+  // overload guard (a process with fewer CPUs than the queue has slots): overflowing callers in numbers mean the CPUs are
+  // gone - everybody goes through the front, whose waiters sleep, for `front_ns`; then the queue is tried again
+  bool guard = false;
+  int ovf_threshold = 0;
+  int64_t front_ns = 0;
+  std::atomic<int64_t> front_until_ns{0}, ovf_window_ns{0};
+  std::atomic<int> ovf_count{0};
   std::atomic<uint64_t> est_dev_ns{0};  // what a request takes on the device (input copy + ranking + write-back), smoothed
   std::mutex mu;
   std::condition_variable cv;
@@ -1447,6 +1456,7 @@ bool drain_gang(mrk_server &srv, ServeGang &g, int seconds) {
   }
   tell_gang(srv, g, 0u);
   g.running = false;   // it left (or its launch failed): nothing of this gang touches the device any more
+  if (g.counted) { g.counted = false; resident_gangs().fetch_sub(1, std::memory_order_acq_rel); }
   return true;
 }
 
@@ -1464,6 +1474,7 @@ void launch_gang(mrk_server &srv, ServeGang &g) {
                     g.n, SERVE_THREADS, SERVE_LDS, srv.f64, srv.jit_fn);
   g.launch_id.store(d.launch_id);
   g.running = true;
+  if (!g.counted) { g.counted = true; resident_gangs().fetch_add(1, std::memory_order_acq_rel); }
   srv.n_launches.fetch_add(1);
 }
 
@@ -1478,10 +1489,51 @@ uint32_t revive_gang(mrk_server &srv, ServeGang &g, uint32_t seen) {
   return g.launch_id.load();
 }
 
+// The CPUs this process may use: its affinity mask, cut by the cgroup's quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us).
+int cpu_budget() {
+  static const int budget = [] {
+    cpu_set_t set;
+    int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+      fclose(g);
+      if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(h, "%lld", &period) != 1) period = 0;
+        fclose(h);
+      }
+    }
+    if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+    return n;
+  }();
+  return budget;
+}
+
+void note_overflow(mrk_server &srv, int64_t now_ns) {   // a caller found every slot busy
+  const int64_t w = srv.ovf_window_ns.load(std::memory_order_relaxed);
+  if (now_ns - w > 10000000) {   // 10 ms windows
+    srv.ovf_window_ns.store(now_ns, std::memory_order_relaxed);
+    srv.ovf_count.store(1, std::memory_order_relaxed);
+    return;
+  }
+  if (srv.ovf_count.fetch_add(1, std::memory_order_relaxed) + 1 >= srv.ovf_threshold) {
+    srv.ovf_count.store(0, std::memory_order_relaxed);
+    srv.front_until_ns.store(now_ns + srv.front_ns, std::memory_order_relaxed);
+  }
+}
+
 // true: ranked through the queue (status = the request's device status word); false: not a request the queue takes
 bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int32_t *out_order, int &status) {
   mrk_ctx *ctx = srv.ctx;
   if (!switches().rank_serve || req->n_items > QS_TILE_ROWS) return false;
+  const auto h0 = std::chrono::steady_clock::now();
+  const int64_t now_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(h0.time_since_epoch()).count();
+  if (srv.guard && now_ns < srv.front_until_ns.load(std::memory_order_relaxed)) return false;   // overloaded a moment ago: the front
   int si = -1;
   {
     std::lock_guard<std::mutex> lk(srv.mu);
@@ -1493,7 +1545,10 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
       si = c;
       break;
     }
-    if (si < 0) return false;  // every slot busy: the batching front of mrk_rank combines the overflow
+    if (si < 0) {  // every slot busy: the batching front of mrk_rank combines the overflow
+      if (srv.guard) note_overflow(srv, now_ns);
+      return false;
+    }
   }
   struct Release {
     mrk_server &s;
@@ -1509,7 +1564,6 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
   ServeSlot &sl = *srv.slots[(size_t)si];
   const Program &prog = locked_program(ctx, srv.model_name.c_str());
   if (&prog != srv.prog || program_mutates_store(prog) || prog.normalises()) return false;
-  const auto h0 = std::chrono::steady_clock::now();
   StoreAccess access(ctx);
   MRK_HIP(hipSetDevice(ctx->device));
   check_model_fits(srv.model, prog);
@@ -1560,7 +1614,8 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
     explicit Waiting(std::atomic<int> &c) : n(c), mine(c.fetch_add(1) + 1) {}
     ~Waiting() { n.fetch_sub(1); }
   } waiting(srv.waiting);
-  if (waiting.mine > switches().serve_spin_callers) {
+  const bool sleeper = waiting.mine > switches().serve_spin_callers;
+  if (sleeper) {
     static thread_local bool slack_set = false;
     if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); slack_set = true; }   // this thread's timers: 1 us instead of 50
     // (publish -> acknowledgement is the device's total + 15 ... 20 us of PCIe round trips: profiles/r06_ad, 96 against 77 us)
@@ -1570,13 +1625,17 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
       (void)nanosleep(&ts, nullptr);
     }
   }
+  // ... and a sleeper does not spin for the rest either: it looks every few microseconds (`serve_poll_us`; 0 = spin).  Spinning
+  // tails kept 64 callers just inside a 16-CPU quota and 80 callers outside it: the whole process was throttled for 100 - 200 ms
+  // at a time and the rate fell from 360 k to 180 k requests/s (profiles/r06_aj).
+  const long poll_ns = sleeper ? (long)switches().serve_poll_us * 1000 : 0;
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(5);
   for (uint32_t spin = 1; !acked(); ++spin) {
-    if ((spin & 31u) == 0u) {
+    if (poll_ns > 0 || (spin & 31u) == 0u) {
       if (gone()) {  // the workgroup left (idle / old / told to stop) - possibly after serving this request
         if (acked()) break;
         seen = revive_gang(srv, g, seen);
-      } else if ((spin & 0xffffu) == 0u && std::chrono::steady_clock::now() > deadline) {
+      } else if ((spin & (poll_ns > 0 ? 0xffu : 0xffffu)) == 0u && std::chrono::steady_clock::now() > deadline) {
         tell_gang(srv, g, 1u);  // should they still be alive: leave
         g.dead.store(true);
         release.dead = true;
@@ -1587,7 +1646,12 @@ bool serve_fast(mrk_server &srv, const mrk_request *req, double *out_scores, int
         throw StatusError(MRK_ERR_DEVICE, why);
       }
     }
-    __builtin_ia32_pause();
+    if (poll_ns > 0) {
+      struct timespec ts = {0, poll_ns};
+      (void)nanosleep(&ts, nullptr);
+    } else {
+      __builtin_ia32_pause();
+    }
   }
   const auto h2 = std::chrono::steady_clock::now();
   if (out_scores && T) memcpy(out_scores, sl.h_out, (size_t)T * 8);
@@ -1642,8 +1706,10 @@ static void quiesce_servers(mrk_ctx *ctx) {  // the caller holds the store exclu
       }
       g->stuck = false;
       g->running = false;   // it left (or its launch failed): nothing of this gang touches the device any more
+      if (g->counted) { g->counted = false; resident_gangs().fetch_sub(1, std::memory_order_acq_rel); }
     }
   }
+  if (resident_gangs().load(std::memory_order_acquire) == 0) flush_deferred_releases();
 }
 }  // namespace mrk
 
@@ -1668,6 +1734,7 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
     srv->idle_ticks = (uint64_t)std::max(1, switches().serve_idle_us) * 100ull;  // wall_clock64: 100 MHz
     srv->life_ticks = (uint64_t)std::max(1, switches().serve_life_us) * 100ull;
     srv->jit_fn = jit_serve_function(prog, srv->f64, switches().thr_stage ? &model->qs_sig : nullptr);  // warm-up: the compile happens here, not under the first request
+    srv->front_ns = (int64_t)switches().serve_overload_ms * 1000000;
     // A resident kernel holds its stream's hardware queue for as long as it stays, and streams that share a hardware queue wait
     // for each other: round 5's "collapse at 32 callers" (p99 76 ms) was a slot whose stream had landed behind another slot's
     // resident kernel (ROCm maps a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default; mrk_init asks for
@@ -1708,6 +1775,8 @@ int mrk_serve_start(mrk_ctx *ctx, mrk_model *model, const char *model_name, int 
       MRK_HIP(hipMemset(g->d_clock.p, 0, 8));
       srv->gangs.push_back(std::move(g));
     }
+    srv->guard = srv->front_ns > 0 && cpu_budget() < n_slots;   // fewer CPUs than slots: callers in overflow are CPUs that are not there
+    srv->ovf_threshold = std::max(3 * n_slots, 96);
     mrk_model_retain(model);
     ctx_retain(ctx);
     {
@@ -1839,6 +1908,7 @@ void mrk_serve_stop(mrk_server *srv) {
   }
   mrk_model_free(srv->model);
   delete srv;
+  if (resident_gangs().load(std::memory_order_acquire) == 0) flush_deferred_releases();
   ctx_release(ctx);
 }
 

@@ -32,6 +32,16 @@ void set_last_error(const std::string &msg);
       throw ::mrk::StatusError(MRK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// hipFree / hipHostFree wait for EVERY resident kernel of the device.  While gangs of the serving queue are resident (capi_rank.cpp:
+// they stay up to MRK_SERVE_LIFE_US and are relaunched at once under traffic, so with 8 of them the device is hardly ever idle) a
+// buffer that regrows - the scratch batches of mrk_rank's front finding their sizes - stalled its caller for 70 ... 190 ms
+// (profiles/r06_al_front_trace.txt: the `build` phase of a combined batch).  So while any gang is resident, memory is not given
+// back at once: release_device / release_pinned put it on a list that is emptied when the last gang has been waited for.
+std::atomic<int> &resident_gangs();           // capi.cpp
+void release_device(void *p);                 // hipFree now, or later
+void release_pinned(void *p);                 // hipHostFree now, or later
+void flush_deferred_releases();               // (no gang resident: give everything back)
+
 // RAII device buffer (hipMalloc / hipFree), grow-only reserve.
 struct DevBuf {
   void *p = nullptr;
@@ -46,7 +56,7 @@ struct DevBuf {
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) release_device(p);
     p = nullptr;
     cap = 0;
   }
@@ -74,11 +84,11 @@ struct PinBuf {
   PinBuf() = default;
   PinBuf(const PinBuf &) = delete;
   PinBuf &operator=(const PinBuf &) = delete;
-  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  ~PinBuf() { if (p) release_pinned(p); }
   void reserve(size_t bytes) {  // (regrowth doubles, like DevBuf's)
     if (bytes <= cap) return;
     const size_t grown = cap >= (256u << 20) ? cap + cap / 4 : cap * 2;
-    if (p) (void)hipHostFree(p);
+    if (p) release_pinned(p);
     p = nullptr;
     cap = 0;
     size_t want = bytes < 4096 ? 4096 : bytes;
@@ -115,6 +125,9 @@ struct Switches {
   int serve_spin_callers = 8;  // MRK_SERVE_SPIN_CALLERS: up to this many callers of the serving queue wait for their answer spinning; the ones beyond
                                // sleep through most of the device's time first (a host with a CPU quota throttles 64 spinning threads)
   int serve_sleep_extra_us = 8;   // MRK_SERVE_SLEEP_EXTRA_US: ... that sleep = the device's smoothed time per request + this
+  int serve_poll_us = 4;          // MRK_SERVE_POLL_US: ... and after it looks for its answer this often instead of spinning (0: spin)
+  int serve_overload_ms = 200;    // MRK_SERVE_OVERLOAD_MS: a queue with more slots than the process has CPUs sends everybody through the front for this long
+                                  // once callers overflow its slots in numbers (0: never)
   int serve_idle_us = 2000;    // MRK_SERVE_IDLE_US: a serving workgroup without a request for this long leaves its CU (relaunched by the next request)
   bool rank_fused_score = false; // MRK_RANK_FUSED_SCORE=1: full batches of small requests in ONE launch (assembly, forest, ordering per request workgroup) - measured slower than the three launches, kept for A/B
   bool rank_one = true;        // MRK_RANK_ONE=0: mrk_rank's small batches take the three-launch path instead of the one-launch kernel

@@ -141,7 +141,10 @@ def main():
             row = run_python(ranker, booster, srv, reqs, threads)
         else:
             h = srv._h if (srv is not None and serve) else None
-            run_native(d, ctx, booster, h, arr, len(reqs), threads if '--warm-full' in flags else min(threads, 8), sc, od)   # warm: lanes, streams, pinned buffers
+            # warm: lanes, streams, pinned buffers.  With a queue started the callers beyond its slots are the front's: a warm-up of 8
+            # callers never reaches it, and the front's scratch batches would find their sizes (allocations: tens of ms each) inside
+            # the measured window
+            run_native(d, ctx, booster, h, arr, len(reqs), threads if ('--warm-full' in flags or srv is not None) else min(threads, 8), sc, od)
             row = run_native(d, ctx, booster, h, arr, len(reqs), threads, sc, od)
         row["path"] = "mrk_serve_rank" if serve else ("mrk_rank+queue" if queue else "mrk_rank")
         if srv is not None:

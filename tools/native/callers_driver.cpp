@@ -4,6 +4,10 @@
 // an interpreter between the calls.  (tools/concurrent_bench.py drove Python threads until round 5: its numbers at 16+ threads
 // were the GIL's - every call re-enters the interpreter - not the library's.)
 //   g++ -O2 -shared -fPIC -std=c++17 -I include tools/native/callers_driver.cpp -o tools/native/libcallers_driver.so -L metarank_amd -lmrk_hip -pthread
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -16,6 +20,30 @@
 namespace {
 using clk = std::chrono::steady_clock;
 inline double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+}  // namespace
+
+// A tool, not the product: a SIGSEGV of the process that loaded this driver prints the native stack before it dies (the
+// callers tool was seen to die AFTER its last row, during process exit, where Python's faulthandler is already off).
+namespace {
+void segv_backtrace(int sig) {
+  void *frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "\n== callers_driver: fatal signal, native stack:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct InstallSegv {
+  InstallSegv() {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = segv_backtrace;
+    sigaction(SIGSEGV, &sa, nullptr);
+    sigaction(SIGBUS, &sa, nullptr);
+    sigaction(SIGABRT, &sa, nullptr);
+  }
+} install_segv;
 }  // namespace
 
 extern "C" {
